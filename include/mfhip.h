@@ -1,0 +1,190 @@
+/*
+ * mfhip.h — C ABI of libmfhip.so, the MI355X (gfx950) kernel library behind the
+ * MirrorFusion (SD1.5 + BrushNet) denoising hot path.
+ *
+ * The reference (val-iisc/Reflecting-Reality, MirrorFusion/src/diffusers) is 100 % Python and has
+ * no native operator boundary; every arithmetic step is an ATen call.  Each entry point below
+ * therefore cites the reference *call site* it replaces (paths relative to
+ * MirrorFusion/src/diffusers/).  All entry points:
+ *   - are extern "C", take plain pointers / sizes / a hipStream_t (passed as void*),
+ *   - never allocate, free, synchronise or retain caller memory (graph-capture safe),
+ *   - return 0 on success, a negative MF_E* code otherwise; mf_last_error() gives the text.
+ * Device buffers are owned by the caller (PyTorch-ROCm allocates them).
+ *
+ * Layout conventions: activations are NHWC ("pixel-major": [batch][y][x][channel]) which is
+ * bit-identical to the [batch][tokens][channels] layout of the transformer blocks, so no
+ * transposes exist between conv and attention.  Weights are [N][K] with K contiguous
+ * (conv: [Cout][ky][kx][Cin]).  dtype codes: MF_F32 = 0, MF_BF16 = 1.
+ */
+#ifndef MFHIP_H
+#define MFHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_F32 0
+#define MF_BF16 1
+
+#define MF_OK 0
+#define MF_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MF_ELAUNCH (-2)  /* hipLaunch failed */
+#define MF_EALIGN (-3)   /* pointer / stride alignment not met */
+
+#define MF_ACT_NONE 0
+#define MF_ACT_SILU 1
+
+/* ABI version, bumped on any struct change; checked by the Python host at load time. */
+#define MF_ABI_VERSION 3
+int mf_abi_version(void);
+const char* mf_last_error(void);
+/* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
+int mf_sizeof_gemm_desc(void);
+int mf_sizeof_groupnorm_desc(void);
+
+/* --------------------------------------------------------------------------------------------
+ * mf_gemm_conv — implicit-GEMM convolution / linear / strided-batched NT GEMM on MFMA.
+ *
+ *   out[z][m][n] = alpha * ( sum_k A[z][m][k] * W[z][n][k] + bias + temb[b(m)][n] )
+ *                  + res0[m][n] + res1[m][n]              (then optional activation)
+ *
+ * A is gathered on the fly from up to two NHWC tensors concatenated along channels
+ * (torch.cat([h, skip], 1) is never materialised), optionally through a nearest-2x upsample,
+ * with zero padding; k = (ky*kw + kx)*(c0+c1) + c.
+ *
+ * Replaces: LoRACompatibleConv/F.conv2d (models/lora.py:293-366; call sites resnet.py:278,294,
+ * 320-327, downsampling.py:118-120,134-154, upsampling.py:170-191, brushnet.py:221,325-447,
+ * transformer_2d.py:162,225, unet_2d_condition.py conv_in/conv_out), LoRACompatibleLinear/F.linear
+ * (lora.py:368-451; attention_processor.py:190-205, activations.py:92, attention.py:663,
+ * resnet.py:282, embeddings.py:225-237), torch.cat (unet_2d_blocks.py:2586,2728), the injection
+ * adds (unet_2d_blocks.py:1389,1398,1484,1493,2627,2635,2752,2761; unet_2d_condition.py:1218,1289)
+ * and, in batched form, the QK^T / PV products of attention_processor.py:577-622.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mf_gemm_desc {
+    /* compute dtype: MF_BF16 (bf16 MFMA 32x32x16, fp32 accumulate) or MF_F32 (fp32 MFMA 32x32x2) */
+    int32_t dtype;
+    /* A operand */
+    const void* a0;       /* segment 0, NHWC */
+    const void* a1;       /* segment 1 or NULL */
+    int32_t c0, c1;       /* channels per segment (c1 = 0 when a1 is NULL) */
+    int64_t lda0, lda1;   /* pixel stride of each segment, in elements (>= c) */
+    int32_t a_dtype;      /* storage dtype of a0/a1: == dtype, or MF_F32 with dtype == MF_BF16 */
+    int32_t batch, h_in, w_in;  /* input geometry (before upsample) */
+    int32_t h_out, w_out;
+    int32_t kh, kw, stride, pad_t, pad_l;
+    int32_t upsample;     /* 1: nearest-neighbour 2x before the convolution */
+    /* W operand, [n][k] row-major, row stride ldw elements, dtype == dtype */
+    const void* w;
+    int64_t ldw;
+    int32_t n;            /* output channels */
+    /* strided batching (attention): blockIdx.z = z, offset = (z / zdiv)*zs_o + (z % zdiv)*zs_i */
+    int32_t nz, zdiv;
+    int64_t a_zs_o, a_zs_i, w_zs_o, w_zs_i, o_zs_o, o_zs_i;
+    /* epilogue */
+    const float* bias;    /* [n] (bias_mode 0) or [m] (bias_mode 1) or NULL */
+    int32_t bias_mode;
+    const float* temb;    /* [batch][ld_temb] fp32 or NULL; row = m / (h_out*w_out) */
+    int64_t ld_temb;
+    const void* res0; int32_t res0_dtype; int64_t ld_res0;
+    const void* res1; int32_t res1_dtype; int64_t ld_res1;
+    float alpha;
+    int32_t act;
+    void* out; int32_t out_dtype; int64_t ldc;
+    /* split-K: 0 = library heuristic (uses `ws` when it is large enough), 1 = off, >1 = forced;
+     * `ws` is a caller-owned scratch of `ws_floats` floats (splitk*nz*M*N are needed) */
+    int32_t splitk;
+    float* ws;
+    int64_t ws_floats;
+    /* tile selection: 0 = library heuristic, else an index into the instantiated tile table */
+    int32_t tile;
+} mf_gemm_desc;
+
+int mf_gemm_conv(const mf_gemm_desc* d, void* stream);
+/* number of instantiated tile configurations and their (BM, BN) */
+int mf_gemm_num_tiles(void);
+int mf_gemm_tile_shape(int tile, int* bm, int* bn);
+
+/* --------------------------------------------------------------------------------------------
+ * mf_groupnorm — GroupNorm over NHWC (optionally over the channel-concat of two tensors),
+ * fused with SiLU.  Replaces torch.nn.GroupNorm + SiLU (resnet.py:337-338,381,393;
+ * transformer_2d.py:158,338; unet_2d_condition.py:1336-1338; vae.py; attention_processor.py:1244).
+ * `ws` is a scratch buffer of mf_groupnorm_ws_floats(batch, groups) floats.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mf_groupnorm_desc {
+    const void* x0; const void* x1;   /* NHWC segments; x1 may be NULL */
+    int32_t c0, c1;
+    int32_t in_dtype;                 /* MF_F32 / MF_BF16 */
+    int32_t batch, hw;                /* hw = H*W */
+    int32_t groups;
+    float eps;
+    const float* gamma; const float* beta;   /* [c0+c1] fp32 */
+    int32_t silu;                     /* 1: y = silu(gn(x)) */
+    void* out; int32_t out_dtype;     /* [batch][hw][c0+c1] */
+    float* ws;
+} mf_groupnorm_desc;
+int mf_groupnorm(const mf_groupnorm_desc* d, void* stream);
+int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups);
+
+/* LayerNorm over the last dim of [rows][c]; replaces nn.LayerNorm (attention.py:203,233,261). */
+int mf_layernorm(const void* x, int32_t in_dtype, void* out, int32_t out_dtype, const float* gamma,
+                 const float* beta, int64_t rows, int32_t c, float eps, void* stream);
+
+/* Row softmax in place over scores[rows][ld] (fp32), valid length `cols`; columns in
+ * [cols, ld) are written as 0 so the buffer can feed a K-padded GEMM.  Writes P in `out`
+ * ([rows][ld], out_dtype).  Replaces attention_probs.softmax(dim=-1) (attention_processor.py:616). */
+int mf_softmax_rows(const float* scores, void* out, int32_t out_dtype, int64_t rows, int32_t cols,
+                    int32_t ld, void* stream);
+
+/* Fused flash-style attention (bf16): out[b][s][h*d + :] = softmax(q k^T * scale) v.
+ * q: [B][Sq][ldq], k: [B][Skv][ldk], vt: V^T as [B][heads*d][ldvt] (keys contiguous),
+ * replaces F.scaled_dot_product_attention (attention_processor.py:1266-1268). */
+int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                      void* out, int64_t ldo, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                      int32_t head_dim, float scale, void* stream);
+
+/* ---- elementwise / layout -------------------------------------------------------------- */
+/* NCHW fp32 -> NHWC (dtype), channels zero-padded to c_pad; two sources concatenated along C
+ * (brushnet.py:810 torch.concat([sample, brushnet_cond], 1)); src1 may be NULL. */
+int mf_pack_nhwc(const float* src0, int32_t c0, const float* src1, int32_t c1, void* dst, int32_t dst_dtype,
+                 int32_t c_pad, int32_t batch, int32_t hw, void* stream);
+/* NHWC (dtype, channel stride ld) -> NCHW fp32, first c channels */
+int mf_unpack_nchw(const void* src, int32_t src_dtype, int64_t ld, float* dst, int32_t c, int32_t batch,
+                   int32_t hw, void* stream);
+/* out = a + b (elementwise over n elements, dtypes independent) (unet_2d_condition.py:1218) */
+int mf_add(const void* a, int32_t a_dtype, const void* b, int32_t b_dtype, void* out, int32_t out_dtype,
+           int64_t n, void* stream);
+/* GEGLU: out[r][j] = h[r][j] * gelu_erf(h[r][c + j]) for h = [rows][2c] (activations.py:100-103) */
+int mf_geglu(const void* h, int32_t in_dtype, void* out, int32_t out_dtype, int64_t rows, int32_t c,
+             void* stream);
+/* sinusoidal timestep embedding, flip_sin_to_cos / freq_shift as embeddings.py:27-67; out [n][dim] fp32 */
+int mf_timestep_embedding(const float* t, float* out, int32_t n, int32_t dim, int32_t flip_sin_to_cos,
+                          float freq_shift, void* stream);
+/* SiLU on fp32 vector (resnet.py:372 nonlinearity(temb)) */
+int mf_silu_f32(const float* x, float* out, int64_t n, void* stream);
+
+/* Fused classifier-free guidance + DDIM step (pipeline_brushnet.py:1310-1315,
+ * scheduling_ddim.py:404-450, eta = 0, no clipping / thresholding):
+ *   eps = eu + g*(ec - eu);  x0 = (x - sqrt_1m_at*eps)/sqrt_at;  x_prev = sqrt_ap*x0 + dir_coef*eps
+ * eps_u/eps_c: the two halves of the UNet output in NCHW fp32; g < 0 disables CFG (eps = eps_u). */
+int mf_cfg_ddim_step(const float* eps_u, const float* eps_c, float g, const float* x, float* x_prev,
+                     float sqrt_at, float sqrt_1m_at, float sqrt_ap, float dir_coef, float* eps_out,
+                     int64_t n, void* stream);
+/* CFG combine only (PNDM keeps its own history on the host side): eps = eu + g*(ec-eu) */
+int mf_cfg_combine(const float* eps_u, const float* eps_c, float g, float* eps, int64_t n, void* stream);
+/* generic y = sum_i c[i]*x[i] (i < nin <= 6) — PNDM/PLMS linear multistep and _get_prev_sample
+ * (scheduling_pndm.py:370-382,436-446) */
+int mf_axpby_n(const float* const* xs, const float* coefs, int32_t nin, float* y, int64_t n, void* stream);
+/* DiagonalGaussianDistribution.sample * scaling (vae.py:769-791, pipeline_brushnet.py:1188):
+ * moments NHWC [b][hw][ld] (mean = ch 0..c-1, logvar = ch c..2c-1) -> z NCHW fp32 [b][c][hw] */
+int mf_vae_sample(const void* moments, int32_t m_dtype, int64_t ld, const float* noise, float* z, int32_t c,
+                  int32_t batch, int32_t hw, float scaling, void* stream);
+/* nearest-neighbour resize of NCHW fp32 planes (F.interpolate default, pipeline_brushnet.py:1189-1200) */
+int mf_nearest_resize(const float* src, float* dst, int32_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
+                      int32_t w_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFHIP_H */

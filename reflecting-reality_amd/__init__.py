@@ -1,0 +1,12 @@
+"""reflecting-reality_amd — MI355X-native MirrorFusion (SD1.5 + BrushNet) denoising hot path.
+
+The directory name carries a hyphen (it is the project name), so the package is imported under the
+module name ``reflecting_reality_amd`` through the shim ``reflecting_reality_amd.py`` at the repo root.
+Sub-modules:
+  hip        ctypes binding of libmfhip.so (include/mfhip.h) — the only compute backend, no fallback
+  ops        layer-level operators (conv2d / linear / attention / norms) over NHWC tensors
+  models     BrushNetModel, UNet2DConditionModel, AutoencoderKL with the reference call surface
+  schedulers DDIMScheduler, PNDMScheduler
+  pipeline   StableDiffusionBrushNetPipeline
+"""
+__version__ = "0.1.0"

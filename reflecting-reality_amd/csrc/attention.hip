@@ -1,0 +1,268 @@
+// Flash-style fused attention for gfx950, bf16 operands / fp32 softmax + accumulation.
+//
+// Replaces F.scaled_dot_product_attention (reference models/attention_processor.py:1266-1268) for
+// the SD1.5 head dims (40 / 80 / 160; also 8 and 64 for tiny test configs).
+//
+// Formulation (CDNA4): a workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32
+// queries.  Per 64-key tile the wave computes S^T = K.Q^T with v_mfma_f32_32x32x16_bf16 (keys on the
+// accumulator rows = registers, queries on the lanes).  With the query on the lane the online
+// softmax needs no cross-lane traffic except one lane^32 exchange for the row max / sum, and the
+// S^T accumulator, converted pairwise to bf16, is *already* the B operand of the second product
+// O^T = V^T.P^T (accumulator rows -> k index, no LDS round trip).  V arrives pre-transposed
+// ([head*d][keys], produced that way by the to_v GEMM with swapped operands) so both K and V^T
+// fragments are single 16-byte LDS reads; the k-permutation implied by the accumulator layout
+// (k = 16s + 8(j>>2) + 4h + (j&3)) is applied when the V^T tile is written to LDS.
+// The softmax rescale factor is per query = per lane, so rescaling O^T is a plain register multiply.
+// O^T is transposed once through LDS at the end so the global stores are row-contiguous.
+#include "mf_common.h"
+
+namespace {
+
+struct AttnArgs {
+    const char* q; int64_t ldq;
+    const char* k; int64_t ldk;
+    const char* vt; int64_t ldvt;
+    char* out; int64_t ldo;
+    int heads, sq, skv;
+    float c;   // softmax scale * log2(e)
+};
+
+__device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    constexpr int DK = (HD + 15) / 16 * 16;   // QK^T reduction length, padded to the MFMA k-step
+    constexpr int KS = DK / 16;
+    constexpr int DV = (HD + 31) / 32 * 32;   // O^T rows, padded to the MFMA tile
+    constexpr int DT = DV / 32;
+    constexpr int RBK = DK * 2 + 16;          // K tile row stride (odd multiple of 16 B: conflict-free b128 reads)
+    constexpr int RBV = 144;                  // V^T tile row stride: 64 keys * 2 B + 16
+    constexpr int RBO = DV * 2 + 16;          // epilogue transpose row stride
+    constexpr int KVEC = 64 * (HD / 8);       // 16-B vectors per K tile
+    constexpr int VVEC = HD * 8;              // 16-B vectors per V^T tile
+    constexpr int KJ = (KVEC + 255) / 256, VJ = (VVEC + 255) / 256;
+    constexpr int K_BYTES = 64 * RBK, V_BYTES = DV * RBV;
+    constexpr int O_BYTES = 4 * 32 * RBO;
+    constexpr int LDS_BYTES = (K_BYTES + V_BYTES) > O_BYTES ? (K_BYTES + V_BYTES) : O_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    char* Ks = smem;
+    char* Vs = smem + K_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qi = q0 + r;
+
+    // zero the whole staging area once: pad columns / rows must never hold NaN bit patterns
+    for (int i = tid * 16; i < K_BYTES + V_BYTES; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+    // Q fragments (B operand of S^T = K.Q^T): lane (query r, half h) holds Q[q][16ks + 8h + j]
+    bf16x8_t qf[KS];
+    {
+        const char* qrow = p.q + (((int64_t)b * p.sq + (qi < p.sq ? qi : 0)) * p.ldq + head * HD) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kk = 16 * ks + 8 * h;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kk < HD && qi < p.sq) v = ldg16(qrow + kk * 2);
+            qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+
+    const char* kbase = p.k + ((int64_t)b * p.skv * p.ldk + head * HD) * 2;
+    const char* vbase = p.vt + ((int64_t)(b * p.heads + head) * HD) * p.ldvt * 2;
+
+    uint4 kreg[KJ], vreg[VJ];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            const int v = tid + 256 * j;
+            kreg[j] = make_uint4(0, 0, 0, 0);
+            if (v < KVEC) {
+                const int row = v / (HD / 8), cv = v - row * (HD / 8);
+                const int key = kv0 + row;
+                if (key < p.skv) kreg[j] = ldg16(kbase + ((int64_t)key * p.ldk + cv * 8) * 2);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VJ; ++j) {
+            const int v = tid + 256 * j;
+            vreg[j] = make_uint4(0, 0, 0, 0);
+            if (v < VVEC) {
+                const int row = v >> 3, cv = v & 7;
+                const int key0 = kv0 + cv * 8;
+                if (key0 + 8 <= p.ldvt) vreg[j] = ldg16(vbase + ((int64_t)row * p.ldvt + key0) * 2);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            const int v = tid + 256 * j;
+            if (v < KVEC) {
+                const int row = v / (HD / 8), cv = v - row * (HD / 8);
+                *reinterpret_cast<uint4*>(Ks + row * RBK + cv * 16) = kreg[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VJ; ++j) {
+            const int v = tid + 256 * j;
+            if (v < VVEC) {
+                const int row = v >> 3, cv = v & 7;
+                // keys cv*8 .. cv*8+7 of a 16-key step; LDS order inside a step is [0-3, 8-11, 4-7, 12-15]
+                char* dst = Vs + row * RBV + (cv >> 1) * 32 + (cv & 1) * 8;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(vreg[j].x, vreg[j].y);
+                *reinterpret_cast<uint2*>(dst + 16) = make_uint2(vreg[j].z, vreg[j].w);
+            }
+        }
+    };
+
+    f32x16_t o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+
+    const int ntiles = (p.skv + 63) / 64;
+    load_tile(0);
+    __syncthreads();   // zero-fill done
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(kv0 + 64);
+
+        // ---- S^T = K . Q^T : two 32-key tiles ----
+        f32x16_t st[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { st[0][e] = 0.0f; st[1][e] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const uint4 a = *reinterpret_cast<const uint4*>(Ks + (32 * tt + r) * RBK + (16 * ks + 8 * h) * 2);
+                st[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), qf[ks], st[tt], 0, 0, 0);
+            }
+        }
+        if (kv0 + 64 > p.skv) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kv0 + 32 * tt + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (key >= p.skv) st[tt][e] = -INFINITY;
+                }
+        }
+        // ---- online softmax (per query = per lane; the two lane halves hold disjoint keys) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[tt][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * p.c);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        float rs = 0.0f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[tt][e], p.c, -m_new));
+                st[tt][e] = pv;
+                rs += pv;
+            }
+        l = l * alpha + rs;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        // ---- P^T fragments: accumulator registers 8s..8s+7 of tile tt are k-step 2*tt+s ----
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                uint4 u;
+                u.x = (uint32_t)f32_to_bf16(st[tt][8 * s + 0]) | ((uint32_t)f32_to_bf16(st[tt][8 * s + 1]) << 16);
+                u.y = (uint32_t)f32_to_bf16(st[tt][8 * s + 2]) | ((uint32_t)f32_to_bf16(st[tt][8 * s + 3]) << 16);
+                u.z = (uint32_t)f32_to_bf16(st[tt][8 * s + 4]) | ((uint32_t)f32_to_bf16(st[tt][8 * s + 5]) << 16);
+                u.w = (uint32_t)f32_to_bf16(st[tt][8 * s + 6]) | ((uint32_t)f32_to_bf16(st[tt][8 * s + 7]) << 16);
+                pf[2 * tt + s] = __builtin_bit_cast(bf16x8_t, u);
+            }
+        // ---- O^T += V^T . P^T ----
+#pragma unroll
+        for (int kst = 0; kst < 4; ++kst)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const uint4 a = *reinterpret_cast<const uint4*>(Vs + (32 * d + r) * RBV + (16 * kst + 8 * h) * 2);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kst], o[d], 0, 0, 0);
+            }
+        __syncthreads();   // everyone is done reading this tile
+    }
+
+    // ---- epilogue: normalise, transpose through LDS, row-contiguous stores ----
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    char* Os = smem + wave * 32 * RBO;   // safe: the loop ended on a barrier
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 u;
+            u.x = (uint32_t)f32_to_bf16(o[d][4 * g + 0] * inv) | ((uint32_t)f32_to_bf16(o[d][4 * g + 1] * inv) << 16);
+            u.y = (uint32_t)f32_to_bf16(o[d][4 * g + 2] * inv) | ((uint32_t)f32_to_bf16(o[d][4 * g + 3] * inv) << 16);
+            *reinterpret_cast<uint2*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 2) = u;
+        }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    constexpr int OV = 32 * (HD / 8);
+    for (int v = lane; v < OV; v += 64) {
+        const int row = v / (HD / 8), cv = v - row * (HD / 8);
+        const int qq = q0 + row;
+        if (qq < p.sq) {
+            const uint4 val = *reinterpret_cast<const uint4*>(Os + row * RBO + cv * 16);
+            *reinterpret_cast<uint4*>(p.out + (((int64_t)b * p.sq + qq) * p.ldo + head * HD + cv * 8) * 2) = val;
+        }
+    }
+}
+
+template <int HD>
+void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
+    dim3 grid((a.sq + 127) / 128, a.heads, batch);
+    hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                                 void* out, int64_t ldo, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                                 int32_t head_dim, float scale, void* stream) {
+    MF_CHECK_ARG(q && k && vt && out, "mf_attention_bf16: null pointer");
+    MF_CHECK_ARG(batch >= 1 && heads >= 1 && sq >= 1 && skv >= 1, "mf_attention_bf16: bad sizes");
+    MF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0 && ldvt >= skv,
+                 "mf_attention_bf16: leading dims must be multiples of 8 and ldvt >= skv");
+    if (!mf_aligned16(q) || !mf_aligned16(k) || !mf_aligned16(vt) || !mf_aligned16(out)) {
+        mf_set_error("mf_attention_bf16: pointers must be 16-byte aligned");
+        return MF_EALIGN;
+    }
+    AttnArgs a{};
+    a.q = (const char*)q; a.ldq = ldq; a.k = (const char*)k; a.ldk = ldk; a.vt = (const char*)vt; a.ldvt = ldvt;
+    a.out = (char*)out; a.ldo = ldo; a.heads = heads; a.sq = sq; a.skv = skv;
+    a.c = scale * 1.44269504088896340736f;
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 8: launch_attn<8>(a, batch, s); break;
+        case 40: launch_attn<40>(a, batch, s); break;
+        case 64: launch_attn<64>(a, batch, s); break;
+        case 80: launch_attn<80>(a, batch, s); break;
+        case 160: launch_attn<160>(a, batch, s); break;
+        default:
+            mf_set_error("mf_attention_bf16: unsupported head_dim %d (have 8, 40, 64, 80, 160)", head_dim);
+            return MF_EINVAL;
+    }
+    MF_CHECK_LAUNCH("mf_attention_bf16");
+    return MF_OK;
+}

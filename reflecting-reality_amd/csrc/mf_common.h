@@ -1,0 +1,52 @@
+// Shared device/host helpers for libmfhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mfhip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef unsigned short bf16_raw;
+
+void mf_set_error(const char* fmt, ...);
+
+#define MF_CHECK_ARG(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            mf_set_error(__VA_ARGS__);   \
+            return MF_EINVAL;            \
+        }                                \
+    } while (0)
+
+#define MF_CHECK_LAUNCH(name)                                                         \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            mf_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+            return MF_ELAUNCH;                                                        \
+        }                                                                             \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_raw v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_raw, b);
+}
+
+// dtype-generic scalar load/store (dt is wave-uniform at every call site)
+__device__ __forceinline__ float load_as_f32(const void* p, int dt, int64_t i) {
+    return dt == MF_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_raw*)p)[i]);
+}
+__device__ __forceinline__ void store_from_f32(void* p, int dt, int64_t i, float v) {
+    if (dt == MF_F32) ((float*)p)[i] = v;
+    else ((bf16_raw*)p)[i] = f32_to_bf16(v);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
+
+static inline int mf_dtype_size(int dt) { return dt == MF_F32 ? 4 : 2; }
+static inline bool mf_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -1,0 +1,371 @@
+"""ctypes binding of libmfhip.so (C ABI in include/mfhip.h) on top of torch-ROCm tensors.
+
+PyTorch is used only to own device memory and the HIP stream; every arithmetic op below is a
+hand-written gfx950 kernel.  There is NO fallback: if the library is missing or a call fails this
+module raises, it never computes on the host or through ATen.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _build
+
+MF_F32, MF_BF16 = 0, 1
+ACT_NONE, ACT_SILU = 0, 1
+ABI_VERSION = 3
+
+
+class MfhipError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("a0", C.c_void_p), ("a1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32),
+        ("lda0", C.c_int64), ("lda1", C.c_int64),
+        ("a_dtype", C.c_int32),
+        ("batch", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
+        ("h_out", C.c_int32), ("w_out", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("upsample", C.c_int32),
+        ("w", C.c_void_p), ("ldw", C.c_int64),
+        ("n", C.c_int32),
+        ("nz", C.c_int32), ("zdiv", C.c_int32),
+        ("a_zs_o", C.c_int64), ("a_zs_i", C.c_int64), ("w_zs_o", C.c_int64), ("w_zs_i", C.c_int64),
+        ("o_zs_o", C.c_int64), ("o_zs_i", C.c_int64),
+        ("bias", C.c_void_p), ("bias_mode", C.c_int32),
+        ("temb", C.c_void_p), ("ld_temb", C.c_int64),
+        ("res0", C.c_void_p), ("res0_dtype", C.c_int32), ("ld_res0", C.c_int64),
+        ("res1", C.c_void_p), ("res1_dtype", C.c_int32), ("ld_res1", C.c_int64),
+        ("alpha", C.c_float), ("act", C.c_int32),
+        ("out", C.c_void_p), ("out_dtype", C.c_int32), ("ldc", C.c_int64),
+        ("splitk", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+        ("tile", C.c_int32),
+    ]
+
+
+class GroupNormDesc(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32),
+        ("in_dtype", C.c_int32),
+        ("batch", C.c_int32), ("hw", C.c_int32),
+        ("groups", C.c_int32),
+        ("eps", C.c_float),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("silu", C.c_int32),
+        ("out", C.c_void_p), ("out_dtype", C.c_int32),
+        ("ws", C.c_void_p),
+    ]
+
+
+# every symbol include/mfhip.h declares (tests/test_abi.py checks the header against this list)
+EXPORTS = [
+    "mf_abi_version", "mf_last_error", "mf_sizeof_gemm_desc", "mf_sizeof_groupnorm_desc",
+    "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape",
+    "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
+    "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
+    "mf_cfg_ddim_step", "mf_cfg_combine", "mf_axpby_n", "mf_vae_sample", "mf_nearest_resize",
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load libmfhip.so (after torch, so that its libamdhip64.so.7 is the one HIP runtime in-process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MfhipError(
+            f"{path} not found: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (needs hipcc). There is no CPU fallback for the MirrorFusion hot path.")
+    lib = C.CDLL(path)
+    lib.mf_last_error.restype = C.c_char_p
+    lib.mf_groupnorm_ws_floats.restype = C.c_int64
+    if lib.mf_abi_version() != ABI_VERSION:
+        raise MfhipError(f"libmfhip ABI {lib.mf_abi_version()} != binding ABI {ABI_VERSION}: rebuild the library")
+    if lib.mf_sizeof_gemm_desc() != C.sizeof(GemmDesc) or lib.mf_sizeof_groupnorm_desc() != C.sizeof(GroupNormDesc):
+        raise MfhipError("descriptor struct layout mismatch between mfhip.h and the ctypes binding")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise MfhipError(f"{what} failed (rc={rc}): {load().mf_last_error().decode()}")
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return MF_F32
+    if dtype == torch.bfloat16:
+        return MF_BF16
+    raise MfhipError(f"unsupported dtype {dtype}")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req_cuda(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MfhipError("libmfhip ops need device tensors (there is no CPU path)")
+
+
+# ---- scratch buffers (split-K slabs, GroupNorm statistics) -------------------------------------
+_scratch: dict = {}
+
+
+def scratch(name: str, nfloats: int, device) -> torch.Tensor:
+    key = (name, torch.device(device).index)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(nfloats, 1), dtype=torch.float32, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+SPLITK_WS_FLOATS = 16 * 1024 * 1024  # 64 MiB of fp32 slabs
+
+
+def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype: torch.dtype,
+              c0: int, lda0: int, batch: int, h_in: int, w_in: int, h_out: int, w_out: int,
+              kh: int = 1, kw: int = 1, stride: int = 1, pad_t: int = 0, pad_l: int = 0, upsample: bool = False,
+              a1: Optional[torch.Tensor] = None, c1: int = 0, lda1: int = 0,
+              ldw: Optional[int] = None, n: int, ldc: Optional[int] = None,
+              bias: Optional[torch.Tensor] = None, bias_mode: int = 0,
+              temb: Optional[torch.Tensor] = None, ld_temb: int = 0,
+              res0: Optional[torch.Tensor] = None, ld_res0: Optional[int] = None,
+              res1: Optional[torch.Tensor] = None, ld_res1: Optional[int] = None,
+              alpha: float = 1.0, act: int = ACT_NONE,
+              nz: int = 1, zdiv: int = 1, a_zs=(0, 0), w_zs=(0, 0), o_zs=(0, 0),
+              splitk: int = 0, tile: int = 0) -> torch.Tensor:
+    """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements."""
+    _req_cuda(a0, a1, w, out, bias, temb, res0, res1)
+    d = GemmDesc()
+    d.dtype = dt_code(dtype)
+    d.a0, d.a1 = _ptr(a0), _ptr(a1)
+    d.c0, d.c1, d.lda0, d.lda1 = c0, c1, lda0, lda1
+    d.a_dtype = dt_code(a0.dtype)
+    d.batch, d.h_in, d.w_in, d.h_out, d.w_out = batch, h_in, w_in, h_out, w_out
+    d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.upsample = kh, kw, stride, pad_t, pad_l, int(upsample)
+    if w.dtype != dtype:
+        raise MfhipError(f"weight dtype {w.dtype} != compute dtype {dtype}")
+    d.w = _ptr(w)
+    d.ldw = ldw if ldw is not None else kh * kw * (c0 + c1)
+    d.n = n
+    d.nz, d.zdiv = nz, zdiv
+    d.a_zs_o, d.a_zs_i = a_zs
+    d.w_zs_o, d.w_zs_i = w_zs
+    d.o_zs_o, d.o_zs_i = o_zs
+    for t in (bias, temb):
+        if t is not None and t.dtype != torch.float32:
+            raise MfhipError("bias / temb must be fp32")
+    d.bias, d.bias_mode = _ptr(bias), bias_mode
+    d.temb, d.ld_temb = _ptr(temb), ld_temb
+    d.res0, d.res0_dtype = _ptr(res0), (dt_code(res0.dtype) if res0 is not None else 0)
+    d.ld_res0 = ld_res0 if ld_res0 is not None else n
+    d.res1, d.res1_dtype = _ptr(res1), (dt_code(res1.dtype) if res1 is not None else 0)
+    d.ld_res1 = ld_res1 if ld_res1 is not None else n
+    d.alpha, d.act = alpha, act
+    d.out, d.out_dtype = _ptr(out), dt_code(out.dtype)
+    d.ldc = ldc if ldc is not None else n
+    ws = scratch("splitk", SPLITK_WS_FLOATS, out.device)
+    d.splitk, d.ws, d.ws_floats = splitk, ws.data_ptr(), ws.numel()
+    d.tile = tile
+    _check(load().mf_gemm_conv(C.byref(d), _stream()), "mf_gemm_conv")
+    return out
+
+
+def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int, eps: float, silu: bool,
+              out_dtype: torch.dtype, x1: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None
+              ) -> torch.Tensor:
+    """x0/x1: NHWC [B, H, W, C] (or [B, HW, C]); returns the normalised tensor over cat([x0, x1], -1)."""
+    _req_cuda(x0, x1, gamma, beta)
+    b = x0.shape[0]
+    c0 = x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    hw = x0.numel() // (b * c0)
+    if not x0.is_contiguous() or (x1 is not None and not x1.is_contiguous()):
+        raise MfhipError("groupnorm inputs must be contiguous NHWC")
+    if out is None:
+        out = torch.empty(*x0.shape[:-1], c0 + c1, dtype=out_dtype, device=x0.device)
+    d = GroupNormDesc()
+    d.x0, d.x1, d.c0, d.c1 = _ptr(x0), _ptr(x1), c0, c1
+    d.in_dtype = dt_code(x0.dtype)
+    d.batch, d.hw, d.groups, d.eps = b, hw, groups, eps
+    d.gamma, d.beta, d.silu = _ptr(gamma), _ptr(beta), int(silu)
+    d.out, d.out_dtype = _ptr(out), dt_code(out.dtype)
+    lib = load()
+    ws = scratch("gn", int(lib.mf_groupnorm_ws_floats(b, groups)), x0.device)
+    d.ws = ws.data_ptr()
+    _check(lib.mf_groupnorm(C.byref(d), _stream()), "mf_groupnorm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out_dtype: torch.dtype
+              ) -> torch.Tensor:
+    _req_cuda(x, gamma, beta)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _check(load().mf_layernorm(C.c_void_p(x.data_ptr()), dt_code(x.dtype), C.c_void_p(out.data_ptr()),
+                               dt_code(out_dtype), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()),
+                               C.c_int64(rows), c, C.c_float(eps), _stream()), "mf_layernorm")
+    return out
+
+
+def softmax_rows(scores: torch.Tensor, cols: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """scores: [..., ld] fp32; softmax over the first `cols` entries of each row, pad written as 0."""
+    _req_cuda(scores)
+    ld = scores.shape[-1]
+    rows = scores.numel() // ld
+    out = torch.empty(scores.shape, dtype=out_dtype, device=scores.device)
+    _check(load().mf_softmax_rows(C.c_void_p(scores.data_ptr()), C.c_void_p(out.data_ptr()), dt_code(out_dtype),
+                                  C.c_int64(rows), cols, ld, _stream()), "mf_softmax_rows")
+    return out
+
+
+def attention_bf16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, ldq: int, ldk: int,
+                   ldvt: int, ldo: int, batch: int, heads: int, sq: int, skv: int, head_dim: int, scale: float
+                   ) -> torch.Tensor:
+    _req_cuda(q, k, vt, out)
+    _check(load().mf_attention_bf16(C.c_void_p(q.data_ptr()), C.c_int64(ldq), C.c_void_p(k.data_ptr()), C.c_int64(ldk),
+                                    C.c_void_p(vt.data_ptr()), C.c_int64(ldvt), C.c_void_p(out.data_ptr()),
+                                    C.c_int64(ldo), batch, heads, sq, skv, head_dim, C.c_float(scale), _stream()),
+           "mf_attention_bf16")
+    return out
+
+
+def pack_nhwc(src0: torch.Tensor, src1: Optional[torch.Tensor], c_pad: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """NCHW fp32 (optionally two tensors concatenated on C) -> NHWC out_dtype with channels zero-padded."""
+    _req_cuda(src0, src1)
+    b, c0, h, w = src0.shape
+    c1 = src1.shape[1] if src1 is not None else 0
+    src0 = src0.contiguous().float()
+    if src1 is not None:
+        src1 = src1.contiguous().float()
+    out = torch.empty(b, h, w, c_pad, dtype=out_dtype, device=src0.device)
+    _check(load().mf_pack_nhwc(C.c_void_p(src0.data_ptr()), c0, C.c_void_p(_ptr(src1)), c1,
+                               C.c_void_p(out.data_ptr()), dt_code(out_dtype), c_pad, b, h * w, _stream()),
+           "mf_pack_nhwc")
+    return out
+
+
+def unpack_nchw(src: torch.Tensor, c: int) -> torch.Tensor:
+    """NHWC [B, H, W, ld] -> NCHW fp32 [B, c, H, W] (first c channels)."""
+    _req_cuda(src)
+    b, h, w, ld = src.shape
+    out = torch.empty(b, c, h, w, dtype=torch.float32, device=src.device)
+    _check(load().mf_unpack_nchw(C.c_void_p(src.data_ptr()), dt_code(src.dtype), C.c_int64(ld),
+                                 C.c_void_p(out.data_ptr()), c, b, h * w, _stream()), "mf_unpack_nchw")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    _req_cuda(a, b)
+    if a.shape != b.shape:
+        raise MfhipError(f"mf_add shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    _check(load().mf_add(C.c_void_p(a.data_ptr()), dt_code(a.dtype), C.c_void_p(b.data_ptr()), dt_code(b.dtype),
+                         C.c_void_p(out.data_ptr()), dt_code(out_dtype), C.c_int64(a.numel()), _stream()), "mf_add")
+    return out
+
+
+def geglu(h: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    _req_cuda(h)
+    c = h.shape[-1] // 2
+    rows = h.numel() // (2 * c)
+    out = torch.empty(*h.shape[:-1], c, dtype=out_dtype, device=h.device)
+    _check(load().mf_geglu(C.c_void_p(h.data_ptr()), dt_code(h.dtype), C.c_void_p(out.data_ptr()), dt_code(out_dtype),
+                           C.c_int64(rows), c, _stream()), "mf_geglu")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, flip_sin_to_cos: bool, freq_shift: float) -> torch.Tensor:
+    _req_cuda(t)
+    t = t.float().contiguous()
+    out = torch.empty(t.numel(), dim, dtype=torch.float32, device=t.device)
+    _check(load().mf_timestep_embedding(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), t.numel(), dim,
+                                        int(flip_sin_to_cos), C.c_float(freq_shift), _stream()),
+           "mf_timestep_embedding")
+    return out
+
+
+def silu_f32(x: torch.Tensor) -> torch.Tensor:
+    _req_cuda(x)
+    out = torch.empty_like(x)
+    _check(load().mf_silu_f32(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int64(x.numel()), _stream()),
+           "mf_silu_f32")
+    return out
+
+
+def cfg_ddim_step(eps_u: torch.Tensor, eps_c: Optional[torch.Tensor], g: float, x: torch.Tensor, sqrt_at: float,
+                  sqrt_1m_at: float, sqrt_ap: float, dir_coef: float, eps_out: Optional[torch.Tensor] = None
+                  ) -> torch.Tensor:
+    _req_cuda(eps_u, eps_c, x, eps_out)
+    xp = torch.empty_like(x)
+    _check(load().mf_cfg_ddim_step(C.c_void_p(eps_u.data_ptr()), C.c_void_p(_ptr(eps_c)), C.c_float(g),
+                                   C.c_void_p(x.data_ptr()), C.c_void_p(xp.data_ptr()), C.c_float(sqrt_at),
+                                   C.c_float(sqrt_1m_at), C.c_float(sqrt_ap), C.c_float(dir_coef),
+                                   C.c_void_p(_ptr(eps_out)), C.c_int64(x.numel()), _stream()), "mf_cfg_ddim_step")
+    return xp
+
+
+def cfg_combine(eps_u: torch.Tensor, eps_c: torch.Tensor, g: float) -> torch.Tensor:
+    _req_cuda(eps_u, eps_c)
+    out = torch.empty_like(eps_u)
+    _check(load().mf_cfg_combine(C.c_void_p(eps_u.data_ptr()), C.c_void_p(eps_c.data_ptr()), C.c_float(g),
+                                 C.c_void_p(out.data_ptr()), C.c_int64(eps_u.numel()), _stream()), "mf_cfg_combine")
+    return out
+
+
+def axpby_n(xs, coefs) -> torch.Tensor:
+    """y = sum_i coefs[i] * xs[i] over fp32 tensors of equal shape (at most 6)."""
+    _req_cuda(*xs)
+    n = len(xs)
+    arr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    cf = (C.c_float * n)(*[float(c) for c in coefs])
+    out = torch.empty_like(xs[0])
+    _check(load().mf_axpby_n(arr, cf, n, C.c_void_p(out.data_ptr()), C.c_int64(out.numel()), _stream()), "mf_axpby_n")
+    return out
+
+
+def vae_sample(moments: torch.Tensor, noise: torch.Tensor, c: int, scaling: float) -> torch.Tensor:
+    """moments NHWC [B, H, W, ld >= 2c]; noise NCHW fp32 [B, c, H, W] -> z NCHW fp32."""
+    _req_cuda(moments, noise)
+    b, h, w, ld = moments.shape
+    z = torch.empty(b, c, h, w, dtype=torch.float32, device=moments.device)
+    noise = noise.float().contiguous()
+    _check(load().mf_vae_sample(C.c_void_p(moments.data_ptr()), dt_code(moments.dtype), C.c_int64(ld),
+                                C.c_void_p(noise.data_ptr()), C.c_void_p(z.data_ptr()), c, b, h * w,
+                                C.c_float(scaling), _stream()), "mf_vae_sample")
+    return z
+
+
+def nearest_resize(src: torch.Tensor, h_out: int, w_out: int) -> torch.Tensor:
+    """F.interpolate(src, size=(h_out, w_out)) (default mode='nearest') for NCHW fp32."""
+    _req_cuda(src)
+    b, c, h, w = src.shape
+    src = src.float().contiguous()
+    out = torch.empty(b, c, h_out, w_out, dtype=torch.float32, device=src.device)
+    _check(load().mf_nearest_resize(C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()), b * c, h, w, h_out, w_out,
+                                    _stream()), "mf_nearest_resize")
+    return out

@@ -1,0 +1,150 @@
+"""Layer-level operators of the MirrorFusion hot path on top of the libmfhip C ABI.
+
+Tensors are NHWC ([B, H, W, C]; the same memory as token-major [B, H*W, C]).  ``Precision`` picks the
+compute mode of a whole model: "bf16" (bf16 MFMA operands, fp32 accumulate/statistics — the fast
+path) or "fp32" (fp32 MFMA — the parity path checked at 1e-3 against the fp32 CPU oracle).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import hip
+
+
+@dataclass(frozen=True)
+class Precision:
+    name: str                     # "bf16" | "fp32"
+    compute: torch.dtype          # MFMA operand dtype
+    act: torch.dtype              # activation storage dtype
+
+    @staticmethod
+    def get(name: Union[str, "Precision", torch.dtype]) -> "Precision":
+        if isinstance(name, Precision):
+            return name
+        if name in ("bf16", torch.bfloat16):
+            return Precision("bf16", torch.bfloat16, torch.bfloat16)
+        if name in ("fp32", "f32", torch.float32):
+            return Precision("fp32", torch.float32, torch.float32)
+        raise ValueError(f"unsupported precision {name!r} (use 'bf16' or 'fp32')")
+
+    @property
+    def vec(self) -> int:         # elements per 16-byte vector: channel counts must be multiples of this
+        return 8 if self.compute == torch.bfloat16 else 4
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class ConvWeight:
+    """Conv2d / Linear parameters re-laid-out once for the implicit-GEMM kernel: [N][kh][kw][Cin_pad]."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], prec: Precision, device,
+                 cin_pad: Optional[int] = None):
+        if weight.dim() == 2:
+            weight = weight[:, :, None, None]
+        n, cin, kh, kw = weight.shape
+        cp = cin_pad if cin_pad is not None else _round_up(cin, prec.vec)
+        w = weight.detach().to(device=device, dtype=torch.float32).permute(0, 2, 3, 1)   # [N, kh, kw, Cin]
+        if cp != cin:
+            w = torch.nn.functional.pad(w, (0, cp - cin))
+        self.w = w.reshape(n, kh * kw * cp).to(prec.compute).contiguous()
+        self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.n, self.cin, self.cin_pad, self.kh, self.kw = n, cin, cp, kh, kw
+        self.prec = prec
+
+
+def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
+           padding: Union[int, Tuple[int, int, int, int]] = 1, upsample: bool = False,
+           x1: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
+           res0: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None,
+           alpha: float = 1.0, act: int = hip.ACT_NONE, out_dtype: Optional[torch.dtype] = None,
+           splitk: int = 0, tile: int = 0) -> torch.Tensor:
+    """Convolution over NHWC x (optionally cat([x, x1], C) and/or nearest-2x upsampled), fused epilogue
+    alpha*(conv + bias + temb[b]) + res0 + res1.  padding = int or (top, left, bottom, right)."""
+    b, h, w, c0 = x.shape
+    c1 = x1.shape[-1] if x1 is not None else 0
+    if c0 + c1 != cw.cin_pad:
+        raise hip.MfhipError(f"conv2d: input channels {c0}+{c1} != weight channels {cw.cin_pad}")
+    if not x.is_contiguous() or (x1 is not None and not x1.is_contiguous()):
+        raise hip.MfhipError("conv2d: inputs must be contiguous NHWC")
+    pt, pl, pb, pr = (padding,) * 4 if isinstance(padding, int) else padding
+    hu, wu = (h * 2, w * 2) if upsample else (h, w)
+    ho = (hu + pt + pb - cw.kh) // stride + 1
+    wo = (wu + pl + pr - cw.kw) // stride + 1
+    out = torch.empty(b, ho, wo, cw.n, dtype=out_dtype or cw.prec.act, device=x.device)
+    hip.gemm_conv(x, cw.w, out, dtype=cw.prec.compute, c0=c0, lda0=c0, a1=x1, c1=c1, lda1=c1,
+                  batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, kh=cw.kh, kw=cw.kw, stride=stride,
+                  pad_t=pt, pad_l=pl, upsample=upsample, n=cw.n, bias=cw.bias,
+                  temb=temb, ld_temb=(temb.stride(0) if temb is not None else 0),
+                  res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
+    return out
+
+
+def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = None,
+           res1: Optional[torch.Tensor] = None, alpha: float = 1.0, act: int = hip.ACT_NONE,
+           out_dtype: Optional[torch.dtype] = None, splitk: int = 0, tile: int = 0) -> torch.Tensor:
+    """y = x @ W^T + b over the last dim of x ([..., K] contiguous)."""
+    k = x.shape[-1]
+    if k != lw.cin_pad:
+        raise hip.MfhipError(f"linear: K={k} != weight K={lw.cin_pad}")
+    m = x.numel() // k
+    out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
+    hip.gemm_conv(x, lw.w, out, dtype=lw.prec.compute, c0=k, lda0=k, batch=m, h_in=1, w_in=1, h_out=1, w_out=1,
+                  n=lw.n, bias=lw.bias, res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
+    return out
+
+
+def linear_t(x: torch.Tensor, lw: ConvWeight, ld_out: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Transposed projection per batch: out[b][n][s] = sum_k W[n][k] x[b][s][k] (+ bias[n]).
+
+    The weight plays the A operand and the tokens the [N][K] operand, so V^T comes out of the GEMM
+    with keys contiguous and coalesced stores (attention wants V^T; no transpose kernel exists).
+    x: [B, S, K]; returns [B, n, ld_out] with columns [S, ld_out) left untouched (callers zero them once).
+    """
+    b, s, k = x.shape
+    if out is None:
+        out = torch.zeros(b, lw.n, ld_out, dtype=lw.prec.act, device=x.device)
+    hip.gemm_conv(lw.w, x, out, dtype=lw.prec.compute, c0=k, lda0=k, batch=lw.n, h_in=1, w_in=1, h_out=1, w_out=1,
+                  ldw=k, n=s, ldc=ld_out, bias=lw.bias, bias_mode=1, nz=b, zdiv=1,
+                  a_zs=(0, 0), w_zs=(s * k, 0), o_zs=(lw.n * ld_out, 0))
+    return out
+
+
+def attention_unfused(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, skv: int, scale: float,
+                      prec: Precision) -> torch.Tensor:
+    """softmax(q k^T * scale) v through two strided-batched GEMMs and a row softmax (scores in fp32).
+
+    q: [B, Sq, C], k: [B, Skv, C], vt: [B, C, ldv] (V^T, pad columns zero).  Used by the fp32 parity
+    mode and by head dims the fused kernel does not cover (the VAE's single 512-wide head).
+    """
+    b, sq, c = q.shape
+    d = c // heads
+    ldv = vt.shape[-1]
+    scores = torch.empty(b * heads, sq, ldv, dtype=torch.float32, device=q.device)
+    hip.gemm_conv(q, k, scores, dtype=prec.compute, c0=d, lda0=c, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1,
+                  ldw=c, n=skv, ldc=ldv, alpha=scale, nz=b * heads, zdiv=heads,
+                  a_zs=(sq * c, d), w_zs=(k.shape[1] * c, d), o_zs=(heads * sq * ldv, sq * ldv), splitk=1)
+    p = hip.softmax_rows(scores, skv, prec.act)
+    out = torch.empty(b, sq, c, dtype=prec.act, device=q.device)
+    hip.gemm_conv(p, vt, out, dtype=prec.compute, c0=ldv, lda0=ldv, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1,
+                  ldw=ldv, n=d, ldc=c, nz=b * heads, zdiv=heads,
+                  a_zs=(heads * sq * ldv, sq * ldv), w_zs=(c * ldv, d * ldv), o_zs=(sq * c, d), splitk=1)
+    return out
+
+
+FLASH_HEAD_DIMS = (8, 40, 64, 80, 160)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, skv: int, scale: float,
+              prec: Precision) -> torch.Tensor:
+    b, sq, c = q.shape
+    d = c // heads
+    if prec.compute == torch.bfloat16 and d in FLASH_HEAD_DIMS:
+        out = torch.empty(b, sq, c, dtype=torch.bfloat16, device=q.device)
+        return hip.attention_bf16(q, k, vt, out, ldq=c, ldk=c, ldvt=vt.shape[-1], ldo=c, batch=b, heads=heads,
+                                  sq=sq, skv=skv, head_dim=d, scale=scale)
+    return attention_unfused(q, k, vt, heads, skv, scale, prec)

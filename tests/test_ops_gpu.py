@@ -1,0 +1,313 @@
+"""Per-operator parity of the HIP kernels (through the C ABI) against plain PyTorch fp32 CPU ops.
+
+fp32 mode is held to fp32-accumulation-order tolerances; bf16 mode is compared with the same fp32
+reference evaluated on bf16-rounded operands (what the kernel multiplies), so only accumulation order
+and the final bf16 store differ.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from reflecting_reality_amd import hip, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rb(t):  # round through bf16
+    return t.bfloat16().float()
+
+
+def nhwc(t, dtype):
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+
+
+def nchw(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def check(name, got, ref, atol, rtol):
+    got = got.float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol).sum().item()
+    print(f"{name}: max_abs_err={err.max().item():.3e} ref_max={ref.abs().max().item():.3e} bad={bad}/{ref.numel()}")
+    assert bad == 0, f"{name}: {bad} elements out of tolerance, max err {err.max().item():.3e}"
+
+
+PRECS = [("fp32", 2e-4, 2e-4), ("bf16", 2e-2, 1e-2)]
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+def test_conv3x3_tiles(prec_name, atol, rtol, tile):
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 40, 20, 12, generator=g)       # M = 480 (tails on every tile), Cin = 40
+    w = torch.randn(72, 40, 3, 3, generator=g) * 0.05  # N = 72 (tail)
+    b = torch.randn(72, generator=g)
+    if prec_name == "bf16":
+        x, w = rb(x), rb(w)
+    ref = F.conv2d(x, w, b, padding=1)
+    cw = ops.ConvWeight(w, b, prec, DEV)
+    y = ops.conv2d(nhwc(x, prec.act), cw, tile=tile)
+    check(f"conv3x3[{prec_name},tile{tile}]", nchw(y), ref, atol, rtol)
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
+def test_conv_epilogue_temb_res_alpha_silu(prec_name, atol, rtol):
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 32, 9, 7, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    temb = torch.randn(3, 100, generator=g)            # strided slice [3, 64] of a wider table
+    r0 = torch.randn(3, 64, 9, 7, generator=g)
+    r1 = torch.randn(3, 64, 9, 7, generator=g)
+    if prec_name == "bf16":
+        x, w, r0 = rb(x), rb(w), rb(r0)
+    ref = 0.5 * (F.conv2d(x, w, b, padding=1) + temb[:, 20:84, None, None]) + r0 + r1
+    ref = F.silu(ref)
+    cw = ops.ConvWeight(w, b, prec, DEV)
+    y = ops.conv2d(nhwc(x, prec.act), cw, temb=temb.to(DEV)[:, 20:84], res0=nhwc(r0, prec.act),
+                   res1=nhwc(r1, torch.float32), alpha=0.5, act=hip.ACT_SILU)
+    check(f"conv_epilogue[{prec_name}]", nchw(y), ref, atol, rtol)
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
+@pytest.mark.parametrize("case", ["s2p1", "s2asym", "up", "cat", "cat_up", "1x1", "splitk"])
+def test_conv_variants(prec_name, atol, rtol, case):
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(3)
+    cin, cout = 24, 40
+    x = torch.randn(2, cin, 10, 14, generator=g)
+    x1 = torch.randn(2, 16, 10, 14, generator=g)
+    kw = {}
+    if case in ("cat", "cat_up"):
+        w = torch.randn(cout, cin + 16, 3, 3, generator=g) * 0.05
+    elif case == "1x1":
+        w = torch.randn(cout, cin, 1, 1, generator=g) * 0.2
+    elif case == "splitk":
+        cin = 256
+        x = torch.randn(2, cin, 10, 14, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.02
+    else:
+        w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    if prec_name == "bf16":
+        x, x1, w = rb(x), rb(x1), rb(w)
+    cw = ops.ConvWeight(w, b, prec, DEV)
+    xa = nhwc(x, prec.act)
+    if case == "s2p1":
+        ref = F.conv2d(x, w, b, stride=2, padding=1)
+        y = ops.conv2d(xa, cw, stride=2, padding=1)
+    elif case == "s2asym":   # downsampling.py:140-142: F.pad(x, (0, 1, 0, 1)) then stride-2 conv, padding 0
+        ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+        y = ops.conv2d(xa, cw, stride=2, padding=(0, 0, 1, 1))
+    elif case == "up":
+        ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+        y = ops.conv2d(xa, cw, upsample=True)
+    elif case == "cat":
+        ref = F.conv2d(torch.cat([x, x1], 1), w, b, padding=1)
+        y = ops.conv2d(xa, cw, x1=nhwc(x1, prec.act))
+    elif case == "cat_up":
+        ref = F.conv2d(F.interpolate(torch.cat([x, x1], 1), scale_factor=2.0, mode="nearest"), w, b, padding=1)
+        y = ops.conv2d(xa, cw, x1=nhwc(x1, prec.act), upsample=True)
+    elif case == "1x1":
+        ref = F.conv2d(x, w, b)
+        y = ops.conv2d(xa, cw, padding=0)
+    else:
+        ref = F.conv2d(x, w, b, padding=1)
+        y = ops.conv2d(xa, cw, splitk=5)
+    check(f"conv_{case}[{prec_name}]", nchw(y), ref, atol, rtol)
+
+
+def test_conv_f32_activations_bf16_compute():
+    prec = ops.Precision.get("bf16")
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 32, 8, 8, generator=g)
+    w = rb(torch.randn(48, 32, 3, 3, generator=g) * 0.05)
+    ref = F.conv2d(rb(x), w, None, padding=1)
+    cw = ops.ConvWeight(w, None, prec, DEV)
+    y = ops.conv2d(nhwc(x, torch.float32), cw, out_dtype=torch.float32)
+    check("conv_a_f32", nchw(y), ref, 2e-3, 2e-3)
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
+@pytest.mark.parametrize("m,k,n", [(154, 768, 320), (8, 320, 1280), (300, 40, 77), (4096, 320, 2560), (64, 1280, 4)])
+def test_linear(prec_name, atol, rtol, m, k, n):
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g)
+    if prec_name == "bf16":
+        x, w = rb(x), rb(w)
+    ref = F.linear(x, w, b)
+    lw = ops.ConvWeight(w, b, prec, DEV)
+    y = ops.linear(x.to(DEV, prec.act), lw)
+    check(f"linear[{prec_name},{m}x{k}x{n}]", y, ref, atol, rtol)
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
+def test_linear_t(prec_name, atol, rtol):
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 77, 96, generator=g)
+    w = torch.randn(64, 96, generator=g) * 0.1
+    b = torch.randn(64, generator=g)
+    if prec_name == "bf16":
+        x, w = rb(x), rb(w)
+    ref = F.linear(x, w, b).transpose(1, 2)             # [3, 64, 77]
+    lw = ops.ConvWeight(w, b, prec, DEV)
+    vt = ops.linear_t(x.to(DEV, prec.act), lw, 80)
+    assert vt.shape == (3, 64, 80)
+    check(f"linear_t[{prec_name}]", vt[:, :, :77], ref, atol, rtol)
+    assert vt[:, :, 77:].abs().max().item() == 0.0
+
+
+def sdpa_ref(q, k, v, heads):
+    b, sq, c = q.shape
+    d = c // heads
+    qh = q.view(b, sq, heads, d).transpose(1, 2)
+    kh = k.view(b, -1, heads, d).transpose(1, 2)
+    vh = v.view(b, -1, heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh)
+    return o.transpose(1, 2).reshape(b, sq, c)
+
+
+def make_vt(v, ld, dtype):
+    b, skv, c = v.shape
+    vt = torch.zeros(b, c, ld, dtype=dtype, device=DEV)
+    vt[:, :, :skv] = v.transpose(1, 2).to(DEV, dtype)
+    return vt
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", [("fp32", 2e-4, 2e-4), ("bf16", 2e-2, 2e-2)])
+@pytest.mark.parametrize("heads,d,sq,skv", [(2, 40, 200, 200), (2, 8, 64, 77), (1, 512, 96, 96)])
+def test_attention_unfused(prec_name, atol, rtol, heads, d, sq, skv):
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(7)
+    c = heads * d
+    q = torch.randn(2, sq, c, generator=g)
+    k = torch.randn(2, skv, c, generator=g)
+    v = torch.randn(2, skv, c, generator=g)
+    if prec_name == "bf16":
+        q, k, v = rb(q), rb(k), rb(v)
+    ref = sdpa_ref(q, k, v, heads)
+    ld = (skv + 7) // 8 * 8
+    o = ops.attention_unfused(q.to(DEV, prec.act), k.to(DEV, prec.act), make_vt(v, ld, prec.act), heads, skv,
+                              1.0 / math.sqrt(d), prec)
+    check(f"attn_unfused[{prec_name},h{heads},d{d},{sq}x{skv}]", o, ref, atol, rtol)
+
+
+@pytest.mark.parametrize("heads,d,sq,skv", [(8, 40, 4096, 4096), (8, 80, 1024, 1024), (8, 160, 256, 256),
+                                            (8, 160, 64, 64), (8, 40, 4096, 77), (8, 80, 1024, 77),
+                                            (8, 160, 256, 77), (4, 8, 200, 77), (3, 64, 130, 190)])
+def test_attention_flash_bf16(heads, d, sq, skv):
+    prec = ops.Precision.get("bf16")
+    g = torch.Generator().manual_seed(8)
+    c = heads * d
+    q = rb(torch.randn(2, sq, c, generator=g))
+    k = rb(torch.randn(2, skv, c, generator=g))
+    v = rb(torch.randn(2, skv, c, generator=g))
+    ref = sdpa_ref(q, k, v, heads)
+    ld = (skv + 7) // 8 * 8
+    o = ops.attention(q.to(DEV, torch.bfloat16), k.to(DEV, torch.bfloat16), make_vt(v, ld, torch.bfloat16), heads,
+                      skv, 1.0 / math.sqrt(d), prec)
+    check(f"attn_flash[h{heads},d{d},{sq}x{skv}]", o, ref, 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("in_dt,out_dt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                          (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("c0,c1,hw,groups,silu", [(320, 0, 64 * 64, 32, True), (1280, 640, 16 * 16, 32, True),
+                                                  (640, 320, 32 * 32, 32, False), (32, 0, 9 * 7, 32, True),
+                                                  (64, 32, 5 * 5, 32, False), (512, 0, 1000, 32, True)])
+def test_groupnorm(in_dt, out_dt, c0, c1, hw, groups, silu):
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(2, c0, hw, 1, generator=g) * 2 + 0.7
+    x1 = torch.randn(2, c1, hw, 1, generator=g) - 1.0 if c1 else None
+    gamma = torch.randn(c0 + c1, generator=g)
+    beta = torch.randn(c0 + c1, generator=g)
+    if in_dt == torch.bfloat16:
+        x0 = rb(x0)
+        x1 = rb(x1) if x1 is not None else None
+    xc = torch.cat([x0, x1], 1) if x1 is not None else x0
+    ref = F.group_norm(xc, groups, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    y = hip.groupnorm(nhwc(x0, in_dt), gamma.to(DEV), beta.to(DEV), groups=groups, eps=1e-5, silu=silu,
+                      out_dtype=out_dt, x1=nhwc(x1, in_dt) if x1 is not None else None)
+    tol = 2e-5 if out_dt == torch.float32 else 2e-2
+    check(f"groupnorm[{in_dt},{out_dt},{c0}+{c1},{hw}]", nchw(y), ref, tol * 5, tol)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,c", [(4096 * 2, 320), (77, 1280), (5, 32), (1000, 640)])
+def test_layernorm(dt, rows, c):
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(rows, c, generator=g) * 3 + 1
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    if dt == torch.bfloat16:
+        x = rb(x)
+    ref = F.layer_norm(x, (c,), gamma, beta, 1e-5)
+    y = hip.layernorm(x.to(DEV, dt), gamma.to(DEV), beta.to(DEV), 1e-5, dt)
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    check(f"layernorm[{dt},{rows}x{c}]", y, ref, tol * 5, tol)
+
+
+def test_softmax_rows():
+    g = torch.Generator().manual_seed(11)
+    s = torch.randn(300, 80, generator=g) * 4
+    ref = torch.softmax(s[:, :77], -1)
+    p = hip.softmax_rows(s.to(DEV), 77, torch.float32)
+    check("softmax", p[:, :77], ref, 1e-6, 1e-5)
+    assert p[:, 77:].abs().max().item() == 0.0
+
+
+def test_elementwise_and_layout():
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(2, 4, 8, 8, generator=g)
+    b = torch.randn(2, 6, 8, 8, generator=g)
+    packed = hip.pack_nhwc(a.to(DEV), b.to(DEV), 16, torch.float32)
+    ref = torch.zeros(2, 8, 8, 16)
+    ref[..., :4] = a.permute(0, 2, 3, 1)
+    ref[..., 4:10] = b.permute(0, 2, 3, 1)
+    check("pack", packed, ref, 0, 0)
+    back = hip.unpack_nchw(packed, 10)
+    check("unpack", back, torch.cat([a, b], 1), 0, 0)
+    x = torch.randn(1000, generator=g)
+    y = torch.randn(1000, generator=g)
+    check("add", hip.add(x.to(DEV), y.to(DEV).bfloat16(), torch.float32), x + rb(y), 1e-7, 1e-7)
+    h = torch.randn(50, 2 * 96, generator=g)
+    check("geglu", hip.geglu(h.to(DEV), torch.float32), h[:, :96] * F.gelu(h[:, 96:]), 1e-6, 1e-5)
+    check("silu", hip.silu_f32(x.to(DEV)), F.silu(x), 1e-6, 1e-6)
+    # timestep embedding (embeddings.py:27-67, flip_sin_to_cos=True, shift 0)
+    t = torch.tensor([981.0, 1.0, 500.0])
+    half = 160
+    e = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    emb = t[:, None] * e[None]
+    ref = torch.cat([torch.cos(emb), torch.sin(emb)], -1)
+    check("timestep_embedding", hip.timestep_embedding(t.to(DEV), 320, True, 0.0), ref, 2e-4, 0)
+    # cfg + ddim
+    eu, ec, xx = torch.randn(3, 512, generator=g).unbind(0)
+    sa, s1, sp, dc = 0.3, 0.95, 0.35, 0.93
+    eps = eu + 7.5 * (ec - eu)
+    ref = sp * ((xx - s1 * eps) / sa) + dc * eps
+    got = hip.cfg_ddim_step(eu.to(DEV), ec.to(DEV), 7.5, xx.to(DEV), sa, s1, sp, dc)
+    check("cfg_ddim", got, ref, 1e-5, 1e-5)
+    check("cfg_combine", hip.cfg_combine(eu.to(DEV), ec.to(DEV), 7.5), eps, 1e-5, 1e-5)
+    check("axpby", hip.axpby_n([eu.to(DEV), ec.to(DEV), xx.to(DEV)], [0.5, -2.0, 3.0]), 0.5 * eu - 2 * ec + 3 * xx,
+          1e-5, 1e-5)
+    # vae sample
+    mom = torch.randn(2, 8, 6, 6, generator=g)
+    noise = torch.randn(2, 4, 6, 6, generator=g)
+    ref = (mom[:, :4] + torch.exp(0.5 * mom[:, 4:].clamp(-30, 20)) * noise) * 0.18215
+    check("vae_sample", hip.vae_sample(nhwc(mom, torch.float32), noise.to(DEV), 4, 0.18215), ref, 1e-6, 1e-5)
+    # nearest resize
+    src = torch.randn(2, 3, 64, 48, generator=g)
+    check("nearest", hip.nearest_resize(src.to(DEV), 8, 6), F.interpolate(src, size=(8, 6)), 0, 0)
+    check("nearest2", hip.nearest_resize(src.to(DEV), 20, 10), F.interpolate(src, size=(20, 10)), 0, 0)
