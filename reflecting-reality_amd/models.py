@@ -1,0 +1,906 @@
+"""BrushNetModel, UNet2DConditionModel and AutoencoderKL with the reference call surface, running on
+the libmfhip kernels.
+
+Reference: MirrorFusion/src/diffusers/models/brushnet.py (BrushNetModel.forward :678-925, from_unet
+:452-530), models/unets/unet_2d_condition.py (:1039-1348, BrushNet injection :1202-1324),
+models/unets/unet_2d_blocks.py, models/resnet.py:329-405, models/transformers/transformer_2d.py:257-469,
+models/attention.py:291-412, models/autoencoders/{autoencoder_kl,vae}.py.  State-dict keys, config.json
+fields and the forward signatures are the reference's; the arithmetic is not ATen: every op is a HIP
+kernel behind include/mfhip.h, and nothing here falls back to PyTorch math.
+
+Data layout: activations live as NHWC.  Tensors crossing the public API keep the reference's logical
+NCHW shape but are channels-last *views* of that memory (``nhwc.permute(0, 3, 1, 2)``), so the 28
+BrushNet residuals flow into the UNet without a single layout copy.
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import hip, ops
+from .ops import ConvWeight, Precision
+
+F32 = torch.float32
+
+
+class FrozenConfig(dict):
+    """config.json view with attribute access (reference: configuration_utils.FrozenDict)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+@dataclass
+class BrushNetOutput:
+    up_block_res_samples: List[torch.Tensor]
+    down_block_res_samples: List[torch.Tensor]
+    mid_block_res_sample: torch.Tensor
+
+
+@dataclass
+class UNet2DConditionOutput:
+    sample: torch.Tensor
+
+
+@dataclass
+class DecoderOutput:
+    sample: torch.Tensor
+
+
+@dataclass
+class AutoencoderKLOutput:
+    latent_dist: "DiagonalGaussianDistribution"
+
+
+def _as_tuple(v, n):
+    return tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
+
+
+def to_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def from_nchw(x: torch.Tensor, prec: Precision, c_pad: Optional[int] = None) -> torch.Tensor:
+    """NCHW tensor (any memory format) -> contiguous NHWC in the activation dtype (zero-copy when the
+    tensor already is a channels-last view of the right dtype)."""
+    b, c, h, w = x.shape
+    cp = c_pad or c
+    nhwc = x.permute(0, 2, 3, 1)
+    if nhwc.is_contiguous() and x.dtype == prec.act and cp == c:
+        return nhwc
+    if x.dtype != F32 or not x.is_contiguous():
+        x = x.contiguous().float() if not nhwc.is_contiguous() else nhwc.float().permute(0, 3, 1, 2).contiguous()
+    return hip.pack_nhwc(x, None, cp, prec.act)
+
+
+class HipModel:
+    """Minimal ModelMixin/ConfigMixin counterpart (modeling_utils.py, configuration_utils.py)."""
+
+    config_name = "config.json"
+    weights_name = "diffusion_pytorch_model.safetensors"
+    _class_name = "HipModel"
+
+    def __init__(self, config: Dict[str, Any], precision: Union[str, Precision, torch.dtype] = "bf16",
+                 device: Union[str, torch.device] = "cuda"):
+        self.config = FrozenConfig(config)
+        self.prec = Precision.get(precision)
+        self.device = torch.device(device)
+        self._src: Optional[Dict[str, torch.Tensor]] = None   # fp32 master copy (CPU), for save_pretrained
+        self._ready = False
+
+    # -- dtype / device surface the callers touch ----------------------------------------------
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.prec.act
+
+    def to(self, *args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, (str, torch.device)) and torch.device(a) != self.device:
+                self.device = torch.device(a)
+                if self._src is not None:
+                    self.load_state_dict(self._src)
+        return self
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    # -- parameters -----------------------------------------------------------------------------
+    def param_shapes(self) -> "OrderedDict[str, Tuple[int, ...]]":
+        raise NotImplementedError
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        if self._src is None:
+            raise RuntimeError("no parameters loaded")
+        return dict(self._src)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        shapes = self.param_shapes()
+        sd = self._convert_deprecated_keys(dict(sd))
+        missing = [k for k in shapes if k not in sd]
+        unexpected = [k for k in sd if k not in shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"{type(self).__name__}.load_state_dict: missing {missing[:5]}... ({len(missing)}), "
+                               f"unexpected {unexpected[:5]}... ({len(unexpected)})")
+        for k, shp in shapes.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shp):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(shp)}")
+        self._src = {k: sd[k].detach().to("cpu", F32) for k in shapes if k in sd}
+        self._prepare(self._src)
+        self._ready = True
+        return self
+
+    def _convert_deprecated_keys(self, sd):
+        return sd
+
+    def _prepare(self, sd: Dict[str, torch.Tensor]) -> None:
+        raise NotImplementedError
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        return cls(dict(config), **kw)
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, torch_dtype=None, precision=None,
+                        device="cuda", **unused):
+        from safetensors.torch import load_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, cls.config_name)) as f:
+            config = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        prec = precision or (torch_dtype if torch_dtype in (torch.bfloat16, torch.float32) else "bf16")
+        model = cls(config, precision=prec, device=device)
+        model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
+        return model
+
+    def save_pretrained(self, path: str, **unused):
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        cfg = dict(self.config)
+        cfg["_class_name"] = self._class_name
+        cfg["_diffusers_version"] = "0.27.0.dev0"
+        with open(os.path.join(path, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2, sort_keys=True)
+        save_file({k: v.contiguous() for k, v in self.state_dict().items()}, os.path.join(path, self.weights_name))
+
+    # -- helpers shared by the three models -------------------------------------------------------
+    def _conv(self, sd, name, prec=None, cin_pad=None) -> ConvWeight:
+        return ConvWeight(sd[name + ".weight"], sd.get(name + ".bias"), prec or self.prec, self.device, cin_pad)
+
+    def _norm(self, sd, name):
+        return (sd[name + ".weight"].to(self.device, F32).contiguous(), sd[name + ".bias"].to(self.device, F32).contiguous())
+
+
+def _resnet_shapes(out, p, cin, cout, temb_ch):
+    out[p + "norm1.weight"] = (cin,); out[p + "norm1.bias"] = (cin,)
+    out[p + "conv1.weight"] = (cout, cin, 3, 3); out[p + "conv1.bias"] = (cout,)
+    if temb_ch:
+        out[p + "time_emb_proj.weight"] = (cout, temb_ch); out[p + "time_emb_proj.bias"] = (cout,)
+    out[p + "norm2.weight"] = (cout,); out[p + "norm2.bias"] = (cout,)
+    out[p + "conv2.weight"] = (cout, cout, 3, 3); out[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        out[p + "conv_shortcut.weight"] = (cout, cin, 1, 1); out[p + "conv_shortcut.bias"] = (cout,)
+
+
+def _transformer_shapes(out, p, c, cross, depth=1):
+    out[p + "norm.weight"] = (c,); out[p + "norm.bias"] = (c,)
+    out[p + "proj_in.weight"] = (c, c, 1, 1); out[p + "proj_in.bias"] = (c,)
+    for i in range(depth):
+        b = f"{p}transformer_blocks.{i}."
+        for n in ("norm1", "norm2", "norm3"):
+            out[b + n + ".weight"] = (c,); out[b + n + ".bias"] = (c,)
+        for a, kv in (("attn1", c), ("attn2", cross)):
+            out[b + a + ".to_q.weight"] = (c, c)
+            out[b + a + ".to_k.weight"] = (c, kv)
+            out[b + a + ".to_v.weight"] = (c, kv)
+            out[b + a + ".to_out.0.weight"] = (c, c); out[b + a + ".to_out.0.bias"] = (c,)
+        out[b + "ff.net.0.proj.weight"] = (8 * c, c); out[b + "ff.net.0.proj.bias"] = (8 * c,)
+        out[b + "ff.net.2.weight"] = (c, 4 * c); out[b + "ff.net.2.bias"] = (c,)
+    out[p + "proj_out.weight"] = (c, c, 1, 1); out[p + "proj_out.bias"] = (c,)
+
+
+class _UNetCore(HipModel):
+    """What BrushNetModel and UNet2DConditionModel share: time embedding, resnets, samplers."""
+
+    def _common_defaults(self):
+        c = self.config
+        c.setdefault("in_channels", 4)
+        c.setdefault("block_out_channels", (320, 640, 1280, 1280))
+        c.setdefault("layers_per_block", 2)
+        c.setdefault("norm_num_groups", 32)
+        c.setdefault("norm_eps", 1e-5)
+        c.setdefault("cross_attention_dim", 1280)
+        c.setdefault("attention_head_dim", 8)
+        c.setdefault("num_attention_heads", None)
+        c.setdefault("flip_sin_to_cos", True)
+        c.setdefault("freq_shift", 0)
+        c.setdefault("transformer_layers_per_block", 1)
+        c.setdefault("downsample_padding", 1)
+        c.setdefault("mid_block_scale_factor", 1)
+        c.setdefault("act_fn", "silu")
+        c.setdefault("use_linear_projection", False)
+        c.setdefault("resnet_time_scale_shift", "default")
+        c["block_out_channels"] = tuple(c["block_out_channels"])
+        unsupported = []
+        if c["act_fn"] not in ("silu", "swish"): unsupported.append("act_fn")
+        if c["use_linear_projection"]: unsupported.append("use_linear_projection")
+        if c["resnet_time_scale_shift"] != "default": unsupported.append("resnet_time_scale_shift")
+        if c["mid_block_scale_factor"] != 1: unsupported.append("mid_block_scale_factor")
+        if c["downsample_padding"] != 1: unsupported.append("downsample_padding")
+        for k in ("class_embed_type", "addition_embed_type", "encoder_hid_dim_type", "num_class_embeds"):
+            if c.get(k) is not None: unsupported.append(k)
+        if unsupported:
+            raise NotImplementedError(f"{type(self).__name__}: config options outside the SD1.5 hot path: {unsupported}")
+
+    def _heads(self, level: int) -> int:
+        c = self.config
+        h = c["num_attention_heads"] or c["attention_head_dim"]     # unet_2d_condition.py:~300 (sic)
+        return h if isinstance(h, int) else h[level]
+
+    # ---- parameter preparation ------------------------------------------------------------------
+    def _prepare_time(self, sd):
+        f32 = Precision.get("fp32")
+        self.te1 = self._conv(sd, "time_embedding.linear_1", f32)
+        self.te2 = self._conv(sd, "time_embedding.linear_2", f32)
+        # all time_emb_proj layers as ONE [sum(Cout), temb] GEMM; each resnet reads a column slice
+        names = [k[: -len(".time_emb_proj.weight")] for k in self.param_shapes() if k.endswith(".time_emb_proj.weight")]
+        self.temb_slices = {}
+        off = 0
+        ws, bs = [], []
+        for n in names:
+            w = sd[n + ".time_emb_proj.weight"]
+            self.temb_slices[n + "."] = (off, off + w.shape[0])
+            off += w.shape[0]
+            ws.append(w); bs.append(sd[n + ".time_emb_proj.bias"])
+        self.temb_proj = ConvWeight(torch.cat(ws, 0), torch.cat(bs, 0), f32, self.device)
+
+    def _prepare_resnet(self, sd, p):
+        self.P[p + "norm1"] = self._norm(sd, p + "norm1")
+        self.P[p + "conv1"] = self._conv(sd, p + "conv1")
+        self.P[p + "norm2"] = self._norm(sd, p + "norm2")
+        self.P[p + "conv2"] = self._conv(sd, p + "conv2")
+        if p + "conv_shortcut.weight" in sd:
+            self.P[p + "conv_shortcut"] = self._conv(sd, p + "conv_shortcut")
+
+    def _prepare_transformer(self, sd, p):
+        self.P[p + "norm"] = self._norm(sd, p + "norm")
+        self.P[p + "proj_in"] = self._conv(sd, p + "proj_in")
+        self.P[p + "proj_out"] = self._conv(sd, p + "proj_out")
+        i = 0
+        while f"{p}transformer_blocks.{i}.norm1.weight" in sd:
+            b = f"{p}transformer_blocks.{i}."
+            for n in ("norm1", "norm2", "norm3"):
+                self.P[b + n] = self._norm(sd, b + n)
+            for a in ("attn1", "attn2"):
+                for l in ("to_q", "to_k", "to_v", "to_out.0"):
+                    self.P[b + a + "." + l] = self._conv(sd, b + a + "." + l)
+            self.P[b + "ff.net.0.proj"] = self._conv(sd, b + "ff.net.0.proj")
+            self.P[b + "ff.net.2"] = self._conv(sd, b + "ff.net.2")
+            i += 1
+        self.tdepth[p] = i
+
+    # ---- forward pieces ---------------------------------------------------------------------------
+    def _time_embedding(self, timestep, batch: int) -> torch.Tensor:
+        """Timesteps + TimestepEmbedding + every resnet's time_emb_proj(SiLU(emb)) -> [batch, sum(Cout)] fp32.
+        (embeddings.py:27-67,225-254; resnet.py:369-376).  Always fp32, like the reference."""
+        if not torch.is_tensor(timestep):
+            t = torch.full((batch,), float(timestep), dtype=F32, device=self.device)
+        else:
+            t = timestep.to(self.device, F32).reshape(-1)
+            if t.numel() == 1:
+                t = t.expand(batch)
+            t = t.contiguous()
+        c0 = self.config["block_out_channels"][0]
+        e = hip.timestep_embedding(t, c0, self.config["flip_sin_to_cos"], float(self.config["freq_shift"]))
+        e = ops.linear(e, self.te1, act=hip.ACT_SILU, out_dtype=F32)
+        e = ops.linear(e, self.te2, act=hip.ACT_SILU, out_dtype=F32)   # SiLU(emb): every consumer applies it first
+        return ops.linear(e, self.temb_proj, out_dtype=F32)
+
+    def _temb(self, temb_all: Optional[torch.Tensor], p: str) -> Optional[torch.Tensor]:
+        if temb_all is None:
+            return None
+        a, b = self.temb_slices[p]
+        return temb_all[:, a:b]
+
+    def _resnet(self, p: str, x: torch.Tensor, temb_all, x1: Optional[torch.Tensor] = None,
+                inj: Optional[torch.Tensor] = None, eps: Optional[float] = None) -> torch.Tensor:
+        """ResnetBlock2D (resnet.py:329-405) on NHWC x (or the never-materialised cat([x, x1], C)), with the
+        BrushNet injection add fused into conv2's epilogue."""
+        g = self.config["norm_num_groups"]
+        eps = self.config["norm_eps"] if eps is None else eps
+        P = self.P
+        h = hip.groupnorm(x, *P[p + "norm1"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act, x1=x1)
+        h = ops.conv2d(h, P[p + "conv1"], temb=self._temb(temb_all, p))
+        h = hip.groupnorm(h, *P[p + "norm2"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act)
+        if p + "conv_shortcut" in P:
+            sc = ops.conv2d(x, P[p + "conv_shortcut"], padding=0, x1=x1)
+        else:
+            sc = x
+        return ops.conv2d(h, P[p + "conv2"], res0=sc, res1=inj)
+
+    def _attention(self, b: str, x: torch.Tensor, ctx: Optional[torch.Tensor], heads: int, residual: torch.Tensor
+                   ) -> torch.Tensor:
+        """Attention + AttnProcessor2_0 (attention_processor.py:1213-1286) + the block's residual add."""
+        P = self.P
+        src = x if ctx is None else ctx
+        skv = src.shape[1]
+        q = ops.linear(x, P[b + "to_q"])
+        k = ops.linear(src, P[b + "to_k"])
+        ld = (skv + 7) // 8 * 8
+        vt = ops.linear_t(src, P[b + "to_v"], ld)
+        d = q.shape[-1] // heads
+        o = ops.attention(q, k, vt, heads, skv, 1.0 / (d ** 0.5), self.prec)
+        return ops.linear(o, P[b + "to_out.0"], res0=residual)
+
+    def _transformer(self, p: str, x: torch.Tensor, ehs: torch.Tensor, heads: int,
+                     inj: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Transformer2DModel + BasicTransformerBlock(s) (transformer_2d.py:334-430, attention.py:291-412)."""
+        P = self.P
+        bsz, hh, ww, c = x.shape
+        g = self.config["norm_num_groups"]
+        h = hip.groupnorm(x, *P[p + "norm"], groups=g, eps=1e-6, silu=False, out_dtype=self.prec.act)
+        h = ops.conv2d(h, P[p + "proj_in"], padding=0).view(bsz, hh * ww, c)
+        for i in range(self.tdepth[p]):
+            b = f"{p}transformer_blocks.{i}."
+            n = hip.layernorm(h, *P[b + "norm1"], 1e-5, self.prec.act)
+            h = self._attention(b + "attn1.", n, None, heads, h)
+            n = hip.layernorm(h, *P[b + "norm2"], 1e-5, self.prec.act)
+            h = self._attention(b + "attn2.", n, ehs, heads, h)
+            n = hip.layernorm(h, *P[b + "norm3"], 1e-5, self.prec.act)
+            gg = hip.geglu(ops.linear(n, P[b + "ff.net.0.proj"]), self.prec.act)
+            h = ops.linear(gg, P[b + "ff.net.2"], res0=h)
+        return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj)
+
+    def _ehs(self, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+        return encoder_hidden_states.to(self.device, self.prec.act).contiguous()
+
+    def _inj(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        return None if t is None else from_nchw(t, self.prec)
+
+
+# =================================================================================================
+class BrushNetModel(_UNetCore):
+    """models/brushnet.py — attention-free UNet clone emitting 12 down + 1 mid + 15 up residuals."""
+
+    _class_name = "BrushNetModel"
+
+    def __init__(self, config=None, precision="bf16", device="cuda", **kwargs):
+        cfg = dict(config or {})
+        cfg.update(kwargs)
+        cfg.setdefault("conditioning_channels", 5)
+        n = len(cfg.get("block_out_channels", (320, 640, 1280, 1280)))
+        cfg.setdefault("down_block_types", ("DownBlock2D",) * n)
+        cfg.setdefault("up_block_types", ("UpBlock2D",) * n)
+        cfg.setdefault("mid_block_type", "MidBlock2D")
+        cfg.setdefault("brushnet_conditioning_channel_order", "rgb")
+        cfg.setdefault("global_pool_conditions", False)
+        super().__init__(cfg, precision, device)
+        self._common_defaults()
+        c = self.config
+        if any(t != "DownBlock2D" for t in c["down_block_types"]) or any(t != "UpBlock2D" for t in c["up_block_types"]) \
+                or c["mid_block_type"] != "MidBlock2D":
+            raise NotImplementedError("BrushNetModel: only the attention-free layout produced by from_unet "
+                                      "(DownBlock2D / MidBlock2D / UpBlock2D, brushnet.py:484-486) is built")
+        if c["global_pool_conditions"]:
+            raise NotImplementedError("global_pool_conditions is off in every MirrorFusion config")
+
+    @classmethod
+    def from_unet(cls, unet: "UNet2DConditionModel", brushnet_conditioning_channel_order: str = "rgb",
+                  conditioning_embedding_out_channels=(16, 32, 96, 256), load_weights_from_unet: bool = True,
+                  conditioning_channels: int = 5) -> "BrushNetModel":
+        """brushnet.py:452-530: same widths as the UNet, attention-free blocks; optionally clone its weights."""
+        uc = unet.config
+        n = len(uc["block_out_channels"])
+        cfg = {k: uc[k] for k in ("in_channels", "flip_sin_to_cos", "freq_shift", "block_out_channels",
+                                  "layers_per_block", "downsample_padding", "mid_block_scale_factor", "act_fn",
+                                  "norm_num_groups", "norm_eps", "cross_attention_dim", "attention_head_dim",
+                                  "num_attention_heads", "use_linear_projection", "resnet_time_scale_shift",
+                                  "transformer_layers_per_block")}
+        cfg.update(conditioning_channels=conditioning_channels, down_block_types=("DownBlock2D",) * n,
+                   mid_block_type="MidBlock2D", up_block_types=("UpBlock2D",) * n,
+                   brushnet_conditioning_channel_order=brushnet_conditioning_channel_order,
+                   conditioning_embedding_out_channels=tuple(conditioning_embedding_out_channels))
+        bn = cls(cfg, precision=unet.prec, device=unet.device)
+        if load_weights_from_unet:
+            usd = unet.state_dict()
+            sd = {}
+            for k, shp in bn.param_shapes().items():
+                if k.startswith("brushnet_"):
+                    sd[k] = torch.zeros(shp)                                  # zero_module (brushnet.py:928-931)
+                elif k == "conv_in_condition.weight":
+                    w = torch.zeros(shp)
+                    w[:, :4] = usd["conv_in.weight"]
+                    w[:, 4:8] = usd["conv_in.weight"]                          # brushnet.py:514-518
+                    sd[k] = w
+                elif k == "conv_in_condition.bias":
+                    sd[k] = usd["conv_in.bias"].clone()
+                else:
+                    sd[k] = usd[k].clone()
+            bn.load_state_dict(sd)
+        return bn
+
+    def param_shapes(self):
+        c = self.config
+        out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+        boc = c["block_out_channels"]
+        temb = boc[0] * 4
+        cin = c["in_channels"] + c["conditioning_channels"]
+        out["conv_in_condition.weight"] = (boc[0], cin, 3, 3); out["conv_in_condition.bias"] = (boc[0],)
+        out["time_embedding.linear_1.weight"] = (temb, boc[0]); out["time_embedding.linear_1.bias"] = (temb,)
+        out["time_embedding.linear_2.weight"] = (temb, temb); out["time_embedding.linear_2.bias"] = (temb,)
+        lpb = c["layers_per_block"]
+        n = len(boc)
+        zero = [boc[0]]
+        ch = boc[0]
+        for i in range(n):
+            for j in range(lpb):
+                _resnet_shapes(out, f"down_blocks.{i}.resnets.{j}.", ch if j == 0 else boc[i], boc[i], temb)
+                zero.append(boc[i])
+            ch = boc[i]
+            if i != n - 1:
+                out[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (ch, ch, 3, 3)
+                out[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (ch,)
+                zero.append(ch)
+        for k, z in enumerate(zero):
+            out[f"brushnet_down_blocks.{k}.weight"] = (z, z, 1, 1); out[f"brushnet_down_blocks.{k}.bias"] = (z,)
+        out["brushnet_mid_block.weight"] = (boc[-1], boc[-1], 1, 1); out["brushnet_mid_block.bias"] = (boc[-1],)
+        for j in range(2):
+            _resnet_shapes(out, f"mid_block.resnets.{j}.", boc[-1], boc[-1], temb)
+        rev = list(reversed(boc))
+        skip_ch = list(zero)
+        uz = []
+        prev = rev[0]
+        for i in range(n):
+            oc = rev[i]
+            for j in range(lpb + 1):
+                sk = skip_ch.pop()
+                _resnet_shapes(out, f"up_blocks.{i}.resnets.{j}.", (prev if j == 0 else oc) + sk, oc, temb)
+                uz.append(oc)
+            prev = oc
+            if i != n - 1:
+                out[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (oc, oc, 3, 3)
+                out[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (oc,)
+                uz.append(oc)
+        for k, z in enumerate(uz):
+            out[f"brushnet_up_blocks.{k}.weight"] = (z, z, 1, 1); out[f"brushnet_up_blocks.{k}.bias"] = (z,)
+        return out
+
+    def _prepare(self, sd):
+        c = self.config
+        self.P: Dict[str, Any] = {}
+        self.tdepth: Dict[str, int] = {}
+        cin = c["in_channels"] + c["conditioning_channels"]
+        self.cin_pad = (cin + 7) // 8 * 8
+        self.P["conv_in_condition"] = self._conv(sd, "conv_in_condition", cin_pad=self.cin_pad)
+        self._prepare_time(sd)
+        for k in self.param_shapes():
+            if k.endswith(".norm1.weight") and ".resnets." in k:
+                self._prepare_resnet(sd, k[: -len("norm1.weight")])
+            elif k.endswith("samplers.0.conv.weight"):
+                self.P[k[: -len(".weight")]] = self._conv(sd, k[: -len(".weight")])
+            elif k.startswith("brushnet_") and k.endswith(".weight"):
+                self.P[k[: -len(".weight")]] = self._conv(sd, k[: -len(".weight")])
+
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: Optional[torch.Tensor] = None,
+                brushnet_cond: torch.Tensor = None, conditioning_scale: float = 1.0, class_labels=None,
+                timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
+                guess_mode: bool = False, return_dict: bool = True):
+        """brushnet.py:678-925.  Returns NCHW-shaped channels-last views (see module docstring)."""
+        if not self._ready:
+            raise RuntimeError("BrushNetModel has no parameters loaded")
+        c = self.config
+        order = c["brushnet_conditioning_channel_order"]
+        if order == "bgr":
+            brushnet_cond = torch.flip(brushnet_cond, dims=[1])
+        elif order != "rgb":
+            raise ValueError(f"unknown `brushnet_conditioning_channel_order`: {order}")        # brushnet.py:741
+        if guess_mode:
+            raise NotImplementedError("guess_mode logspace scaling (brushnet.py:896-902) is off in every MirrorFusion config")
+        if class_labels is not None or timestep_cond is not None or attention_mask is not None or added_cond_kwargs:
+            raise NotImplementedError("class/timestep_cond/attention_mask/added_cond inputs are outside the SD1.5 hot path")
+        bsz = sample.shape[0]
+        temb = self._time_embedding(timestep, bsz)
+        x = hip.pack_nhwc(sample.to(self.device).float().contiguous(), brushnet_cond.to(self.device).float().contiguous(),
+                          self.cin_pad, self.prec.act)                                            # :810 cat + pad
+        x = ops.conv2d(x, self.P["conv_in_condition"])
+        n = len(c["block_out_channels"])
+        lpb = c["layers_per_block"]
+        down = [x]
+        for i in range(n):                                                                        # :815-828
+            for j in range(lpb):
+                x = self._resnet(f"down_blocks.{i}.resnets.{j}.", x, temb)
+                down.append(x)
+            if i != n - 1:
+                x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1)
+                down.append(x)
+        s = float(conditioning_scale)
+        bn_down = [ops.conv2d(r, self.P[f"brushnet_down_blocks.{k}"], padding=0, alpha=s) for k, r in enumerate(down)]
+        for j in range(2):                                                                        # MidBlock2D
+            x = self._resnet(f"mid_block.resnets.{j}.", x, temb)
+        bn_mid = ops.conv2d(x, self.P["brushnet_mid_block"], padding=0, alpha=s)
+        ups: List[torch.Tensor] = []
+        skips = list(down)
+        for i in range(n):                                                                        # :856-887
+            for j in range(lpb + 1):
+                x = self._resnet(f"up_blocks.{i}.resnets.{j}.", x, temb, x1=skips.pop())
+                ups.append(x)
+            if i != n - 1:
+                x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True)
+                ups.append(x)
+        bn_up = [ops.conv2d(r, self.P[f"brushnet_up_blocks.{k}"], padding=0, alpha=s) for k, r in enumerate(ups)]
+        d = [to_nchw_view(t) for t in bn_down]
+        m = to_nchw_view(bn_mid)
+        u = [to_nchw_view(t) for t in bn_up]
+        if not return_dict:
+            return d, m, u
+        return BrushNetOutput(down_block_res_samples=d, mid_block_res_sample=m, up_block_res_samples=u)
+
+    __call__ = forward
+
+
+# =================================================================================================
+class UNet2DConditionModel(_UNetCore):
+    """models/unets/unet_2d_condition.py with the BrushNet injection kwargs."""
+
+    _class_name = "UNet2DConditionModel"
+
+    def __init__(self, config=None, precision="bf16", device="cuda", **kwargs):
+        cfg = dict(config or {})
+        cfg.update(kwargs)
+        cfg.setdefault("out_channels", 4)
+        cfg.setdefault("down_block_types", ("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",))
+        cfg.setdefault("up_block_types", ("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3)
+        cfg.setdefault("mid_block_type", "UNetMidBlock2DCrossAttn")
+        super().__init__(cfg, precision, device)
+        self._common_defaults()
+        c = self.config
+        ok_d = {"CrossAttnDownBlock2D", "DownBlock2D"}
+        ok_u = {"CrossAttnUpBlock2D", "UpBlock2D"}
+        if not set(c["down_block_types"]) <= ok_d or not set(c["up_block_types"]) <= ok_u \
+                or c["mid_block_type"] != "UNetMidBlock2DCrossAttn":
+            raise NotImplementedError("UNet2DConditionModel: only the SD1.5 block zoo is built "
+                                      "(CrossAttn{Down,Up}Block2D, {Down,Up}Block2D, UNetMidBlock2DCrossAttn)")
+
+    def param_shapes(self):
+        c = self.config
+        out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+        boc = c["block_out_channels"]
+        temb = boc[0] * 4
+        cross = c["cross_attention_dim"]
+        depth = _as_tuple(c["transformer_layers_per_block"], len(boc))
+        out["conv_in.weight"] = (boc[0], c["in_channels"], 3, 3); out["conv_in.bias"] = (boc[0],)
+        out["time_embedding.linear_1.weight"] = (temb, boc[0]); out["time_embedding.linear_1.bias"] = (temb,)
+        out["time_embedding.linear_2.weight"] = (temb, temb); out["time_embedding.linear_2.bias"] = (temb,)
+        lpb = c["layers_per_block"]
+        n = len(boc)
+        skip = [boc[0]]
+        ch = boc[0]
+        for i, bt in enumerate(c["down_block_types"]):
+            for j in range(lpb):
+                _resnet_shapes(out, f"down_blocks.{i}.resnets.{j}.", ch if j == 0 else boc[i], boc[i], temb)
+                if bt == "CrossAttnDownBlock2D":
+                    _transformer_shapes(out, f"down_blocks.{i}.attentions.{j}.", boc[i], cross, depth[i])
+                skip.append(boc[i])
+            ch = boc[i]
+            if i != n - 1:
+                out[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (ch, ch, 3, 3)
+                out[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (ch,)
+                skip.append(ch)
+        _resnet_shapes(out, "mid_block.resnets.0.", boc[-1], boc[-1], temb)
+        _transformer_shapes(out, "mid_block.attentions.0.", boc[-1], cross, depth[-1])
+        _resnet_shapes(out, "mid_block.resnets.1.", boc[-1], boc[-1], temb)
+        rev = list(reversed(boc))
+        rdepth = list(reversed(depth))
+        prev = rev[0]
+        for i, bt in enumerate(c["up_block_types"]):
+            oc = rev[i]
+            for j in range(lpb + 1):
+                sk = skip.pop()
+                _resnet_shapes(out, f"up_blocks.{i}.resnets.{j}.", (prev if j == 0 else oc) + sk, oc, temb)
+                if bt == "CrossAttnUpBlock2D":
+                    _transformer_shapes(out, f"up_blocks.{i}.attentions.{j}.", oc, cross, rdepth[i])
+            prev = oc
+            if i != n - 1:
+                out[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (oc, oc, 3, 3)
+                out[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (oc,)
+        out["conv_norm_out.weight"] = (boc[0],); out["conv_norm_out.bias"] = (boc[0],)
+        out["conv_out.weight"] = (c["out_channels"], boc[0], 3, 3); out["conv_out.bias"] = (c["out_channels"],)
+        return out
+
+    def _prepare(self, sd):
+        c = self.config
+        self.P = {}
+        self.tdepth = {}
+        self.cin_pad = (c["in_channels"] + 7) // 8 * 8
+        self.P["conv_in"] = self._conv(sd, "conv_in", cin_pad=self.cin_pad)
+        self._prepare_time(sd)
+        for k in self.param_shapes():
+            if k.endswith(".norm1.weight") and ".resnets." in k:
+                self._prepare_resnet(sd, k[: -len("norm1.weight")])
+            elif k.endswith("samplers.0.conv.weight"):
+                self.P[k[: -len(".weight")]] = self._conv(sd, k[: -len(".weight")])
+            elif k.endswith(".proj_in.weight"):
+                self._prepare_transformer(sd, k[: -len("proj_in.weight")])
+        self.P["conv_norm_out"] = self._norm(sd, "conv_norm_out")
+        self.P["conv_out"] = self._conv(sd, "conv_out")
+
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
+                timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None,
+                down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict: bool = True,
+                down_block_add_samples: Optional[List[torch.Tensor]] = None,
+                mid_block_add_sample: Optional[torch.Tensor] = None,
+                up_block_add_samples: Optional[List[torch.Tensor]] = None):
+        """unet_2d_condition.py:1039-1348.  `down_block_add_samples` / `up_block_add_samples` are consumed with
+        pop(0) exactly like the reference does (the caller's lists are emptied)."""
+        if not self._ready:
+            raise RuntimeError("UNet2DConditionModel has no parameters loaded")
+        if any(v is not None for v in (class_labels, timestep_cond, attention_mask, added_cond_kwargs,
+                                       down_block_additional_residuals, mid_block_additional_residual,
+                                       down_intrablock_additional_residuals, encoder_attention_mask)) \
+                or (cross_attention_kwargs not in (None, {})):
+            raise NotImplementedError("ControlNet / T2I-adapter / mask / LoRA-scale inputs are outside the MirrorFusion hot path")
+        c = self.config
+        n = len(c["block_out_channels"])
+        lpb = c["layers_per_block"]
+        is_brushnet = down_block_add_samples is not None and mid_block_add_sample is not None \
+            and up_block_add_samples is not None                                                    # :1202
+        bsz = sample.shape[0]
+        temb = self._time_embedding(timestep, bsz)
+        ehs = self._ehs(encoder_hidden_states)
+        x = from_nchw(sample.to(self.device), self.prec, self.cin_pad)
+        x = ops.conv2d(x, self.P["conv_in"])
+        skips = [x]                                                                                 # :1215 pre-add
+        if is_brushnet:
+            x = hip.add(x, self._inj(down_block_add_samples.pop(0)), self.prec.act)                 # :1218
+
+        def take(lst):
+            return self._inj(lst.pop(0)) if (is_brushnet and len(lst) > 0) else None
+
+        for i, bt in enumerate(c["down_block_types"]):
+            has_attn = bt == "CrossAttnDownBlock2D"
+            for j in range(lpb):
+                inj = take(down_block_add_samples) if is_brushnet else None
+                if has_attn:
+                    x = self._resnet(f"down_blocks.{i}.resnets.{j}.", x, temb)
+                    x = self._transformer(f"down_blocks.{i}.attentions.{j}.", x, ehs, self._heads(i), inj)
+                else:
+                    x = self._resnet(f"down_blocks.{i}.resnets.{j}.", x, temb, inj=inj)
+                skips.append(x)                                                                     # post-add (:1388-1391)
+            if i != n - 1:
+                inj = take(down_block_add_samples) if is_brushnet else None
+                x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1, res0=inj)
+                skips.append(x)
+        x = self._resnet("mid_block.resnets.0.", x, temb)
+        x = self._transformer("mid_block.attentions.0.", x, ehs, self._heads(n - 1))
+        x = self._resnet("mid_block.resnets.1.", x, temb,
+                         inj=self._inj(mid_block_add_sample) if is_brushnet else None)              # :1288-1289
+        for i, bt in enumerate(c["up_block_types"]):
+            has_attn = bt == "CrossAttnUpBlock2D"
+            for j in range(lpb + 1):
+                inj = take(up_block_add_samples) if is_brushnet else None
+                sk = skips.pop()
+                if has_attn:
+                    x = self._resnet(f"up_blocks.{i}.resnets.{j}.", x, temb, x1=sk)
+                    x = self._transformer(f"up_blocks.{i}.attentions.{j}.", x, ehs, self._heads(n - 1 - i), inj)
+                else:
+                    x = self._resnet(f"up_blocks.{i}.resnets.{j}.", x, temb, x1=sk, inj=inj)
+            if i != n - 1:
+                inj = take(up_block_add_samples) if is_brushnet else None
+                x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True, res0=inj)
+        x = hip.groupnorm(x, *self.P["conv_norm_out"], groups=c["norm_num_groups"], eps=c["norm_eps"], silu=True,
+                          out_dtype=self.prec.act)
+        y = ops.conv2d(x, self.P["conv_out"], out_dtype=F32)
+        out = hip.unpack_nchw(y, c["out_channels"])
+        if not return_dict:
+            return (out,)
+        return UNet2DConditionOutput(sample=out)
+
+    __call__ = forward
+
+
+# =================================================================================================
+class DiagonalGaussianDistribution:
+    """vae.py:769-822, moments kept NHWC on the device; `sample` needs explicit or generator noise."""
+
+    def __init__(self, moments_nhwc: torch.Tensor, latent_channels: int):
+        self._m = moments_nhwc
+        self._c = latent_channels
+
+    @property
+    def parameters(self) -> torch.Tensor:
+        return hip.unpack_nchw(self._m, 2 * self._c)
+
+    def sample(self, generator: Optional[torch.Generator] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        b, h, w, _ = self._m.shape
+        if noise is None:
+            # the reference draws on the parameter device with the global RNG (vae.py:782-791); draw on the CPU
+            # so results do not depend on the device RNG implementation
+            noise = torch.randn(b, self._c, h, w, generator=generator, dtype=F32)
+        return hip.vae_sample(self._m, noise.to(self._m.device), self._c, 1.0)
+
+    def mode(self) -> torch.Tensor:
+        return hip.unpack_nchw(self._m, self._c)
+
+
+class AutoencoderKL(HipModel):
+    """models/autoencoders/autoencoder_kl.py:238-309 + vae.py Encoder/Decoder."""
+
+    _class_name = "AutoencoderKL"
+
+    def __init__(self, config=None, precision="bf16", device="cuda", **kwargs):
+        cfg = dict(config or {})
+        cfg.update(kwargs)
+        cfg.setdefault("in_channels", 3); cfg.setdefault("out_channels", 3); cfg.setdefault("latent_channels", 4)
+        cfg.setdefault("block_out_channels", (128, 256, 512, 512)); cfg.setdefault("layers_per_block", 2)
+        cfg.setdefault("norm_num_groups", 32); cfg.setdefault("scaling_factor", 0.18215)
+        cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
+        super().__init__(cfg, precision, device)
+
+    def _convert_deprecated_keys(self, sd):
+        # modeling_utils.py:929-971: query/key/value/proj_attn -> to_q/to_k/to_v/to_out.0
+        ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+        out = {}
+        for k, v in sd.items():
+            parts = k.split(".")
+            if len(parts) >= 2 and parts[-2] in ren and "attentions" in k:
+                parts[-2] = ren[parts[-2]]
+                k = ".".join(parts)
+            out[k] = v
+        return out
+
+    def param_shapes(self):
+        c = self.config
+        out = OrderedDict()
+        boc = c["block_out_channels"]
+        n, lpb, lat = len(boc), c["layers_per_block"], c["latent_channels"]
+
+        def mid(p, ch):
+            _resnet_shapes(out, p + "resnets.0.", ch, ch, 0)
+            a = p + "attentions.0."
+            out[a + "group_norm.weight"] = (ch,); out[a + "group_norm.bias"] = (ch,)
+            for l in ("to_q", "to_k", "to_v", "to_out.0"):
+                out[a + l + ".weight"] = (ch, ch); out[a + l + ".bias"] = (ch,)
+            _resnet_shapes(out, p + "resnets.1.", ch, ch, 0)
+
+        out["encoder.conv_in.weight"] = (boc[0], c["in_channels"], 3, 3); out["encoder.conv_in.bias"] = (boc[0],)
+        ch = boc[0]
+        for i in range(n):
+            for j in range(lpb):
+                _resnet_shapes(out, f"encoder.down_blocks.{i}.resnets.{j}.", ch if j == 0 else boc[i], boc[i], 0)
+            ch = boc[i]
+            if i != n - 1:
+                out[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (ch, ch, 3, 3)
+                out[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (ch,)
+        mid("encoder.mid_block.", boc[-1])
+        out["encoder.conv_norm_out.weight"] = (boc[-1],); out["encoder.conv_norm_out.bias"] = (boc[-1],)
+        out["encoder.conv_out.weight"] = (2 * lat, boc[-1], 3, 3); out["encoder.conv_out.bias"] = (2 * lat,)
+        out["decoder.conv_in.weight"] = (boc[-1], lat, 3, 3); out["decoder.conv_in.bias"] = (boc[-1],)
+        mid("decoder.mid_block.", boc[-1])
+        rev = list(reversed(boc))
+        ch = rev[0]
+        for i in range(n):
+            for j in range(lpb + 1):
+                _resnet_shapes(out, f"decoder.up_blocks.{i}.resnets.{j}.", ch if j == 0 else rev[i], rev[i], 0)
+            ch = rev[i]
+            if i != n - 1:
+                out[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (ch, ch, 3, 3)
+                out[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (ch,)
+        out["decoder.conv_norm_out.weight"] = (boc[0],); out["decoder.conv_norm_out.bias"] = (boc[0],)
+        out["decoder.conv_out.weight"] = (c["out_channels"], boc[0], 3, 3); out["decoder.conv_out.bias"] = (c["out_channels"],)
+        out["quant_conv.weight"] = (2 * lat, 2 * lat, 1, 1); out["quant_conv.bias"] = (2 * lat,)
+        out["post_quant_conv.weight"] = (lat, lat, 1, 1); out["post_quant_conv.bias"] = (lat,)
+        return out
+
+    def _prepare(self, sd):
+        c = self.config
+        self.P = {}
+        v = self.prec.vec
+        for k in self.param_shapes():
+            if k.endswith(".norm1.weight") and ".resnets." in k:
+                p = k[: -len("norm1.weight")]
+                self.P[p + "norm1"] = self._norm(sd, p + "norm1"); self.P[p + "conv1"] = self._conv(sd, p + "conv1")
+                self.P[p + "norm2"] = self._norm(sd, p + "norm2"); self.P[p + "conv2"] = self._conv(sd, p + "conv2")
+                if p + "conv_shortcut.weight" in sd:
+                    self.P[p + "conv_shortcut"] = self._conv(sd, p + "conv_shortcut")
+            elif k.endswith("samplers.0.conv.weight"):
+                self.P[k[: -len(".weight")]] = self._conv(sd, k[: -len(".weight")])
+            elif k.endswith("group_norm.weight"):
+                a = k[: -len("group_norm.weight")]
+                self.P[a + "group_norm"] = self._norm(sd, a + "group_norm")
+                for l in ("to_q", "to_k", "to_v", "to_out.0"):
+                    self.P[a + l] = self._conv(sd, a + l)
+        self.cin_pad = (c["in_channels"] + 7) // 8 * 8
+        lat = c["latent_channels"]
+        self.lat_pad = (lat + 7) // 8 * 8
+        self.P["encoder.conv_in"] = self._conv(sd, "encoder.conv_in", cin_pad=self.cin_pad)
+        self.P["encoder.conv_norm_out"] = self._norm(sd, "encoder.conv_norm_out")
+        # encoder.conv_out -> quant_conv are two linear maps with nothing in between: keep them separate (exact
+        # reference order) but give quant_conv an 8-aligned input by padding conv_out's N to 8 with zero rows
+        w, b = sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"]
+        mom_pad = (2 * lat + 7) // 8 * 8
+        wp = torch.zeros(mom_pad, *w.shape[1:]); wp[: 2 * lat] = w
+        bp = torch.zeros(mom_pad); bp[: 2 * lat] = b
+        self.P["encoder.conv_out"] = ConvWeight(wp, bp, self.prec, self.device)
+        self.P["quant_conv"] = self._conv(sd, "quant_conv", cin_pad=mom_pad)
+        # post_quant_conv output feeds decoder.conv_in: pad its N to 8 the same way
+        w, b = sd["post_quant_conv.weight"], sd["post_quant_conv.bias"]
+        wp = torch.zeros(self.lat_pad, *w.shape[1:]); wp[:lat] = w
+        bp = torch.zeros(self.lat_pad); bp[:lat] = b
+        self.P["post_quant_conv"] = ConvWeight(wp, bp, self.prec, self.device, cin_pad=self.lat_pad)
+        self.P["decoder.conv_in"] = self._conv(sd, "decoder.conv_in", cin_pad=self.lat_pad)
+        self.P["decoder.conv_norm_out"] = self._norm(sd, "decoder.conv_norm_out")
+        self.P["decoder.conv_out"] = self._conv(sd, "decoder.conv_out")
+
+    # ---- blocks -------------------------------------------------------------------------------------
+    def _resnet(self, p, x):
+        g = self.config["norm_num_groups"]
+        P = self.P
+        h = hip.groupnorm(x, *P[p + "norm1"], groups=g, eps=1e-6, silu=True, out_dtype=self.prec.act)
+        h = ops.conv2d(h, P[p + "conv1"])
+        h = hip.groupnorm(h, *P[p + "norm2"], groups=g, eps=1e-6, silu=True, out_dtype=self.prec.act)
+        sc = ops.conv2d(x, P[p + "conv_shortcut"], padding=0) if p + "conv_shortcut" in P else x
+        return ops.conv2d(h, P[p + "conv2"], res0=sc)
+
+    def _mid(self, p, x):
+        """UNetMidBlock2D (unet_2d_blocks.py:601-753): resnet, 1-head spatial self-attention, resnet."""
+        P = self.P
+        x = self._resnet(p + "resnets.0.", x)
+        b, hh, ww, c = x.shape
+        a = p + "attentions.0."
+        n = hip.groupnorm(x, *P[a + "group_norm"], groups=self.config["norm_num_groups"], eps=1e-6, silu=False,
+                          out_dtype=self.prec.act).view(b, hh * ww, c)
+        q = ops.linear(n, P[a + "to_q"])
+        k = ops.linear(n, P[a + "to_k"])
+        s = hh * ww
+        vt = ops.linear_t(n, P[a + "to_v"], (s + 7) // 8 * 8)
+        o = ops.attention(q, k, vt, 1, s, 1.0 / (c ** 0.5), self.prec)
+        x = ops.linear(o, P[a + "to_out.0"], res0=x.view(b, s, c)).view(b, hh, ww, c)
+        return self._resnet(p + "resnets.1.", x)
+
+    def _moments(self, x: torch.Tensor) -> torch.Tensor:
+        c = self.config
+        n = len(c["block_out_channels"])
+        h = from_nchw(x.to(self.device).float(), self.prec, self.cin_pad)
+        h = ops.conv2d(h, self.P["encoder.conv_in"])
+        for i in range(n):
+            for j in range(c["layers_per_block"]):
+                h = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}.", h)
+            if i != n - 1:   # Downsample2D(padding=0): asymmetric (0,1,0,1) pad (downsampling.py:140-142)
+                h = ops.conv2d(h, self.P[f"encoder.down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=(0, 0, 1, 1))
+        h = self._mid("encoder.mid_block.", h)
+        h = hip.groupnorm(h, *self.P["encoder.conv_norm_out"], groups=c["norm_num_groups"], eps=1e-6, silu=True,
+                          out_dtype=self.prec.act)
+        h = ops.conv2d(h, self.P["encoder.conv_out"])
+        return ops.conv2d(h, self.P["quant_conv"], padding=0, out_dtype=F32)
+
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        d = DiagonalGaussianDistribution(self._moments(x), self.config["latent_channels"])
+        return AutoencoderKLOutput(latent_dist=d) if return_dict else (d,)
+
+    def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
+        c = self.config
+        n = len(c["block_out_channels"])
+        h = from_nchw(z.to(self.device).float(), self.prec, self.lat_pad)
+        h = ops.conv2d(h, self.P["post_quant_conv"], padding=0)
+        h = ops.conv2d(h, self.P["decoder.conv_in"])
+        h = self._mid("decoder.mid_block.", h)
+        for i in range(n):
+            for j in range(c["layers_per_block"] + 1):
+                h = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}.", h)
+            if i != n - 1:
+                h = ops.conv2d(h, self.P[f"decoder.up_blocks.{i}.upsamplers.0.conv"], upsample=True)
+        h = hip.groupnorm(h, *self.P["decoder.conv_norm_out"], groups=c["norm_num_groups"], eps=1e-6, silu=True,
+                          out_dtype=self.prec.act)
+        y = ops.conv2d(h, self.P["decoder.conv_out"], out_dtype=F32)
+        img = hip.unpack_nchw(y, c["out_channels"])
+        return DecoderOutput(sample=img) if return_dict else (img,)

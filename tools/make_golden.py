@@ -1,0 +1,264 @@
+"""Generate the golden fixtures under tests/golden/ by running the IMPORTED REFERENCE.
+
+Runs only in the build container (needs /root/reference); nothing under tests/, bench.py or the
+package reads /root/reference at run time.  The fixtures are data: seeded inputs are regenerated from
+`reflecting_reality_amd.synth`, only the reference's OUTPUTS (and key/shape tables) are stored.
+
+    python tools/make_golden.py            # tiny fixtures (seconds)
+    python tools/make_golden.py --full     # + full-size SD1.5-shape single-step fixtures (~2 min, ~12 GB RAM)
+
+While generating it also checks the oracle restatement (oracle/mirrorfusion_ref.py) against the
+reference on every case and prints the max abs difference.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/MirrorFusion/src")
+import transformers.utils as _tu  # noqa: E402
+
+if not hasattr(_tu, "FLAX_WEIGHTS_NAME"):          # removed in transformers 5; the reference imports it
+    _tu.FLAX_WEIGHTS_NAME = "flax_model.msgpack"
+
+from diffusers import AutoencoderKL, BrushNetModel, DDIMScheduler, PNDMScheduler, UNet2DConditionModel  # noqa: E402
+from diffusers.pipelines.brushnet.pipeline_brushnet import StableDiffusionBrushNetPipeline  # noqa: E402
+
+from oracle import mirrorfusion_ref as R  # noqa: E402
+from reflecting_reality_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+
+def build_unet(cfg):
+    return UNet2DConditionModel(
+        sample_size=8, in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
+        down_block_types=cfg["down_block_types"], up_block_types=cfg["up_block_types"],
+        block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"],
+        cross_attention_dim=cfg["cross_attention_dim"], attention_head_dim=cfg["attention_head_dim"],
+        norm_num_groups=cfg["norm_num_groups"]).eval()
+
+
+def build_vae(cfg):
+    n = len(cfg["block_out_channels"])
+    return AutoencoderKL(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * n,
+                         up_block_types=("UpDecoderBlock2D",) * n, block_out_channels=cfg["block_out_channels"],
+                         layers_per_block=cfg["layers_per_block"], latent_channels=cfg["latent_channels"],
+                         norm_num_groups=cfg["norm_num_groups"], scaling_factor=cfg["scaling_factor"]).eval()
+
+
+def load_synth(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    sd = synth.state_dict_for(shapes, seed)
+    module.load_state_dict(sd, strict=True)
+    return sd, shapes
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def summarize(t: torch.Tensor, nsample: int = 256):
+    """checksum + strided sample of a large tensor (full-size fixtures stay small)."""
+    f = t.double().flatten()
+    stride = max(1, f.numel() // nsample)
+    return dict(shape=list(t.shape), sum=float(f.sum()), abssum=float(f.abs().sum()),
+                sample_stride=stride, sample=f[::stride][:nsample].float().numpy())
+
+
+def models(unet_cfg, vae_cfg, seed):
+    unet = build_unet(unet_cfg)
+    unet_sd, unet_shapes = load_synth(unet, seed)
+    # load_weights_from_unet=True would alias unet.conv_in.bias into the BrushNet (brushnet.py:519), so loading
+    # the BrushNet's synthetic weights would silently overwrite the UNet's bias
+    brushnet = BrushNetModel.from_unet(unet, conditioning_channels=6, load_weights_from_unet=False).eval()
+    bn_sd, bn_shapes = load_synth(brushnet, seed + 1)
+    vae = build_vae(vae_cfg)
+    vae_sd, vae_shapes = load_synth(vae, seed + 2)
+    return (unet, unet_sd, unet_shapes), (brushnet, bn_sd, bn_shapes), (vae, vae_sd, vae_shapes)
+
+
+def tiny():
+    ucfg, vcfg = R.TINY_UNET, R.TINY_VAE
+    (unet, unet_sd, unet_shapes), (brushnet, bn_sd, bn_shapes), (vae, vae_sd, vae_shapes) = models(ucfg, vcfg, 0)
+    bcfg = R.brushnet_config(ucfg, 6)
+    with open(os.path.join(GOLD, "keys_tiny.json"), "w") as f:
+        json.dump(dict(unet=unet_shapes, brushnet=bn_shapes, vae=vae_shapes), f, indent=0, sort_keys=True)
+
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    cond = torch.randn(2, 6, 8, 8, generator=g)
+    ehs = torch.randn(2, 77, ucfg["cross_attention_dim"], generator=g)
+    t = 501
+    out = {}
+    # --- F3: BrushNet residuals -------------------------------------------------------------
+    down, mid, up = brushnet(x, t, encoder_hidden_states=ehs, brushnet_cond=cond, conditioning_scale=0.8,
+                             return_dict=False)
+    od, om, ou = R.brushnet_forward(bn_sd, bcfg, x, t, cond, 0.8)
+    print("brushnet oracle-vs-ref:", max(maxdiff(a, b) for a, b in zip(down + [mid] + up, od + [om] + ou)))
+    for i, d in enumerate(down):
+        out[f"bn_down_{i}"] = d.numpy()
+    out["bn_mid"] = mid.numpy()
+    for i, u in enumerate(up):
+        out[f"bn_up_{i}"] = u.numpy()
+    # --- F4: UNet with injection (the lists are consumed by pop(0): pass copies) --------------
+    eps = unet(x, t, encoder_hidden_states=ehs, down_block_add_samples=list(down), mid_block_add_sample=mid,
+               up_block_add_samples=list(up), return_dict=False)[0]
+    oeps = R.unet_forward(unet_sd, ucfg, x, t, ehs, od, om, ou)
+    print("unet+inj oracle-vs-ref:", maxdiff(eps, oeps))
+    out["unet_eps_inj"] = eps.numpy()
+    eps0 = unet(x, t, encoder_hidden_states=ehs, return_dict=False)[0]
+    print("unet    oracle-vs-ref:", maxdiff(eps0, R.unet_forward(unet_sd, ucfg, x, t, ehs)))
+    out["unet_eps_plain"] = eps0.numpy()
+    # --- F8: VAE ---------------------------------------------------------------------------------
+    img = torch.rand(2, 3, 16, 16, generator=g) * 2 - 1
+    mom = vae.encode(img).latent_dist.parameters
+    print("vae enc oracle-vs-ref:", maxdiff(mom, R.vae_encode_moments(vae_sd, vcfg, img)))
+    out["vae_moments"] = mom.numpy()
+    z = torch.randn(2, 4, 8, 8, generator=g)
+    dec = vae.decode(z, return_dict=False)[0]
+    print("vae dec oracle-vs-ref:", maxdiff(dec, R.vae_decode(vae_sd, vcfg, z)))
+    out["vae_decode"] = dec.numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_models.npz"), **out)
+
+    # --- F5: tiny pipeline, per-step latents for DDIM and PNDM ------------------------------------
+    pout = {}
+    sched_cfg = {k: v for k, v in R.SD15_SCHED.items()}
+    for name, cls, kw in (("ddim", DDIMScheduler, dict(clip_sample=False, set_alpha_to_one=False, steps_offset=1)),
+                          ("pndm", PNDMScheduler, dict(skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1))):
+        sched = cls(num_train_timesteps=1000, beta_start=sched_cfg["beta_start"], beta_end=sched_cfg["beta_end"],
+                    beta_schedule="scaled_linear", **kw)
+        pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet,
+                                               brushnet=brushnet, scheduler=sched, safety_checker=None,
+                                               feature_extractor=None, requires_safety_checker=False,
+                                               depth_conditioning_mode="concat")
+        pipe.set_progress_bar_config(disable=True)
+        inp = synth.pipeline_inputs(1, 16, 16, seed=1234, cross_dim=ucfg["cross_attention_dim"], vae_scale=2)
+        captured = {}
+        hook = brushnet.register_forward_pre_hook(
+            lambda mod, args, kwargs: captured.update(cond=kwargs["brushnet_cond"].clone()), with_kwargs=True)
+        trace = []
+
+        def cb(p, i, t, kw_):
+            trace.append(kw_["latents"].clone())
+            return {}
+
+        torch.manual_seed(777)       # the reference draws the VAE posterior noise from the global RNG (:1188)
+        res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+                   image=inp["image"], mask=inp["mask"], depth=inp["depth"], num_inference_steps=4,
+                   guidance_scale=7.5, latents=inp["latents"].clone(), output_type="pt",
+                   brushnet_conditioning_scale=1.0, callback_on_step_end=cb, height=16, width=16)
+        hook.remove()
+        torch.manual_seed(777)
+        vae_noise = torch.randn(2, 4, 8, 8)
+        # oracle replay with the explicit noise
+        ocond = R.build_conditioning(vae_sd, vcfg, inp["image"], inp["mask"], inp["depth"], vae_noise)
+        print(f"[{name}] conditioning oracle-vs-ref:", maxdiff(ocond, captured["cond"]))
+        osched = (R.DDIMRef if name == "ddim" else R.PNDMRef)(**R.SD15_SCHED)
+        otrace = []
+        pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+        olat = R.denoise(unet_sd, ucfg, bn_sd, bcfg, osched, inp["latents"], ocond, pe, 4, 7.5, 1.0, otrace)
+        print(f"[{name}] per-step latents oracle-vs-ref:", [round(maxdiff(a, b), 8) for a, b in zip(trace, otrace)])
+        oimg = (R.vae_decode(vae_sd, vcfg, olat / vcfg["scaling_factor"]) / 2 + 0.5).clamp(0, 1)
+        print(f"[{name}] image oracle-vs-ref:", maxdiff(oimg, res.images))
+        pout[f"{name}_timesteps"] = pipe.scheduler.timesteps.numpy()
+        pout[f"{name}_cond"] = captured["cond"].numpy()
+        pout[f"{name}_vae_noise"] = vae_noise.numpy()
+        for i, l in enumerate(trace):
+            pout[f"{name}_latents_{i}"] = l.numpy()
+        pout[f"{name}_image"] = res.images.numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_pipeline.npz"), **pout)
+
+    # --- F1: scheduler traces with the SD1.5 constants -------------------------------------------
+    sout = {}
+    for n in (4, 50):
+        d = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+        d.set_timesteps(n)
+        sout[f"ddim_timesteps_{n}"] = d.timesteps.numpy()
+        p = PNDMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1)
+        p.set_timesteps(n)
+        sout[f"pndm_timesteps_{n}"] = p.timesteps.numpy()
+        for nm, s in (("ddim", d), ("pndm", p)):
+            gg = torch.Generator().manual_seed(5)
+            x = torch.randn(2, 4, 8, 8, generator=gg)
+            xs = []
+            for t in s.timesteps:
+                eps = torch.sin(x * 3.0 + float(t) * 0.01)          # deterministic stand-in model
+                x = s.step(eps, t, x, return_dict=False)[0]
+                xs.append(x.clone())
+            sout[f"{nm}_trace_{n}"] = torch.stack(xs).numpy()
+    sout["alphas_cumprod"] = d.alphas_cumprod.numpy()
+    np.savez_compressed(os.path.join(GOLD, "schedulers.npz"), **sout)
+    print("tiny fixtures written")
+
+
+def full():
+    """F6/F7: full-size SD1.5-shape single step at 32x32 latents (1 image with CFG) + VAE decode/encode."""
+    ucfg, vcfg = R.SD15_UNET, R.SD15_VAE
+    (unet, unet_sd, unet_shapes), (brushnet, bn_sd, bn_shapes), (vae, vae_sd, vae_shapes) = models(ucfg, vcfg, 0)
+    bcfg = R.brushnet_config(ucfg, 6)
+    with open(os.path.join(GOLD, "keys_sd15.json"), "w") as f:
+        json.dump(dict(unet=unet_shapes, brushnet=bn_shapes, vae=vae_shapes), f, indent=0, sort_keys=True)
+    g = torch.Generator().manual_seed(43)
+    lat = torch.randn(1, 4, 32, 32, generator=g)
+    cond = torch.randn(2, 6, 32, 32, generator=g)
+    ehs = torch.randn(2, 77, 768, generator=g)
+    t = 981
+    x2 = torch.cat([lat] * 2)
+    down, mid, up = brushnet(x2, t, encoder_hidden_states=ehs, brushnet_cond=cond, conditioning_scale=1.0,
+                             return_dict=False)
+    eps = unet(x2, t, encoder_hidden_states=ehs, down_block_add_samples=list(down), mid_block_add_sample=mid,
+               up_block_add_samples=list(up), return_dict=False)[0]
+    od, om, ou = R.brushnet_forward(bn_sd, bcfg, x2, t, cond, 1.0)
+    oeps = R.unet_forward(unet_sd, ucfg, x2, t, ehs, od, om, ou)
+    print("full brushnet oracle-vs-ref:", max(maxdiff(a, b) for a, b in zip(down + [mid] + up, od + [om] + ou)))
+    print("full unet eps oracle-vs-ref:", maxdiff(eps, oeps), "eps absmax", float(eps.abs().max()))
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    sched.set_timesteps(50)
+    eu, ec = eps.chunk(2)
+    guided = eu + 7.5 * (ec - eu)
+    lat1 = sched.step(guided, t, lat, return_dict=False)[0]
+    out = dict(eps=eps.numpy(), latents_after_step=lat1.numpy())
+    for i, d in enumerate(down):
+        s = summarize(d)
+        out[f"bn_down_{i}_sample"] = s["sample"]
+        out[f"bn_down_{i}_stats"] = np.array([s["sum"], s["abssum"], s["sample_stride"]])
+    s = summarize(mid)
+    out["bn_mid_sample"], out["bn_mid_stats"] = s["sample"], np.array([s["sum"], s["abssum"], s["sample_stride"]])
+    for i, u in enumerate(up):
+        s = summarize(u)
+        out[f"bn_up_{i}_sample"] = s["sample"]
+        out[f"bn_up_{i}_stats"] = np.array([s["sum"], s["abssum"], s["sample_stride"]])
+    # VAE at 128x128 image (16x16 latents) keeps the fixture generation fast
+    z = torch.randn(1, 4, 16, 16, generator=g)
+    dec = vae.decode(z / vcfg["scaling_factor"], return_dict=False)[0]
+    print("full vae dec oracle-vs-ref:", maxdiff(dec, R.vae_decode(vae_sd, vcfg, z / vcfg["scaling_factor"])))
+    s = summarize(dec, 1024)
+    out["vae_dec_sample"], out["vae_dec_stats"] = s["sample"], np.array([s["sum"], s["abssum"], s["sample_stride"]])
+    img = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1
+    mom = vae.encode(img).latent_dist.parameters
+    print("full vae enc oracle-vs-ref:", maxdiff(mom, R.vae_encode_moments(vae_sd, vcfg, img)))
+    out["vae_moments"] = mom.numpy()
+    np.savez_compressed(os.path.join(GOLD, "sd15_step.npz"), **out)
+    print("full-size fixtures written")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only-full", action="store_true")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    if not a.only_full:
+        tiny()
+    if a.full or a.only_full:
+        full()
