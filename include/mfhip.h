@@ -37,7 +37,7 @@ extern "C" {
 #define MF_ACT_SILU 1
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 3
+#define MF_ABI_VERSION 4
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -165,12 +165,16 @@ int mf_timestep_embedding(const float* t, float* out, int32_t n, int32_t dim, in
 int mf_silu_f32(const float* x, float* out, int64_t n, void* stream);
 
 /* Fused classifier-free guidance + DDIM step (pipeline_brushnet.py:1310-1315,
- * scheduling_ddim.py:404-450, eta = 0, no clipping / thresholding):
- *   eps = eu + g*(ec - eu);  x0 = (x - sqrt_1m_at*eps)/sqrt_at;  x_prev = sqrt_ap*x0 + dir_coef*eps
- * eps_u/eps_c: the two halves of the UNet output in NCHW fp32; g < 0 disables CFG (eps = eps_u). */
+ * scheduling_ddim.py:404-450, eta = 0):
+ *   e = eu + g*(ec - eu)                       (g < 0: e = eu, no guidance)
+ *   pred_type 0 (epsilon):      x0 = (x - sqrt_1m_at*e)/sqrt_at ; eps = e
+ *   pred_type 1 (v_prediction): x0 = sqrt_at*x - sqrt_1m_at*e   ; eps = sqrt_at*e + sqrt_1m_at*x
+ *   clip > 0: x0 = clamp(x0, -clip, clip)      (clip_sample, :427-430)
+ *   x_prev = sqrt_ap*x0 + dir_coef*eps
+ * eps_u/eps_c: the two halves of the UNet output in NCHW fp32; eps_out (nullable) receives e. */
 int mf_cfg_ddim_step(const float* eps_u, const float* eps_c, float g, const float* x, float* x_prev,
-                     float sqrt_at, float sqrt_1m_at, float sqrt_ap, float dir_coef, float* eps_out,
-                     int64_t n, void* stream);
+                     float sqrt_at, float sqrt_1m_at, float sqrt_ap, float dir_coef, int32_t pred_type,
+                     float clip, float* eps_out, int64_t n, void* stream);
 /* CFG combine only (PNDM keeps its own history on the host side): eps = eu + g*(ec-eu) */
 int mf_cfg_combine(const float* eps_u, const float* eps_c, float g, float* eps, int64_t n, void* stream);
 /* generic y = sum_i c[i]*x[i] (i < nin <= 6) — PNDM/PLMS linear multistep and _get_prev_sample

@@ -10,3 +10,17 @@ Sub-modules:
   pipeline   StableDiffusionBrushNetPipeline
 """
 __version__ = "0.1.0"
+
+_LAZY = {
+    "BrushNetModel": "models", "UNet2DConditionModel": "models", "AutoencoderKL": "models",
+    "BrushNetOutput": "models", "DDIMScheduler": "schedulers", "PNDMScheduler": "schedulers",
+    "StableDiffusionBrushNetPipeline": "pipeline", "StableDiffusionPipelineOutput": "pipeline",
+    "VaeImageProcessor": "pipeline", "Precision": "ops",
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        return getattr(importlib.import_module(f"{__name__}.{_LAZY[name]}"), name)
+    raise AttributeError(name)

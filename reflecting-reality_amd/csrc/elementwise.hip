@@ -93,14 +93,23 @@ __global__ void silu_f32_kernel(const float* x, float* o, int64_t n) {
 }
 
 __global__ void cfg_ddim_kernel(const float* eu, const float* ec, float g, const float* x, float* xp, float sqrt_at,
-                                float sqrt_1m_at, float sqrt_ap, float dir_coef, float* eps_out, int64_t n) {
+                                float sqrt_1m_at, float sqrt_ap, float dir_coef, int pred_type, float clip,
+                                float* eps_out, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float e = eu[i];
         if (g >= 0.0f) e = e + g * (ec[i] - e);
         if (eps_out) eps_out[i] = e;
-        const float x0 = (x[i] - sqrt_1m_at * e) / sqrt_at;     // scheduling_ddim.py:412
-        const float dir = dir_coef * e;                          // :443
-        xp[i] = sqrt_ap * x0 + dir;                              // :446
+        float x0, ep;
+        if (pred_type == 0) {
+            x0 = (x[i] - sqrt_1m_at * e) / sqrt_at;              // scheduling_ddim.py:412
+            ep = e;
+        } else {
+            x0 = sqrt_at * x[i] - sqrt_1m_at * e;                // :418-420
+            ep = sqrt_at * e + sqrt_1m_at * x[i];
+        }
+        if (clip > 0.0f) x0 = fminf(fmaxf(x0, -clip), clip);     // :427-430
+        const float dir = dir_coef * ep;                          // :443
+        xp[i] = sqrt_ap * x0 + dir;                               // :446
     }
 }
 
@@ -213,11 +222,12 @@ extern "C" int mf_silu_f32(const float* x, float* out, int64_t n, void* stream) 
 }
 
 extern "C" int mf_cfg_ddim_step(const float* eps_u, const float* eps_c, float g, const float* x, float* x_prev,
-                                float sqrt_at, float sqrt_1m_at, float sqrt_ap, float dir_coef, float* eps_out,
-                                int64_t n, void* stream) {
+                                float sqrt_at, float sqrt_1m_at, float sqrt_ap, float dir_coef, int32_t pred_type,
+                                float clip, float* eps_out, int64_t n, void* stream) {
     MF_CHECK_ARG(eps_u && x && x_prev && n > 0 && (g < 0.0f || eps_c), "mf_cfg_ddim_step: bad arguments");
+    MF_CHECK_ARG(pred_type == 0 || pred_type == 1, "mf_cfg_ddim_step: pred_type must be 0 (epsilon) or 1 (v_prediction)");
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps_u, eps_c, g, x,
-                       x_prev, sqrt_at, sqrt_1m_at, sqrt_ap, dir_coef, eps_out, n);
+                       x_prev, sqrt_at, sqrt_1m_at, sqrt_ap, dir_coef, pred_type, clip, eps_out, n);
     MF_CHECK_LAUNCH("mf_cfg_ddim_step");
     return MF_OK;
 }

@@ -16,7 +16,7 @@ from . import _build
 
 MF_F32, MF_BF16 = 0, 1
 ACT_NONE, ACT_SILU = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MfhipError(RuntimeError):
@@ -318,14 +318,15 @@ def silu_f32(x: torch.Tensor) -> torch.Tensor:
 
 
 def cfg_ddim_step(eps_u: torch.Tensor, eps_c: Optional[torch.Tensor], g: float, x: torch.Tensor, sqrt_at: float,
-                  sqrt_1m_at: float, sqrt_ap: float, dir_coef: float, eps_out: Optional[torch.Tensor] = None
-                  ) -> torch.Tensor:
+                  sqrt_1m_at: float, sqrt_ap: float, dir_coef: float, eps_out: Optional[torch.Tensor] = None,
+                  pred_type: int = 0, clip: float = 0.0) -> torch.Tensor:
     _req_cuda(eps_u, eps_c, x, eps_out)
     xp = torch.empty_like(x)
     _check(load().mf_cfg_ddim_step(C.c_void_p(eps_u.data_ptr()), C.c_void_p(_ptr(eps_c)), C.c_float(g),
                                    C.c_void_p(x.data_ptr()), C.c_void_p(xp.data_ptr()), C.c_float(sqrt_at),
-                                   C.c_float(sqrt_1m_at), C.c_float(sqrt_ap), C.c_float(dir_coef),
-                                   C.c_void_p(_ptr(eps_out)), C.c_int64(x.numel()), _stream()), "mf_cfg_ddim_step")
+                                   C.c_float(sqrt_1m_at), C.c_float(sqrt_ap), C.c_float(dir_coef), pred_type,
+                                   C.c_float(clip), C.c_void_p(_ptr(eps_out)), C.c_int64(x.numel()), _stream()),
+           "mf_cfg_ddim_step")
     return xp
 
 

@@ -1,0 +1,392 @@
+"""StableDiffusionBrushNetPipeline with the reference call surface on the HIP models.
+
+Reference: MirrorFusion/src/diffusers/pipelines/brushnet/pipeline_brushnet.py — __init__ :185-233,
+check_inputs :573-693, prepare_image :741-774, prepare_latents :777-791, __call__ :848-1363 (hot loop
+:1250-1332), and image_processor.py:446-610 (VaeImageProcessor).
+
+Result-preserving shortcuts relative to the reference:
+  * the masked image is VAE-encoded once for B images; the reference encodes the CFG-duplicated 2B batch
+    (:771-772, :1188) whose two halves have identical moments and differ only in the posterior noise — the
+    noise is still drawn for 2B so both halves match the reference;
+  * classifier-free guidance and the DDIM update run as one kernel.
+CLIP text encoding is outside the accelerated path: pass `prompt_embeds` / `negative_prompt_embeds`, or give
+the pipeline a transformers `text_encoder` + `tokenizer` pair.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import hip
+from .models import AutoencoderKL, BrushNetModel, UNet2DConditionModel
+from .schedulers import DDIMScheduler
+
+try:
+    import PIL.Image
+except Exception:  # pragma: no cover
+    PIL = None
+
+
+@dataclass
+class StableDiffusionPipelineOutput:
+    images: Any
+    nsfw_content_detected: Optional[List[bool]]
+
+
+class VaeImageProcessor:
+    """image_processor.py:446-610 for the formats the BrushNet pipeline feeds it (host side, once per image)."""
+
+    def __init__(self, vae_scale_factor: int = 8, do_resize: bool = True, do_normalize: bool = True,
+                 do_convert_rgb: bool = False):
+        self.vae_scale_factor = vae_scale_factor
+        self.do_resize, self.do_normalize, self.do_convert_rgb = do_resize, do_normalize, do_convert_rgb
+
+    def preprocess(self, image, height: Optional[int] = None, width: Optional[int] = None) -> torch.Tensor:
+        supported = (torch.Tensor, np.ndarray) + ((PIL.Image.Image,) if PIL is not None else ())
+        if isinstance(image, supported):
+            image = [image]
+        elif not (isinstance(image, list) and all(isinstance(i, supported) for i in image)):
+            raise ValueError(f"Input is in incorrect format: {[type(i) for i in image]}. Currently, we only support "
+                             "PIL.Image.Image, np.ndarray, torch.Tensor")
+        first = image[0]
+        if PIL is not None and isinstance(first, PIL.Image.Image):
+            if self.do_resize and height is not None:
+                image = [i.resize((width, height), resample=PIL.Image.LANCZOS) for i in image]
+            if self.do_convert_rgb:
+                image = [i.convert("RGB") for i in image]
+            arr = np.stack([np.array(i).astype(np.float32) / 255.0 for i in image], axis=0)
+            if arr.ndim == 3:
+                arr = arr[..., None]
+            t = torch.from_numpy(arr.transpose(0, 3, 1, 2))
+        elif isinstance(first, np.ndarray):
+            arr = np.concatenate(image, axis=0) if first.ndim == 4 else np.stack(image, axis=0)
+            if arr.ndim == 3:
+                arr = arr[..., None]
+            t = torch.from_numpy(arr.transpose(0, 3, 1, 2)).float()
+        else:
+            t = torch.cat(image, dim=0) if first.ndim == 4 else torch.stack(image, dim=0)
+            if t.shape[1] == 4:                                             # already latents (:532-533)
+                return t
+        t = t.float()
+        if self.do_resize and height is not None and tuple(t.shape[-2:]) != (height, width):
+            t = torch.nn.functional.interpolate(t, size=(height, width))    # :resize() for tensors (host, once)
+        if self.do_normalize and t.min() >= 0:                              # negatives pass through un-normalised
+            t = 2.0 * t - 1.0
+        return t
+
+    def postprocess(self, image: torch.Tensor, output_type: str = "pil", do_denormalize=None):
+        if output_type not in ("latent", "pt", "np", "pil"):
+            output_type = "np"
+        if output_type == "latent":
+            return image
+        if do_denormalize is None:
+            do_denormalize = [self.do_normalize] * image.shape[0]
+        image = torch.stack([(image[i] / 2 + 0.5).clamp(0, 1) if do_denormalize[i] else image[i]
+                             for i in range(image.shape[0])])
+        if output_type == "pt":
+            return image
+        arr = image.cpu().permute(0, 2, 3, 1).float().numpy()
+        if output_type == "np":
+            return arr
+        arr = (arr * 255).round().astype("uint8")
+        if arr.shape[-1] == 1:
+            return [PIL.Image.fromarray(a.squeeze(), mode="L") for a in arr]
+        return [PIL.Image.fromarray(a) for a in arr]
+
+
+class StableDiffusionBrushNetPipeline:
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
+
+    def __init__(self, vae: AutoencoderKL, text_encoder, tokenizer, unet: UNet2DConditionModel,
+                 brushnet: BrushNetModel, scheduler, safety_checker=None, feature_extractor=None, image_encoder=None,
+                 requires_safety_checker: bool = True, depth_conditioning_mode=None, normals_conditioning_mode=None):
+        if safety_checker is not None and feature_extractor is None:
+            raise ValueError("Make sure to define a feature extractor when loading the pipeline if you want to use "
+                             "the safety checker. If you do not want to use the safety checker, you can pass "
+                             "`'safety_checker=None'` instead.")
+        if safety_checker is not None:
+            raise NotImplementedError("the safety checker (a CLIP vision model) is outside the accelerated path; "
+                                      "pass safety_checker=None as examples/brushnet/test_brushnet.py:150 does")
+        if normals_conditioning_mode not in (None,):
+            raise NotImplementedError("normals conditioning is not part of the BASELINE configs (SURVEY.md §8f-4)")
+        if depth_conditioning_mode not in (None, "concat"):
+            raise NotImplementedError("depth_conditioning_mode='latents' is a 'next' row (SURVEY.md §8f-4)")
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.unet, self.brushnet, self.scheduler = unet, brushnet, scheduler
+        self.safety_checker, self.feature_extractor, self.image_encoder = safety_checker, feature_extractor, image_encoder
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True)
+        self.depth_conditioning_mode = depth_conditioning_mode
+        self.normals_conditioning_mode = normals_conditioning_mode
+        self.config = dict(requires_safety_checker=requires_safety_checker)
+        self._progress_bar_config: Dict[str, Any] = {}
+        self._guidance_scale = 7.5
+        self._num_timesteps = 0
+
+    # ---- DiffusionPipeline surface ----------------------------------------------------------------
+    @property
+    def device(self):
+        return self.unet.device
+
+    _execution_device = device
+
+    def to(self, *args, **kwargs):
+        for m in (self.vae, self.unet, self.brushnet):
+            m.to(*args, **kwargs)
+        return self
+
+    def set_progress_bar_config(self, **kwargs):
+        self._progress_bar_config = kwargs
+
+    def progress_bar(self, total):
+        try:
+            from tqdm.auto import tqdm
+            return tqdm(total=total, **self._progress_bar_config)
+        except Exception:  # pragma: no cover
+            class _N:
+                def __enter__(s): return s
+                def __exit__(s, *a): return False
+                def update(s, *a): pass
+            return _N()
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    # ---- input validation (pipeline_brushnet.py:573-693) -------------------------------------------
+    def check_inputs(self, prompt, image, mask, callback_steps, negative_prompt=None, prompt_embeds=None,
+                     negative_prompt_embeds=None, brushnet_conditioning_scale=1.0, control_guidance_start=0.0,
+                     control_guidance_end=1.0, callback_on_step_end_tensor_inputs=None, depth=None, normals=None):
+        if callback_steps is not None and (not isinstance(callback_steps, int) or callback_steps <= 0):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+        if callback_on_step_end_tensor_inputs is not None and not all(
+                k in self._callback_tensor_inputs for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`. Please make sure to only forward one of the two.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None \
+                and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, "
+                             f"but got: `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` {negative_prompt_embeds.shape}.")
+        for nm, im in (("image", image), ("mask", mask)):
+            if im is None:
+                raise TypeError(f"`{nm}` must be passed (PIL image, numpy array, torch tensor or a list of those)")
+        if self.depth_conditioning_mode is not None and depth is None:
+            raise ValueError(f"depth_conditioning_mode={self.depth_conditioning_mode!r} needs a `depth` input")
+        if not isinstance(brushnet_conditioning_scale, float):
+            raise TypeError("For single brushnet: `brushnet_conditioning_scale` must be type `float`.")
+        starts = control_guidance_start if isinstance(control_guidance_start, (tuple, list)) else [control_guidance_start]
+        ends = control_guidance_end if isinstance(control_guidance_end, (tuple, list)) else [control_guidance_end]
+        if len(starts) != len(ends):
+            raise ValueError(f"`control_guidance_start` has {len(starts)} elements, but `control_guidance_end` has {len(ends)} elements.")
+        for s, e in zip(starts, ends):
+            if s >= e:
+                raise ValueError(f"control guidance start: {s} cannot be larger or equal to control guidance end: {e}.")
+            if s < 0.0:
+                raise ValueError(f"control guidance start: {s} can't be smaller than 0.")
+            if e > 1.0:
+                raise ValueError(f"control guidance end: {e} can't be larger than 1.0.")
+
+    # ---- prompt --------------------------------------------------------------------------------------
+    def encode_prompt(self, prompt, num_images_per_prompt, do_cfg, negative_prompt=None, prompt_embeds=None,
+                      negative_prompt_embeds=None):
+        """pipeline_brushnet.py:271-450 without LoRA / textual inversion / clip_skip."""
+        if prompt_embeds is None:
+            if self.text_encoder is None or self.tokenizer is None:
+                raise ValueError("pass `prompt_embeds` or construct the pipeline with a text_encoder and tokenizer")
+            def enc(txt):
+                ids = self.tokenizer(txt, padding="max_length", max_length=self.tokenizer.model_max_length,
+                                     truncation=True, return_tensors="pt").input_ids
+                with torch.no_grad():
+                    return self.text_encoder(ids.to(next(self.text_encoder.parameters()).device))[0]
+            plist = [prompt] if isinstance(prompt, str) else prompt
+            prompt_embeds = enc(plist)
+            if do_cfg and negative_prompt_embeds is None:
+                neg = negative_prompt if negative_prompt is not None else [""] * len(plist)
+                neg = [neg] * len(plist) if isinstance(neg, str) else neg
+                negative_prompt_embeds = enc(neg)
+        b, s, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.float().repeat(1, num_images_per_prompt, 1).view(b * num_images_per_prompt, s, -1)
+        if do_cfg:
+            if negative_prompt_embeds is None:
+                raise ValueError("classifier-free guidance needs `negative_prompt_embeds` when `prompt_embeds` is given")
+            negative_prompt_embeds = negative_prompt_embeds.float().repeat(1, num_images_per_prompt, 1).view(
+                b * num_images_per_prompt, s, -1)
+        return prompt_embeds, negative_prompt_embeds
+
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, do_cfg=False):
+        """pipeline_brushnet.py:741-774 — WITHOUT the CFG duplication (done after the VAE, see module docstring)."""
+        image = self.image_processor.preprocess(image, height=height, width=width).to(dtype=torch.float32)
+        repeat_by = batch_size if image.shape[0] == 1 else num_images_per_prompt
+        return image.repeat_interleave(repeat_by, dim=0)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, generator, latents=None):
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}.")
+        if latents is None:
+            if isinstance(generator, list):
+                noise = torch.cat([torch.randn((1,) + shape[1:], generator=g, dtype=torch.float32) for g in generator])
+            else:
+                noise = torch.randn(shape, generator=generator, dtype=torch.float32)   # host draw: device-independent
+        else:
+            noise = latents
+        noise = noise.to(self.device, torch.float32)
+        if self.scheduler.init_noise_sigma != 1.0:
+            noise = hip.axpby_n([noise.contiguous()], [float(self.scheduler.init_noise_sigma)])
+        return noise.contiguous(), noise
+
+    def build_conditioning(self, image, mask, depth, height, width, batch, num_images_per_prompt, do_cfg,
+                           conditioning_noise=None):
+        """pipeline_brushnet.py:1116-1202: [masked-image latents | mask | depth] at latent resolution."""
+        img = self.prepare_image(image, width, height, batch, num_images_per_prompt)
+        m3 = self.prepare_image(mask, width, height, batch, num_images_per_prompt)
+        original_mask = (m3.sum(1)[:, None, :, :] < 0).to(torch.float32)                           # :1139 (1 = keep)
+        height, width = img.shape[-2:]
+        hl, wl = height // self.vae_scale_factor, width // self.vae_scale_factor
+        dup = 2 if do_cfg else 1
+        moments = self.vae._moments(img)                                                           # B images, once
+        lat_c = self.vae.config["latent_channels"]
+        if conditioning_noise is None:
+            # reference: latent_dist.sample() on the CFG-duplicated batch, global RNG (:1188, vae.py:782-791)
+            conditioning_noise = torch.randn(dup * batch, lat_c, hl, wl, dtype=torch.float32)
+        conditioning_noise = conditioning_noise.to(self.device, torch.float32)
+        if conditioning_noise.shape[0] != dup * batch:
+            raise ValueError(f"conditioning_noise must have batch {dup * batch}")
+        sf = float(self.vae.config["scaling_factor"])
+        halves = [hip.vae_sample(moments, conditioning_noise[i * batch:(i + 1) * batch].contiguous(), lat_c, sf)
+                  for i in range(dup)]
+        mask_l = hip.nearest_resize(original_mask.to(self.device), hl, wl)                         # :1189-1195
+        parts = [mask_l]
+        if self.depth_conditioning_mode == "concat":
+            d = self.prepare_image(depth, width, height, batch, num_images_per_prompt)
+            parts.append(hip.nearest_resize(d.to(self.device), hl, wl))                            # :1198-1202
+        extra = torch.cat(parts, 1)
+        return torch.cat([torch.cat([h, extra], 1) for h in halves], 0).contiguous()
+
+    # ---- the call --------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt=None, image=None, mask=None, depth=None, normals=None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, timesteps: List[int] = None,
+                 guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: Optional[int] = 1,
+                 eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 ip_adapter_image=None, ip_adapter_image_embeds=None, output_type: Optional[str] = "pil",
+                 return_dict: bool = True, cross_attention_kwargs=None,
+                 brushnet_conditioning_scale: Union[float, List[float]] = 1.0, guess_mode: bool = False,
+                 control_guidance_start: Union[float, List[float]] = 0.0,
+                 control_guidance_end: Union[float, List[float]] = 1.0, clip_skip: Optional[int] = None,
+                 callback_on_step_end: Optional[Callable] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+                 conditioning_noise: Optional[torch.Tensor] = None, **kwargs):
+        callback = kwargs.pop("callback", None)
+        callback_steps = kwargs.pop("callback_steps", None)
+        if ip_adapter_image is not None or ip_adapter_image_embeds is not None or normals is not None:
+            raise NotImplementedError("IP-Adapter / normals inputs are outside the BASELINE configs (SURVEY.md §2 #14)")
+        if guess_mode or cross_attention_kwargs or clip_skip is not None or timesteps is not None:
+            raise NotImplementedError("guess_mode / cross_attention_kwargs / clip_skip / custom timesteps are not built")
+        if isinstance(control_guidance_start, list) or isinstance(control_guidance_end, list):
+            control_guidance_start = control_guidance_start[0] if isinstance(control_guidance_start, list) else control_guidance_start
+            control_guidance_end = control_guidance_end[0] if isinstance(control_guidance_end, list) else control_guidance_end
+        self.check_inputs(prompt, image, mask, callback_steps, negative_prompt, prompt_embeds, negative_prompt_embeds,
+                          brushnet_conditioning_scale, control_guidance_start, control_guidance_end,
+                          callback_on_step_end_tensor_inputs, depth=depth, normals=normals)
+        self._guidance_scale = guidance_scale
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None:
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        do_cfg = self.do_classifier_free_guidance
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds)
+        pe = torch.cat([negative_prompt_embeds, prompt_embeds]) if do_cfg else prompt_embeds         # :1103
+        pe = pe.to(self.device)
+        nb = batch_size * num_images_per_prompt
+
+        first = image[0] if isinstance(image, list) else image
+        if height is None or width is None:
+            if torch.is_tensor(first) or isinstance(first, np.ndarray):
+                hh, ww = (first.shape[-2:] if torch.is_tensor(first) else first.shape[-3:-1] if first.ndim == 4 else first.shape[:2])
+            else:
+                ww, hh = first.size
+            height, width = height or int(hh), width or int(ww)
+        cond = self.build_conditioning(image, mask, depth, height, width, nb, num_images_per_prompt, do_cfg,
+                                       conditioning_noise)
+
+        self.scheduler.set_timesteps(num_inference_steps, device=self.device)                       # :1171
+        ts = self.scheduler.timesteps
+        self._num_timesteps = len(ts)
+        latents, _ = self.prepare_latents(nb, self.unet.config["in_channels"], height, width, generator, latents)
+
+        keep = [1.0 - float(i / len(ts) < control_guidance_start or (i + 1) / len(ts) > control_guidance_end)
+                for i in range(len(ts))]                                                             # :1236-1242
+        fused_ddim = isinstance(self.scheduler, DDIMScheduler) and eta == 0.0
+        num_warmup = len(ts) - num_inference_steps * self.scheduler.order
+        with self.progress_bar(total=num_inference_steps) as bar:
+            for i, t in enumerate(ts):                                                               # :1250 HOT LOOP
+                x_in = torch.cat([latents] * 2) if do_cfg else latents                               # :1256
+                x_in = self.scheduler.scale_model_input(x_in, t)
+                cond_scale = float(brushnet_conditioning_scale) * keep[i]
+                down, mid, up = self.brushnet(x_in, t, encoder_hidden_states=pe, brushnet_cond=cond,
+                                              conditioning_scale=cond_scale, return_dict=False)      # :1277
+                eps = self.unet(x_in, t, encoder_hidden_states=pe, down_block_add_samples=down,
+                                mid_block_add_sample=mid, up_block_add_samples=up, return_dict=False)[0]   # :1296
+                if do_cfg:
+                    eu, ec = eps[:nb], eps[nb:]
+                    if fused_ddim:
+                        latents = self.scheduler.step(None, t, latents, return_dict=False, _cfg=(eu, ec, guidance_scale))[0]
+                    else:
+                        noise_pred = hip.cfg_combine(eu, ec, float(guidance_scale))                 # :1310-1312
+                        latents = self._sched_step(noise_pred, t, latents, eta, generator)
+                else:
+                    latents = self._sched_step(eps, t, latents, eta, generator)                     # :1315
+                if callback_on_step_end is not None:
+                    avail = dict(latents=latents, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+                    cb_kwargs = {k: avail[k] for k in callback_on_step_end_tensor_inputs}
+                    outs = callback_on_step_end(self, i, t, cb_kwargs) or {}
+                    latents = outs.pop("latents", latents)
+                if i == len(ts) - 1 or ((i + 1) > num_warmup and (i + 1) % self.scheduler.order == 0):
+                    bar.update()
+                    if callback is not None and callback_steps and i % callback_steps == 0:
+                        callback(i // getattr(self.scheduler, "order", 1), t, latents)
+
+        if output_type != "latent":
+            sf = float(self.vae.config["scaling_factor"])
+            z = hip.axpby_n([latents.contiguous()], [1.0 / sf])                                     # :1342
+            img = self.vae.decode(z, return_dict=False)[0]
+        else:
+            img = latents
+        img = self.image_processor.postprocess(img, output_type=output_type, do_denormalize=[True] * img.shape[0])
+        if not return_dict:
+            return (img, None)
+        return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)
+
+    def _sched_step(self, noise_pred, t, latents, eta, generator):
+        import inspect
+        params = inspect.signature(self.scheduler.step).parameters
+        extra = {}
+        if "eta" in params:
+            extra["eta"] = eta
+        if "generator" in params:
+            extra["generator"] = generator
+        return self.scheduler.step(noise_pred, t, latents, **extra, return_dict=False)[0]

@@ -1,0 +1,287 @@
+"""DDIMScheduler and PNDMScheduler with the reference call surface, stepping on the device.
+
+Reference: MirrorFusion/src/diffusers/schedulers/scheduling_ddim.py (set_timesteps :299-342, step :344-470,
+add_noise :473-497) and scheduling_pndm.py (set_timesteps :168-226, step_prk :261-319, step_plms :321-390,
+_get_prev_sample :407-448).  The scalar coefficients are computed on the host exactly like the reference
+does (fp32 0-dim tensor arithmetic on the alphas_cumprod table); the per-element update is one HIP kernel
+(mf_cfg_ddim_step / mf_axpby_n).  Latents stay fp32 whatever the model precision.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import hip
+from .models import FrozenConfig
+
+
+@dataclass
+class SchedulerOutput:
+    prev_sample: torch.Tensor
+    pred_original_sample: Optional[torch.Tensor] = None
+
+
+def _betas(cfg) -> torch.Tensor:
+    n = cfg["num_train_timesteps"]
+    if cfg.get("trained_betas") is not None:
+        return torch.tensor(cfg["trained_betas"], dtype=torch.float32)
+    sch = cfg["beta_schedule"]
+    if sch == "linear":
+        return torch.linspace(cfg["beta_start"], cfg["beta_end"], n, dtype=torch.float32)
+    if sch == "scaled_linear":
+        return torch.linspace(cfg["beta_start"] ** 0.5, cfg["beta_end"] ** 0.5, n, dtype=torch.float32) ** 2
+    raise NotImplementedError(f"{sch} is not implemented (reference supports it; outside the MirrorFusion path)")
+
+
+class _SchedulerBase:
+    order = 1
+    _defaults: dict = {}
+
+    def __init__(self, **kwargs):
+        cfg = dict(self._defaults)
+        unknown = [k for k in kwargs if k not in cfg]
+        cfg.update({k: v for k, v in kwargs.items() if k in cfg})
+        self.config = FrozenConfig(cfg)
+        self._unknown = unknown
+        self.betas = _betas(cfg)
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if cfg["set_alpha_to_one"] else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps = torch.from_numpy(np.arange(0, cfg["num_train_timesteps"])[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        """configuration_utils.py:~250: keys the target class does not know are dropped; keys the source left at
+        its default fall back to the TARGET's defaults (`_use_default_values`)."""
+        cfg = {k: v for k, v in dict(config).items() if not k.startswith("_")}
+        use_default = dict(config).get("_use_default_values", [])
+        cfg = {k: v for k, v in cfg.items() if k not in use_default}
+        cfg.update(kwargs)
+        return cls(**{k: v for k, v in cfg.items() if k in cls._defaults})
+
+    def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
+        return sample
+
+    def __len__(self):
+        return self.config["num_train_timesteps"]
+
+    def _alpha(self, t: int) -> torch.Tensor:
+        return self.alphas_cumprod[t] if t >= 0 else self.final_alpha_cumprod
+
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """scheduling_ddim.py:473-497 (== DDPM): sqrt(a_t) x + sqrt(1 - a_t) eps, per-sample t."""
+        ts = timesteps.cpu().long().reshape(-1)
+        a = self.alphas_cumprod[ts]
+        sa, sb = a ** 0.5, (1 - a) ** 0.5
+        outs = []
+        for i in range(original_samples.shape[0]):
+            k = i if ts.numel() > 1 else 0
+            outs.append(hip.axpby_n([original_samples[i].float().contiguous(), noise[i].float().contiguous()],
+                                    [float(sa[k]), float(sb[k])]))
+        return torch.stack(outs)
+
+
+class DDIMScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0,
+                     prediction_type="epsilon", thresholding=False, dynamic_thresholding_ratio=0.995,
+                     clip_sample_range=1.0, sample_max_value=1.0, timestep_spacing="leading",
+                     rescale_betas_zero_snr=False)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        c = self.config
+        if c["thresholding"] or c["rescale_betas_zero_snr"]:
+            raise NotImplementedError("thresholding / rescale_betas_zero_snr are outside the MirrorFusion path")
+        if c["prediction_type"] not in ("epsilon", "v_prediction"):
+            raise NotImplementedError(f"prediction_type {c['prediction_type']}")
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        c = self.config
+        if num_inference_steps > c["num_train_timesteps"]:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                             f"`self.config.train_timesteps`: {c['num_train_timesteps']}")
+        self.num_inference_steps = num_inference_steps
+        sp = c["timestep_spacing"]
+        if sp == "linspace":
+            ts = np.linspace(0, c["num_train_timesteps"] - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+        elif sp == "leading":
+            ratio = c["num_train_timesteps"] // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
+            ts += c["steps_offset"]
+        elif sp == "trailing":
+            ratio = c["num_train_timesteps"] / num_inference_steps
+            ts = np.round(np.arange(c["num_train_timesteps"], 0, -ratio)).astype(np.int64) - 1
+        else:
+            raise ValueError(f"{sp} is not supported. Please make sure to choose one of 'leading' or 'trailing'.")
+        self.timesteps = torch.from_numpy(ts)           # kept on the host: the loop indexes coefficient tables
+
+    def _get_variance(self, timestep, prev_timestep):
+        a_t, a_p = self._alpha(int(timestep)), self._alpha(int(prev_timestep))
+        return ((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)
+
+    def step_coefficients(self, timestep: int, eta: float = 0.0) -> Tuple[float, float, float, float, float]:
+        """(sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2), sigma) as the reference computes them."""
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        timestep = int(timestep)
+        prev_t = timestep - self.config["num_train_timesteps"] // self.num_inference_steps
+        a_t, a_p = self._alpha(timestep), self._alpha(prev_t)
+        b_t = 1 - a_t
+        std = eta * self._get_variance(timestep, prev_t) ** 0.5 if eta > 0 else torch.tensor(0.0)
+        return (float(a_t ** 0.5), float(b_t ** 0.5), float(a_p ** 0.5), float((1 - a_p - std ** 2) ** 0.5), float(std))
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, eta: float = 0.0,
+             use_clipped_model_output: bool = False, generator=None, variance_noise: Optional[torch.Tensor] = None,
+             return_dict: bool = True, _cfg: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None):
+        """scheduling_ddim.py:344-470.  `_cfg=(eps_uncond, eps_cond, guidance)` fuses the guidance combine
+        (pipeline_brushnet.py:1310-1312) into the same kernel."""
+        if use_clipped_model_output:
+            raise NotImplementedError("use_clipped_model_output")
+        sa, sb, sp, dirc, std = self.step_coefficients(timestep, eta)
+        c = self.config
+        clip = float(c["clip_sample_range"]) if c["clip_sample"] else 0.0
+        ptype = 0 if c["prediction_type"] == "epsilon" else 1
+        x = sample.float().contiguous()
+        if _cfg is not None:
+            eu, ec, g = _cfg
+            prev = hip.cfg_ddim_step(eu, ec, float(g), x, sa, sb, sp, dirc, pred_type=ptype, clip=clip)
+        else:
+            prev = hip.cfg_ddim_step(model_output.float().contiguous(), None, -1.0, x, sa, sb, sp, dirc,
+                                     pred_type=ptype, clip=clip)
+        if eta > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, dtype=torch.float32)
+            prev = hip.axpby_n([prev, variance_noise.to(prev.device).float().contiguous()], [1.0, std])
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev_sample=prev)
+
+
+class PNDMScheduler(_SchedulerBase):
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, skip_prk_steps=False, set_alpha_to_one=False, prediction_type="epsilon",
+                     timestep_spacing="leading", steps_offset=0)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        if self.config["prediction_type"] not in ("epsilon", "v_prediction"):
+            raise ValueError(f"prediction_type given as {self.config['prediction_type']} must be one of `epsilon` or `v_prediction`")
+        self.pndm_order = 4
+        self.cur_model_output = None
+        self.counter = 0
+        self.cur_sample = None
+        self.ets: List[torch.Tensor] = []
+        self.prk_timesteps = None
+        self.plms_timesteps = None
+        self.timesteps = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        c = self.config
+        self.num_inference_steps = num_inference_steps
+        nt = c["num_train_timesteps"]
+        sp = c["timestep_spacing"]
+        if sp == "linspace":
+            _ts = np.linspace(0, nt - 1, num_inference_steps).round().astype(np.int64)
+        elif sp == "leading":
+            _ts = (np.arange(0, num_inference_steps) * (nt // num_inference_steps)).round()
+            _ts = _ts + c["steps_offset"]
+        elif sp == "trailing":
+            _ts = np.round(np.arange(nt, 0, -nt / num_inference_steps))[::-1].astype(np.int64) - 1
+        else:
+            raise ValueError(f"{sp} is not supported. Please make sure to choose one of 'linspace', 'leading' or 'trailing'.")
+        if c["skip_prk_steps"]:
+            self.prk_timesteps = np.array([])
+            self.plms_timesteps = np.concatenate([_ts[:-1], _ts[-2:-1], _ts[-1:]])[::-1].copy()
+        else:
+            prk = np.array(_ts[-self.pndm_order:]).repeat(2) + np.tile(
+                np.array([0, nt // num_inference_steps // 2]), self.pndm_order)
+            self.prk_timesteps = (prk[:-1].repeat(2)[1:-1])[::-1].copy()
+            self.plms_timesteps = _ts[:-3][::-1].copy()
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64))
+        self.ets = []
+        self.counter = 0
+        self.cur_model_output = None
+        self.cur_sample = None
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = True):
+        if self.counter < len(self.prk_timesteps) and not self.config["skip_prk_steps"]:
+            return self.step_prk(model_output, timestep, sample, return_dict)
+        return self.step_plms(model_output, timestep, sample, return_dict)
+
+    def _check_ready(self):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+
+    def step_prk(self, model_output, timestep, sample, return_dict: bool = True):
+        self._check_ready()
+        timestep = int(timestep)
+        ratio = self.config["num_train_timesteps"] // self.num_inference_steps
+        diff_to_prev = 0 if self.counter % 2 else ratio // 2
+        prev_t = timestep - diff_to_prev
+        timestep = int(self.prk_timesteps[self.counter // 4 * 4])
+        mo = model_output.float().contiguous()
+        acc = self.cur_model_output
+        if self.counter % 4 == 0:
+            self.cur_model_output = hip.axpby_n([mo], [1 / 6]) if acc is None else hip.axpby_n([acc, mo], [1.0, 1 / 6])
+            self.ets.append(mo)
+            self.cur_sample = sample
+        elif (self.counter - 1) % 4 == 0 or (self.counter - 2) % 4 == 0:
+            self.cur_model_output = hip.axpby_n([acc, mo], [1.0, 1 / 3])
+        else:
+            mo = hip.axpby_n([acc, mo], [1.0, 1 / 6])
+            self.cur_model_output = None
+        cur_sample = self.cur_sample if self.cur_sample is not None else sample
+        prev = self._get_prev_sample(cur_sample, timestep, prev_t, mo)
+        self.counter += 1
+        return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)
+
+    def step_plms(self, model_output, timestep, sample, return_dict: bool = True):
+        self._check_ready()
+        if not self.config["skip_prk_steps"] and len(self.ets) < 3:
+            raise ValueError(f"{self.__class__} can only be run AFTER scheduler has been run in 'prk' mode for at "
+                             "least 12 iterations")
+        timestep = int(timestep)
+        ratio = self.config["num_train_timesteps"] // self.num_inference_steps
+        prev_t = timestep - ratio
+        mo = model_output.float().contiguous()
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(mo)
+        else:
+            prev_t = timestep
+            timestep = timestep + ratio
+        e = self.ets
+        if len(e) == 1 and self.counter == 0:
+            self.cur_sample = sample
+        elif len(e) == 1 and self.counter == 1:
+            mo = hip.axpby_n([mo, e[-1]], [0.5, 0.5])
+            sample = self.cur_sample
+            self.cur_sample = None
+        elif len(e) == 2:
+            mo = hip.axpby_n([e[-1], e[-2]], [3 / 2, -1 / 2])
+        elif len(e) == 3:
+            mo = hip.axpby_n([e[-1], e[-2], e[-3]], [23 / 12, -16 / 12, 5 / 12])
+        else:
+            mo = hip.axpby_n([e[-1], e[-2], e[-3], e[-4]], [55 / 24, -59 / 24, 37 / 24, -9 / 24])
+        prev = self._get_prev_sample(sample, timestep, prev_t, mo)
+        self.counter += 1
+        return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)
+
+    def _get_prev_sample(self, sample, timestep, prev_timestep, model_output):
+        """Formula (9) of PNDM (scheduling_pndm.py:407-448) as one fused linear combination."""
+        a_t, a_p = self._alpha(int(timestep)), self._alpha(int(prev_timestep))
+        b_t, b_p = 1 - a_t, 1 - a_p
+        sample_coeff = (a_p / a_t) ** 0.5
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        k = -(a_p - a_t) / denom
+        x = sample.float().contiguous()
+        if self.config["prediction_type"] == "v_prediction":
+            # eps = sqrt(a_t) v + sqrt(b_t) x  ->  prev = (sample_coeff + k sqrt(b_t)) x + k sqrt(a_t) v
+            return hip.axpby_n([x, model_output], [float(sample_coeff + k * b_t ** 0.5), float(k * a_t ** 0.5)])
+        return hip.axpby_n([x, model_output], [float(sample_coeff), float(k)])
