@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the MirrorFusion hot path (SD1.5 + BrushNet depth-conditioned inpainting) on MI355X.
+
+Contract (one JSON line on rank 0): a "step" is one pass of the whole accelerated path over one batch of synthetic
+inputs: conditioning build (incl. VAE-encode of the masked image) + `--denoise-steps` DDIM steps of BrushNet+UNet
+with classifier-free guidance 7.5 + VAE decode.  Default workload = BASELINE.json configs[1]:
+batch 4 x 512x512, 50-step DDIM, bf16, one MI355X.  With --gpus N each rank runs the same per-GPU batch on its own
+images (weak scaling, no data-path collective); value = images all ranks produced / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        bench.py --gpus 8 --steps 3 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE_STEP = {512: 2489.2, 256: 581.0}      # BASELINE.md §2 (CFG on): BrushNet 882.6 + UNet 1606.5 @512
+PEAK_BF16_TFLOPS = 2500.0                             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_pipeline(precision, device, keep_cpu_sd=False):
+    from reflecting_reality_amd import (AutoencoderKL, BrushNetModel, DDIMScheduler, StableDiffusionBrushNetPipeline,
+                                        UNet2DConditionModel, synth)
+    from reflecting_reality_amd.configs import SD15_SCHED, SD15_UNET, SD15_VAE, brushnet_config
+    t0 = time.time()
+    sds = {}
+    unet = UNet2DConditionModel(dict(SD15_UNET), precision=precision, device=device)
+    sd = synth.state_dict_for(unet.param_shapes(), 0)
+    unet.load_state_dict(sd)
+    sds["unet"] = sd
+    bn = BrushNetModel(dict(brushnet_config(SD15_UNET, 6)), precision=precision, device=device)
+    sd = synth.state_dict_for(bn.param_shapes(), 1)
+    bn.load_state_dict(sd)
+    sds["brushnet"] = sd
+    vae = AutoencoderKL(dict(SD15_VAE), precision=precision, device=device)
+    sd = synth.state_dict_for(vae.param_shapes(), 2)
+    vae.load_state_dict(sd)
+    sds["vae"] = sd
+    for m in (unet, bn, vae):
+        m._src = None
+    sched = DDIMScheduler(**{k: v for k, v in SD15_SCHED.items() if k != "skip_prk_steps"})
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                           scheduler=sched, safety_checker=None, feature_extractor=None,
+                                           requires_safety_checker=False, depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    log(f"[bench] models built in {time.time() - t0:.1f}s (seeded random weights, SD1.5 shapes)")
+    return pipe, (sds if keep_cpu_sd else None)
+
+
+def cpu_baseline(sds, size, threads):
+    """The CPU oracle (a port of the reference's arithmetic, pinned bit-exact to it) on the host cores, on a bounded
+    sample: ONE image, ONE denoise step (BrushNet + UNet, CFG batch of 2) + VAE encode + decode at `size`, extrapolated
+    to the 50-step pipeline (per-step cost is constant)."""
+    from oracle import mirrorfusion_ref as R
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(7)
+    hl = size // 8
+    lat = torch.randn(1, 4, hl, hl, generator=g)
+    cond = torch.randn(2, 6, hl, hl, generator=g)
+    ehs = torch.randn(2, 77, 768, generator=g)
+    bcfg = R.brushnet_config(R.SD15_UNET, 6)
+    with torch.no_grad():
+        t0 = time.time()
+        x2 = torch.cat([lat] * 2)
+        d, m, u = R.brushnet_forward(sds["brushnet"], bcfg, x2, 981, cond, 1.0)
+        R.unet_forward(sds["unet"], R.SD15_UNET, x2, 981, ehs, d, m, u)
+        t_step = time.time() - t0
+        t0 = time.time()
+        R.vae_decode(sds["vae"], R.SD15_VAE, lat)
+        R.vae_encode_moments(sds["vae"], R.SD15_VAE, torch.randn(1, 3, size, size, generator=g))
+        t_vae = time.time() - t0
+    return t_step, t_vae
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    from reflecting_reality_amd import distributed as D, hip, synth
+    rank, world, local = D.init_process_group()
+    if world != a.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {a.gpus}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    hip.load()
+
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
+    pipe, sds = build_pipeline(a.precision, device, keep_cpu_sd=want_cpu)
+    # every rank works on its own images: rank-dependent seed, same shapes (weak scaling)
+    inp = synth.pipeline_inputs(a.batch, a.size, a.size, seed=1234 + rank)
+    timing = {}
+
+    def one_pass():
+        return pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+                    image=inp["image"], mask=inp["mask"], depth=inp["depth"], num_inference_steps=a.denoise_steps,
+                    guidance_scale=7.5, latents=inp["latents"], output_type="pt", brushnet_conditioning_scale=1.0,
+                    height=a.size, width=a.size, conditioning_noise=inp["vae_noise"], _timing=timing).images
+
+    for _ in range(a.warmup):
+        one_pass()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    denoise_ms = 0.0
+    for _ in range(a.steps):
+        img = one_pass()
+        torch.cuda.synchronize()
+        denoise_ms += timing["denoise_start"].elapsed_time(timing["denoise_end"])
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=device)
+    assert torch.isfinite(img).all(), "non-finite output image"
+
+    images = a.batch * a.steps * world
+    value = images / elapsed
+    gflop = GFLOP_PER_IMAGE_STEP.get(a.size, 2489.2 * (a.size / 512.0) ** 2)
+    peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+    step_s = denoise_ms * 1e-3 / (a.steps * a.denoise_steps)
+    step_tflops = a.batch * gflop * 1e9 / step_s / 1e12
+
+    roofline = None
+    if rank == 0 and not a.no_profile:
+        # live per-launch timing of the dominant kernel family (mf_gemm_conv: every conv / linear, ~90 % of the
+        # algorithmic FLOPs) over ONE denoise step, HIP events on the launch stream
+        x2 = torch.cat([inp["latents"].to(device)] * 2)
+        cond = torch.randn(2 * a.batch, 6, a.size // 8, a.size // 8, device=device)
+        pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]]).to(device)
+        for rep in range(2):
+            if rep == 1:
+                hip.profile_begin()
+            d, m, u = pipe.brushnet(x2, 981, encoder_hidden_states=pe, brushnet_cond=cond, return_dict=False)
+            pipe.unet(x2, 981, pe, down_block_add_samples=d, mid_block_add_sample=m, up_block_add_samples=u)
+        n_launch, secs, flops = hip.profile_end()
+        roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel (all tile instantiations)",
+                    "achieved": round(flops / secs / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(flops / secs / 1e12 / peak, 4), "traffic": None,
+                    "launches_per_denoise_step": n_launch, "avg_launch_us": round(secs / n_launch * 1e6, 2),
+                    "flop_per_denoise_step": flops,
+                    "denoise_step": {"ms": round(step_s * 1e3, 3), "achieved": round(step_tflops, 2),
+                                     "frac": round(step_tflops / peak, 4),
+                                     "algorithmic_gflop_per_image_step": gflop}}
+
+    cpu = None
+    if want_cpu:
+        # cores this process may actually use (cgroup / affinity aware), capped: PyTorch's CPU conv/GEMM kernels
+        # degrade badly when oversubscribed on very wide hosts
+        threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32)
+        csize = 256
+        t_step, t_vae = cpu_baseline(sds, csize, threads)
+        scale = (a.size / csize) ** 2          # work scales with pixel count (attention slightly more)
+        per_image = (a.denoise_steps * t_step + t_vae) * scale
+        cpu = {"value": round(1.0 / per_image, 6), "unit": "images/sec", "cores": threads, "kind": "port",
+               "sample": f"CPU oracle (PyTorch fp32, pinned bit-exact to the reference): 1 image @ {csize}x{csize}, "
+                         f"1 denoise step with CFG ({t_step:.2f}s) + VAE encode+decode ({t_vae:.2f}s), extrapolated to "
+                         f"{a.denoise_steps} steps and x{scale:.0f} pixels for {a.size}x{a.size}"}
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec at 512x512, 50-step DDIM, SD1.5+BrushNet",
+            "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+            "config": {"workload": f"SD1.5 + BrushNet(6 cond ch) depth-cond inpaint, batch {a.batch}x{a.size}x{a.size} per GPU, "
+                                   f"{a.denoise_steps}-step DDIM, CFG 7.5, VAE encode+decode included, random-init weights",
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world, "height": a.size, "width": a.size,
+                       "denoise_steps": a.denoise_steps, "parallelism": f"batch-shard x{world} (no collective)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,29 +7,34 @@
 //
 // Design (CDNA4):
 //   * M = batch*Ho*Wo pixels, N = Cout, K = kh*kw*Cin.  Activations NHWC, weights [N][K].
-//   * A block stages BM x 128 B of A and BN x 128 B of W per K-tile into LDS (double buffered).
-//     A K-tile is 128 bytes of K per row in BOTH precisions (64 bf16 / 32 f32), so the staging,
-//     swizzle and fragment addressing are byte-identical for bf16 and f32; only the MFMA differs:
+//   * A K-tile is 128 bytes of K per row in BOTH precisions (64 bf16 / 32 f32), so staging, swizzle and
+//     fragment addressing are byte-identical for bf16 and f32; only the MFMA differs:
 //       bf16: one v_mfma_f32_32x32x16_bf16 per 16-byte fragment (k = 8h + j),
 //       f32 : four v_mfma_f32_32x32x2_f32 per 16-byte fragment (element e covers k = 4h + e of the
 //             8-wide step; A and W use the same k permutation so the dot product is unchanged).
-//   * LDS image [row][8 x 16 B], chunk index XOR ((row >> 1) & 7): conflict-free ds_read_b128 for
-//     the 32x32 fragment pattern (16 distinct rows per lane group -> 16 distinct 16-B slots of the
-//     256-B bank row); ds_write_b128 writes whole 128-B rows per 8 lanes (conflict-free).
-//   * Register-staged global->LDS pipeline: tile t+2 is in flight in registers while tile t+1 sits
-//     in LDS and tile t is being multiplied (write after the barrier, re-issue immediately).
-//   * fp32 accumulate; fused epilogue: alpha*(acc + bias + temb) + res0 + res1, SiLU, dtype cast.
-//   * split-K (deterministic fp32 slabs + reduce kernel that runs the same epilogue) for the
-//     small-spatial layers (8x8 / 16x16 latents) that cannot fill 256 CUs otherwise.
+//   * Staging is LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write.  The DMA destination
+//     is lane-linear (wave base + lane*16 B), i.e. 8 lanes fill one 128-B row, so the XOR swizzle
+//     chunk ^ ((row >> 1) & 7) is applied to the per-lane SOURCE address (lane l fetches logical chunk
+//     (l & 7) ^ key) and again on the fragment read: conflict-free ds_read_b128 for the 32x32 fragment
+//     pattern.  Zero padding / tails: a lane whose element is out of range reads a 16-byte zero page, so the
+//     gather has no divergent branches.  Two LDS stages: the DMA of tile t+1 flies while tile t is multiplied.
+//   * fp32 accumulate.  Epilogue: each wave transposes its accumulators through LDS (32-row slabs) so that
+//     every lane owns 8 consecutive output channels of one pixel: bias / temb / residual reads and the store
+//     are 16-byte vectors; alpha*(acc + bias + temb) + res0 + res1, SiLU, dtype cast are fused.
+//   * split-K (deterministic fp32 slabs + a reduce kernel running the same epilogue) for small-spatial layers
+//     (8x8 / 16x16 latents) that cannot fill 256 CUs otherwise; XCD-aware block order (consecutive tiles of
+//     one XCD share A rows and stay in that XCD's L2).
+//   * activations stored as fp32 with bf16 compute (A_F32) use a register-staged path that converts on load.
 #include "mf_common.h"
 
 namespace {
 
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];   // zero-initialised module global
+
 struct GemmArgs {
     const char* a0; const char* a1;
     int C0, Ctot;
-    int64_t lda0, lda1;
-    int a_f32;
+    int ld0b, ld1b;          // pixel strides in BYTES of the A storage dtype
     int Hin, Win, Ho, Wo, HoWo, KW, stride, pad_t, pad_l, ups;
     const char* w; int64_t ldw;
     int M, N, K;
@@ -42,10 +47,10 @@ struct GemmArgs {
     const char* res1; int res1_dt; int64_t ld_res1;
     float alpha; int act;
     char* out; int out_dt; int64_t ldc;
-    int tiles_n;
+    int tiles_n, nblk, vec_ok;
 };
 
-// Final epilogue for one output element (all branches are wave-uniform).
+// Scalar epilogue for one output element (tails, misaligned outputs, split-K reduce).
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int64_t zo, int m, int n, float v) {
     if (p.bias) v += p.bias_mode ? p.bias[m] : p.bias[n];
     if (p.temb) v += p.temb[(int64_t)(m / p.HoWo) * p.ld_temb + n];
@@ -56,7 +61,71 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int64_t zo, in
     store_from_f32(p.out, p.out_dt, zo + (int64_t)m * p.ldc + n, v);
 }
 
-__device__ __forceinline__ uint4 ld16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void load8_as_f32(const char* p, int dt, int64_t idx, float* o) {
+    if (dt == MF_F32) {
+        const float4 a = *reinterpret_cast<const float4*>(p + idx * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p + idx * 4 + 16);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(p + idx * 2);
+        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+        o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+        o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+}
+
+// Vector epilogue: 8 consecutive output channels of one pixel.
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, int m, int n, float* v) {
+    if (p.bias) {
+        if (p.bias_mode) {
+            const float b = p.bias[m];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b;
+        } else {
+            float b[8];
+            load8_as_f32((const char*)p.bias, MF_F32, n, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b[j];
+        }
+    }
+    if (p.temb) {
+        float t[8];
+        load8_as_f32((const char*)p.temb, MF_F32, (int64_t)(m / p.HoWo) * p.ld_temb + n, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += t[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+    if (p.res0) {
+        float r[8];
+        load8_as_f32(p.res0, p.res0_dt, (int64_t)m * p.ld_res0 + n, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (p.res1) {
+        float r[8];
+        load8_as_f32(p.res1, p.res1_dt, (int64_t)m * p.ld_res1 + n, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (p.act == MF_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = silu_precise(v[j]);
+    }
+    const int64_t o = zo + (int64_t)m * p.ldc + n;
+    if (p.out_dt == MF_F32) {
+        *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p.out + o * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        uint4 u;
+        u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+        u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+        *reinterpret_cast<uint4*>(p.out + o * 2) = u;
+    }
+}
 
 // 8 consecutive fp32 -> 8 bf16 (RNE) packed in 16 bytes
 __device__ __forceinline__ uint4 ld8f_to_bf16(const char* p) {
@@ -70,42 +139,60 @@ __device__ __forceinline__ uint4 ld8f_to_bf16(const char* p) {
     return r;
 }
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N>
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+__device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
+    // 64 lanes x 16 B -> LDS [lds_wave_base, +1 KiB), lane-linear; lds_wave_base must be wave-uniform
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;
     constexpr int ES = (DT == MF_F32) ? 4 : 2;   // element size of the compute dtype
-    constexpr int VEC = 16 / ES;                 // elements per 16-byte vector
+    constexpr int AES = A_F32 ? 4 : ES;          // element size of the A storage dtype
+    constexpr int VEC = 16 / ES;                 // elements per 16-byte LDS chunk
     constexpr int BK = 128 / ES;                 // K elements per tile (128 bytes per row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int RPP = NTHR / 8;                // rows staged per pass
+    constexpr int RPP = NTHR / 8;                // rows staged per pass (8 lanes per 128-B row)
     constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
+    constexpr int EP_RS = (WN + 4) * 4;          // epilogue slab row stride (bytes)
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+    static_assert(WAVES_M * WAVES_N * 32 * EP_RS <= 2 * STAGE_BYTES, "epilogue slabs must fit in the staging LDS");
+    static_assert(!A_F32 || DT == MF_BF16, "A_F32 only converts fp32 activations for bf16 compute");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    const int tile_m = blockIdx.x / p.tiles_n;
-    const int tile_n = blockIdx.x - tile_m * p.tiles_n;
+    // XCD-aware order: the 8 XCDs take blocks round-robin, so give each XCD a contiguous run of logical tiles
+    int bid = blockIdx.x;
+    {
+        const int q = p.nblk >> 3, r = p.nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tile_m = bid / p.tiles_n;
+    const int tile_n = bid - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z / p.splitk;
     const int ksplit = blockIdx.z - z * p.splitk;
     const int zq = z / p.zdiv, zr = z - zq * p.zdiv;
 
-    const int aes = p.a_f32 ? 4 : ES;            // A storage element size
-    const char* a0 = p.a0 + (zq * p.a_zs_o + zr * p.a_zs_i) * aes;
-    const char* a1 = p.a1 ? p.a1 + (zq * p.a_zs_o + zr * p.a_zs_i) * aes : nullptr;
+    const char* a0 = p.a0 + (zq * p.a_zs_o + zr * p.a_zs_i) * AES;
+    const char* a1 = p.a1 ? p.a1 + (zq * p.a_zs_o + zr * p.a_zs_i) * AES : a0;
     const char* wbase = p.w + (zq * p.w_zs_o + zr * p.w_zs_i) * ES;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
     // ---- per-thread staging coordinates -------------------------------------------------
-    const int chunk = tid & 7;       // which 16-B chunk of the 128-B K-tile row
-    const int lrow = tid >> 3;       // row within a staging pass
+    const int lrow = tid >> 3;                                   // row within a staging pass
+    const int chunk = (tid & 7) ^ ((lrow >> 1) & 7);             // LOGICAL 16-B chunk this lane fetches (swizzled)
     int a_pix[A_IT], a_iy0[A_IT], a_ix0[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -120,11 +207,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
             a_ix0[i] = ox * p.stride - p.pad_l;
         } else {
             a_pix[i] = 0;
-            a_iy0[i] = -(1 << 28);   // forces the bounds test to fail -> zero fill
+            a_iy0[i] = -(1 << 28);   // fails the bounds test -> zero page
             a_ix0[i] = 0;
         }
     }
     const int Hlim = p.Hin << p.ups, Wlim = p.Win << p.ups;
+    const char* w_row[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int n = n0 + lrow + i * RPP;
+        w_row[i] = n < p.N ? wbase + (int64_t)n * p.ldw * ES : nullptr;
+    }
 
     const int kt_begin = ksplit * p.kt_per_split;
     int kt_end = kt_begin + p.kt_per_split;
@@ -140,32 +233,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
         kx = tap - ky * p.KW;
     }
 
-    uint4 ra[A_IT], rb[B_IT];
-
-    auto load_tile = [&]() {
-        const bool kvalid = kk < p.K;
-        const char* base; int64_t ld; int cc;
-        if (c < p.C0) { base = a0; ld = p.lda0; cc = c; }
-        else { base = a1; ld = p.lda1; cc = c - p.C0; }
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-            const bool ok = kvalid && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
-            if (ok) {
-                const int64_t off = (int64_t)(a_pix[i] + (iy >> p.ups) * p.Win + (ix >> p.ups)) * ld + cc;
-                if (DT == MF_BF16 && p.a_f32) ra[i] = ld8f_to_bf16(base + off * 4);
-                else ra[i] = ld16(base + off * ES);
-            } else {
-                ra[i] = make_uint4(0, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int n = n0 + lrow + i * RPP;
-            if (kvalid && n < p.N) rb[i] = ld16(wbase + ((int64_t)n * p.ldw + kk) * ES);
-            else rb[i] = make_uint4(0, 0, 0, 0);
-        }
-        // advance to the next K tile
+    // source address of this lane's 16-B (or 32-B when A_F32) vector of A row i in the current K tile
+    auto a_src = [&](int i, bool kvalid, const char* base, int ldb, int ccb) -> const char* {
+        const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+        const bool ok = kvalid && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+        const int pix = a_pix[i] + (iy >> p.ups) * p.Win + (ix >> p.ups);
+        const char* src = base + ((int64_t)pix * ldb + ccb);
+        return ok ? src : nullptr;
+    };
+    auto advance_k = [&]() {
         kk += BK;
         c += BK;
         while (c >= p.Ctot) {
@@ -174,19 +250,55 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
         }
     };
 
-    auto store_tile = [&](int stage) {
-        char* As = smem + stage * STAGE_BYTES;
+    // ---- staging: LDS-DMA (default) --------------------------------------------------------
+    auto issue_tile = [&](int stage) {
+        char* As = smem + stage * STAGE_BYTES + wave * (8 * 128);      // this wave's first row of each pass
         char* Bs = As + BM * 128;
+        const bool kvalid = kk < p.K;
+        const bool seg0 = c < p.C0;
+        const char* base = seg0 ? a0 : a1;
+        const int ldb = seg0 ? p.ld0b : p.ld1b;
+        const int ccb = (seg0 ? c : c - p.C0) * AES;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const int row = lrow + i * RPP;
-            *reinterpret_cast<uint4*>(As + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = ra[i];
+            const char* src = a_src(i, kvalid, base, ldb, ccb);
+            dma16(src ? src : zero, As + i * RPP * 128);
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const int row = lrow + i * RPP;
-            *reinterpret_cast<uint4*>(Bs + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = rb[i];
+            const char* src = (kvalid && w_row[i]) ? w_row[i] + (int64_t)kk * ES : zero;
+            dma16(src, Bs + i * RPP * 128);
         }
+        advance_k();
+    };
+
+    // ---- staging: registers with fp32 -> bf16 conversion (A_F32) -------------------------------
+    uint4 ra[A_F32 ? A_IT : 1], rb[A_F32 ? B_IT : 1];
+    auto load_tile_regs = [&]() {
+        const bool kvalid = kk < p.K;
+        const bool seg0 = c < p.C0;
+        const char* base = seg0 ? a0 : a1;
+        const int ldb = seg0 ? p.ld0b : p.ld1b;
+        const int ccb = (seg0 ? c : c - p.C0) * AES;
+#pragma unroll
+        for (int i = 0; i < (A_F32 ? A_IT : 1); ++i) {
+            const char* src = a_src(i, kvalid, base, ldb, ccb);
+            ra[i] = src ? ld8f_to_bf16(src) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < (A_F32 ? B_IT : 1); ++i) {
+            const char* src = (kvalid && w_row[i]) ? w_row[i] + (int64_t)kk * ES : zero;
+            rb[i] = *reinterpret_cast<const uint4*>(src);
+        }
+        advance_k();
+    };
+    auto store_tile_regs = [&](int stage) {
+        char* As = smem + stage * STAGE_BYTES + tid * 16;               // lane-linear, like the DMA
+        char* Bs = As + BM * 128;
+#pragma unroll
+        for (int i = 0; i < (A_F32 ? A_IT : 1); ++i) *reinterpret_cast<uint4*>(As + i * RPP * 128) = ra[i];
+#pragma unroll
+        for (int i = 0; i < (A_F32 ? B_IT : 1); ++i) *reinterpret_cast<uint4*>(Bs + i * RPP * 128) = rb[i];
     };
 
     f32x16_t acc[MT][NT];
@@ -232,52 +344,74 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
 
     // ---- main loop ------------------------------------------------------------------------
     if (nt > 0) {
-        load_tile();
-        store_tile(0);
-        if (nt > 1) load_tile();
-        __syncthreads();
-        for (int t = 0; t < nt; ++t) {
-            compute(t & 1);
-            if (t + 1 < nt) {
-                store_tile((t + 1) & 1);
-                if (t + 2 < nt) load_tile();
+        if constexpr (!A_F32) {
+            issue_tile(0);
+            for (int t = 0; t < nt; ++t) {
+                __syncthreads();     // vmcnt(0)+barrier: tile t has landed for every wave, stage (t+1)&1 is free
+                if (t + 1 < nt) issue_tile((t + 1) & 1);
+                compute(t & 1);
             }
+        } else {
+            load_tile_regs();
+            store_tile_regs(0);
+            if (nt > 1) load_tile_regs();
             __syncthreads();
+            for (int t = 0; t < nt; ++t) {
+                compute(t & 1);
+                if (t + 1 < nt) {
+                    store_tile_regs((t + 1) & 1);
+                    if (t + 2 < nt) load_tile_regs();
+                }
+                __syncthreads();
+            }
         }
     }
+    __syncthreads();   // every wave is done reading the staging LDS: reuse it for the epilogue slabs
 
     // ---- epilogue ---------------------------------------------------------------------------
-    const int ncol0 = n0 + wn * WN + (lane & 31);
-    if (p.splitk > 1) {
-        float* ws = p.ws + ((int64_t)ksplit * p.nz + z) * (int64_t)p.M * p.N;
+    char* slab = smem + wave * (32 * EP_RS);        // private to this wave: [32 rows][WN + 4] fp32
+    constexpr int LPR = WN / 8;                      // lanes per output row (8 channels each)
+    constexpr int RPS = 64 / LPR;                    // rows per pass
+    const int er = lane / LPR, ec = (lane - er * LPR) * 8;
+    float* ws = p.splitk > 1 ? p.ws + ((int64_t)ksplit * p.nz + z) * (int64_t)p.M * p.N : nullptr;
+    const int64_t zo = zq * p.o_zs_o + zr * p.o_zs_i;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (m < p.M) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int n = ncol0 + j * 32;
-                        if (n < p.N) ws[(int64_t)m * p.N + n] = acc[i][j][e];
-                    }
-                }
-            }
-    } else {
-        const int64_t zo = zq * p.o_zs_o + zr * p.o_zs_i;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-                if (m < p.M) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                *reinterpret_cast<float*>(slab + row * EP_RS + (j * 32 + frow) * 4) = acc[i][j][e];
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the slab is written (LDS ops are in order per wave)
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int n = ncol0 + j * 32;
-                        if (n < p.N) epilogue_store(p, zo, m, n, acc[i][j][e]);
+        for (int ps = 0; ps < 32 / RPS; ++ps) {
+            const int row = ps * RPS + er;
+            const int m = m0 + wm * WM + i * 32 + row;
+            const int n = n0 + wn * WN + ec;
+            float v[8];
+            const float4 lo = *reinterpret_cast<const float4*>(slab + row * EP_RS + ec * 4);
+            const float4 hi = *reinterpret_cast<const float4*>(slab + row * EP_RS + ec * 4 + 16);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            if (m < p.M && n < p.N) {
+                if (ws) {
+                    if (n + 8 <= p.N && (p.N & 3) == 0) {
+                        *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n) = lo;
+                        *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n + 4) = hi;
+                    } else {
+                        for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
                     }
+                } else if (p.vec_ok && n + 8 <= p.N) {
+                    epilogue_store8(p, zo, m, n, v);
+                } else {
+                    for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj]);
                 }
             }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // slab reads done before the next slab overwrites it
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -309,35 +443,34 @@ const TileCfg kTiles[] = {
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int DT, int BM, int BN, int WMv, int WNv>
+template <int DT, int BM, int BN, int WMv, int WNv, bool AF>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv>), grid, dim3(WMv * WNv * 64), smem, s, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF>), grid, dim3(WMv * WNv * 64), smem, s, a);
 }
 
-template <int DT>
+template <int DT, bool AF>
 void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
     switch (tile) {
-        case 1: launch_one<DT, 128, 128, 2, 2>(a, grid, s); break;
-        case 2: launch_one<DT, 128, 64, 2, 2>(a, grid, s); break;
-        case 3: launch_one<DT, 64, 64, 2, 2>(a, grid, s); break;
-        case 4: launch_one<DT, 256, 64, 4, 1>(a, grid, s); break;
-        case 5: launch_one<DT, 256, 128, 4, 2>(a, grid, s); break;
-        case 6: launch_one<DT, 64, 128, 2, 2>(a, grid, s); break;
+        case 1: launch_one<DT, 128, 128, 2, 2, AF>(a, grid, s); break;
+        case 2: launch_one<DT, 128, 64, 2, 2, AF>(a, grid, s); break;
+        case 3: launch_one<DT, 64, 64, 2, 2, AF>(a, grid, s); break;
+        case 4: launch_one<DT, 256, 64, 4, 1, AF>(a, grid, s); break;
+        case 5: launch_one<DT, 256, 128, 4, 2, AF>(a, grid, s); break;
+        case 6: launch_one<DT, 64, 128, 2, 2, AF>(a, grid, s); break;
         default: break;
     }
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Heuristic tile choice: the largest tile whose padded work is close to the minimum and whose grid
-// still covers the 256 CUs; smaller tiles otherwise.
+// Heuristic tile choice (mf_gemm_desc.tile overrides it; the Python host autotunes per shape).
 int pick_tile(int M, int N, int nz, int splitk) {
     int best = 1;
     double best_cost = 1e300;
@@ -349,7 +482,6 @@ int pick_tile(int M, int N, int nz, int splitk) {
         double per_cu = tiles / 256.0;
         if (per_cu < 1.0) per_cu = 1.0;
         if (per_cu > bpc) per_cu = bpc;
-        // efficiency prior ~ arithmetic intensity of the tile against the LDS/L2 feed
         const double inten = (double)c.bm * c.bn / (c.bm + c.bn);
         const double eff = inten / (inten + 24.0);
         const double cost = rounds * per_cu * c.bm * c.bn / eff;
@@ -394,10 +526,13 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
                  "mf_gemm_conv: batch strides must be multiples of %d elements", vec);
 
     GemmArgs a{};
+    const bool a_f32 = (d->a_dtype == MF_F32 && d->dtype == MF_BF16);
+    const int aes = a_f32 ? 4 : es;
     a.a0 = (const char*)d->a0; a.a1 = (const char*)d->a1;
     a.C0 = d->c0; a.Ctot = d->c0 + d->c1;
-    a.lda0 = d->lda0; a.lda1 = d->lda1;
-    a.a_f32 = (d->a_dtype == MF_F32 && d->dtype == MF_BF16) ? 1 : 0;
+    MF_CHECK_ARG(d->lda0 * aes < (1ll << 31) && d->lda1 * aes < (1ll << 31), "mf_gemm_conv: pixel stride too large");
+    MF_CHECK_ARG((int64_t)d->batch * d->h_in * d->w_in < (1ll << 31), "mf_gemm_conv: too many input pixels");
+    a.ld0b = (int)(d->lda0 * aes); a.ld1b = (int)(d->lda1 * aes);
     a.Hin = d->h_in; a.Win = d->w_in; a.Ho = d->h_out; a.Wo = d->w_out; a.HoWo = d->h_out * d->w_out;
     a.KW = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.ups = d->upsample;
     a.w = (const char*)d->w; a.ldw = d->ldw;
@@ -415,6 +550,13 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ldc = d->ldc;
     MF_CHECK_ARG(d->nz == 1 || (d->res0 == nullptr && d->res1 == nullptr && d->temb == nullptr),
                  "mf_gemm_conv: residual/temb epilogue is not defined for batched (nz > 1) calls");
+    // the 8-wide vector epilogue needs 8-channel-aligned rows and 16-byte aligned bases everywhere
+    a.vec_ok = (d->n % 8 == 0) && (d->ldc % 8 == 0) && mf_aligned16(d->out) && (d->o_zs_o % 8 == 0) &&
+               (d->o_zs_i % 8 == 0) &&
+               (!d->bias || d->bias_mode == 1 || mf_aligned16(d->bias)) &&
+               (!d->temb || (mf_aligned16(d->temb) && d->ld_temb % 4 == 0)) &&
+               (!d->res0 || (mf_aligned16(d->res0) && d->ld_res0 % 8 == 0)) &&
+               (!d->res1 || (mf_aligned16(d->res1) && d->ld_res1 % 8 == 0));
 
     int tile = d->tile;
     if (tile <= 0 || tile > kNumTiles) tile = pick_tile(a.M, a.N, a.nz, d->splitk);
@@ -426,8 +568,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     if (splitk == 0) {
         // heuristic: fill the 256 CUs when the output grid alone cannot, keeping >= 4 K-tiles per split
         splitk = 1;
-        if (tiles_mn < 160 && a.nkt >= 8 && d->ws != nullptr) {
-            splitk = (int)((256 + tiles_mn - 1) / tiles_mn);
+        if (tiles_mn <= 192 && a.nkt >= 8 && d->ws != nullptr) {
+            splitk = (int)((384 + tiles_mn - 1) / tiles_mn);
             if (splitk > a.nkt / 4) splitk = a.nkt / 4;
             const int64_t per_split = (int64_t)a.nz * a.M * a.N;
             if ((int64_t)splitk * per_split > d->ws_floats) splitk = (int)(d->ws_floats / per_split);
@@ -445,10 +587,15 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.tiles_n = cdiv(a.N, tc.bn);
     const int64_t nblk = (int64_t)cdiv(a.M, tc.bm) * a.tiles_n;
     MF_CHECK_ARG(nblk < (1ll << 31) && (int64_t)a.nz * a.splitk < 65536, "mf_gemm_conv: grid too large");
+    a.nblk = (int)nblk;
     dim3 grid((unsigned)nblk, 1, (unsigned)(a.nz * a.splitk));
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == MF_BF16) launch_tile<MF_BF16>(tile, a, grid, s);
-    else launch_tile<MF_F32>(tile, a, grid, s);
+    if (d->dtype == MF_BF16) {
+        if (a_f32) launch_tile<MF_BF16, true>(tile, a, grid, s);
+        else launch_tile<MF_BF16, false>(tile, a, grid, s);
+    } else {
+        launch_tile<MF_F32, false>(tile, a, grid, s);
+    }
     MF_CHECK_LAUNCH("mf_gemm_conv");
     if (a.splitk > 1) {
         const int64_t total = (int64_t)a.M * a.N * a.nz;

@@ -144,6 +144,108 @@ def scratch(name: str, nfloats: int, device) -> torch.Tensor:
 
 SPLITK_WS_FLOATS = 16 * 1024 * 1024  # 64 MiB of fp32 slabs
 
+# Optional live profiler used by bench.py: when PROFILE is a list, every mf_gemm_conv launch is bracketed by
+# HIP events on the launch stream and appended as (start_event, end_event, algorithmic_flops).
+PROFILE = None
+
+
+def profile_begin():
+    global PROFILE
+    PROFILE = []
+
+
+def profile_end():
+    """Returns (n_launches, total_seconds, total_flops) for the bracketed mf_gemm_conv launches."""
+    global PROFILE
+    rec, PROFILE = PROFILE, None
+    torch.cuda.synchronize()
+    global LAST_PROFILE
+    LAST_PROFILE = [(a.elapsed_time(b) * 1e-3, f, k) for a, b, f, k in rec]
+    secs = sum(t for t, _, _ in LAST_PROFILE)
+    return len(rec), secs, float(sum(f for _, f, _ in LAST_PROFILE))
+
+
+LAST_PROFILE = []
+
+
+# ---- per-shape autotuning of (tile, split-K) ---------------------------------------------------------
+# The library's heuristic is only a prior; the host times every instantiated tile (and a few split-K factors
+# for grids that cannot fill 256 CUs) the first time a GEMM shape is seen and remembers the winner.  Winners
+# are persisted in tune_cache.json next to this file so later processes (and graph capture) start tuned.
+AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
+_TUNE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_cache.json")
+_tune: Optional[dict] = None
+_tune_dirty = False
+
+
+def _tune_load() -> dict:
+    global _tune
+    if _tune is None:
+        _tune = {}
+        try:
+            import json
+            with open(_TUNE_PATH) as f:
+                _tune = {k: tuple(v) for k, v in json.load(f).items()}
+        except Exception:
+            _tune = {}
+    return _tune
+
+
+def tune_save() -> None:
+    global _tune_dirty
+    if _tune is not None and _tune_dirty:
+        import json
+        try:
+            with open(_TUNE_PATH, "w") as f:
+                json.dump({k: list(v) for k, v in sorted(_tune.items())}, f, indent=0)
+            _tune_dirty = False
+        except OSError:
+            pass
+
+
+def _tuned_config(d: "GemmDesc", key: tuple):
+    global _tune_dirty
+    cache = _tune_load()
+    ks = ",".join(str(int(x)) for x in key)
+    hit = cache.get(ks)
+    if hit is not None:
+        return hit
+    if torch.cuda.is_current_stream_capturing():
+        return (0, 0)
+    lib = load()
+    m, n, k = key[2], key[3], key[4]
+    es = 2 if key[0] == MF_BF16 else 4
+    nkt = (k * es + 127) // 128
+    cands = []
+    ntiles = lib.mf_gemm_num_tiles()
+    bm, bn = C.c_int(), C.c_int()
+    for t in range(1, ntiles + 1):
+        lib.mf_gemm_tile_shape(t, C.byref(bm), C.byref(bn))
+        blocks = -(-m // bm.value) * -(-n // bn.value) * key[9]
+        sks = [1]
+        if blocks < 512 and nkt >= 8:
+            sks += [s for s in (2, 3, 4, 6, 8, 12, 16, 24) if s <= nkt // 4 and blocks * s <= 2048
+                    and s * key[9] * m * n <= d.ws_floats]
+        cands += [(t, s) for s in sks]
+    best, best_t = (0, 0), float("inf")
+    st = _stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for t, s in cands:
+        d.tile, d.splitk = t, s
+        if lib.mf_gemm_conv(C.byref(d), st) != 0:
+            continue
+        e0.record()
+        for _ in range(3):
+            lib.mf_gemm_conv(C.byref(d), st)
+        e1.record()
+        e1.synchronize()
+        dt = e0.elapsed_time(e1)
+        if dt < best_t:
+            best, best_t = (t, s), dt
+    cache[ks] = best
+    _tune_dirty = True
+    return best
+
 
 def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype: torch.dtype,
               c0: int, lda0: int, batch: int, h_in: int, w_in: int, h_out: int, w_out: int,
@@ -190,6 +292,17 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype: to
     ws = scratch("splitk", SPLITK_WS_FLOATS, out.device)
     d.splitk, d.ws, d.ws_floats = splitk, ws.data_ptr(), ws.numel()
     d.tile = tile
+    if tile == 0 and splitk == 0 and AUTOTUNE:
+        d.tile, d.splitk = _tuned_config(d, (dt_code(dtype), d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh,
+                                             stride, int(upsample), int(c1 > 0), nz))
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(load().mf_gemm_conv(C.byref(d), _stream()), "mf_gemm_conv")
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * batch * h_out * w_out * n * kh * kw * (c0 + c1) * nz,
+                        (batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), nz, d.tile, d.splitk)))
+        return out
     _check(load().mf_gemm_conv(C.byref(d), _stream()), "mf_gemm_conv")
     return out
 

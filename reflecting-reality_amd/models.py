@@ -495,14 +495,14 @@ class BrushNetModel(_UNetCore):
                 timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
                 guess_mode: bool = False, return_dict: bool = True):
         """brushnet.py:678-925.  Returns NCHW-shaped channels-last views (see module docstring)."""
-        if not self._ready:
-            raise RuntimeError("BrushNetModel has no parameters loaded")
         c = self.config
         order = c["brushnet_conditioning_channel_order"]
         if order == "bgr":
             brushnet_cond = torch.flip(brushnet_cond, dims=[1])
         elif order != "rgb":
             raise ValueError(f"unknown `brushnet_conditioning_channel_order`: {order}")        # brushnet.py:741
+        if not self._ready:
+            raise RuntimeError("BrushNetModel has no parameters loaded")
         if guess_mode:
             raise NotImplementedError("guess_mode logspace scaling (brushnet.py:896-902) is off in every MirrorFusion config")
         if class_labels is not None or timestep_cond is not None or attention_mask is not None or added_cond_kwargs:

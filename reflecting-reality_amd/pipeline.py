@@ -296,7 +296,7 @@ class StableDiffusionBrushNetPipeline:
                  control_guidance_end: Union[float, List[float]] = 1.0, clip_skip: Optional[int] = None,
                  callback_on_step_end: Optional[Callable] = None,
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"],
-                 conditioning_noise: Optional[torch.Tensor] = None, **kwargs):
+                 conditioning_noise: Optional[torch.Tensor] = None, _timing: Optional[dict] = None, **kwargs):
         callback = kwargs.pop("callback", None)
         callback_steps = kwargs.pop("callback_steps", None)
         if ip_adapter_image is not None or ip_adapter_image_embeds is not None or normals is not None:
@@ -342,6 +342,10 @@ class StableDiffusionBrushNetPipeline:
                 for i in range(len(ts))]                                                             # :1236-1242
         fused_ddim = isinstance(self.scheduler, DDIMScheduler) and eta == 0.0
         num_warmup = len(ts) - num_inference_steps * self.scheduler.order
+        if _timing is not None:          # HIP events on the launch stream around the denoise loop (bench.py)
+            _timing["denoise_start"] = torch.cuda.Event(enable_timing=True)
+            _timing["denoise_end"] = torch.cuda.Event(enable_timing=True)
+            _timing["denoise_start"].record()
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(ts):                                                               # :1250 HOT LOOP
                 x_in = torch.cat([latents] * 2) if do_cfg else latents                               # :1256
@@ -370,6 +374,8 @@ class StableDiffusionBrushNetPipeline:
                     if callback is not None and callback_steps and i % callback_steps == 0:
                         callback(i // getattr(self.scheduler, "order", 1), t, latents)
 
+        if _timing is not None:
+            _timing["denoise_end"].record()
         if output_type != "latent":
             sf = float(self.vae.config["scaling_factor"])
             z = hip.axpby_n([latents.contiguous()], [1.0 / sf])                                     # :1342

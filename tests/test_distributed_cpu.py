@@ -1,0 +1,42 @@
+"""world_size-2 gloo run of the multi-GPU harness logic (sharding, barrier, max-over-ranks timing) on CPU."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch
+    from reflecting_reality_amd import distributed as D
+    rank, world, local = D.init_process_group("gloo")
+    assert world == 2 and torch.distributed.get_backend() == "gloo"
+    items = list(range(9))
+    mine = D.shard(items, rank, world)
+    D.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))                     # rank 1 is the slow one
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    total = D.sum_over_ranks(len(mine))
+    D.barrier()
+    print("RESULT " + json.dumps(dict(rank=rank, mine=mine, dt=dt, total=total)), flush=True)
+""") % ROOT
+
+
+def test_two_rank_gloo_sharding_and_timing(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    res = sorted((json.loads(l.split("RESULT ", 1)[1]) for l in out.stdout.splitlines() if "RESULT " in l),
+                 key=lambda r: r["rank"])
+    assert len(res) == 2
+    assert res[0]["mine"] == [0, 1, 2, 3, 4] and res[1]["mine"] == [5, 6, 7, 8]      # contiguous, extra item to rank 0
+    assert res[0]["total"] == res[1]["total"] == 9
+    assert abs(res[0]["dt"] - res[1]["dt"]) < 1e-9 and res[0]["dt"] >= 0.1             # both report the slow rank's time

@@ -1,0 +1,159 @@
+"""Host-side logic that needs no GPU: scheduler tables / coefficients against the reference's golden vectors,
+parameter enumeration against the reference's state-dict tables, input validation, image-processor semantics,
+batch sharding."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mirrorfusion_ref as R
+from reflecting_reality_amd import configs, distributed as D, synth
+from reflecting_reality_amd.models import AutoencoderKL, BrushNetModel, UNet2DConditionModel
+from reflecting_reality_amd.pipeline import StableDiffusionBrushNetPipeline, VaeImageProcessor
+from reflecting_reality_amd.schedulers import DDIMScheduler, PNDMScheduler
+from util import golden, keys
+
+SD = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+          steps_offset=1, set_alpha_to_one=False)
+
+
+@pytest.mark.parametrize("size,ucfg,vcfg", [("tiny", configs.TINY_UNET, configs.TINY_VAE),
+                                            ("sd15", configs.SD15_UNET, configs.SD15_VAE)])
+def test_param_tables_match_reference_state_dicts(size, ucfg, vcfg):
+    ref = keys(size)
+    models = dict(unet=UNet2DConditionModel(dict(ucfg), device="cpu"),
+                  brushnet=BrushNetModel(dict(configs.brushnet_config(ucfg, 6)), device="cpu"),
+                  vae=AutoencoderKL(dict(vcfg), device="cpu"))
+    for name, m in models.items():
+        mine = {k: tuple(v) for k, v in m.param_shapes().items()}
+        assert mine == ref[name], f"{size}/{name}: parameter table differs from the reference state dict"
+    if size == "sd15":   # BASELINE.md §2 parameter counts
+        count = {n: sum(int(np.prod(s)) for s in m.param_shapes().values()) for n, m in models.items()}
+        assert round(count["unet"] / 1e6, 1) == 859.5 and round(count["brushnet"] / 1e6, 1) == 618.8
+        assert round(count["vae"] / 1e6, 1) == 83.7
+
+
+def test_scheduler_tables_and_coefficients():
+    G = golden("schedulers.npz")
+    for n in (4, 50):
+        d = DDIMScheduler(**SD, clip_sample=False)
+        d.set_timesteps(n)
+        assert d.timesteps.tolist() == G[f"ddim_timesteps_{n}"].tolist()
+        p = PNDMScheduler(**SD, skip_prk_steps=True)
+        p.set_timesteps(n)
+        assert p.timesteps.tolist() == G[f"pndm_timesteps_{n}"].tolist()
+    assert np.allclose(d.alphas_cumprod.numpy(), G["alphas_cumprod"], rtol=0, atol=0)
+    d = DDIMScheduler(**SD, clip_sample=False)
+    d.set_timesteps(50)
+    sa, sb, sp, dirc, std = d.step_coefficients(981)
+    a_t, a_p = float(d.alphas_cumprod[981]), float(d.alphas_cumprod[961])
+    assert abs(sa - a_t ** 0.5) < 1e-7 and abs(sb - (1 - a_t) ** 0.5) < 1e-7
+    assert abs(sp - a_p ** 0.5) < 1e-7 and abs(dirc - (1 - a_p) ** 0.5) < 1e-7 and std == 0.0
+    # last step uses final_alpha_cumprod = alphas_cumprod[0] (set_alpha_to_one False)
+    assert abs(d.step_coefficients(1)[2] - float(d.alphas_cumprod[0]) ** 0.5) < 1e-7
+    # reference test_scheduler_ddim.py:110-120 (_get_variance) with its own config
+    t = DDIMScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear")
+    for (a, b), v in {(0, 0): 0.0, (420, 400): 0.14771, (980, 960): 0.32460, (487, 486): 0.00979, (999, 998): 0.02}.items():
+        assert abs(float(t._get_variance(a, b)) - v) < 1e-5
+    t.set_timesteps(5)
+    t2 = DDIMScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, steps_offset=1)
+    t2.set_timesteps(5)
+    assert t2.timesteps.tolist() == [801, 601, 401, 201, 1]          # test_scheduler_ddim.py:63-67
+    with pytest.raises(ValueError):
+        DDIMScheduler().step_coefficients(10)                          # "run set_timesteps first" (:387-390)
+
+
+def test_from_config_uses_target_defaults_for_unset_keys():
+    """configuration_utils.py:458-459,649: a PNDM config carries no clip_sample -> DDIM's own default applies."""
+    p = PNDMScheduler(**SD, skip_prk_steps=True)
+    d = DDIMScheduler.from_config(p.config)
+    assert d.config.steps_offset == 1 and d.config.beta_schedule == "scaled_linear" and d.config.clip_sample is True
+    assert "skip_prk_steps" not in d.config
+
+
+def test_image_processor_semantics():
+    ip = VaeImageProcessor(vae_scale_factor=8, do_convert_rgb=True)
+    img = torch.rand(2, 3, 16, 16)
+    assert torch.equal(ip.preprocess(img, 16, 16), 2.0 * img - 1.0)
+    neg = torch.rand(1, 1, 16, 16) * 2 - 1                       # depth in [-1,1] passes through (image_processor.py:540-547)
+    assert torch.equal(ip.preprocess(neg, 16, 16), neg)
+    lat = torch.rand(1, 4, 8, 8)
+    assert ip.preprocess(lat) is lat or torch.equal(ip.preprocess(lat), lat)   # 4 channels = latents (:532-533)
+    # mask polarity (pipeline_brushnet.py:1139): white (1.0) -> 0 = hole, black -> 1 = keep
+    m = torch.zeros(1, 3, 4, 4); m[:, :, :2] = 1.0
+    pm = ip.preprocess(m, 4, 4)
+    one_ch = (pm.sum(1)[:, None] < 0).float()
+    assert one_ch[0, 0, 0, 0] == 0.0 and one_ch[0, 0, 3, 3] == 1.0
+    arr = ip.postprocess(torch.zeros(1, 3, 4, 4), output_type="np")
+    assert arr.shape == (1, 4, 4, 3) and np.allclose(arr, 0.5)
+    with pytest.raises(ValueError):
+        ip.preprocess("not an image")
+
+
+def _pipe():
+    mk = lambda cls, cfg: cls(dict(cfg), device="cpu")
+    return StableDiffusionBrushNetPipeline(
+        vae=mk(AutoencoderKL, configs.TINY_VAE), text_encoder=None, tokenizer=None,
+        unet=mk(UNet2DConditionModel, configs.TINY_UNET),
+        brushnet=mk(BrushNetModel, configs.brushnet_config(configs.TINY_UNET, 6)),
+        scheduler=DDIMScheduler(**SD, clip_sample=False), safety_checker=None, feature_extractor=None,
+        requires_safety_checker=False, depth_conditioning_mode="concat")
+
+
+def test_check_inputs_error_conventions():
+    """pipeline_brushnet.py:573-693."""
+    pipe = _pipe()
+    img = torch.rand(1, 3, 16, 16)
+    pe = torch.zeros(1, 77, 32)
+    ok = dict(prompt=None, image=img, mask=img, callback_steps=None, prompt_embeds=pe, negative_prompt_embeds=pe,
+              depth=img[:, :1])
+    pipe.check_inputs(**ok)
+    with pytest.raises(TypeError):
+        pipe.check_inputs(**{**ok, "brushnet_conditioning_scale": 1})          # must be float (:649-650)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(**{**ok, "prompt": "x"})                              # both prompt and embeds
+    with pytest.raises(ValueError):
+        pipe.check_inputs(**{**ok, "prompt_embeds": None})                      # neither
+    with pytest.raises(ValueError):
+        pipe.check_inputs(**{**ok, "negative_prompt_embeds": torch.zeros(1, 7, 32)})
+    with pytest.raises(ValueError):
+        pipe.check_inputs(**{**ok, "control_guidance_start": 0.6, "control_guidance_end": 0.5})
+    with pytest.raises(ValueError):
+        pipe.check_inputs(**{**ok, "callback_steps": 0})
+    with pytest.raises(ValueError):
+        pipe.check_inputs(**{**ok, "depth": None})
+    with pytest.raises(ValueError):
+        BrushNetModel(dict(configs.brushnet_config(configs.TINY_UNET, 6), brushnet_conditioning_channel_order="xyz"),
+                      device="cpu").forward(img, 1, None, img)                  # brushnet.py:741 (after "no parameters")
+
+
+def test_models_fail_loudly_without_gpu_or_weights():
+    u = UNet2DConditionModel(dict(configs.TINY_UNET), device="cpu")
+    with pytest.raises(RuntimeError):
+        u(torch.zeros(1, 4, 8, 8), 1, torch.zeros(1, 77, 32))                   # no parameters loaded
+    with pytest.raises(RuntimeError):
+        u.load_state_dict({})                                                    # strict key check
+    with pytest.raises(NotImplementedError):
+        UNet2DConditionModel(dict(configs.TINY_UNET, down_block_types=("AttnDownBlock2D", "DownBlock2D")), device="cpu")
+
+
+def test_synth_is_key_seeded_and_order_independent():
+    a = synth.fill("down_blocks.0.resnets.0.conv1.weight", (8, 4, 3, 3), 0)
+    b = synth.fill("down_blocks.0.resnets.0.conv1.weight", (8, 4, 3, 3), 0)
+    c = synth.fill("down_blocks.0.resnets.0.conv1.weight", (8, 4, 3, 3), 1)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert abs(float(synth.fill("x.norm1.weight", (64,)).mean()) - 1.0) < 0.1
+    assert float(synth.fill("brushnet_down_blocks.0.weight", (32, 32, 1, 1)).abs().max()) > 0   # zero-convs made live
+    i1, i2 = synth.pipeline_inputs(2, 16, 16, vae_scale=2), synth.pipeline_inputs(2, 16, 16, vae_scale=2)
+    assert all(torch.equal(i1[k], i2[k]) for k in i1)
+    assert i1["vae_noise"].shape == (4, 4, 8, 8) and float(i1["mask"].mean()) == 0.25
+
+
+def test_shard_range_matches_accelerate_split():
+    # accelerate.PartialState.split_between_processes: first `n % world` ranks get one extra item, contiguous
+    assert [D.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [D.shard_range(3, r, 8) for r in range(8)] == [(0, 1), (1, 2), (2, 3)] + [(3, 3)] * 5
+    items = list(range(37))
+    got = sum((D.shard(items, r, 8) for r in range(8)), [])
+    assert got == items
