@@ -35,6 +35,8 @@ extern "C" {
 
 #define MF_ACT_NONE 0
 #define MF_ACT_SILU 1
+/* GEGLU fused into the GEMM: weight rows interleaved [4 value rows | 4 gate rows]; writes n/2 channels */
+#define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
 #define MF_ABI_VERSION 4

@@ -47,7 +47,7 @@ struct GemmArgs {
     const char* res1; int res1_dt; int64_t ld_res1;
     float alpha; int act;
     char* out; int out_dt; int64_t ldc;
-    int tiles_n, nblk, vec_ok;
+    int tiles_n, nblk, vec_ok, fast;
 };
 
 // Scalar epilogue for one output element (tails, misaligned outputs, split-K reduce).
@@ -112,6 +112,22 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
     if (p.act == MF_ACT_SILU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = silu_precise(v[j]);
+    }
+    if (p.act == MF_ACT_GEGLU4) {
+        // weight rows are interleaved [4 values | 4 gates]: out[n/2 + j] = v[j] * gelu_erf(v[4 + j])  (activations.py:100-103)
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = v[j] * (0.5f * v[4 + j] * (1.0f + erff(v[4 + j] * 0.70710678118654752440f)));
+        const int64_t o = zo + (int64_t)m * p.ldc + (n >> 1);
+        if (p.out_dt == MF_F32) {
+            *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(g[0], g[1], g[2], g[3]);
+        } else {
+            uint2 u;
+            u.x = (uint32_t)f32_to_bf16(g[0]) | ((uint32_t)f32_to_bf16(g[1]) << 16);
+            u.y = (uint32_t)f32_to_bf16(g[2]) | ((uint32_t)f32_to_bf16(g[3]) << 16);
+            *reinterpret_cast<uint2*>(p.out + o * 2) = u;
+        }
+        return;
     }
     const int64_t o = zo + (int64_t)m * p.ldc + n;
     if (p.out_dt == MF_F32) {
@@ -272,6 +288,65 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
         advance_k();
     };
 
+    // ---- fast staging path: every K tile lies inside one (tap, segment) -----------------------------
+    // (all channel counts multiples of BK): per-row source pointers advance by a constant per tile and are
+    // recomputed only when the tap or the segment changes, which is uniform for the whole block.
+    const char* aptr[A_IT]; int ainc[A_IT];
+    const char* wptr[B_IT]; int winc[B_IT];
+    int f_ky = 0, f_kx = 0, f_seg = 0, f_left = 0, f_cin = 0;    // scalar (block-uniform) state
+    auto fast_retarget = [&]() {
+        const char* base = f_seg ? a1 : a0;
+        const int ldb = f_seg ? p.ld1b : p.ld0b;
+        const int ccb = (f_cin + chunk * VEC) * AES;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int iy = a_iy0[i] + f_ky, ix = a_ix0[i] + f_kx;
+            const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+            const int pix = a_pix[i] + (iy >> p.ups) * p.Win + (ix >> p.ups);
+            aptr[i] = ok ? base + ((int64_t)pix * ldb + ccb) : zero;
+            ainc[i] = ok ? BK * AES : 0;
+        }
+    };
+    auto fast_init = [&]() {
+        const int k0 = kt_begin * BK;
+        const int tap = k0 / p.Ctot;
+        const int c0 = k0 - tap * p.Ctot;
+        f_ky = tap / p.KW; f_kx = tap - f_ky * p.KW;
+        f_seg = c0 >= p.C0;
+        f_cin = f_seg ? c0 - p.C0 : c0;
+        f_left = ((f_seg ? p.Ctot - p.C0 : p.C0) - f_cin) / BK;
+        fast_retarget();
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            wptr[i] = w_row[i] ? w_row[i] + ((int64_t)k0 + chunk * VEC) * ES : zero;
+            winc[i] = w_row[i] ? 128 : 0;
+        }
+    };
+    auto issue_tile_fast = [&](int stage) {
+        char* As = smem + stage * STAGE_BYTES + wave * (8 * 128);
+        char* Bs = As + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            dma16(aptr[i], As + i * RPP * 128);
+            aptr[i] += ainc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            dma16(wptr[i], Bs + i * RPP * 128);
+            wptr[i] += winc[i];
+        }
+        if (--f_left == 0) {          // block-uniform: next tile starts a new segment or tap
+            if (f_seg == 0 && p.Ctot > p.C0) {
+                f_seg = 1; f_left = (p.Ctot - p.C0) / BK;
+            } else {
+                f_seg = 0; f_left = p.C0 / BK;
+                if (++f_kx == p.KW) { f_kx = 0; ++f_ky; }
+            }
+            f_cin = 0;
+            fast_retarget();
+        }
+    };
+
     // ---- staging: registers with fp32 -> bf16 conversion (A_F32) -------------------------------
     uint4 ra[A_F32 ? A_IT : 1], rb[A_F32 ? B_IT : 1];
     auto load_tile_regs = [&]() {
@@ -345,11 +420,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
     // ---- main loop ------------------------------------------------------------------------
     if (nt > 0) {
         if constexpr (!A_F32) {
-            issue_tile(0);
-            for (int t = 0; t < nt; ++t) {
-                __syncthreads();     // vmcnt(0)+barrier: tile t has landed for every wave, stage (t+1)&1 is free
-                if (t + 1 < nt) issue_tile((t + 1) & 1);
-                compute(t & 1);
+            if (p.fast) {
+                fast_init();
+                issue_tile_fast(0);
+                for (int t = 0; t < nt; ++t) {
+                    __syncthreads();     // vmcnt(0)+barrier: tile t has landed for every wave, stage (t+1)&1 is free
+                    if (t + 1 < nt) issue_tile_fast((t + 1) & 1);
+                    compute(t & 1);
+                }
+            } else {
+                issue_tile(0);
+                for (int t = 0; t < nt; ++t) {
+                    __syncthreads();
+                    if (t + 1 < nt) issue_tile((t + 1) & 1);
+                    compute(t & 1);
+                }
             }
         } else {
             load_tile_regs();
@@ -417,6 +502,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int64_t mn = (int64_t)p.M * p.N;
+    if (p.vec_ok) {           // N % 8 == 0: 8 channels per thread, 16/32-byte accesses everywhere
+        const int64_t total8 = mn * p.nz / 8;
+        for (int64_t i8 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i8 < total8;
+             i8 += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t idx = i8 * 8;
+            const int z = (int)(idx / mn);
+            const int64_t r = idx - (int64_t)z * mn;
+            const int m = (int)(r / p.N);
+            const int n = (int)(r - (int64_t)m * p.N);
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < p.splitk; ++s) {
+                const float* src = p.ws + ((int64_t)s * p.nz + z) * mn + r;
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                const float4 b = *reinterpret_cast<const float4*>(src + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+            const int zq = z / p.zdiv, zr = z - zq * p.zdiv;
+            epilogue_store8(p, zq * p.o_zs_o + zr * p.o_zs_i, m, n, v);
+        }
+        return;
+    }
     const int64_t total = mn * p.nz;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -548,10 +654,13 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.res1 = (const char*)d->res1; a.res1_dt = d->res1_dtype; a.ld_res1 = d->ld_res1;
     a.alpha = d->alpha; a.act = d->act;
     a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ldc = d->ldc;
+    MF_CHECK_ARG(d->act != MF_ACT_GEGLU4 || (d->n % 8 == 0 && d->ldc % 4 == 0 && d->res0 == nullptr && d->res1 == nullptr &&
+                                             (d->splitk == 0 || d->splitk == 1)),
+                 "mf_gemm_conv: the GEGLU epilogue needs n %% 8 == 0, ldc %% 4 == 0, no residuals and no forced split-K");
     MF_CHECK_ARG(d->nz == 1 || (d->res0 == nullptr && d->res1 == nullptr && d->temb == nullptr),
                  "mf_gemm_conv: residual/temb epilogue is not defined for batched (nz > 1) calls");
     // the 8-wide vector epilogue needs 8-channel-aligned rows and 16-byte aligned bases everywhere
-    a.vec_ok = (d->n % 8 == 0) && (d->ldc % 8 == 0) && mf_aligned16(d->out) && (d->o_zs_o % 8 == 0) &&
+    a.vec_ok = (d->n % 8 == 0) && (d->ldc % (d->act == MF_ACT_GEGLU4 ? 4 : 8) == 0) && mf_aligned16(d->out) && (d->o_zs_o % 8 == 0) &&
                (d->o_zs_i % 8 == 0) &&
                (!d->bias || d->bias_mode == 1 || mf_aligned16(d->bias)) &&
                (!d->temb || (mf_aligned16(d->temb) && d->ld_temb % 4 == 0)) &&
@@ -568,7 +677,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     if (splitk == 0) {
         // heuristic: fill the 256 CUs when the output grid alone cannot, keeping >= 4 K-tiles per split
         splitk = 1;
-        if (tiles_mn <= 192 && a.nkt >= 8 && d->ws != nullptr) {
+        if (tiles_mn <= 192 && a.nkt >= 8 && d->ws != nullptr && d->act != MF_ACT_GEGLU4) {
             splitk = (int)((384 + tiles_mn - 1) / tiles_mn);
             if (splitk > a.nkt / 4) splitk = a.nkt / 4;
             const int64_t per_split = (int64_t)a.nz * a.M * a.N;
@@ -584,6 +693,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(a.splitk == 1 || (a.ws != nullptr && (int64_t)a.splitk * a.nz * a.M * a.N <= d->ws_floats),
                  "mf_gemm_conv: split-K=%d needs a workspace of %lld floats", a.splitk,
                  (long long)a.splitk * a.nz * a.M * a.N);
+    a.fast = (a.C0 % bk == 0) && (a.Ctot % bk == 0);   // every K tile inside one (tap, segment)
+    MF_CHECK_ARG(d->act != MF_ACT_GEGLU4 || a.vec_ok, "mf_gemm_conv: GEGLU epilogue needs 16-byte aligned bias/out");
     a.tiles_n = cdiv(a.N, tc.bn);
     const int64_t nblk = (int64_t)cdiv(a.M, tc.bm) * a.tiles_n;
     MF_CHECK_ARG(nblk < (1ll << 31) && (int64_t)a.nz * a.splitk < 65536, "mf_gemm_conv: grid too large");
@@ -598,9 +709,10 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     }
     MF_CHECK_LAUNCH("mf_gemm_conv");
     if (a.splitk > 1) {
-        const int64_t total = (int64_t)a.M * a.N * a.nz;
+        const int64_t total = (int64_t)a.M * a.N * a.nz / (a.vec_ok ? 8 : 1);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
         MF_CHECK_LAUNCH("mf_gemm_conv(split-K reduce)");
     }

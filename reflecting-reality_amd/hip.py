@@ -15,7 +15,7 @@ import torch
 from . import _build
 
 MF_F32, MF_BF16 = 0, 1
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
 ABI_VERSION = 4
 
 
@@ -223,7 +223,7 @@ def _tuned_config(d: "GemmDesc", key: tuple):
         lib.mf_gemm_tile_shape(t, C.byref(bm), C.byref(bn))
         blocks = -(-m // bm.value) * -(-n // bn.value) * key[9]
         sks = [1]
-        if blocks < 512 and nkt >= 8:
+        if blocks < 512 and nkt >= 8 and not key[10]:
             sks += [s for s in (2, 3, 4, 6, 8, 12, 16, 24) if s <= nkt // 4 and blocks * s <= 2048
                     and s * key[9] * m * n <= d.ws_floats]
         cands += [(t, s) for s in sks]
@@ -292,9 +292,9 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype: to
     ws = scratch("splitk", SPLITK_WS_FLOATS, out.device)
     d.splitk, d.ws, d.ws_floats = splitk, ws.data_ptr(), ws.numel()
     d.tile = tile
-    if tile == 0 and splitk == 0 and AUTOTUNE:
+    if tile == 0 and splitk in (0, 1) and AUTOTUNE:
         d.tile, d.splitk = _tuned_config(d, (dt_code(dtype), d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh,
-                                             stride, int(upsample), int(c1 > 0), nz))
+                                             stride, int(upsample), int(c1 > 0), nz, int(splitk == 1), act))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

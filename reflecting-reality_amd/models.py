@@ -283,7 +283,11 @@ class _UNetCore(HipModel):
             for a in ("attn1", "attn2"):
                 for l in ("to_q", "to_k", "to_v", "to_out.0"):
                     self.P[b + a + "." + l] = self._conv(sd, b + a + "." + l)
-            self.P[b + "ff.net.0.proj"] = self._conv(sd, b + "ff.net.0.proj")
+            # self-attention: q and k read the same tokens -> one GEMM with N = 2C
+            self.P[b + "attn1.to_qk"] = ConvWeight(torch.cat([sd[b + "attn1.to_q.weight"], sd[b + "attn1.to_k.weight"]], 0),
+                                                   None, self.prec, self.device)
+            self.P[b + "ff.net.0.proj"] = ops.geglu_weight(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"],
+                                                           self.prec, self.device)
             self.P[b + "ff.net.2"] = self._conv(sd, b + "ff.net.2")
             i += 1
         self.tdepth[p] = i
@@ -329,17 +333,45 @@ class _UNetCore(HipModel):
 
     def _attention(self, b: str, x: torch.Tensor, ctx: Optional[torch.Tensor], heads: int, residual: torch.Tensor
                    ) -> torch.Tensor:
-        """Attention + AttnProcessor2_0 (attention_processor.py:1213-1286) + the block's residual add."""
+        """Attention + AttnProcessor2_0 (attention_processor.py:1213-1286) + the block's residual add.
+        Self-attention projects q and k with one GEMM; cross-attention K / V^T depend only on the prompt
+        embeddings (attention_processor.py:1253-1254) and are cached across denoise steps."""
         P = self.P
-        src = x if ctx is None else ctx
-        skv = src.shape[1]
-        q = ops.linear(x, P[b + "to_q"])
-        k = ops.linear(src, P[b + "to_k"])
-        ld = (skv + 7) // 8 * 8
-        vt = ops.linear_t(src, P[b + "to_v"], ld)
-        d = q.shape[-1] // heads
-        o = ops.attention(q, k, vt, heads, skv, 1.0 / (d ** 0.5), self.prec)
+        c = x.shape[-1]
+        d = c // heads
+        if ctx is None:
+            skv = x.shape[1]
+            qk = ops.linear(x, P[b + "to_qk"])
+            q, k = qk[..., :c], qk[..., c:]
+            vt = ops.linear_t(x, P[b + "to_v"], (skv + 7) // 8 * 8, out=self._vt_buffer(x, c, skv))
+        else:
+            skv = ctx.shape[1]
+            q = ops.linear(x, P[b + "to_q"])
+            kv = self._cross_kv.get(b)
+            if kv is None:
+                k = ops.linear(ctx, P[b + "to_k"])
+                vt = ops.linear_t(ctx, P[b + "to_v"], (skv + 7) // 8 * 8)
+                self._cross_kv[b] = (k, vt)
+            else:
+                k, vt = kv
+        o = ops.attention(q, k, vt, heads, skv, 1.0 / (d ** 0.5), self.prec, c=c)
         return ops.linear(o, P[b + "to_out.0"], res0=residual)
+
+    def _vt_buffer(self, x: torch.Tensor, c: int, skv: int) -> Optional[torch.Tensor]:
+        """Self-attention V^T needs no zero padding when the token count is a multiple of 8."""
+        if skv % 8 != 0:
+            return None
+        return torch.empty(x.shape[0], c, skv, dtype=self.prec.act, device=x.device)
+
+    def _bind_prompt(self, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+        """Convert the prompt embeddings once and invalidate the cross-attention K/V cache when they change."""
+        key = (encoder_hidden_states.data_ptr(), encoder_hidden_states._version, tuple(encoder_hidden_states.shape),
+               encoder_hidden_states.dtype)
+        if getattr(self, "_ehs_key", None) != key:
+            self._ehs_key = key
+            self._ehs_val = self._ehs(encoder_hidden_states)
+            self._cross_kv = {}
+        return self._ehs_val
 
     def _transformer(self, p: str, x: torch.Tensor, ehs: torch.Tensor, heads: int,
                      inj: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -356,7 +388,7 @@ class _UNetCore(HipModel):
             n = hip.layernorm(h, *P[b + "norm2"], 1e-5, self.prec.act)
             h = self._attention(b + "attn2.", n, ehs, heads, h)
             n = hip.layernorm(h, *P[b + "norm3"], 1e-5, self.prec.act)
-            gg = hip.geglu(ops.linear(n, P[b + "ff.net.0.proj"]), self.prec.act)
+            gg = ops.linear_geglu(n, P[b + "ff.net.0.proj"])
             h = ops.linear(gg, P[b + "ff.net.2"], res0=h)
         return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj)
 
@@ -632,6 +664,7 @@ class UNet2DConditionModel(_UNetCore):
                 self._prepare_transformer(sd, k[: -len("proj_in.weight")])
         self.P["conv_norm_out"] = self._norm(sd, "conv_norm_out")
         self.P["conv_out"] = self._conv(sd, "conv_out")
+        self._cross_kv, self._ehs_key = {}, None
 
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
                 timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
@@ -656,7 +689,7 @@ class UNet2DConditionModel(_UNetCore):
             and up_block_add_samples is not None                                                    # :1202
         bsz = sample.shape[0]
         temb = self._time_embedding(timestep, bsz)
-        ehs = self._ehs(encoder_hidden_states)
+        ehs = self._bind_prompt(encoder_hidden_states)
         x = from_nchw(sample.to(self.device), self.prec, self.cin_pad)
         x = ops.conv2d(x, self.P["conv_in"])
         skips = [x]                                                                                 # :1215 pre-add

@@ -98,6 +98,27 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
     return out
 
 
+def geglu_weight(weight: torch.Tensor, bias: torch.Tensor, prec: Precision, device) -> ConvWeight:
+    """GEGLU.proj ([2*inner, dim]: value rows then gate rows, activations.py:92,100-103) with rows interleaved
+    [4 value | 4 gate] so that mf_gemm_conv's 8-channel epilogue lanes hold matching value/gate pairs."""
+    inner = weight.shape[0] // 2
+    assert inner % 4 == 0
+    idx = torch.arange(inner).view(-1, 4)
+    order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
+    return ConvWeight(weight[order], bias[order], prec, device)
+
+
+def linear_geglu(x: torch.Tensor, lw: ConvWeight, tile: int = 0) -> torch.Tensor:
+    """hidden * gelu(gate) of FeedForward's GEGLU in the GEMM epilogue: [..., K] -> [..., inner]."""
+    k = x.shape[-1]
+    m = x.numel() // k
+    inner = lw.n // 2
+    out = torch.empty(*x.shape[:-1], inner, dtype=lw.prec.act, device=x.device)
+    hip.gemm_conv(x, lw.w, out, dtype=lw.prec.compute, c0=k, lda0=k, batch=m, h_in=1, w_in=1, h_out=1, w_out=1,
+                  n=lw.n, ldc=inner, bias=lw.bias, act=hip.ACT_GEGLU4, splitk=1, tile=tile)
+    return out
+
+
 def linear_t(x: torch.Tensor, lw: ConvWeight, ld_out: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Transposed projection per batch: out[b][n][s] = sum_k W[n][k] x[b][s][k] (+ bias[n]).
 
@@ -140,11 +161,15 @@ FLASH_HEAD_DIMS = (8, 40, 64, 80, 160)
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, skv: int, scale: float,
-              prec: Precision) -> torch.Tensor:
-    b, sq, c = q.shape
+              prec: Precision, c: Optional[int] = None) -> torch.Tensor:
+    """q: [B, Sq, ldq] and k: [B, Skv, ldk] may be column slices of a fused projection (`c` = model width)."""
+    b, sq, ldq = q.shape
+    c = c or ldq
     d = c // heads
     if prec.compute == torch.bfloat16 and d in FLASH_HEAD_DIMS:
         out = torch.empty(b, sq, c, dtype=torch.bfloat16, device=q.device)
-        return hip.attention_bf16(q, k, vt, out, ldq=c, ldk=c, ldvt=vt.shape[-1], ldo=c, batch=b, heads=heads,
-                                  sq=sq, skv=skv, head_dim=d, scale=scale)
+        return hip.attention_bf16(q, k, vt, out, ldq=q.stride(1), ldk=k.stride(1), ldvt=vt.shape[-1], ldo=c, batch=b,
+                                  heads=heads, sq=sq, skv=skv, head_dim=d, scale=scale)
+    if q.stride(1) != c or k.stride(1) != c:
+        q, k = q.contiguous(), k.contiguous()
     return attention_unfused(q, k, vt, heads, skv, scale, prec)

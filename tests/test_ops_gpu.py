@@ -311,3 +311,20 @@ def test_elementwise_and_layout():
     src = torch.randn(2, 3, 64, 48, generator=g)
     check("nearest", hip.nearest_resize(src.to(DEV), 8, 6), F.interpolate(src, size=(8, 6)), 0, 0)
     check("nearest2", hip.nearest_resize(src.to(DEV), 20, 10), F.interpolate(src, size=(20, 10)), 0, 0)
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
+def test_linear_geglu_fused(prec_name, atol, rtol):
+    """FeedForward's GEGLU (activations.py:100-103) computed in the GEMM epilogue on interleaved weight rows."""
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(300, 64, generator=g)
+    w = torch.randn(2 * 256, 64, generator=g) / 8
+    b = torch.randn(2 * 256, generator=g)
+    if prec_name == "bf16":
+        x, w = rb(x), rb(w)
+    h, gate = F.linear(x, w, b).chunk(2, dim=-1)
+    ref = h * F.gelu(gate)
+    y = ops.linear_geglu(x.to(DEV, prec.act), ops.geglu_weight(w, b, prec, DEV))
+    assert y.shape == (300, 256)
+    check(f"linear_geglu[{prec_name}]", y, ref, atol, rtol)
