@@ -39,7 +39,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 4
+#define MF_ABI_VERSION 6
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -112,7 +112,7 @@ int mf_gemm_tile_shape(int tile, int* bm, int* bn);
  * mf_groupnorm — GroupNorm over NHWC (optionally over the channel-concat of two tensors),
  * fused with SiLU.  Replaces torch.nn.GroupNorm + SiLU (resnet.py:337-338,381,393;
  * transformer_2d.py:158,338; unet_2d_condition.py:1336-1338; vae.py; attention_processor.py:1244).
- * `ws` is a scratch buffer of mf_groupnorm_ws_floats(batch, groups) floats.
+ * `ws` is a scratch buffer of mf_groupnorm_ws_floats(batch, groups, c0 + c1) floats.
  * ------------------------------------------------------------------------------------------ */
 typedef struct mf_groupnorm_desc {
     const void* x0; const void* x1;   /* NHWC segments; x1 may be NULL */
@@ -127,7 +127,7 @@ typedef struct mf_groupnorm_desc {
     float* ws;
 } mf_groupnorm_desc;
 int mf_groupnorm(const mf_groupnorm_desc* d, void* stream);
-int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups);
+int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups, int32_t channels);
 
 /* LayerNorm over the last dim of [rows][c]; replaces nn.LayerNorm (attention.py:203,233,261). */
 int mf_layernorm(const void* x, int32_t in_dtype, void* out, int32_t out_dtype, const float* gamma,
@@ -177,6 +177,11 @@ int mf_silu_f32(const float* x, float* out, int64_t n, void* stream);
 int mf_cfg_ddim_step(const float* eps_u, const float* eps_c, float g, const float* x, float* x_prev,
                      float sqrt_at, float sqrt_1m_at, float sqrt_ap, float dir_coef, int32_t pred_type,
                      float clip, float* eps_out, int64_t n, void* stream);
+/* Same update with the four coefficients {sqrt_at, sqrt_1m_at, sqrt_ap, dir_coef} read from DEVICE memory, so a
+ * captured hipGraph of the whole denoise step can be replayed for every timestep (the host only refreshes the
+ * coefficient / timestep buffers between replays).  x_prev may alias x (in-place). */
+int mf_cfg_ddim_step_dev(const float* eps_u, const float* eps_c, float g, const float* x, float* x_prev,
+                         const float* coef4, int32_t pred_type, float clip, int64_t n, void* stream);
 /* CFG combine only (PNDM keeps its own history on the host side): eps = eu + g*(ec-eu) */
 int mf_cfg_combine(const float* eps_u, const float* eps_c, float g, float* eps, int64_t n, void* stream);
 /* generic y = sum_i c[i]*x[i] (i < nin <= 6) — PNDM/PLMS linear multistep and _get_prev_sample

@@ -113,6 +113,22 @@ __global__ void cfg_ddim_kernel(const float* eu, const float* ec, float g, const
     }
 }
 
+__global__ void cfg_ddim_dev_kernel(const float* eu, const float* ec, float g, const float* x, float* xp,
+                                    const float* coef, int pred_type, float clip, int64_t n) {
+    const float sqrt_at = coef[0], sqrt_1m_at = coef[1], sqrt_ap = coef[2], dir_coef = coef[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float e = eu[i];
+        if (g >= 0.0f) e = e + g * (ec[i] - e);
+        float x0, ep;
+        const float xi = x[i];
+        if (pred_type == 0) { x0 = (xi - sqrt_1m_at * e) / sqrt_at; ep = e; }
+        else { x0 = sqrt_at * xi - sqrt_1m_at * e; ep = sqrt_at * e + sqrt_1m_at * xi; }
+        if (clip > 0.0f) x0 = fminf(fmaxf(x0, -clip), clip);
+        const float dir = dir_coef * ep;
+        xp[i] = sqrt_ap * x0 + dir;
+    }
+}
+
 __global__ void cfg_combine_kernel(const float* eu, const float* ec, float g, float* eps, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float u = eu[i];
@@ -229,6 +245,16 @@ extern "C" int mf_cfg_ddim_step(const float* eps_u, const float* eps_c, float g,
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps_u, eps_c, g, x,
                        x_prev, sqrt_at, sqrt_1m_at, sqrt_ap, dir_coef, pred_type, clip, eps_out, n);
     MF_CHECK_LAUNCH("mf_cfg_ddim_step");
+    return MF_OK;
+}
+
+extern "C" int mf_cfg_ddim_step_dev(const float* eps_u, const float* eps_c, float g, const float* x, float* x_prev,
+                                    const float* coef4, int32_t pred_type, float clip, int64_t n, void* stream) {
+    MF_CHECK_ARG(eps_u && x && x_prev && coef4 && n > 0 && (g < 0.0f || eps_c), "mf_cfg_ddim_step_dev: bad arguments");
+    MF_CHECK_ARG(pred_type == 0 || pred_type == 1, "mf_cfg_ddim_step_dev: pred_type must be 0 or 1");
+    hipLaunchKernelGGL(cfg_ddim_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, eps_u, eps_c, g, x,
+                       x_prev, coef4, pred_type, clip, n);
+    MF_CHECK_LAUNCH("mf_cfg_ddim_step_dev");
     return MF_OK;
 }
 

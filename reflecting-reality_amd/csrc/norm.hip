@@ -15,6 +15,7 @@ struct GnArgs {
     int silu;
     char* out; int out_dt;
     float* ws;   // [batch][G][nchunks][2] = (mean, M2) of each chunk
+    float* ws_ab;   // [batch][2][C] per-channel scale / shift
 };
 
 __device__ __forceinline__ float4 load4(const char* p, int dt, int64_t idx) {
@@ -38,6 +39,33 @@ __device__ __forceinline__ void store4(char* p, int dt, int64_t idx, float4 v) {
     }
 }
 
+__device__ __forceinline__ void load8(const char* p, int dt, int64_t idx, float* o) {
+    if (dt == MF_F32) {
+        const float4 a = *reinterpret_cast<const float4*>(p + idx * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p + idx * 4 + 16);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(p + idx * 2);
+        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+        o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+        o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void store8(char* p, int dt, int64_t idx, const float* v) {
+    if (dt == MF_F32) {
+        *reinterpret_cast<float4*>(p + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + idx * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        uint4 u;
+        u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+        u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+        *reinterpret_cast<uint4*>(p + idx * 2) = u;
+    }
+}
+
 // grid (nchunks, gslices, batch), 256 threads = 4 waves; wave w takes rows r0+w, r0+w+4, ...;
 // lanes take 4-channel column vectors of the slice.  Per-(wave, channel) sums go to LDS, then a
 // fixed-order tree reduces them to one (mean, M2) per group of the slice.
@@ -54,6 +82,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
     int r1 = r0 + p.rows_per_chunk;
     if (r1 > p.HW) r1 = p.HW;
 
+    if (p.C0 % 8 == 0 && p.C1 % 8 == 0 && slice_c % 8 == 0) {
+        const int c8n = slice_c >> 3;
+        for (int c8 = lane; c8 < c8n; c8 += 64) {
+            const int c = cs + c8 * 8;
+            const char* base; int64_t ld; int cc;
+            if (c < p.C0) { base = p.x0; ld = p.C0; cc = c; }
+            else { base = p.x1; ld = p.C1; cc = c - p.C0; }
+            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ss[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int r = r0 + w; r < r1; r += 4) {
+                float v[8];
+                load8(base, p.in_dt, ((int64_t)b * p.HW + r) * ld + cc, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                chan[((w * slice_c) + c8 * 8 + e) * 2 + 0] = s[e];
+                chan[((w * slice_c) + c8 * 8 + e) * 2 + 1] = ss[e];
+            }
+        }
+    } else
     for (int c4 = lane; c4 < c4n; c4 += 64) {
         const int c = cs + c4 * 4;
         const char* base; int64_t ld; int cc;
@@ -102,7 +151,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
 }
 
 // grid (nblocks, batch): combine the chunk statistics (Chan et al., in double), build per-channel
-// scale/shift in LDS, then stream rows: y = silu(x*a[c] + b[c]).
+// scale/shift in LDS, then stream rows: y = silu(x*a[c] + b[c]).  16-byte accesses (8 channels) when both
+// segment widths are multiples of 8, else 4 channels; 32-bit index arithmetic only.
+// grid (nblocks, batch).  Prologue (fully parallel, every load issued before the first use): 8 lanes per
+// group Chan-combine that group's chunk statistics with a fixed-order butterfly, then every thread turns
+// (mean, rstd, gamma, beta) into the per-channel affine y = x*a + b kept in LDS.  Body: stream rows with 16-byte
+// accesses (8 channels) when both segment widths are multiples of 8, else 4 channels.
+template <int VW>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sa = reinterpret_cast<float*>(smem_raw);   // [C] scale
@@ -110,20 +165,44 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int rows_
     float* gm = sb + p.C;                              // [G] mean
     float* gr = gm + p.G;                              // [G] rstd
     const int b = blockIdx.y;
-    for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
-        const float* st = p.ws + ((int64_t)b * p.G + g) * p.nchunks * 2;
+    for (int g0 = 0; g0 < p.G; g0 += 32) {
+        const int g = g0 + (threadIdx.x >> 3), j = threadIdx.x & 7;
+        float pm[8], pq[8];
+        int nk = 0;
+        if (g < p.G) {
+            const float2* st = reinterpret_cast<const float2*>(p.ws + ((int64_t)b * p.G + g) * p.nchunks * 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = j + 8 * u;
+                if (k < p.nchunks) { const float2 t = st[k]; pm[u] = t.x; pq[u] = t.y; nk = u + 1; }
+            }
+        }
         double n = 0.0, mean = 0.0, m2 = 0.0;
-        for (int k = 0; k < p.nchunks; ++k) {
+        for (int u = 0; u < nk; ++u) {
+            const int k = j + 8 * u;
             int rows = p.rows_per_chunk;
             if ((k + 1) * p.rows_per_chunk > p.HW) rows = p.HW - k * p.rows_per_chunk;
-            const double nb = (double)rows * p.cpg, mb = st[2 * k], m2b = st[2 * k + 1];
-            const double nt = n + nb, delta = mb - mean;
+            const double nb = (double)rows * p.cpg, nt = n + nb, delta = (double)pm[u] - mean;
             mean += delta * nb / nt;
-            m2 += m2b + delta * delta * n * nb / nt;
+            m2 += (double)pq[u] + delta * delta * n * nb / nt;
             n = nt;
         }
-        gm[g] = (float)mean;
-        gr[g] = (float)(1.0 / sqrt(m2 / n + (double)p.eps));
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {          // fixed-order butterfly over the 8 lanes of a group
+            const double n2 = __shfl_xor(n, off, 8), mean2 = __shfl_xor(mean, off, 8), m22 = __shfl_xor(m2, off, 8);
+            const double nt = n + n2;
+            if (nt > 0.0) {
+                const double delta = mean2 - mean;
+                const double mnew = (mean * n + mean2 * n2) / nt;      // symmetric: both partners agree bit for bit
+                m2 = m2 + m22 + delta * delta * n * n2 / nt;
+                mean = mnew;
+                n = nt;
+            }
+        }
+        if (g < p.G && j == 0) {
+            gm[g] = (float)mean;
+            gr[g] = (float)(1.0 / sqrt(m2 / n + (double)p.eps));
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
@@ -133,25 +212,34 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int rows_
         sb[c] = p.beta[c] - gm[g] * a;
     }
     __syncthreads();
-    const int c4n = p.C >> 2;
+    const unsigned cvn = (unsigned)p.C / VW;
     const int r0 = blockIdx.x * rows_per_block;
     int r1 = r0 + rows_per_block;
     if (r1 > p.HW) r1 = p.HW;
-    const int64_t items = (int64_t)(r1 - r0) * c4n;
-    for (int64_t it = threadIdx.x; it < items; it += blockDim.x) {
-        const int r = r0 + (int)(it / c4n);
-        const int c = (int)(it % c4n) * 4;
+    const unsigned items = (unsigned)(r1 - r0) * cvn;
+    const bool fast_silu = p.out_dt == MF_BF16;         // bf16 output: __expf is far inside the rounding
+    for (unsigned it = threadIdx.x; it < items; it += 256) {
+        const unsigned rr = it / cvn;
+        const int c = (int)(it - rr * cvn) * VW;
         const char* base; int64_t ld; int cc;
         if (c < p.C0) { base = p.x0; ld = p.C0; cc = c; }
         else { base = p.x1; ld = p.C1; cc = c - p.C0; }
-        const int64_t row = (int64_t)b * p.HW + r;
-        float4 v = load4(base, p.in_dt, row * ld + cc);
-        v.x = v.x * sa[c] + sb[c];
-        v.y = v.y * sa[c + 1] + sb[c + 1];
-        v.z = v.z * sa[c + 2] + sb[c + 2];
-        v.w = v.w * sa[c + 3] + sb[c + 3];
-        if (p.silu) { v.x = silu_precise(v.x); v.y = silu_precise(v.y); v.z = silu_precise(v.z); v.w = silu_precise(v.w); }
-        store4(p.out, p.out_dt, row * p.C + c, v);
+        const int64_t row = (int64_t)b * p.HW + r0 + (int)rr;
+        float v[8];
+        if (VW == 8) {
+            load8(base, p.in_dt, row * ld + cc, v);
+        } else {
+            const float4 t = load4(base, p.in_dt, row * ld + cc);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+            float y = v[j] * sa[c + j] + sb[c + j];
+            if (p.silu) y = fast_silu ? silu_f(y) : silu_precise(y);
+            v[j] = y;
+        }
+        if (VW == 8) store8(p.out, p.out_dt, row * p.C + c, v);
+        else store4(p.out, p.out_dt, row * p.C + c, make_float4(v[0], v[1], v[2], v[3]));
     }
 }
 
@@ -232,8 +320,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, char*
 
 }  // namespace
 
-extern "C" int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups) {
-    return (int64_t)batch * groups * GN_MAX_CHUNKS * 2;
+extern "C" int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups, int32_t channels) {
+    return (int64_t)batch * groups * GN_MAX_CHUNKS * 2 + (int64_t)batch * channels * 2;
 }
 
 extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
@@ -256,6 +344,8 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     a.nchunks = (d->hw + a.rows_per_chunk - 1) / a.rows_per_chunk;
     a.eps = d->eps; a.gamma = d->gamma; a.beta = d->beta; a.silu = d->silu;
     a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ws = d->ws;
+    a.ws_ab = d->ws + (int64_t)d->batch * d->groups * GN_MAX_CHUNKS * 2;
+    MF_CHECK_ARG(d->groups <= 64, "mf_groupnorm: at most 64 groups");
     const int slice_c = (a.G / a.gslices) * a.cpg;
     const size_t smem1 = (size_t)4 * slice_c * 2 * sizeof(float);
     MF_CHECK_ARG(smem1 <= 64 * 1024, "mf_groupnorm: slice of %d channels too large", slice_c);
@@ -265,10 +355,13 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     const size_t smem2 = (size_t)(2 * C + 2 * a.G) * sizeof(float);
     MF_CHECK_ARG(smem2 <= 64 * 1024, "mf_groupnorm: C=%d too large", C);
     // ~8 blocks per CU worth of row blocks, at least 4 rows each
-    int rows_per_block = (int)(((int64_t)d->hw * d->batch + 2047) / 2048);
-    if (rows_per_block < 4) rows_per_block = 4;
+    int rows_per_block = (int)(((int64_t)d->hw * d->batch + 1023) / 1024);
+    if (rows_per_block < 8) rows_per_block = 8;
     const int nblk = (d->hw + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, d->batch), dim3(256), smem2, s, a, rows_per_block);
+    if (d->c0 % 8 == 0 && d->c1 % 8 == 0)
+        hipLaunchKernelGGL(gn_apply_kernel<8>, dim3(nblk, d->batch), dim3(256), smem2, s, a, rows_per_block);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nblk, d->batch), dim3(256), smem2, s, a, rows_per_block);
     MF_CHECK_LAUNCH("mf_groupnorm(apply)");
     return MF_OK;
 }

@@ -16,7 +16,7 @@ from . import _build
 
 MF_F32, MF_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 6
 
 
 class MfhipError(RuntimeError):
@@ -71,7 +71,7 @@ EXPORTS = [
     "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape",
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
-    "mf_cfg_ddim_step", "mf_cfg_combine", "mf_axpby_n", "mf_vae_sample", "mf_nearest_resize",
+    "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_vae_sample", "mf_nearest_resize",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -327,7 +327,7 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, grou
     d.gamma, d.beta, d.silu = _ptr(gamma), _ptr(beta), int(silu)
     d.out, d.out_dtype = _ptr(out), dt_code(out.dtype)
     lib = load()
-    ws = scratch("gn", int(lib.mf_groupnorm_ws_floats(b, groups)), x0.device)
+    ws = scratch("gn", int(lib.mf_groupnorm_ws_floats(b, groups, c0 + c1)), x0.device)
     d.ws = ws.data_ptr()
     _check(lib.mf_groupnorm(C.byref(d), _stream()), "mf_groupnorm")
     return out
@@ -440,6 +440,18 @@ def cfg_ddim_step(eps_u: torch.Tensor, eps_c: Optional[torch.Tensor], g: float, 
                                    C.c_float(sqrt_1m_at), C.c_float(sqrt_ap), C.c_float(dir_coef), pred_type,
                                    C.c_float(clip), C.c_void_p(_ptr(eps_out)), C.c_int64(x.numel()), _stream()),
            "mf_cfg_ddim_step")
+    return xp
+
+
+def cfg_ddim_step_dev(eps_u: torch.Tensor, eps_c: Optional[torch.Tensor], g: float, x: torch.Tensor, coef4: torch.Tensor,
+                      pred_type: int = 0, clip: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """DDIM update with device-resident coefficients (graph replay); `out` may be `x` itself (in place)."""
+    _req_cuda(eps_u, eps_c, x, coef4, out)
+    xp = out if out is not None else torch.empty_like(x)
+    _check(load().mf_cfg_ddim_step_dev(C.c_void_p(eps_u.data_ptr()), C.c_void_p(_ptr(eps_c)), C.c_float(g),
+                                       C.c_void_p(x.data_ptr()), C.c_void_p(xp.data_ptr()),
+                                       C.c_void_p(coef4.data_ptr()), pred_type, C.c_float(clip),
+                                       C.c_int64(x.numel()), _stream()), "mf_cfg_ddim_step_dev")
     return xp
 
 
