@@ -159,12 +159,53 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
 __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
-    // 64 lanes x 16 B -> LDS [lds_wave_base, +1 KiB), lane-linear; lds_wave_base must be wave-uniform
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+    // 64 lanes x 16 B -> LDS [lds_wave_base, +1 KiB), lane-linear; lds_wave_base must be wave-uniform.
+    // Issued through inline asm ON PURPOSE: hipcc's waitcnt pass cannot tell which LDS bytes a
+    // __builtin_amdgcn_global_load_lds writes, so it drains vmcnt(0) before the next ds_read and serialises the
+    // DMA of tile t+1 behind the MFMAs of tile t.  An asm DMA is invisible to that pass; the ring below orders it
+    // with its own counted s_waitcnt vmcnt(N) + s_barrier (cdna_hip_programming.md 5.7 item 1).
+    const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_off) : "memory");
 }
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const GemmArgs p) {
+typedef __attribute__((ext_vector_type(4))) int srd_t;   // buffer resource descriptor (4 SGPRs)
+
+__device__ __forceinline__ srd_t make_srd(const char* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    srd_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));     // stride 0 (raw buffer)
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);                      // num_records: loads at offset >= this return 0
+    r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ void dma16_buf(unsigned voff, srd_t srd, unsigned lds_off) {
+    // buffer_load ... lds: per-lane 32-bit byte offset into the descriptor, hardware range check (an offset past
+    // num_records writes zeros: that IS the conv zero padding / tile tail), wave-uniform LDS destination in M0.
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 ::"v"(voff), "s"(srd), "s"(lds_off) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// waves per SIMD the LDS footprint allows (register budget follows from it: 512 / waves per lane)
+constexpr int min_waves(int bm, int bn, int stages, int nthr) {
+    const int smem = stages * (bm + bn) * 128;
+    int blocks = 160 * 1024 / smem;
+    if (blocks > 8) blocks = 8;
+    int w = blocks * (nthr / 64) / 4;
+    return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, min_waves(BM, BN, STAGES, WAVES_M* WAVES_N * 64))
+void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;
     constexpr int ES = (DT == MF_F32) ? 4 : 2;   // element size of the compute dtype
     constexpr int AES = A_F32 ? 4 : ES;          // element size of the A storage dtype
@@ -178,7 +219,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
     constexpr int EP_RS = (WN + 4) * 4;          // epilogue slab row stride (bytes)
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-    static_assert(WAVES_M * WAVES_N * 32 * EP_RS <= 2 * STAGE_BYTES, "epilogue slabs must fit in the staging LDS");
+    static_assert(WAVES_M * WAVES_N * 32 * EP_RS <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the staging LDS");
+    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
+    static_assert(!A_F32 || STAGES == 2, "the register-staged path is double buffered");
     static_assert(!A_F32 || DT == MF_BF16, "A_F32 only converts fp32 activations for bf16 compute");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -289,13 +332,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
     };
 
     // ---- fast staging path: every K tile lies inside one (tap, segment) -----------------------------
-    // (all channel counts multiples of BK): per-row source pointers advance by a constant per tile and are
-    // recomputed only when the tap or the segment changes, which is uniform for the whole block.
-    const char* aptr[A_IT]; int ainc[A_IT];
-    const char* wptr[B_IT]; int winc[B_IT];
+    // (all channel counts multiples of BK, tensors < 2 GiB).  Sources are buffer descriptors + a per-lane 32-bit
+    // byte offset that advances by a constant per tile (ONE v_add per row per tile); offsets are recomputed only when
+    // the tap or the segment changes, which is uniform for the whole block.  Out-of-image taps and rows past M / N
+    // carry an offset >= 2^31 > num_records, so the hardware range check writes zeros for them.
+    unsigned aoff[A_IT], woff[B_IT];
+    srd_t srdA0, srdA1, srdW, srdCur;
     int f_ky = 0, f_kx = 0, f_seg = 0, f_left = 0, f_cin = 0;    // scalar (block-uniform) state
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem) + wave * 1024;
     auto fast_retarget = [&]() {
-        const char* base = f_seg ? a1 : a0;
+        srdCur = f_seg ? srdA1 : srdA0;
         const int ldb = f_seg ? p.ld1b : p.ld0b;
         const int ccb = (f_cin + chunk * VEC) * AES;
 #pragma unroll
@@ -303,11 +349,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
             const int iy = a_iy0[i] + f_ky, ix = a_ix0[i] + f_kx;
             const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
             const int pix = a_pix[i] + (iy >> p.ups) * p.Win + (ix >> p.ups);
-            aptr[i] = ok ? base + ((int64_t)pix * ldb + ccb) : zero;
-            ainc[i] = ok ? BK * AES : 0;
+            aoff[i] = ok ? (unsigned)(pix * ldb + ccb) : 0x80000000u;
         }
     };
     auto fast_init = [&]() {
+        const int nb = p.M / p.HoWo;                                    // images in the batch
+        srdA0 = make_srd(a0, (unsigned)((nb * p.Hin * p.Win - 1) * p.ld0b + p.C0 * AES));
+        srdA1 = make_srd(a1, (unsigned)((nb * p.Hin * p.Win - 1) * p.ld1b + (p.Ctot - p.C0) * AES));
+        srdW = make_srd(wbase, (unsigned)(((int64_t)(p.N - 1) * p.ldw + p.K) * ES));
         const int k0 = kt_begin * BK;
         const int tap = k0 / p.Ctot;
         const int c0 = k0 - tap * p.Ctot;
@@ -318,22 +367,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
         fast_retarget();
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            wptr[i] = w_row[i] ? w_row[i] + ((int64_t)k0 + chunk * VEC) * ES : zero;
-            winc[i] = w_row[i] ? 128 : 0;
+            const int n = n0 + lrow + i * RPP;
+            woff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + k0 + chunk * VEC) * ES) : 0x80000000u;
         }
     };
     auto issue_tile_fast = [&](int stage) {
-        char* As = smem + stage * STAGE_BYTES + wave * (8 * 128);
-        char* Bs = As + BM * 128;
+        const unsigned la = lds_base + stage * STAGE_BYTES;
+        const unsigned lb = la + BM * 128;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            dma16(aptr[i], As + i * RPP * 128);
-            aptr[i] += ainc[i];
+            dma16_buf(aoff[i], srdCur, la + i * RPP * 128);
+            aoff[i] += BK * AES;
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            dma16(wptr[i], Bs + i * RPP * 128);
-            wptr[i] += winc[i];
+            dma16_buf(woff[i], srdW, lb + i * RPP * 128);
+            woff[i] += 128;
         }
         if (--f_left == 0) {          // block-uniform: next tile starts a new segment or tap
             if (f_seg == 0 && p.Ctot > p.C0) {
@@ -388,53 +437,81 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_conv_kernel(const 
     const int fh = lane >> 5;                // which half of the k-step this lane holds
     const int fkey = (frow >> 1) & 7;        // swizzle key (tile bases are multiples of 32 rows)
 
+    auto mma = [&](const uint4 (&fa)[MT], const uint4 (&fb)[NT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (DT == MF_BF16) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8_t, fa[i]), __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+                } else {
+                    const f32x4_t av = __builtin_bit_cast(f32x4_t, fa[i]);
+                    const f32x4_t bv = __builtin_bit_cast(f32x4_t, fb[j]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[i][j], 0, 0, 0);
+                }
+            }
+    };
+    // Fragment reads are software-pipelined: the ds_read_b128s of k-step ks+1 are in flight while the MFMAs of
+    // k-step ks run, so one wave alone keeps its matrix pipe fed across the LDS latency.
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE_BYTES + (wm * WM + frow) * 128;
         const char* Bs = smem + stage * STAGE_BYTES + BM * 128 + (wn * WN + frow) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        uint4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        auto ldfrag = [&](int ks, uint4 (&fa)[MT], uint4 (&fb)[NT]) {
             const int coff = (((2 * ks + fh) ^ fkey) << 4);
-            uint4 fa[MT], fb[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(As + i * 32 * 128 + coff);
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + j * 32 * 128 + coff);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if constexpr (DT == MF_BF16) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8_t, fa[i]), __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
-                    } else {
-                        const f32x4_t av = __builtin_bit_cast(f32x4_t, fa[i]);
-                        const f32x4_t bv = __builtin_bit_cast(f32x4_t, fb[j]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[i][j], 0, 0, 0);
-                    }
-                }
-        }
+        };
+        // sched_barrier(0) pins the phase order: without it hipcc folds the two fragment sets into one register set
+        // and re-serialises every k-step behind its own ds_read latency
+        ldfrag(0, fa0, fb0);
+        ldfrag(1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        ldfrag(3, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        mma(fa1, fb1);
     };
 
     // ---- main loop ------------------------------------------------------------------------
     if (nt > 0) {
         if constexpr (!A_F32) {
+            // LDS ring, STAGES-1 tiles in flight while tile t is multiplied.  Only a COUNTED vmcnt (all but the newer
+            // tiles' G = A_IT + B_IT DMAs each) and a raw s_barrier order the ring.  RAW: a tile is read only after
+            // every wave's vmcnt + the barrier; WAR: stage (t + PF) % STAGES was last read in compute(t - 1), which
+            // every wave finished (its MFMAs consumed the ds_reads) before arriving at this barrier.
+            constexpr int G = A_IT + B_IT;
+            constexpr int PF = STAGES - 1;
+            auto ring = [&](auto issue) {
+                for (int s0 = 0; s0 < PF; ++s0)
+                    if (s0 < nt) issue(s0);
+                int st_c = 0, st_i = PF;                 // stage being computed / stage being filled
+                for (int t = 0; t < nt; ++t) {
+                    if (PF == 2 && t + 1 < nt) wait_vmcnt<G>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    if (t + PF < nt) issue(st_i);
+                    compute(st_c);
+                    st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
+                    st_i = st_i == STAGES - 1 ? 0 : st_i + 1;
+                }
+            };
             if (p.fast) {
                 fast_init();
-                issue_tile_fast(0);
-                for (int t = 0; t < nt; ++t) {
-                    __syncthreads();     // vmcnt(0)+barrier: tile t has landed for every wave, stage (t+1)&1 is free
-                    if (t + 1 < nt) issue_tile_fast((t + 1) & 1);
-                    compute(t & 1);
-                }
+                ring(issue_tile_fast);
             } else {
-                issue_tile(0);
-                for (int t = 0; t < nt; ++t) {
-                    __syncthreads();
-                    if (t + 1 < nt) issue_tile((t + 1) & 1);
-                    compute(t & 1);
-                }
+                ring(issue_tile);
             }
         } else {
             load_tile_regs();
@@ -537,40 +614,63 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-struct TileCfg { int bm, bn, threads; };
+struct TileCfg { int bm, bn, threads, stages; };
 // keep in sync with launch_tile()
 const TileCfg kTiles[] = {
-    {128, 128, 256},  // 1
-    {128, 64, 256},   // 2
-    {64, 64, 256},    // 3
-    {256, 64, 256},   // 4
-    {256, 128, 512},  // 5
-    {64, 128, 256},   // 6
+    {128, 128, 256, 2},  // 1
+    {128, 64, 256, 2},   // 2
+    {64, 64, 256, 2},    // 3
+    {256, 64, 256, 2},   // 4
+    {256, 128, 512, 2},  // 5
+    {64, 128, 256, 2},   // 6
+    {128, 128, 256, 3},  // 7   3-stage ring variants (tiles t+1, t+2 in flight)
+    {128, 64, 256, 3},   // 8
+    {64, 64, 256, 3},    // 9
+    {256, 64, 256, 3},   // 10
+    {256, 128, 512, 3},  // 11
+    {64, 128, 256, 3},   // 12
+    {256, 128, 256, 3},  // 13  one wave per SIMD, 128x64 per wave
+    {128, 256, 256, 3},  // 14  one wave per SIMD, 64x128 per wave
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int DT, int BM, int BN, int WMv, int WNv, bool AF>
+template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int smem = 2 * (BM + BN) * 128;
+    constexpr int smem = ST * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF>), grid, dim3(WMv * WNv * 64), smem, s, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST>), grid, dim3(WMv * WNv * 64), smem, s, a);
 }
 
 template <int DT, bool AF>
 void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if (AF && tile > 12) tile = 5;        // the fp32->bf16 converting path is register staged (2 stages)
+    if (AF && tile > 6) tile -= 6;
     switch (tile) {
-        case 1: launch_one<DT, 128, 128, 2, 2, AF>(a, grid, s); break;
-        case 2: launch_one<DT, 128, 64, 2, 2, AF>(a, grid, s); break;
-        case 3: launch_one<DT, 64, 64, 2, 2, AF>(a, grid, s); break;
-        case 4: launch_one<DT, 256, 64, 4, 1, AF>(a, grid, s); break;
-        case 5: launch_one<DT, 256, 128, 4, 2, AF>(a, grid, s); break;
-        case 6: launch_one<DT, 64, 128, 2, 2, AF>(a, grid, s); break;
+        case 1: launch_one<DT, 128, 128, 2, 2, AF, 2>(a, grid, s); break;
+        case 2: launch_one<DT, 128, 64, 2, 2, AF, 2>(a, grid, s); break;
+        case 3: launch_one<DT, 64, 64, 2, 2, AF, 2>(a, grid, s); break;
+        case 4: launch_one<DT, 256, 64, 4, 1, AF, 2>(a, grid, s); break;
+        case 5: launch_one<DT, 256, 128, 4, 2, AF, 2>(a, grid, s); break;
+        case 6: launch_one<DT, 64, 128, 2, 2, AF, 2>(a, grid, s); break;
         default: break;
+    }
+    if constexpr (!AF) {
+        switch (tile) {
+            case 7: launch_one<DT, 128, 128, 2, 2, false, 3>(a, grid, s); break;
+            case 8: launch_one<DT, 128, 64, 2, 2, false, 3>(a, grid, s); break;
+            case 9: launch_one<DT, 64, 64, 2, 2, false, 3>(a, grid, s); break;
+            case 10: launch_one<DT, 256, 64, 4, 1, false, 3>(a, grid, s); break;
+            case 11: launch_one<DT, 256, 128, 4, 2, false, 3>(a, grid, s); break;
+            case 12: launch_one<DT, 64, 128, 2, 2, false, 3>(a, grid, s); break;
+            case 13: launch_one<DT, 256, 128, 2, 2, false, 3>(a, grid, s); break;
+            case 14: launch_one<DT, 128, 256, 2, 2, false, 3>(a, grid, s); break;
+            default: break;
+        }
     }
 }
 
@@ -583,6 +683,7 @@ int pick_tile(int M, int N, int nz, int splitk) {
     for (int t = 1; t <= kNumTiles; ++t) {
         const TileCfg& c = kTiles[t - 1];
         const double tiles = (double)cdiv(M, c.bm) * cdiv(N, c.bn) * nz * (splitk > 1 ? splitk : 1);
+        if (c.stages != 2) continue;                                      // the ring variants are picked by the host autotuner
         const int bpc = (2 * (c.bm + c.bn) * 128 <= 80 * 1024) ? 2 : 1;   // blocks per CU that fit in LDS
         const double rounds = (double)(int64_t)((tiles + 256.0 * bpc - 1) / (256.0 * bpc));
         double per_cu = tiles / 256.0;
@@ -693,7 +794,12 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(a.splitk == 1 || (a.ws != nullptr && (int64_t)a.splitk * a.nz * a.M * a.N <= d->ws_floats),
                  "mf_gemm_conv: split-K=%d needs a workspace of %lld floats", a.splitk,
                  (long long)a.splitk * a.nz * a.M * a.N);
-    a.fast = (a.C0 % bk == 0) && (a.Ctot % bk == 0);   // every K tile inside one (tap, segment)
+    {   // fast staging: every K tile inside one (tap, segment) and every operand addressable with 31-bit offsets
+        const int64_t npix = (int64_t)d->batch * d->h_in * d->w_in;
+        const int64_t ext_a = (npix - 1) * (int64_t)(a.ld0b > a.ld1b ? a.ld0b : a.ld1b) + (int64_t)a.Ctot * aes;
+        const int64_t ext_w = ((int64_t)(a.N - 1) * a.ldw + a.K) * es;
+        a.fast = (a.C0 % bk == 0) && (a.Ctot % bk == 0) && ext_a < (1ll << 31) - (1 << 20) && ext_w < (1ll << 31) - (1 << 20);
+    }
     MF_CHECK_ARG(d->act != MF_ACT_GEGLU4 || a.vec_ok, "mf_gemm_conv: GEGLU epilogue needs 16-byte aligned bias/out");
     a.tiles_n = cdiv(a.N, tc.bn);
     const int64_t nblk = (int64_t)cdiv(a.M, tc.bm) * a.tiles_n;

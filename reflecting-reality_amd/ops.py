@@ -86,13 +86,15 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
 
 def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = None,
            res1: Optional[torch.Tensor] = None, alpha: float = 1.0, act: int = hip.ACT_NONE,
-           out_dtype: Optional[torch.dtype] = None, splitk: int = 0, tile: int = 0) -> torch.Tensor:
+           out_dtype: Optional[torch.dtype] = None, splitk: int = 0, tile: int = 0,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = x @ W^T + b over the last dim of x ([..., K] contiguous)."""
     k = x.shape[-1]
     if k != lw.cin_pad:
         raise hip.MfhipError(f"linear: K={k} != weight K={lw.cin_pad}")
     m = x.numel() // k
-    out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
     hip.gemm_conv(x, lw.w, out, dtype=lw.prec.compute, c0=k, lda0=k, batch=m, h_in=1, w_in=1, h_out=1, w_out=1,
                   n=lw.n, bias=lw.bias, res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
     return out
