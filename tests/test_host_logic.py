@@ -157,3 +157,24 @@ def test_shard_range_matches_accelerate_split():
     items = list(range(37))
     got = sum((D.shard(items, r, 8) for r in range(8)), [])
     assert got == items
+
+
+def test_compat_diffusers_alias_exposes_the_hot_path_names():
+    import importlib
+    import os
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "reflecting-reality_amd", "compat")
+    saved = sys.modules.pop("diffusers", None)
+    sys.path.insert(0, compat)
+    try:
+        d = importlib.import_module("diffusers")
+        for name in ("BrushNetModel", "UNet2DConditionModel", "AutoencoderKL", "DDIMScheduler", "PNDMScheduler",
+                     "StableDiffusionBrushNetPipeline"):
+            assert hasattr(d, name)
+        with pytest.raises(AttributeError):
+            d.UniPCMultistepScheduler
+    finally:
+        sys.path.remove(compat)
+        sys.modules.pop("diffusers", None)
+        if saved is not None:
+            sys.modules["diffusers"] = saved
