@@ -219,7 +219,8 @@ void gemm_conv_kernel(const GemmArgs p) {
     constexpr int EP_RS = (WN + 4) * 4;          // epilogue slab row stride (bytes)
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
-    static_assert(WAVES_M * WAVES_N * 32 * EP_RS <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the staging LDS");
+    constexpr int SR = (WAVES_M * WAVES_N * 32 * EP_RS <= STAGES * STAGE_BYTES) ? 32 : 16;   // rows per epilogue slab
+    static_assert(WAVES_M * WAVES_N * SR * EP_RS <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the staging LDS");
     static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
     static_assert(!A_F32 || STAGES == 2, "the register-staged path is double buffered");
     static_assert(!A_F32 || DT == MF_BF16, "A_F32 only converts fp32 activations for bf16 compute");
@@ -531,27 +532,29 @@ void gemm_conv_kernel(const GemmArgs p) {
     __syncthreads();   // every wave is done reading the staging LDS: reuse it for the epilogue slabs
 
     // ---- epilogue ---------------------------------------------------------------------------
-    char* slab = smem + wave * (32 * EP_RS);        // private to this wave: [32 rows][WN + 4] fp32
-    constexpr int LPR = WN / 8;                      // lanes per output row (8 channels each)
-    constexpr int RPS = 64 / LPR;                    // rows per pass
-    const int er = lane / LPR, ec = (lane - er * LPR) * 8;
+    char* slab = smem + wave * (SR * EP_RS);        // private to this wave: [SR rows][WN + 4] fp32
+    constexpr int CPR = WN / 8;                      // 8-channel groups per output row
+    constexpr int ITEMS = SR * CPR;                  // (row, group) items per slab
     float* ws = p.splitk > 1 ? p.ws + ((int64_t)ksplit * p.nz + z) * (int64_t)p.M * p.N : nullptr;
     const int64_t zo = zq * p.o_zs_o + zr * p.o_zs_i;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int ih = 0; ih < MT * (32 / SR); ++ih) {
+        const int i = ih / (32 / SR), half = ih % (32 / SR);     // accumulator rows [half*SR, half*SR + SR) of tile i
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+            for (int e = half * (SR / 2); e < half * (SR / 2) + SR / 2; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh - half * SR;
                 *reinterpret_cast<float*>(slab + row * EP_RS + (j * 32 + frow) * 4) = acc[i][j][e];
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the slab is written (LDS ops are in order per wave)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int ps = 0; ps < 32 / RPS; ++ps) {
-            const int row = ps * RPS + er;
-            const int m = m0 + wm * WM + i * 32 + row;
+        for (int it0 = 0; it0 < ITEMS; it0 += 64) {
+            const int it = it0 + lane;
+            if (ITEMS % 64 != 0 && it >= ITEMS) continue;
+            const int row = it / CPR, ec = (it - row * CPR) * 8;
+            const int m = m0 + wm * WM + i * 32 + half * SR + row;
             const int n = n0 + wn * WN + ec;
             float v[8];
             const float4 lo = *reinterpret_cast<const float4*>(slab + row * EP_RS + ec * 4);
@@ -629,8 +632,9 @@ const TileCfg kTiles[] = {
     {256, 64, 256, 3},   // 10
     {256, 128, 512, 3},  // 11
     {64, 128, 256, 3},   // 12
-    {256, 128, 256, 3},  // 13  one wave per SIMD, 128x64 per wave
-    {128, 256, 256, 3},  // 14  one wave per SIMD, 64x128 per wave
+    {192, 128, 256, 2},  // 13  96x64 per wave, 80 KB: still two blocks per CU
+    {128, 160, 256, 2},  // 14  4x1 waves, 32x160 per wave: exact fit for N = 320 / 640 / 1280
+    {128, 192, 256, 2},  // 15  64x96 per wave
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -667,8 +671,9 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
             case 10: launch_one<DT, 256, 64, 4, 1, false, 3>(a, grid, s); break;
             case 11: launch_one<DT, 256, 128, 4, 2, false, 3>(a, grid, s); break;
             case 12: launch_one<DT, 64, 128, 2, 2, false, 3>(a, grid, s); break;
-            case 13: launch_one<DT, 256, 128, 2, 2, false, 3>(a, grid, s); break;
-            case 14: launch_one<DT, 128, 256, 2, 2, false, 3>(a, grid, s); break;
+            case 13: launch_one<DT, 192, 128, 2, 2, false, 2>(a, grid, s); break;
+            case 14: launch_one<DT, 128, 160, 4, 1, false, 2>(a, grid, s); break;
+            case 15: launch_one<DT, 128, 192, 2, 2, false, 2>(a, grid, s); break;
             default: break;
         }
     }

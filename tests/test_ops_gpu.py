@@ -42,7 +42,7 @@ PRECS = [("fp32", 2e-4, 2e-4), ("bf16", 2e-2, 1e-2)]
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
-@pytest.mark.parametrize("tile", list(range(15)))
+@pytest.mark.parametrize("tile", list(range(16)))
 def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     prec = ops.Precision.get(prec_name)
     g = torch.Generator().manual_seed(1)
