@@ -14,6 +14,7 @@
 // (k = 16s + 8(j>>2) + 4h + (j&3)) is applied when the V^T tile is written to LDS.
 // The softmax rescale factor is per query = per lane, so rescaling O^T is a plain register multiply.
 // O^T is transposed once through LDS at the end so the global stores are row-contiguous.
+#include <stdlib.h>
 #include "mf_common.h"
 
 namespace {
@@ -29,7 +30,7 @@ struct AttnArgs {
 
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <int HD>
+template <int HD, bool DB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int DK = (HD + 15) / 16 * 16;   // QK^T reduction length, padded to the MFMA k-step
     constexpr int KS = DK / 16;
@@ -43,10 +44,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int KJ = (KVEC + 255) / 256, VJ = (VVEC + 255) / 256;
     constexpr int K_BYTES = 64 * RBK, V_BYTES = DV * RBV;
     constexpr int O_BYTES = 4 * 32 * RBO;
-    constexpr int LDS_BYTES = (K_BYTES + V_BYTES) > O_BYTES ? (K_BYTES + V_BYTES) : O_BYTES;
+    constexpr int BUF_BYTES = K_BYTES + V_BYTES;            // one K + V^T tile
+    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int LDS_BYTES = (NBUF * BUF_BYTES) > O_BYTES ? (NBUF * BUF_BYTES) : O_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-    char* Ks = smem;
-    char* Vs = smem + K_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const int qi = q0 + r;
 
     // zero the whole staging area once: pad columns / rows must never hold NaN bit patterns
-    for (int i = tid * 16; i < K_BYTES + V_BYTES; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+    for (int i = tid * 16; i < NBUF * BUF_BYTES; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
 
     // Q fragments (B operand of S^T = K.Q^T): lane (query r, half h) holds Q[q][16ks + 8h + j]
     bf16x8_t qf[KS];
@@ -96,7 +97,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        char* Ks = smem + buf * BUF_BYTES;
+        char* Vs = Ks + K_BYTES;
 #pragma unroll
         for (int j = 0; j < KJ; ++j) {
             const int v = tid + 256 * j;
@@ -128,11 +131,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const int ntiles = (p.skv + 63) / 64;
     load_tile(0);
     __syncthreads();   // zero-fill done
+    if (DB) {
+        store_tile(0);
+        __syncthreads();
+    }
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
-        store_tile();
-        __syncthreads();
-        if (t + 1 < ntiles) load_tile(kv0 + 64);
+        const char* Ks = smem + (DB ? (t & 1) : 0) * BUF_BYTES;
+        const char* Vs = Ks + K_BYTES;
+        if (!DB) {
+            store_tile(0);
+            __syncthreads();
+        }
+        if (t + 1 < ntiles) load_tile(kv0 + 64);       // global loads fly under this tile's MFMAs
 
         // ---- S^T = K . Q^T : two 32-key tiles ----
         f32x16_t st[2];
@@ -200,7 +211,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 const uint4 a = *reinterpret_cast<const uint4*>(Vs + (32 * d + r) * RBV + (16 * kst + 8 * h) * 2);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kst], o[d], 0, 0, 0);
             }
-        __syncthreads();   // everyone is done reading this tile
+        // the other buffer was last read in iteration t-1, which every wave finished before the previous barrier
+        if (DB && t + 1 < ntiles) store_tile((t + 1) & 1);
+        __syncthreads();
     }
 
     // ---- epilogue: normalise, transpose through LDS, row-contiguous stores ----
@@ -231,8 +244,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
 template <int HD>
 void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
+    static const bool db = getenv("MFHIP_ATTN_SINGLE_BUFFER") == nullptr;
     dim3 grid((a.sq + 127) / 128, a.heads, batch);
-    hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), 0, s, a);
+    if (db) hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace

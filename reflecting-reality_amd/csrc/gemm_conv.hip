@@ -221,7 +221,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     constexpr int SR = (WAVES_M * WAVES_N * 32 * EP_RS <= STAGES * STAGE_BYTES) ? 32 : 16;   // rows per epilogue slab
     static_assert(WAVES_M * WAVES_N * SR * EP_RS <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the staging LDS");
-    static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
+    static_assert(STAGES >= 2 && STAGES <= 4, "2 to 4 LDS stages");
     static_assert(!A_F32 || STAGES == 2, "the register-staged path is double buffered");
     static_assert(!A_F32 || DT == MF_BF16, "A_F32 only converts fp32 activations for bf16 compute");
 
@@ -499,8 +499,12 @@ void gemm_conv_kernel(const GemmArgs p) {
                     if (s0 < nt) issue(s0);
                 int st_c = 0, st_i = PF;                 // stage being computed / stage being filled
                 for (int t = 0; t < nt; ++t) {
-                    if (PF == 2 && t + 1 < nt) wait_vmcnt<G>();
-                    else wait_vmcnt<0>();
+                    {   // allow the DMAs of the (up to PF-1) newer tiles to stay in flight
+                        const int newer = nt - 1 - t < PF - 1 ? nt - 1 - t : PF - 1;
+                        if (PF >= 3 && newer == 2) wait_vmcnt<2 * G>();
+                        else if (PF >= 2 && newer == 1) wait_vmcnt<G>();
+                        else wait_vmcnt<0>();
+                    }
                     __builtin_amdgcn_s_barrier();
                     if (t + PF < nt) issue(st_i);
                     compute(st_c);
@@ -652,7 +656,7 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
 
 template <int DT, bool AF>
 void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
-    if (AF && tile > 12) tile = 5;        // the fp32->bf16 converting path is register staged (2 stages)
+    if (AF && tile > 12) tile = 1;        // the fp32->bf16 converting path is register staged (2 stages)
     if (AF && tile > 6) tile -= 6;
     switch (tile) {
         case 1: launch_one<DT, 128, 128, 2, 2, AF, 2>(a, grid, s); break;
