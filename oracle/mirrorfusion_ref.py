@@ -465,6 +465,105 @@ class PNDMRef:
         return out
 
 
+class UniPCRef:
+    """schedulers/scheduling_unipc_multistep.py (bh1/bh2, predict_x0, lower_order_final, no Karras sigmas):
+    set_timesteps :229-300, convert_model_output :385-453, predictor :455-582, corrector :584-719, step :754-830."""
+
+    def __init__(self, **cfg):
+        self.cfg = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                        solver_order=2, prediction_type="epsilon", predict_x0=True, solver_type="bh2",
+                        lower_order_final=True, timestep_spacing="linspace", steps_offset=0)
+        self.cfg.update({k: v for k, v in cfg.items() if k in self.cfg})
+        self.alphas_cumprod = _alphas_cumprod(self.cfg)
+        self.init_noise_sigma = 1.0
+
+    def set_timesteps(self, n: int):
+        nt = self.cfg["num_train_timesteps"]
+        if self.cfg["timestep_spacing"] == "linspace":
+            ts = np.linspace(0, nt - 1, n + 1).round()[::-1][:-1].copy().astype(np.int64)
+        else:  # leading
+            ts = (np.arange(0, n + 1) * (nt // (n + 1))).round()[::-1][:-1].copy().astype(np.int64) + self.cfg["steps_offset"]
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sigmas = np.interp(ts, np.arange(0, len(sig)), sig)
+        last = ((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5
+        self.sigmas = torch.from_numpy(np.concatenate([sigmas, [last]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+        self.num_inference_steps = len(ts)
+        self.model_outputs = [None] * self.cfg["solver_order"]
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self.step_index = 0
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def _convert(self, model_output, sample):
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[self.step_index])
+        if self.cfg["prediction_type"] == "epsilon":
+            return (sample - sigma_t * model_output) / alpha_t
+        return alpha_t * sample - sigma_t * model_output          # v_prediction
+
+    def _rb(self, order, idx_t, idx_s0, hist_offset):
+        """Shared coefficient set-up of the predictor (:507-548) and corrector (:642-690)."""
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[idx_t])
+        alpha_s0, sigma_s0 = self._alpha_sigma(self.sigmas[idx_s0])
+        lambda_t = torch.log(alpha_t) - torch.log(sigma_t)
+        lambda_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
+        h = lambda_t - lambda_s0
+        rks = []
+        for i in range(1, order):
+            a_si, s_si = self._alpha_sigma(self.sigmas[self.step_index - (i + hist_offset)])
+            rks.append((torch.log(a_si) - torch.log(s_si) - lambda_s0) / h)
+        rks_t = torch.tensor([float(r) for r in rks] + [1.0])
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = hh if self.cfg["solver_type"] == "bh1" else torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks_t, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        return dict(alpha_t=alpha_t, sigma_t=sigma_t, sigma_s0=sigma_s0, h_phi_1=h_phi_1, B_h=B_h, rks=rks,
+                    R=torch.stack(R), b=torch.tensor([float(v) for v in b]))
+
+    def step(self, model_output, timestep, sample):
+        order_cfg = self.cfg["solver_order"]
+        use_corrector = self.step_index > 0 and self.last_sample is not None
+        m_t = self._convert(model_output, sample)
+        if use_corrector:
+            order = self.this_order
+            c = self._rb(order, self.step_index, self.step_index - 1, 1)
+            m0 = self.model_outputs[-1]
+            x = self.last_sample
+            D1s = [(self.model_outputs[-(i + 1)] - m0) / c["rks"][i - 1] for i in range(1, order)]
+            rhos = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(c["R"], c["b"])
+            x_t_ = c["sigma_t"] / c["sigma_s0"] * x - c["alpha_t"] * c["h_phi_1"] * m0
+            corr = sum(rhos[i] * D1s[i] for i in range(len(D1s))) if D1s else 0
+            sample = x_t_ - c["alpha_t"] * c["B_h"] * (corr + rhos[-1] * (m_t - m0))
+        for i in range(order_cfg - 1):
+            self.model_outputs[i] = self.model_outputs[i + 1]
+        self.model_outputs[-1] = m_t
+        this_order = min(order_cfg, len(self.timesteps) - self.step_index) if self.cfg["lower_order_final"] else order_cfg
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = sample
+        order = self.this_order
+        c = self._rb(order, self.step_index + 1, self.step_index, 0)
+        m0 = self.model_outputs[-1]
+        D1s = [(self.model_outputs[-(i + 1)] - m0) / c["rks"][i - 1] for i in range(1, order)]
+        x_t = c["sigma_t"] / c["sigma_s0"] * sample - c["alpha_t"] * c["h_phi_1"] * m0
+        if D1s:
+            rhos_p = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(c["R"][:-1, :-1], c["b"][:-1])
+            x_t = x_t - c["alpha_t"] * c["B_h"] * sum(rhos_p[i] * D1s[i] for i in range(len(D1s)))
+        if self.lower_order_nums < order_cfg:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return x_t
+
+
 # ---------------------------------------------------------------------------------------------
 # pipeline (pipelines/brushnet/pipeline_brushnet.py:848-1363, tensor inputs, prompt_embeds given)
 # ---------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ __version__ = "0.1.0"
 
 _LAZY = {
     "BrushNetModel": "models", "UNet2DConditionModel": "models", "AutoencoderKL": "models",
-    "BrushNetOutput": "models", "DDIMScheduler": "schedulers", "PNDMScheduler": "schedulers",
+    "BrushNetOutput": "models", "DDIMScheduler": "schedulers", "PNDMScheduler": "schedulers", "UniPCMultistepScheduler": "schedulers",
     "StableDiffusionBrushNetPipeline": "pipeline", "StableDiffusionPipelineOutput": "pipeline",
     "VaeImageProcessor": "pipeline", "Precision": "ops",
 }

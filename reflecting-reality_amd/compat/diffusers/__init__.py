@@ -1,6 +1,6 @@
 """Drop-in alias: put `<repo>/reflecting-reality_amd/compat` (and `<repo>`) on PYTHONPATH and the reference's
 scripts' `from diffusers import BrushNetModel, UNet2DConditionModel, AutoencoderKL, DDIMScheduler, PNDMScheduler,
-StableDiffusionBrushNetPipeline` (examples/brushnet/test_brushnet.py:13, train_brushnet_mirror.py:35-42) resolve to
+UniPCMultistepScheduler, StableDiffusionBrushNetPipeline` (examples/brushnet/test_brushnet.py:13, train_brushnet_mirror.py:35-42) resolve to
 the MI355X implementations.  Only the names of the accelerated hot path exist here; anything else raises."""
 import os
 import sys
@@ -11,7 +11,7 @@ if _ROOT not in sys.path:
 
 from reflecting_reality_amd.models import AutoencoderKL, BrushNetModel, UNet2DConditionModel  # noqa: E402,F401
 from reflecting_reality_amd.pipeline import StableDiffusionBrushNetPipeline  # noqa: E402,F401
-from reflecting_reality_amd.schedulers import DDIMScheduler, PNDMScheduler  # noqa: E402,F401
+from reflecting_reality_amd.schedulers import DDIMScheduler, PNDMScheduler, UniPCMultistepScheduler  # noqa: E402,F401
 
 __version__ = "0.27.0.dev0+mi355x"
 

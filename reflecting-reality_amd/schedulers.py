@@ -44,6 +44,9 @@ class _SchedulerBase:
         cfg = dict(self._defaults)
         unknown = [k for k in kwargs if k not in cfg]
         cfg.update({k: v for k, v in kwargs.items() if k in cfg})
+        # configuration_utils.py register_to_config: remember which keys were left at their defaults, so that
+        # from_config into another scheduler class falls back to THAT class's defaults for them
+        cfg["_use_default_values"] = [k for k in self._defaults if k not in kwargs]
         self.config = FrozenConfig(cfg)
         self._unknown = unknown
         self.betas = _betas(cfg)
@@ -285,3 +288,148 @@ class PNDMScheduler(_SchedulerBase):
             # eps = sqrt(a_t) v + sqrt(b_t) x  ->  prev = (sample_coeff + k sqrt(b_t)) x + k sqrt(a_t) v
             return hip.axpby_n([x, model_output], [float(sample_coeff + k * b_t ** 0.5), float(k * a_t ** 0.5)])
         return hip.axpby_n([x, model_output], [float(sample_coeff), float(k)])
+
+
+class UniPCMultistepScheduler(_SchedulerBase):
+    """schedulers/scheduling_unipc_multistep.py (bh1/bh2, predict_x0, lower_order_final; what the reference's own
+    scripts select: examples/brushnet/test_brushnet.py:158, train_brushnet_mirror.py:179).  Predictor (:455-582) and
+    corrector (:584-719) are linear in {sample, last_sample, converted model outputs}: the host evaluates the scalar
+    coefficients exactly like the reference (fp32 0-dim tensor arithmetic on lambda = log(alpha) - log(sigma), expm1)
+    and each update is ONE fused mf_axpby_n launch."""
+
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, solver_order=2, prediction_type="epsilon", thresholding=False,
+                     dynamic_thresholding_ratio=0.995, sample_max_value=1.0, predict_x0=True, solver_type="bh2",
+                     lower_order_final=True, disable_corrector=[], solver_p=None, use_karras_sigmas=False,
+                     timestep_spacing="linspace", steps_offset=0, set_alpha_to_one=True)
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        c = self.config
+        if c["thresholding"] or c["use_karras_sigmas"] or c["solver_p"] is not None or not c["predict_x0"]:
+            raise NotImplementedError("thresholding / Karras sigmas / solver_p / noise-prediction UniPC are outside the MirrorFusion path")
+        if c["solver_type"] not in ("bh1", "bh2"):
+            raise NotImplementedError(f"{c['solver_type']} does is not implemented for {self.__class__}")
+        if c["prediction_type"] not in ("epsilon", "v_prediction"):
+            raise ValueError(f"prediction_type given as {c['prediction_type']} must be one of `epsilon` or `v_prediction`")
+        if c["solver_order"] > 3:
+            raise NotImplementedError("solver_order > 3")
+        self.sigmas = ((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5
+        self.model_outputs = [None] * c["solver_order"]
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self._step_index = None
+        self.disable_corrector = list(c["disable_corrector"])
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        c = self.config
+        nt = c["num_train_timesteps"]
+        if c["timestep_spacing"] == "linspace":
+            ts = np.linspace(0, nt - 1, num_inference_steps + 1).round()[::-1][:-1].copy().astype(np.int64)
+        elif c["timestep_spacing"] == "leading":
+            ts = (np.arange(0, num_inference_steps + 1) * (nt // (num_inference_steps + 1))).round()[::-1][:-1].copy().astype(np.int64)
+            ts += c["steps_offset"]
+        elif c["timestep_spacing"] == "trailing":
+            ts = np.arange(nt, 0, -nt / num_inference_steps).round().copy().astype(np.int64) - 1
+        else:
+            raise ValueError(f"{c['timestep_spacing']} is not supported. Please make sure to choose one of 'linspace', 'leading' or 'trailing'.")
+        sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
+        sigmas = np.interp(ts, np.arange(0, len(sig)), sig)
+        last = ((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5
+        self.sigmas = torch.from_numpy(np.concatenate([sigmas, [last]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+        self.num_inference_steps = len(ts)
+        self.model_outputs = [None] * c["solver_order"]
+        self.lower_order_nums = 0
+        self.last_sample = None
+        self._step_index = None
+
+    @staticmethod
+    def _alpha_sigma(sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)
+        return alpha_t, sigma * alpha_t
+
+    def _coefs(self, order, idx_t, idx_s0, hist_offset):
+        alpha_t, sigma_t = self._alpha_sigma(self.sigmas[idx_t])
+        alpha_s0, sigma_s0 = self._alpha_sigma(self.sigmas[idx_s0])
+        lambda_s0 = torch.log(alpha_s0) - torch.log(sigma_s0)
+        h = (torch.log(alpha_t) - torch.log(sigma_t)) - lambda_s0
+        rks = []
+        for i in range(1, order):
+            a_si, s_si = self._alpha_sigma(self.sigmas[self._step_index - (i + hist_offset)])
+            rks.append((torch.log(a_si) - torch.log(s_si) - lambda_s0) / h)
+        rks_t = torch.tensor([float(r) for r in rks] + [1.0])
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = hh if self.config["solver_type"] == "bh1" else torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks_t, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        return alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, torch.stack(R), torch.tensor([float(v) for v in b])
+
+    def _index_for_timestep(self, timestep):
+        cand = (self.timesteps == int(timestep)).nonzero()
+        if len(cand) == 0:
+            return len(self.timesteps) - 1
+        return int(cand[1]) if len(cand) > 1 else int(cand[0])
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self._step_index is None:
+            self._step_index = self._index_for_timestep(timestep)
+        c = self.config
+        eps = model_output.float().contiguous()
+        x = sample.float().contiguous()
+        use_corrector = self._step_index > 0 and self._step_index - 1 not in self.disable_corrector \
+            and self.last_sample is not None
+        # convert_model_output (:385-453): x0 prediction, linear in (sample, model_output)
+        a_c, s_c = self._alpha_sigma(self.sigmas[self._step_index])
+        if c["prediction_type"] == "epsilon":
+            m_t = hip.axpby_n([x, eps], [float(1 / a_c), float(-s_c / a_c)])
+        else:
+            m_t = hip.axpby_n([x, eps], [float(a_c), float(-s_c)])
+        if use_corrector:                                                       # UniC (:584-719)
+            order = self.this_order
+            alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coefs(order, self._step_index, self._step_index - 1, 1)
+            rhos = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+            m0 = self.model_outputs[-1]
+            k = -alpha_t * B_h
+            terms, coefs, cm0 = [self.last_sample, m_t], [float(sigma_t / sigma_s0), float(k * rhos[-1])], -alpha_t * h_phi_1 - k * rhos[-1]
+            for i in range(1, order):
+                w = k * rhos[i - 1] / rks[i - 1]
+                terms.append(self.model_outputs[-(i + 1)]); coefs.append(float(w)); cm0 = cm0 - w
+            terms.append(m0); coefs.append(float(cm0))
+            x = hip.axpby_n(terms, coefs)
+        for i in range(c["solver_order"] - 1):
+            self.model_outputs[i] = self.model_outputs[i + 1]
+        self.model_outputs[-1] = m_t
+        this_order = min(c["solver_order"], len(self.timesteps) - self._step_index) if c["lower_order_final"] else c["solver_order"]
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        self.last_sample = x
+        order = self.this_order                                                 # UniP (:455-582)
+        alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coefs(order, self._step_index + 1, self._step_index, 0)
+        terms, coefs, cm0 = [x], [float(sigma_t / sigma_s0)], -alpha_t * h_phi_1
+        if order > 1:
+            rhos_p = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+            k = -alpha_t * B_h
+            for i in range(1, order):
+                w = k * rhos_p[i - 1] / rks[i - 1]
+                terms.append(self.model_outputs[-(i + 1)]); coefs.append(float(w)); cm0 = cm0 - w
+        terms.append(m_t); coefs.append(float(cm0))
+        prev = hip.axpby_n(terms, coefs)
+        if self.lower_order_nums < c["solver_order"]:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        return (prev,) if not return_dict else SchedulerOutput(prev_sample=prev)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        raise NotImplementedError("UniPC.add_noise is only used by the training script (SURVEY.md §8 f-2)")

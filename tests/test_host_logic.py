@@ -11,7 +11,7 @@ from oracle import mirrorfusion_ref as R
 from reflecting_reality_amd import configs, distributed as D, synth
 from reflecting_reality_amd.models import AutoencoderKL, BrushNetModel, UNet2DConditionModel
 from reflecting_reality_amd.pipeline import StableDiffusionBrushNetPipeline, VaeImageProcessor
-from reflecting_reality_amd.schedulers import DDIMScheduler, PNDMScheduler
+from reflecting_reality_amd.schedulers import DDIMScheduler, PNDMScheduler, UniPCMultistepScheduler
 from util import golden, keys
 
 SD = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
@@ -43,6 +43,11 @@ def test_scheduler_tables_and_coefficients():
         p = PNDMScheduler(**SD, skip_prk_steps=True)
         p.set_timesteps(n)
         assert p.timesteps.tolist() == G[f"pndm_timesteps_{n}"].tolist()
+        u = UniPCMultistepScheduler.from_config(p.config)     # examples/brushnet/test_brushnet.py:158
+        u.set_timesteps(n)
+        assert u.timesteps.tolist() == G[f"unipc_timesteps_{n}"].tolist()
+        assert u.config["timestep_spacing"] == "linspace" and u.config["beta_schedule"] == "scaled_linear"
+        assert len(u.sigmas) == n + 1
     assert np.allclose(d.alphas_cumprod.numpy(), G["alphas_cumprod"], rtol=0, atol=0)
     d = DDIMScheduler(**SD, clip_sample=False)
     d.set_timesteps(50)
@@ -169,10 +174,10 @@ def test_compat_diffusers_alias_exposes_the_hot_path_names():
     try:
         d = importlib.import_module("diffusers")
         for name in ("BrushNetModel", "UNet2DConditionModel", "AutoencoderKL", "DDIMScheduler", "PNDMScheduler",
-                     "StableDiffusionBrushNetPipeline"):
+                     "UniPCMultistepScheduler", "StableDiffusionBrushNetPipeline"):
             assert hasattr(d, name)
         with pytest.raises(AttributeError):
-            d.UniPCMultistepScheduler
+            d.StableDiffusionXLPipeline
     finally:
         sys.path.remove(compat)
         sys.modules.pop("diffusers", None)

@@ -42,7 +42,7 @@ def test_tiny_models_match_reference():
     report("vae_decode", R.vae_decode(vsd, R.TINY_VAE, z), G["vae_decode"], **TOL)
 
 
-@pytest.mark.parametrize("name", ["ddim", "pndm"])
+@pytest.mark.parametrize("name", ["ddim", "pndm", "unipc"])
 def test_tiny_pipeline_matches_reference(name):
     usd, bsd, vsd = sds("tiny")
     G = golden("tiny_pipeline.npz")
@@ -50,7 +50,7 @@ def test_tiny_pipeline_matches_reference(name):
     noise = torch.from_numpy(G[f"{name}_vae_noise"])
     cond = R.build_conditioning(vsd, R.TINY_VAE, inp["image"], inp["mask"], inp["depth"], noise)
     report("conditioning", cond, G[f"{name}_cond"], **TOL)
-    sched = (R.DDIMRef if name == "ddim" else R.PNDMRef)(**R.SD15_SCHED)
+    sched = {"ddim": R.DDIMRef, "pndm": R.PNDMRef, "unipc": R.UniPCRef}[name](**R.SD15_SCHED)
     trace = []
     pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
     lat = R.denoise(usd, R.TINY_UNET, bsd, R.brushnet_config(R.TINY_UNET, 6), sched, inp["latents"], cond, pe, 4, 7.5,
@@ -65,7 +65,7 @@ def test_tiny_pipeline_matches_reference(name):
 def test_scheduler_traces_match_reference():
     G = golden("schedulers.npz")
     for n in (4, 50):
-        for name, cls in (("ddim", R.DDIMRef), ("pndm", R.PNDMRef)):
+        for name, cls in (("ddim", R.DDIMRef), ("pndm", R.PNDMRef), ("unipc", R.UniPCRef)):
             s = cls(**R.SD15_SCHED)
             s.set_timesteps(n)
             assert s.timesteps.tolist() == G[f"{name}_timesteps_{n}"].tolist()
@@ -119,6 +119,23 @@ def test_pndm_reference_known_answers(kw, expect):
     s2.set_timesteps(10)
     assert s2.timesteps.tolist() == [901, 851, 851, 801, 801, 751, 751, 701, 701, 651, 651, 601, 601, 501, 401, 301,
                                      201, 101, 1]          # test_scheduler_pndm.py:150-163
+
+
+@pytest.mark.parametrize("kw,expect", [({}, 0.2464), ({"prediction_type": "v_prediction"}, 0.1014),
+                                       ({"solver_type": "bh1"}, None)])
+def test_unipc_reference_known_answers(kw, expect):
+    """MirrorFusion/tests/schedulers/test_scheduler_unipc.py:90-108 (full_loop), :144-148, :218-222."""
+    s = R.UniPCRef(solver_order=2, solver_type=kw.get("solver_type", "bh2"), **{k: v for k, v in kw.items() if k != "solver_type"})
+    s.set_timesteps(10)
+    x = _deter()
+    for t in s.timesteps:
+        x = s.step(x * t / (t + 1), t, x)
+    assert torch.isfinite(x).all()
+    if expect is not None:
+        assert abs(x.abs().mean().item() - expect) < 1e-3
+    u = R.UniPCRef(**R.SD15_SCHED)                 # from_config(PNDM config) leaves timestep_spacing = "linspace"
+    u.set_timesteps(50)
+    assert u.timesteps[:3].tolist() == [999, 979, 959] and len(u.timesteps) == 50
 
 
 def test_sd15_full_size_brushnet_matches_reference():

@@ -7,7 +7,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import mirrorfusion_ref as R  # noqa: E402
-from reflecting_reality_amd import DDIMScheduler, PNDMScheduler, StableDiffusionBrushNetPipeline, synth  # noqa: E402
+from reflecting_reality_amd import (DDIMScheduler, PNDMScheduler, StableDiffusionBrushNetPipeline,  # noqa: E402
+                                    UniPCMultistepScheduler, synth)  # noqa: E402
 from test_models_gpu import build  # noqa: E402
 from util import golden, report  # noqa: E402
 
@@ -61,8 +62,28 @@ def test_pndm_reference_kat(kw, expect_sum, expect_mean):
     assert abs(x.abs().mean().item() - expect_mean) < 1e-3
 
 
+@pytest.mark.parametrize("kw,expect_mean", [({}, 0.2464), ({"prediction_type": "v_prediction"}, 0.1014)])
+def test_unipc_reference_kat(kw, expect_mean):
+    """tests/schedulers/test_scheduler_unipc.py:90-108,144-148,218-222 of the reference."""
+    s = UniPCMultistepScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                                solver_order=2, solver_type="bh2", **kw)
+    s.set_timesteps(10)
+    x = deter_sample().to(DEV)
+    for t in s.timesteps:
+        x = s.step(dummy_model(x, t), t, x).prev_sample
+    assert abs(x.abs().mean().item() - expect_mean) < 1e-3
+    # the oracle on the same loop, elementwise
+    o = R.UniPCRef(solver_order=2, **kw)
+    o.set_timesteps(10)
+    y = deter_sample()
+    for t in o.timesteps:
+        y = o.step(dummy_model(y, t), t, y)
+    assert float((x.cpu() - y).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("name,cls,extra", [("ddim", DDIMScheduler, dict(clip_sample=False)),
-                                             ("pndm", PNDMScheduler, dict(skip_prk_steps=True))])
+                                             ("pndm", PNDMScheduler, dict(skip_prk_steps=True)),
+                                             ("unipc", UniPCMultistepScheduler, dict())])
 @pytest.mark.parametrize("n", [4, 50])
 def test_scheduler_traces(name, cls, extra, n):
     G = golden("schedulers.npz")
@@ -87,13 +108,15 @@ def test_scheduler_traces(name, cls, extra, n):
 # sqrt(alpha_t) ~ 0.2, so individual latents can be off by O(1) on this random-weight net; the test bounds the mean
 # error and reports the max (DESIGN.md "Precision modes").
 @pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", None)])
-@pytest.mark.parametrize("name", ["ddim", "pndm"])
+@pytest.mark.parametrize("name", ["ddim", "pndm", "unipc"])
 def test_tiny_pipeline_per_step(prec, tol, name):
     """4-step tiny pipeline, CFG 7.5: conditioning latents, per-step latents and final image vs the reference."""
     unet, bn, vae = build("tiny", prec)
     G = golden("tiny_pipeline.npz")
     sched = (DDIMScheduler(**SD_SCHED, clip_sample=False) if name == "ddim"
              else PNDMScheduler(**SD_SCHED, skip_prk_steps=True))
+    if name == "unipc":              # the way the reference's inference script builds it (test_brushnet.py:158)
+        sched = UniPCMultistepScheduler.from_config(sched.config)
     pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
                                            scheduler=sched, safety_checker=None, feature_extractor=None,
                                            requires_safety_checker=False, depth_conditioning_mode="concat")

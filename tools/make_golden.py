@@ -26,7 +26,8 @@ import transformers.utils as _tu  # noqa: E402
 if not hasattr(_tu, "FLAX_WEIGHTS_NAME"):          # removed in transformers 5; the reference imports it
     _tu.FLAX_WEIGHTS_NAME = "flax_model.msgpack"
 
-from diffusers import AutoencoderKL, BrushNetModel, DDIMScheduler, PNDMScheduler, UNet2DConditionModel  # noqa: E402
+from diffusers import (AutoencoderKL, BrushNetModel, DDIMScheduler, PNDMScheduler, UNet2DConditionModel,  # noqa: E402
+                       UniPCMultistepScheduler)
 from diffusers.pipelines.brushnet.pipeline_brushnet import StableDiffusionBrushNetPipeline  # noqa: E402
 
 from oracle import mirrorfusion_ref as R  # noqa: E402
@@ -127,13 +128,16 @@ def tiny():
     out["vae_decode"] = dec.numpy()
     np.savez_compressed(os.path.join(GOLD, "tiny_models.npz"), **out)
 
-    # --- F5: tiny pipeline, per-step latents for DDIM and PNDM ------------------------------------
+    # --- F5: tiny pipeline, per-step latents for DDIM, PNDM and UniPC ------------------------------------
     pout = {}
     sched_cfg = {k: v for k, v in R.SD15_SCHED.items()}
     for name, cls, kw in (("ddim", DDIMScheduler, dict(clip_sample=False, set_alpha_to_one=False, steps_offset=1)),
-                          ("pndm", PNDMScheduler, dict(skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1))):
+                          ("pndm", PNDMScheduler, dict(skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1)),
+                          ("unipc", PNDMScheduler, dict(skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1))):
         sched = cls(num_train_timesteps=1000, beta_start=sched_cfg["beta_start"], beta_end=sched_cfg["beta_end"],
                     beta_schedule="scaled_linear", **kw)
+        if name == "unipc":          # examples/brushnet/test_brushnet.py:158
+            sched = UniPCMultistepScheduler.from_config(sched.config)
         pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet,
                                                brushnet=brushnet, scheduler=sched, safety_checker=None,
                                                feature_extractor=None, requires_safety_checker=False,
@@ -160,7 +164,7 @@ def tiny():
         # oracle replay with the explicit noise
         ocond = R.build_conditioning(vae_sd, vcfg, inp["image"], inp["mask"], inp["depth"], vae_noise)
         print(f"[{name}] conditioning oracle-vs-ref:", maxdiff(ocond, captured["cond"]))
-        osched = (R.DDIMRef if name == "ddim" else R.PNDMRef)(**R.SD15_SCHED)
+        osched = {"ddim": R.DDIMRef, "pndm": R.PNDMRef, "unipc": R.UniPCRef}[name](**R.SD15_SCHED)
         otrace = []
         pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
         olat = R.denoise(unet_sd, ucfg, bn_sd, bcfg, osched, inp["latents"], ocond, pe, 4, 7.5, 1.0, otrace)
@@ -186,7 +190,11 @@ def tiny():
                           skip_prk_steps=True, set_alpha_to_one=False, steps_offset=1)
         p.set_timesteps(n)
         sout[f"pndm_timesteps_{n}"] = p.timesteps.numpy()
-        for nm, s in (("ddim", d), ("pndm", p)):
+        # UniPC the way test_brushnet.py:158 builds it: from_config of the (PNDM) SD1.5 scheduler config
+        u = UniPCMultistepScheduler.from_config(p.config)
+        u.set_timesteps(n)
+        sout[f"unipc_timesteps_{n}"] = u.timesteps.numpy()
+        for nm, s in (("ddim", d), ("pndm", p), ("unipc", u)):
             gg = torch.Generator().manual_seed(5)
             x = torch.randn(2, 4, 8, 8, generator=gg)
             xs = []
