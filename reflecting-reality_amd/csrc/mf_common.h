@@ -45,7 +45,8 @@ __device__ __forceinline__ void store_from_f32(void* p, int dt, int64_t i, float
     else ((bf16_raw*)p)[i] = f32_to_bf16(v);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): only where the result is rounded to bf16 anyway
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
 
 static inline int mf_dtype_size(int dt) { return dt == MF_F32 ? 4 : 2; }

@@ -6,10 +6,12 @@
 namespace {
 
 constexpr int GN_MAX_CHUNKS = 64;
+constexpr int GN_BLK = 512;
 
 struct GnArgs {
     const char* x0; const char* x1;
-    int C0, C1, C, in_dt, HW, G, cpg, gslices, rows_per_chunk, nchunks;
+    int C0, C1, C, in_dt, HW, G, cpg, rows_per_chunk, nchunks;
+    int cvn, tpr, rif;                 // vector columns per row, threads per row, rows in flight per block
     float eps;
     const float* gamma; const float* beta;
     int silu;
@@ -66,180 +68,200 @@ __device__ __forceinline__ void store8(char* p, int dt, int64_t idx, const float
     }
 }
 
-// grid (nchunks, gslices, batch), 256 threads = 4 waves; wave w takes rows r0+w, r0+w+4, ...;
-// lanes take 4-channel column vectors of the slice.  Per-(wave, channel) sums go to LDS, then a
-// fixed-order tree reduces them to one (mean, M2) per group of the slice.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs p) {
+template <int VW>
+__device__ __forceinline__ void loadv(const char* p, int dt, float* o) {
+    if (VW == 8) {
+        load8(p, dt, 0, o);
+    } else {
+        const float4 t = load4(p, dt, 0);
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    }
+}
+
+// Thread geometry shared by both passes: a row of C channels is cvn = C/VW vector columns; tpr = min(cvn, 512)
+// threads cover one row and rif = 512/tpr rows are in flight per block, so every lane issues a 16-byte access
+// (VW = 8 bf16 / 2 x 16 bytes fp32) and a block's footprint is whole contiguous rows.  A thread keeps the same
+// column(s) for all of its rows: per-channel state (sums, or scale/shift) lives in registers.
+//
+// Pass 1, grid (nchunks, batch): per-(thread-row, channel) fp32 sums -> LDS -> one (mean, M2) per group of the
+// chunk, in double.  No atomics: bitwise reproducible.
+template <int VW>
+__global__ __launch_bounds__(GN_BLK) void gn_stats_kernel(const GnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* chan = reinterpret_cast<float*>(smem_raw);   // [4 waves][slice_c][2]
-    const int chunk = blockIdx.x, gs = blockIdx.y, b = blockIdx.z;
-    const int gps = p.G / p.gslices;                 // groups per slice
-    const int slice_c = gps * p.cpg;                 // channels per slice
-    const int cs = gs * slice_c;
-    const int c4n = slice_c >> 2;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float2* chan = reinterpret_cast<float2*>(smem_raw);   // [rif][C] (sum, sum of squares)
+    const int chunk = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int lcol = t % p.tpr, trow = t / p.tpr;
     const int r0 = chunk * p.rows_per_chunk;
     int r1 = r0 + p.rows_per_chunk;
     if (r1 > p.HW) r1 = p.HW;
-
-    if (p.C0 % 8 == 0 && p.C1 % 8 == 0 && slice_c % 8 == 0) {
-        const int c8n = slice_c >> 3;
-        for (int c8 = lane; c8 < c8n; c8 += 64) {
-            const int c = cs + c8 * 8;
+    const int esz = p.in_dt == MF_F32 ? 4 : 2;
+    if (trow < p.rif) {
+        for (int col = lcol; col < p.cvn; col += p.tpr) {
+            const int c = col * VW;
             const char* base; int64_t ld; int cc;
             if (c < p.C0) { base = p.x0; ld = p.C0; cc = c; }
             else { base = p.x1; ld = p.C1; cc = c - p.C0; }
-            float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ss[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int r = r0 + w; r < r1; r += 4) {
-                float v[8];
-                load8(base, p.in_dt, ((int64_t)b * p.HW + r) * ld + cc, v);
+            float s[VW], ss[VW];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s[e] += v[e]; ss[e] += v[e] * v[e]; }
+            for (int e = 0; e < VW; ++e) { s[e] = 0.0f; ss[e] = 0.0f; }
+            const int64_t step = (int64_t)p.rif * ld * esz;
+            const char* ptr = base + (((int64_t)b * p.HW + r0 + trow) * ld + cc) * esz;
+            int r = r0 + trow;
+            for (; r + 3 * p.rif < r1; r += 4 * p.rif, ptr += 4 * step) {
+                float v0[VW], v1[VW], v2[VW], v3[VW];
+                loadv<VW>(ptr, p.in_dt, v0);
+                loadv<VW>(ptr + step, p.in_dt, v1);
+                loadv<VW>(ptr + 2 * step, p.in_dt, v2);
+                loadv<VW>(ptr + 3 * step, p.in_dt, v3);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    s[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+                    ss[e] += (v0[e] * v0[e] + v1[e] * v1[e]) + (v2[e] * v2[e] + v3[e] * v3[e]);
+                }
+            }
+            for (; r < r1; r += p.rif, ptr += step) {
+                float v0[VW];
+                loadv<VW>(ptr, p.in_dt, v0);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) { s[e] += v0[e]; ss[e] += v0[e] * v0[e]; }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                chan[((w * slice_c) + c8 * 8 + e) * 2 + 0] = s[e];
-                chan[((w * slice_c) + c8 * 8 + e) * 2 + 1] = ss[e];
-            }
-        }
-    } else
-    for (int c4 = lane; c4 < c4n; c4 += 64) {
-        const int c = cs + c4 * 4;
-        const char* base; int64_t ld; int cc;
-        if (c < p.C0) { base = p.x0; ld = p.C0; cc = c; }
-        else { base = p.x1; ld = p.C1; cc = c - p.C0; }
-        float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-        for (int r = r0 + w; r < r1; r += 4) {
-            const float4 v = load4(base, p.in_dt, ((int64_t)b * p.HW + r) * ld + cc);
-            s[0] += v.x; ss[0] += v.x * v.x;
-            s[1] += v.y; ss[1] += v.y * v.y;
-            s[2] += v.z; ss[2] += v.z * v.z;
-            s[3] += v.w; ss[3] += v.w * v.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            chan[((w * slice_c) + c4 * 4 + e) * 2 + 0] = s[e];
-            chan[((w * slice_c) + c4 * 4 + e) * 2 + 1] = ss[e];
+            for (int e = 0; e < VW; ++e) chan[trow * p.C + c + e] = make_float2(s[e], ss[e]);
         }
     }
     __syncthreads();
-    // 32 threads per group: thread (g, l) sums items l, l+32, ... of the 4*cpg (wave, channel) list
-    const int g = threadIdx.x >> 5, l = threadIdx.x & 31;
-    for (int gg = g; gg < gps; gg += 8) {
-        double s = 0.0, ss = 0.0;
-        const int items = 4 * p.cpg;
-        for (int it = l; it < items; it += 32) {
-            const int ww = it / p.cpg, ch = gg * p.cpg + (it - ww * p.cpg);
-            s += (double)chan[(ww * slice_c + ch) * 2 + 0];
-            ss += (double)chan[(ww * slice_c + ch) * 2 + 1];
-        }
+    {   // 8 lanes per group: fixed-order partial sums over the (thread-row, channel) list, then a butterfly
+        const int l = t & 7;
+        const int items = p.rif * p.cpg;
+        for (int g = t >> 3; g < p.G; g += (int)blockDim.x >> 3) {
+            double s = 0.0, ss = 0.0;
+            for (int it = l; it < items; it += 8) {
+                const int tr = it / p.cpg;
+                const float2 v = chan[tr * p.C + g * p.cpg + (it - tr * p.cpg)];
+                s += (double)v.x;
+                ss += (double)v.y;
+            }
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) {
-            s += __shfl_xor(s, off, 32);
-            ss += __shfl_xor(ss, off, 32);
-        }
-        if (l == 0) {
-            const double n = (double)(r1 - r0) * p.cpg;
-            const double mean = s / n;
-            double m2 = ss - s * mean;
-            if (m2 < 0.0) m2 = 0.0;
-            float* o = p.ws + (((int64_t)b * p.G + gs * gps + gg) * p.nchunks + chunk) * 2;
-            o[0] = (float)mean;
-            o[1] = (float)m2;
+            for (int off = 1; off < 8; off <<= 1) {
+                s += __shfl_xor(s, off, 8);
+                ss += __shfl_xor(ss, off, 8);
+            }
+            if (l == 0) {
+                const double n = (double)(r1 - r0) * p.cpg;
+                const double mean = s / n;
+                double m2 = ss - s * mean;
+                if (m2 < 0.0) m2 = 0.0;
+                float* o = p.ws + (((int64_t)b * p.G + g) * p.nchunks + chunk) * 2;
+                o[0] = (float)mean;
+                o[1] = (float)m2;
+            }
         }
     }
 }
 
-// grid (nblocks, batch): combine the chunk statistics (Chan et al., in double), build per-channel
-// scale/shift in LDS, then stream rows: y = silu(x*a[c] + b[c]).  16-byte accesses (8 channels) when both
-// segment widths are multiples of 8, else 4 channels; 32-bit index arithmetic only.
-// grid (nblocks, batch).  Prologue (fully parallel, every load issued before the first use): 8 lanes per
-// group Chan-combine that group's chunk statistics with a fixed-order butterfly, then every thread turns
-// (mean, rstd, gamma, beta) into the per-channel affine y = x*a + b kept in LDS.  Body: stream rows with 16-byte
-// accesses (8 channels) when both segment widths are multiples of 8, else 4 channels.
-template <int VW>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs p, int rows_per_block) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sa = reinterpret_cast<float*>(smem_raw);   // [C] scale
-    float* sb = sa + p.C;                              // [C] shift
-    float* gm = sb + p.C;                              // [G] mean
-    float* gr = gm + p.G;                              // [G] rstd
-    const int b = blockIdx.y;
-    for (int g0 = 0; g0 < p.G; g0 += 32) {
-        const int g = g0 + (threadIdx.x >> 3), j = threadIdx.x & 7;
-        float pm[8], pq[8];
-        int nk = 0;
-        if (g < p.G) {
-            const float2* st = reinterpret_cast<const float2*>(p.ws + ((int64_t)b * p.G + g) * p.nchunks * 2);
+// Pass 1b, grid (batch): combine the chunk statistics of every group in a fixed order (double) and write the
+// per-channel affine y = x*a[c] + b[c].  (An in-kernel "last block finalizes" variant needs agent-scope fences,
+// whose L2 writeback/invalidate on this multi-XCD part cost more than this launch: measured 95 us vs 34 us.)
+__global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
+    __shared__ float gm[64], gr[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    // chunk k holds (mean_k, M2_k) over n_k elements: mean = sum n_k mean_k / N, M2 = sum M2_k + n_k (mean_k - mean)^2.
+    // 8 lanes per group, each over chunks j, j+8, ...; fixed-order butterflies (xor partners add the same two values).
+    for (int g0 = 0; g0 < p.G; g0 += (int)blockDim.x >> 3) {
+        const int g = g0 + (t >> 3), j = t & 7;
+        const bool on = g < p.G;
+        const float* st = p.ws + ((int64_t)b * p.G + (on ? g : 0)) * p.nchunks * 2;
+        float pm[GN_MAX_CHUNKS / 8], pq[GN_MAX_CHUNKS / 8], pn[GN_MAX_CHUNKS / 8];
+        double s1 = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = j + 8 * u;
-                if (k < p.nchunks) { const float2 t = st[k]; pm[u] = t.x; pq[u] = t.y; nk = u + 1; }
-            }
-        }
-        double n = 0.0, mean = 0.0, m2 = 0.0;
-        for (int u = 0; u < nk; ++u) {
+        for (int u = 0; u < GN_MAX_CHUNKS / 8; ++u) {
             const int k = j + 8 * u;
-            int rows = p.rows_per_chunk;
-            if ((k + 1) * p.rows_per_chunk > p.HW) rows = p.HW - k * p.rows_per_chunk;
-            const double nb = (double)rows * p.cpg, nt = n + nb, delta = (double)pm[u] - mean;
-            mean += delta * nb / nt;
-            m2 += (double)pq[u] + delta * delta * n * nb / nt;
-            n = nt;
+            pm[u] = 0.0f; pq[u] = 0.0f; pn[u] = 0.0f;
+            if (on && k < p.nchunks) {
+                const float2 v = *reinterpret_cast<const float2*>(st + 2 * k);
+                int rows = p.rows_per_chunk;
+                if ((k + 1) * p.rows_per_chunk > p.HW) rows = p.HW - k * p.rows_per_chunk;
+                pm[u] = v.x; pq[u] = v.y; pn[u] = (float)(rows * p.cpg);
+            }
+            s1 += (double)pn[u] * (double)pm[u];
         }
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {          // fixed-order butterfly over the 8 lanes of a group
-            const double n2 = __shfl_xor(n, off, 8), mean2 = __shfl_xor(mean, off, 8), m22 = __shfl_xor(m2, off, 8);
-            const double nt = n + n2;
-            if (nt > 0.0) {
-                const double delta = mean2 - mean;
-                const double mnew = (mean * n + mean2 * n2) / nt;      // symmetric: both partners agree bit for bit
-                m2 = m2 + m22 + delta * delta * n * n2 / nt;
-                mean = mnew;
-                n = nt;
-            }
+        for (int off = 1; off < 8; off <<= 1) s1 += __shfl_xor(s1, off, 8);
+        const double n = (double)p.HW * p.cpg;
+        const double mean = s1 / n;
+        double m2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < GN_MAX_CHUNKS / 8; ++u) {
+            const double d = (double)pm[u] - mean;
+            m2 += (double)pq[u] + (double)pn[u] * d * d;
         }
-        if (g < p.G && j == 0) {
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) m2 += __shfl_xor(m2, off, 8);
+        if (on && j == 0) {
             gm[g] = (float)mean;
             gr[g] = (float)(1.0 / sqrt(m2 / n + (double)p.eps));
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
+    for (int c = t; c < p.C; c += blockDim.x) {
         const int g = c / p.cpg;
         const float a = gr[g] * p.gamma[c];
-        sa[c] = a;
-        sb[c] = p.beta[c] - gm[g] * a;
+        ab[c] = a;
+        ab[p.C + c] = p.beta[c] - gm[g] * a;
     }
-    __syncthreads();
-    const unsigned cvn = (unsigned)p.C / VW;
+}
+
+// Pass 2, grid (row blocks, batch): pure streaming y = silu(x*a[c] + b[c]) with the thread's a/b in registers.
+template <int VW>
+__global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int rows_per_block) {
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int lcol = t % p.tpr, trow = t / p.tpr;
+    if (trow >= p.rif) return;
     const int r0 = blockIdx.x * rows_per_block;
     int r1 = r0 + rows_per_block;
     if (r1 > p.HW) r1 = p.HW;
-    const unsigned items = (unsigned)(r1 - r0) * cvn;
+    const int esz = p.in_dt == MF_F32 ? 4 : 2, osz = p.out_dt == MF_F32 ? 4 : 2;
+    const float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
     const bool fast_silu = p.out_dt == MF_BF16;         // bf16 output: __expf is far inside the rounding
-    for (unsigned it = threadIdx.x; it < items; it += 256) {
-        const unsigned rr = it / cvn;
-        const int c = (int)(it - rr * cvn) * VW;
+    for (int col = lcol; col < p.cvn; col += p.tpr) {
+        const int c = col * VW;
         const char* base; int64_t ld; int cc;
         if (c < p.C0) { base = p.x0; ld = p.C0; cc = c; }
         else { base = p.x1; ld = p.C1; cc = c - p.C0; }
-        const int64_t row = (int64_t)b * p.HW + r0 + (int)rr;
-        float v[8];
-        if (VW == 8) {
-            load8(base, p.in_dt, row * ld + cc, v);
-        } else {
-            const float4 t = load4(base, p.in_dt, row * ld + cc);
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        }
+        float sa[VW], sb[VW];
+        loadv<VW>(reinterpret_cast<const char*>(ab + c), MF_F32, sa);
+        loadv<VW>(reinterpret_cast<const char*>(ab + p.C + c), MF_F32, sb);
+        const int64_t step = (int64_t)p.rif * ld * esz, ostep = (int64_t)p.rif * p.C * osz;
+        const char* ptr = base + (((int64_t)b * p.HW + r0 + trow) * ld + cc) * esz;
+        char* optr = p.out + (((int64_t)b * p.HW + r0 + trow) * p.C + c) * osz;
+        auto finish = [&](float* v, char* o) {
 #pragma unroll
-        for (int j = 0; j < VW; ++j) {
-            float y = v[j] * sa[c + j] + sb[c + j];
-            if (p.silu) y = fast_silu ? silu_f(y) : silu_precise(y);
-            v[j] = y;
+            for (int e = 0; e < VW; ++e) {
+                float y = v[e] * sa[e] + sb[e];
+                if (p.silu) y = fast_silu ? silu_f(y) : silu_precise(y);
+                v[e] = y;
+            }
+            if (VW == 8) store8(o, p.out_dt, 0, v);
+            else store4(o, p.out_dt, 0, make_float4(v[0], v[1], v[2], v[3]));
+        };
+        int r = r0 + trow;
+        for (; r + 3 * p.rif < r1; r += 4 * p.rif, ptr += 4 * step, optr += 4 * ostep) {
+            float v0[VW], v1[VW], v2[VW], v3[VW];
+            loadv<VW>(ptr, p.in_dt, v0);
+            loadv<VW>(ptr + step, p.in_dt, v1);
+            loadv<VW>(ptr + 2 * step, p.in_dt, v2);
+            loadv<VW>(ptr + 3 * step, p.in_dt, v3);
+            finish(v0, optr);
+            finish(v1, optr + ostep);
+            finish(v2, optr + 2 * ostep);
+            finish(v3, optr + 3 * ostep);
         }
-        if (VW == 8) store8(p.out, p.out_dt, row * p.C + c, v);
-        else store4(p.out, p.out_dt, row * p.C + c, make_float4(v[0], v[1], v[2], v[3]));
+        for (; r < r1; r += p.rif, ptr += step, optr += ostep) {
+            float v0[VW];
+            loadv<VW>(ptr, p.in_dt, v0);
+            finish(v0, optr);
+        }
     }
 }
 
@@ -335,10 +357,6 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     a.x0 = (const char*)d->x0; a.x1 = (const char*)d->x1;
     a.C0 = d->c0; a.C1 = d->c1; a.C = C; a.in_dt = d->in_dtype; a.HW = d->hw; a.G = d->groups;
     a.cpg = C / d->groups;
-    // slices of whole groups whose channel count is a multiple of 4 (vector loads never straddle a slice)
-    a.gslices = 1;
-    for (int s = 4; s >= 2; s >>= 1)
-        if (d->groups % s == 0 && ((d->groups / s) * a.cpg) % 4 == 0) { a.gslices = s; break; }
     a.rows_per_chunk = (d->hw + GN_MAX_CHUNKS - 1) / GN_MAX_CHUNKS;
     if (a.rows_per_chunk < 16) a.rows_per_chunk = 16;
     a.nchunks = (d->hw + a.rows_per_chunk - 1) / a.rows_per_chunk;
@@ -346,22 +364,30 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ws = d->ws;
     a.ws_ab = d->ws + (int64_t)d->batch * d->groups * GN_MAX_CHUNKS * 2;
     MF_CHECK_ARG(d->groups <= 64, "mf_groupnorm: at most 64 groups");
-    const int slice_c = (a.G / a.gslices) * a.cpg;
-    const size_t smem1 = (size_t)4 * slice_c * 2 * sizeof(float);
-    MF_CHECK_ARG(smem1 <= 64 * 1024, "mf_groupnorm: slice of %d channels too large", slice_c);
+    const int vw = (d->c0 % 8 == 0 && d->c1 % 8 == 0) ? 8 : 4;
+    a.cvn = C / vw;
+    a.tpr = a.cvn < GN_BLK ? a.cvn : GN_BLK;
+    a.rif = GN_BLK / a.tpr;
+    const int nthr = (a.tpr * a.rif + 63) / 64 * 64;
+    const size_t smem1 = (size_t)a.rif * C * sizeof(float2) > (size_t)2 * d->groups * sizeof(float)
+                             ? (size_t)a.rif * C * sizeof(float2) : (size_t)2 * d->groups * sizeof(float);
+    MF_CHECK_ARG(smem1 <= 64 * 1024, "mf_groupnorm: C=%d too large", C);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunks, a.gslices, d->batch), dim3(256), smem1, s, a);
-    MF_CHECK_LAUNCH("mf_groupnorm(stats)");
-    const size_t smem2 = (size_t)(2 * C + 2 * a.G) * sizeof(float);
-    MF_CHECK_ARG(smem2 <= 64 * 1024, "mf_groupnorm: C=%d too large", C);
-    // ~8 blocks per CU worth of row blocks, at least 4 rows each
+    // ~4 row blocks per CU, at least 4 rows per thread
     int rows_per_block = (int)(((int64_t)d->hw * d->batch + 1023) / 1024);
-    if (rows_per_block < 8) rows_per_block = 8;
+    if (rows_per_block < 4 * a.rif) rows_per_block = 4 * a.rif;
     const int nblk = (d->hw + rows_per_block - 1) / rows_per_block;
-    if (d->c0 % 8 == 0 && d->c1 % 8 == 0)
-        hipLaunchKernelGGL(gn_apply_kernel<8>, dim3(nblk, d->batch), dim3(256), smem2, s, a, rows_per_block);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nblk, d->batch), dim3(256), smem2, s, a, rows_per_block);
+    if (vw == 8) {
+        hipLaunchKernelGGL(gn_stats_kernel<8>, dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
+        MF_CHECK_LAUNCH("mf_groupnorm(stats)");
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
+        hipLaunchKernelGGL(gn_apply_kernel<8>, dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<4>, dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
+        MF_CHECK_LAUNCH("mf_groupnorm(stats)");
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
+        hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
+    }
     MF_CHECK_LAUNCH("mf_groupnorm(apply)");
     return MF_OK;
 }

@@ -134,7 +134,8 @@ _scratch: dict = {}
 
 
 def scratch(name: str, nfloats: int, device) -> torch.Tensor:
-    key = (name, torch.device(device).index)
+    # one buffer per (purpose, device, stream): launches on different streams may run concurrently
+    key = (name, torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(nfloats, 1), dtype=torch.float32, device=device)

@@ -406,7 +406,20 @@ class _UNetCore(HipModel):
         return encoder_hidden_states.to(self.device, self.prec.act).contiguous()
 
     def _inj(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-        return None if t is None else from_nchw(t, self.prec)
+        if t is None:
+            return None
+        ev = _RESIDUAL_EVENTS.pop(t.data_ptr(), None)          # produced on BrushNet's side stream: order after it
+        if ev is not None:
+            torch.cuda.current_stream(t.device).wait_event(ev)
+        return from_nchw(t, self.prec)
+
+
+# BrushNet || UNet overlap.  BrushNet has no data dependence on the UNet, and the UNet needs BrushNet's residual k
+# only at its k-th injection point (unet_2d_condition.py:1218 ff.).  With `BrushNetModel.side_stream` set (the
+# pipeline does that inside its denoise loops), BrushNet runs on that HIP stream, records an event after every
+# zero-conv and the UNet waits on that event right before the add.  Neither network fills 256 CUs during its
+# low-resolution / short-K launches, and every launch has a ramp and a drain: two streams fill those holes.
+_RESIDUAL_EVENTS: Dict[int, "torch.cuda.Event"] = {}
 
 
 # =================================================================================================
@@ -549,42 +562,71 @@ class BrushNetModel(_UNetCore):
             raise NotImplementedError("guess_mode logspace scaling (brushnet.py:896-902) is off in every MirrorFusion config")
         if class_labels is not None or timestep_cond is not None or attention_mask is not None or added_cond_kwargs:
             raise NotImplementedError("class/timestep_cond/attention_mask/added_cond inputs are outside the SD1.5 hot path")
+        side = self.side_stream
+        if side is None:
+            d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, None)
+        else:
+            main = torch.cuda.current_stream(self.device)
+            _RESIDUAL_EVENTS.clear()
+            side.wait_stream(main)                                                                # inputs are ready
+
+            def publish(t: torch.Tensor):
+                ev = torch.cuda.Event()
+                ev.record(side)
+                t.record_stream(main)                     # consumed on `main`: the allocator must not recycle it early
+                _RESIDUAL_EVENTS[t.data_ptr()] = ev
+
+            with torch.cuda.stream(side):
+                d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, publish)
+        if not return_dict:
+            return d, m, u
+        return BrushNetOutput(down_block_res_samples=d, mid_block_res_sample=m, up_block_res_samples=u)
+
+    side_stream: Optional["torch.cuda.Stream"] = None
+
+    def _forward_impl(self, sample, timestep, brushnet_cond, conditioning_scale, publish):
+        """Each zero-conv (brushnet.py:889-894) runs right after the feature it reads is produced — the same
+        arithmetic as the reference's end-of-forward loops, but residual k is final as early as possible."""
+        c = self.config
         bsz = sample.shape[0]
+        s = float(conditioning_scale)
         temb = self._time_embedding(timestep, bsz)
         x = hip.pack_nhwc(sample.to(self.device).float().contiguous(), brushnet_cond.to(self.device).float().contiguous(),
                           self.cin_pad, self.prec.act)                                            # :810 cat + pad
         x = ops.conv2d(x, self.P["conv_in_condition"])
         n = len(c["block_out_channels"])
         lpb = c["layers_per_block"]
+
+        def zero_conv(name: str, r: torch.Tensor) -> torch.Tensor:
+            y = ops.conv2d(r, self.P[name], padding=0, alpha=s)
+            if publish is not None:
+                publish(y)
+            return to_nchw_view(y)
+
         down = [x]
+        d = [zero_conv("brushnet_down_blocks.0", x)]
         for i in range(n):                                                                        # :815-828
             for j in range(lpb):
                 x = self._resnet(f"down_blocks.{i}.resnets.{j}.", x, temb)
                 down.append(x)
+                d.append(zero_conv(f"brushnet_down_blocks.{len(d)}", x))
             if i != n - 1:
                 x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1)
                 down.append(x)
-        s = float(conditioning_scale)
-        bn_down = [ops.conv2d(r, self.P[f"brushnet_down_blocks.{k}"], padding=0, alpha=s) for k, r in enumerate(down)]
+                d.append(zero_conv(f"brushnet_down_blocks.{len(d)}", x))
         for j in range(2):                                                                        # MidBlock2D
             x = self._resnet(f"mid_block.resnets.{j}.", x, temb)
-        bn_mid = ops.conv2d(x, self.P["brushnet_mid_block"], padding=0, alpha=s)
-        ups: List[torch.Tensor] = []
+        m = zero_conv("brushnet_mid_block", x)
+        u: List[torch.Tensor] = []
         skips = list(down)
         for i in range(n):                                                                        # :856-887
             for j in range(lpb + 1):
                 x = self._resnet(f"up_blocks.{i}.resnets.{j}.", x, temb, x1=skips.pop())
-                ups.append(x)
+                u.append(zero_conv(f"brushnet_up_blocks.{len(u)}", x))
             if i != n - 1:
                 x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True)
-                ups.append(x)
-        bn_up = [ops.conv2d(r, self.P[f"brushnet_up_blocks.{k}"], padding=0, alpha=s) for k, r in enumerate(ups)]
-        d = [to_nchw_view(t) for t in bn_down]
-        m = to_nchw_view(bn_mid)
-        u = [to_nchw_view(t) for t in bn_up]
-        if not return_dict:
-            return d, m, u
-        return BrushNetOutput(down_block_res_samples=d, mid_block_res_sample=m, up_block_res_samples=u)
+                u.append(zero_conv(f"brushnet_up_blocks.{len(u)}", x))
+        return d, m, u
 
     __call__ = forward
 

@@ -126,6 +126,8 @@ class StableDiffusionBrushNetPipeline:
         self._guidance_scale = 7.5
         self._num_timesteps = 0
         self.use_hip_graph = True        # capture the denoise step into a hipGraph when the scheduler allows it
+        self.overlap_brushnet = True     # BrushNet on a second HIP stream, ordered against the UNet by per-residual events
+        self._side_stream = None
         self._graph_state = None
 
     # ---- DiffusionPipeline surface ----------------------------------------------------------------
@@ -357,6 +359,7 @@ class StableDiffusionBrushNetPipeline:
                                               negative_prompt_embeds, bar)
                 ts = []
             for i, t in enumerate(ts):                                                               # :1250 HOT LOOP
+                self._overlap(i > 0)                         # step 0 autotunes GEMM tiles: keep its timings undisturbed
                 x_in = torch.cat([latents] * 2) if do_cfg else latents                               # :1256
                 x_in = self.scheduler.scale_model_input(x_in, t)
                 cond_scale = float(brushnet_conditioning_scale) * keep[i]
@@ -383,6 +386,7 @@ class StableDiffusionBrushNetPipeline:
                     if callback is not None and callback_steps and i % callback_steps == 0:
                         callback(i // getattr(self.scheduler, "order", 1), t, latents)
 
+        self._overlap(False)
         if _timing is not None:
             _timing["denoise_end"].record()
         if output_type != "latent":
@@ -395,6 +399,15 @@ class StableDiffusionBrushNetPipeline:
         if not return_dict:
             return (img, None)
         return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)
+
+    def _overlap(self, on: bool):
+        """Turn the BrushNet || UNet stream overlap (models._RESIDUAL_EVENTS) on or off for the next forward calls."""
+        if on and self.overlap_brushnet and self.device.type == "cuda":
+            if self._side_stream is None or self._side_stream.device != self.device:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            self.brushnet.side_stream = self._side_stream
+        else:
+            self.brushnet.side_stream = None
 
     def _denoise_graph(self, latents, ts, pe, cond, nb, guidance_scale, cond_scale, callback_on_step_end,
                        cb_inputs, prompt_embeds, negative_prompt_embeds, bar):
@@ -441,8 +454,12 @@ class StableDiffusionBrushNetPipeline:
                 if st["graph"] is None:
                     torch.cuda.synchronize()
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        one_step()
+                    self._overlap(True)                      # the side stream forks from / joins the capture stream
+                    try:
+                        with torch.cuda.graph(graph):
+                            one_step()
+                    finally:
+                        self._overlap(False)
                     st["graph"] = graph                      # capture does not execute: replay below runs this step
                 st["graph"].replay()
             if callback_on_step_end is not None:

@@ -31,3 +31,6 @@ print(f"{'M':>7} {'N':>6} {'K':>6} kh s u nz tile sk |  n   total_us  avg_us  TF
 for k, (c, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{k[0]:7d} {k[1]:6d} {k[2]:6d} {k[3]:2d} {k[4]} {k[5]} {k[6]:2d} {k[7]:4d} {k[8]:2d} | {c:3d} {t * 1e6:9.1f} {t / c * 1e6:7.1f} {f / t / 1e12:6.1f} {100 * t / secs:5.1f}")
 hip.tune_save()
+if os.path.isdir("gpurun_out"):          # launch-ordered shape keys, to be joined with a rocprofv3 kernel trace
+    import json
+    json.dump([[f, list(k)] for _, f, k in hip.LAST_PROFILE], open("gpurun_out/shape_seq.json", "w"))
