@@ -192,6 +192,10 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+        hip.tune_save()                      # per-shape (tile, split-K) winners found during warmup, for later processes
+        if os.path.isdir("gpurun_out") and os.path.exists(hip._TUNE_PATH):
+            import shutil
+            shutil.copy(hip._TUNE_PATH, "gpurun_out/tune_cache.json")
     D.barrier()
 
 

@@ -27,6 +27,8 @@
 //   * activations stored as fp32 with bf16 compute (A_F32) use a register-staged path that converts on load.
 #include "mf_common.h"
 
+#include <type_traits>
+
 namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];   // zero-initialised module global
@@ -584,6 +586,338 @@ void gemm_conv_kernel(const GemmArgs p) {
     }
 }
 
+// =====================================================================================================
+// 3x3 / stride 1 / pad 1 convolution with the input patch resident in LDS ("halo" tiles), bf16.
+//
+// The implicit-GEMM kernel above re-stages the A tile for each of the 9 taps, so a 3x3 conv moves 9 shifted copies
+// of the same pixels L2 -> LDS, and the chip-wide L2 -> LDS rate (~12-13 TB/s measured) is what bounds it.  Here an
+// M tile is a TH x 16 rectangle of output pixels of one image: per 32-channel chunk the (TH+2) x 18 input patch
+// is DMA'd ONCE (double buffered) and the 9 taps read it at shifted row offsets; only the weights stream per
+// tap, through a ring of SW thin stages (BN rows x 64 B), SW-1 of them in flight.  L2 -> LDS bytes per flop drop
+// ~2x for square-ish tiles and the deeper ring keeps more bytes in flight per CU for the same LDS footprint.
+//
+// LDS rows are 64 B (32 bf16 channels).  16-byte chunk c of row r sits at physical chunk c ^ ((r >> 2) & 3); with
+// ds_read_b128's lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (MI355X_MICROARCH.md, LDS) sixteen rows whose
+// indices are distinct mod 16 are conflict-free.  MFMA fragment row f of fragment I is output pixel
+//     ty = 2 I + (f >> 4),  tx = ((f & 15) + 14 (f >> 4)) & 15
+// (the odd image row of a fragment is rotated by two pixels) so that the patch rows a lane group reads,
+// p0 + {0-3, 12-15} and p0 + 18 + {2-9}, stay distinct mod 16 for every tap shift p0.  The epilogue applies the same map.
+template <int TH, int BN, int WAVES_M, int WAVES_N, int SW>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2)
+void conv3x3_halo_kernel(const GemmArgs p) {
+    constexpr int TW = 16, PW = TW + 2, PH = TH + 2, PPIX = PH * PW;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BM = TH * TW;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    // Wave roles for the DMAs: the last wave fetches the input patches, the others stream the weights.  vmcnt is per
+    // wave and retires in order, so a patch (served from the Infinity Cache / HBM, needed once per 9 tiles) issued by
+    // a weight wave would have to land within the weight ring's 2-3 tiles of slack; on its own wave it has all 9.
+    constexpr int A_INSTR = (PPIX + 15) / 16;                  // wave-instructions (16 rows x 64 B each) per patch
+    constexpr int NWW = NW - 1, AW = NW - 1;
+    constexpr int W_INSTR = (BN + 15) / 16, WP = (W_INSTR + NWW - 1) / NWW;
+    constexpr int A_BYTES = A_INSTR * 1024, W_BYTES = WP * NWW * 1024;
+    constexpr int EP_RS = (WN + 4) * 4;
+    constexpr int SMEM = 2 * A_BYTES + SW * W_BYTES;
+    constexpr int SR = (NW * 32 * EP_RS <= SMEM) ? 32 : 16;
+    static_assert(WM % 32 == 0 && WN % 32 == 0 && TH % 2 == 0, "wave tile must be a multiple of 32x32");
+    static_assert(NW * SR * EP_RS <= SMEM, "epilogue slabs must fit in the staging LDS");
+    static_assert(SW >= 3 && SW <= 8 && (SW - 1) * WP < 64, "ring depth");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int bid = blockIdx.x;
+    {
+        const int q = p.nblk >> 3, r = p.nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tile_m = bid / p.tiles_n;
+    const int tile_n = bid - tile_m * p.tiles_n;
+    const int n0 = tile_n * BN;
+    const int tiles_x = p.Win / TW;
+    const int tiles_img = (p.Hin / TH) * tiles_x;
+    const int img = tile_m / tiles_img;
+    const int tr = tile_m - img * tiles_img;
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr - (tr / tiles_x) * tiles_x) * TW;
+    const int ksplit = blockIdx.z;
+
+    const int c_begin = ksplit * p.kt_per_split;              // 32-channel chunks of this split
+    int c_end = c_begin + p.kt_per_split;
+    if (c_end > p.nkt) c_end = p.nkt;
+    const int nchunks = c_end - c_begin;
+    const int nt = nchunks * 9;
+
+    const int npix = (p.M / p.HoWo) * p.Hin * p.Win;
+    const srd_t srdA0 = make_srd(p.a0, (unsigned)((npix - 1) * p.ld0b + p.C0 * 2));
+    const srd_t srdA1 = make_srd(p.a1 ? p.a1 : p.a0, (unsigned)((npix - 1) * p.ld1b + (p.Ctot - p.C0) * 2));
+    const srd_t srdW = make_srd(p.w, (unsigned)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+
+    // ---- DMA coordinates --------------------------------------------------------------------
+    unsigned aoff[A_INSTR], woff[WP];
+    srd_t srdCur = srdA0;
+    int ai_c = c_begin * 32;                                      // first channel of the next patch to issue
+    auto a_retarget = [&]() {                                      // patch wave only; runs at most twice per kernel
+        const bool seg = ai_c >= p.C0;
+        const int cin = seg ? ai_c - p.C0 : ai_c;
+        const int ldb = seg ? p.ld1b : p.ld0b;
+        srdCur = seg ? srdA1 : srdA0;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int pr = i * 16 + (lane >> 2);                   // patch row this lane fills
+            const int py = pr / PW, px = pr - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool ok = pr < PPIX && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            const int lc = (lane & 3) ^ ((pr >> 2) & 3);
+            aoff[i] = ok ? (unsigned)(((img * p.Hin + iy) * p.Win + ix) * ldb + (cin + lc * 8) * 2) : 0x80000000u;
+        }
+    };
+    auto issue_A = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            dma16_buf(aoff[i], srdCur, lds0 + buf * A_BYTES + i * 1024);
+            aoff[i] += 64;
+        }
+        ai_c += 32;
+        if (ai_c == p.C0 && p.Ctot > p.C0) a_retarget();      // the next patch comes from the second tensor
+    };
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = (wave + NWW * i) * 16 + (lane >> 2);       // weight row (output channel within the tile)
+        const int lc = (lane & 3) ^ ((r >> 2) & 3);
+        const int n = n0 + r;
+        woff[i] = (wave != AW && r < BN && n < p.N) ? (unsigned)(((int64_t)n * p.ldw) * 2 + lc * 16) : 0x80000000u;
+    }
+    int wi_tap = 0;
+    unsigned wi_k = (unsigned)c_begin * 64u;                      // byte offset of the next weight tile inside a row
+    auto issue_W_at = [&](int stage, bool last_tap) {             // last_tap: the tile issued is tap 8 of its chunk
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            dma16_buf(woff[i] + wi_k, srdW, lds0 + 2 * A_BYTES + stage * W_BYTES + (wave + NWW * i) * 1024);
+        wi_k += (unsigned)p.Ctot * 2u;
+        if (last_tap) wi_k -= (unsigned)p.Ctot * 18u - 64u;
+    };
+    auto issue_W = [&](int stage) {
+        const bool last = wi_tap == 8;
+        wi_tap = last ? 0 : wi_tap + 1;
+        issue_W_at(stage, last);
+    };
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    int pr00[MT];                                                  // patch row of this lane's output pixel at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ty = 2 * (wm * MT + i) + (frow >> 4);
+        const int tx = ((frow & 15) + 14 * (frow >> 4)) & 15;
+        pr00[i] = ty * PW + tx;
+    }
+    const int bkey = (frow >> 2) & 3;
+    const char* Wfrag = smem + 2 * A_BYTES + (wn * WN + frow) * 64;
+
+    // Fragment reads run one tile ahead of the MFMAs: while tile t is multiplied from registers, the ds_reads of
+    // tile t+1 are in flight, so neither the LDS latency nor the burst of reads after a barrier sits in front of the
+    // matrix pipe.  Two register sets alternate roles (the loop below is unrolled by two).
+    auto ldfrag = [&](int abuf, int wstage, int tapoff, uint4 (&fa)[2][MT], uint4 (&fb)[2][NT]) {
+        const char* Ab = smem + abuf * A_BYTES;
+        const char* Wb = Wfrag + wstage * W_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int pr = pr00[i] + tapoff;
+                fa[ks][i] = *reinterpret_cast<const uint4*>(Ab + pr * 64 + ((((2 * ks + fh) ^ (pr >> 2)) & 3) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                fb[ks][j] = *reinterpret_cast<const uint4*>(Wb + j * 32 * 64 + (((2 * ks + fh) ^ bkey) << 4));
+        }
+    };
+    auto mma = [&](const uint4 (&fa)[2][MT], const uint4 (&fb)[2][NT]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][i]),
+                                                                        __builtin_bit_cast(bf16x8_t, fb[ks][j]), acc[i][j], 0, 0, 0);
+    };
+
+    // ---- main loop: tile t = (chunk, tap).  Ring invariant at the barrier of iteration t: tile t is in registers,
+    // W(t+1) is resident, W(t+2) .. W(t+SW-1) are in flight and slot t % SW is free (its ds_reads retired: lgkmcnt(0)
+    // precedes the barrier) for W(t+SW).  Weight waves wait with a counted vmcnt (their loads retire in order: all
+    // but the SW-2 youngest tiles); the patch wave waits for its patch only in the iteration that first reads it.
+    if (nt > 0) {
+        uint4 fa0[2][MT], fb0[2][NT], fa1[2][MT], fb1[2][NT];
+        const bool is_aw = wave == AW;
+        auto wait_w = [&](int nw) {                               // at most nw weight tiles of this wave still in flight
+            if (nw >= SW - 1) wait_vmcnt<(SW - 1) * WP>();
+            else if (nw == SW - 2) wait_vmcnt<(SW - 2) * WP>();
+            else if (SW > 3 && nw == SW - 3) wait_vmcnt<(SW > 3 ? SW - 3 : 0) * WP>();
+            else if (SW > 4 && nw == SW - 4) wait_vmcnt<(SW > 4 ? SW - 4 : 0) * WP>();
+            else if (nw >= 1 && nw < SW - 4) wait_vmcnt<WP>();
+            else wait_vmcnt<0>();
+        };
+        if (is_aw) {
+            a_retarget();
+            issue_A(0);
+            wait_vmcnt<0>();
+        } else {
+            for (int s0 = 0; s0 < SW; ++s0)
+                if (s0 < nt) issue_W(s0);
+            wait_w(nt - 1 < SW - 1 ? nt - 1 : SW - 1);
+        }
+        __builtin_amdgcn_s_barrier();
+        ldfrag(0, 0, 0, fa0, fb0);
+        // state of tile t (being multiplied) and of tile t+1 (being read)
+        int tap = 0, chunk = 0, slot = 0;
+        int n_abuf = 0, n_wst = 0, n_tapoff = 0, n_dx = 0, n_tap = 0;
+        auto iteration = [&](int t, const uint4 (&ca)[2][MT], const uint4 (&cb)[2][NT], uint4 (&na)[2][MT], uint4 (&nb)[2][NT]) {
+            const bool has_next = t + 1 < nt;
+            if (has_next) {
+                if (is_aw) {
+                    if (tap == 8) wait_vmcnt<0>();               // tile t+1 is the first to read the next patch
+                } else {
+                    const int rem = nt - 2 - t;
+                    wait_w(rem < SW - 2 ? rem : SW - 2);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wave's reads of tile t have retired
+            __builtin_amdgcn_s_barrier();
+            if (is_aw) {
+                if (tap == 0 && chunk < nchunks - 1) issue_A((chunk & 1) ^ 1);
+            } else if (t + SW < nt) {
+                issue_W(slot);
+            }
+            if (has_next) {
+                n_wst = n_wst == SW - 1 ? 0 : n_wst + 1;
+                ++n_tap; ++n_dx; ++n_tapoff;
+                if (n_dx == 3) { n_dx = 0; n_tapoff += PW - 3; }
+                if (n_tap == 9) { n_tap = 0; n_tapoff = 0; n_abuf ^= 1; }
+                ldfrag(n_abuf, n_wst, n_tapoff, na, nb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            slot = slot == SW - 1 ? 0 : slot + 1;
+            if (++tap == 9) { tap = 0; ++chunk; }
+        };
+        // Steady state (every chunk but the last, two chunks = 18 tiles per trip so the register sets keep their
+        // roles): tap, wait counts, patch offsets and "is there a next tile" are compile-time; only the ring slot
+        // and the patch buffer chunk & 1 are scalar registers.
+        auto steady = [&](auto tapc, const uint4 (&ca)[2][MT], const uint4 (&cb)[2][NT], uint4 (&na)[2][MT], uint4 (&nb)[2][NT]) {
+            constexpr int TAP = decltype(tapc)::value;
+            constexpr int NTAP = (TAP + 1) % 9;
+            if (is_aw) {
+                if constexpr (TAP == 8) wait_vmcnt<0>();
+            } else {
+                wait_vmcnt<(SW - 2) * WP>();
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            if (is_aw) {
+                if constexpr (TAP == 0) issue_A((chunk & 1) ^ 1);
+            } else {
+                issue_W_at(slot, (TAP + SW) % 9 == 8);
+            }
+            const int nslot = slot == SW - 1 ? 0 : slot + 1;
+            ldfrag(TAP == 8 ? (chunk & 1) ^ 1 : (chunk & 1), nslot, (NTAP / 3) * PW + NTAP % 3, na, nb);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(ca, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            slot = nslot;
+        };
+        auto steady_chunk = [&](uint4 (&a0)[2][MT], uint4 (&b0)[2][NT], uint4 (&a1)[2][MT], uint4 (&b1)[2][NT]) {
+            steady(std::integral_constant<int, 0>{}, a0, b0, a1, b1);
+            steady(std::integral_constant<int, 1>{}, a1, b1, a0, b0);
+            steady(std::integral_constant<int, 2>{}, a0, b0, a1, b1);
+            steady(std::integral_constant<int, 3>{}, a1, b1, a0, b0);
+            steady(std::integral_constant<int, 4>{}, a0, b0, a1, b1);
+            steady(std::integral_constant<int, 5>{}, a1, b1, a0, b0);
+            steady(std::integral_constant<int, 6>{}, a0, b0, a1, b1);
+            steady(std::integral_constant<int, 7>{}, a1, b1, a0, b0);
+            steady(std::integral_constant<int, 8>{}, a0, b0, a1, b1);
+            ++chunk;
+        };
+        while (chunk + 2 < nchunks) {
+            steady_chunk(fa0, fb0, fa1, fb1);
+            steady_chunk(fa1, fb1, fa0, fb0);
+        }
+        // tail (the last one or two chunks, and every short split): the generic iteration with run-time checks
+        int t = chunk * 9;
+        n_abuf = chunk & 1; n_wst = slot;
+        wi_tap = SW % 9;                                           // tap of W(t + SW): t is a multiple of 9
+        for (; t + 1 < nt; t += 2) {
+            iteration(t, fa0, fb0, fa1, fb1);
+            iteration(t + 1, fa1, fb1, fa0, fb0);
+        }
+        if (t < nt) iteration(t, fa0, fb0, fa1, fb1);
+    }
+    __syncthreads();
+
+    // ---- epilogue (same slab scheme as gemm_conv_kernel; rows go through the pixel map above) ------------------
+    char* slab = smem + wave * (SR * EP_RS);
+    constexpr int CPR = WN / 8;
+    constexpr int ITEMS = SR * CPR;
+    float* ws = p.splitk > 1 ? p.ws + (int64_t)ksplit * (int64_t)p.M * p.N : nullptr;
+#pragma unroll
+    for (int ih = 0; ih < MT * (32 / SR); ++ih) {
+        const int i = ih / (32 / SR), half = ih % (32 / SR);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = half * (SR / 2); e < half * (SR / 2) + SR / 2; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh - half * SR;
+                *reinterpret_cast<float*>(slab + row * EP_RS + (j * 32 + frow) * 4) = acc[i][j][e];
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it0 = 0; it0 < ITEMS; it0 += 64) {
+            const int it = it0 + lane;
+            if (ITEMS % 64 != 0 && it >= ITEMS) continue;
+            const int row = it / CPR, ec = (it - row * CPR) * 8;
+            const int f = half * SR + row;
+            const int ty = 2 * (wm * MT + i) + (f >> 4);
+            const int tx = ((f & 15) + 14 * (f >> 4)) & 15;
+            const int m = (img * p.Hin + y0 + ty) * p.Win + x0 + tx;
+            const int n = n0 + wn * WN + ec;
+            float v[8];
+            const float4 lo = *reinterpret_cast<const float4*>(slab + row * EP_RS + ec * 4);
+            const float4 hi = *reinterpret_cast<const float4*>(slab + row * EP_RS + ec * 4 + 16);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            if (n < p.N) {
+                if (ws) {
+                    if (n + 8 <= p.N && (p.N & 3) == 0) {
+                        *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n) = lo;
+                        *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n + 4) = hi;
+                    } else {
+                        for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
+                    }
+                } else if (p.vec_ok && n + 8 <= p.N) {
+                    epilogue_store8(p, 0, m, n, v);
+                } else {
+                    for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, 0, m, n + jj, v[jj]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int64_t mn = (int64_t)p.M * p.N;
     if (p.vec_ok) {           // N % 8 == 0: 8 channels per thread, 16/32-byte accesses everywhere
@@ -621,7 +955,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-struct TileCfg { int bm, bn, threads, stages; };
+struct TileCfg { int bm, bn, threads, stages, halo; };   // halo: rows of output pixels per tile of conv3x3_halo_kernel (0 = implicit GEMM)
 // keep in sync with launch_tile()
 const TileCfg kTiles[] = {
     {128, 128, 256, 2},  // 1
@@ -639,6 +973,9 @@ const TileCfg kTiles[] = {
     {192, 128, 256, 2},  // 13  96x64 per wave, 80 KB: still two blocks per CU
     {128, 160, 256, 2},  // 14  4x1 waves, 32x160 per wave: exact fit for N = 320 / 640 / 1280
     {128, 192, 256, 2},  // 15  64x96 per wave
+    {128, 160, 256, 4, 8},  // 16  conv3x3_halo_kernel: 8x16 output pixels x 160 channels, 4x1 waves
+    {128, 128, 256, 4, 8},  // 17  conv3x3_halo_kernel: 8x16 x 128, 2x2 waves
+    {128, 128, 256, 6, 8},  // 18  same with a 6-deep weight ring
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -683,6 +1020,21 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
     }
 }
 
+template <int TH, int BN, int WMv, int WNv, int SW>
+void launch_halo(const GemmArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int NW = WMv * WNv, PPIX = (TH + 2) * 18;
+    constexpr int WP = ((BN + 15) / 16 + NW - 2) / (NW - 1);
+    constexpr int smem = 2 * ((PPIX + 15) / 16) * 1024 + SW * WP * (NW - 1) * 1024;
+    static_assert(smem <= 80 * 1024, "two blocks per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, BN, WMv, WNv, SW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<TH, BN, WMv, WNv, SW>), grid, dim3(NW * 64), smem, s, a);
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Heuristic tile choice (mf_gemm_desc.tile overrides it; the Python host autotunes per shape).
@@ -692,7 +1044,7 @@ int pick_tile(int M, int N, int nz, int splitk) {
     for (int t = 1; t <= kNumTiles; ++t) {
         const TileCfg& c = kTiles[t - 1];
         const double tiles = (double)cdiv(M, c.bm) * cdiv(N, c.bn) * nz * (splitk > 1 ? splitk : 1);
-        if (c.stages != 2) continue;                                      // the ring variants are picked by the host autotuner
+        if (c.stages != 2 || c.halo) continue;                            // the ring / halo variants are picked by the host autotuner
         const int bpc = (2 * (c.bm + c.bn) * 128 <= 80 * 1024) ? 2 : 1;   // blocks per CU that fit in LDS
         const double rounds = (double)(int64_t)((tiles + 256.0 * bpc - 1) / (256.0 * bpc));
         double per_cu = tiles / 256.0;
@@ -780,6 +1132,52 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     int tile = d->tile;
     if (tile <= 0 || tile > kNumTiles) tile = pick_tile(a.M, a.N, a.nz, d->splitk);
     const TileCfg& tc = kTiles[tile - 1];
+    if (tc.halo) {
+        // conv3x3_halo_kernel: bf16, 3x3 / stride 1 / pad 1, whole TH x 16 tiles, 32-channel chunks
+        const int64_t npix = (int64_t)d->batch * d->h_in * d->w_in;
+        const int64_t ext_a = (npix - 1) * (int64_t)(a.ld0b > a.ld1b ? a.ld0b : a.ld1b) + (int64_t)a.Ctot * 2;
+        const int64_t ext_w = ((int64_t)(a.N - 1) * a.ldw + a.K) * 2;
+        const bool ok = d->dtype == MF_BF16 && !a_f32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
+                        d->pad_l == 1 && !d->upsample && d->h_out == d->h_in && d->w_out == d->w_in && d->nz == 1 &&
+                        d->h_in % tc.halo == 0 && d->w_in % 16 == 0 && a.C0 % 32 == 0 && a.Ctot % 32 == 0 &&
+                        ext_a < (1ll << 31) - (1 << 20) && ext_w < (1ll << 31) - (1 << 20) && d->act != MF_ACT_GEGLU4 &&
+                        d->o_zs_o == 0 && d->o_zs_i == 0;
+        MF_CHECK_ARG(ok, "mf_gemm_conv: tile %d (3x3 halo kernel) does not apply to this call", tile);
+        a.nkt = a.Ctot / 32;
+        const int64_t tiles = (int64_t)(a.M / tc.bm) * cdiv(a.N, tc.bn);
+        int sk = d->splitk;
+        if (sk == 0) {
+            sk = 1;
+            if (tiles < 384 && d->ws != nullptr) {
+                sk = (int)((512 + tiles - 1) / tiles);
+                if (sk > a.nkt / 2) sk = a.nkt / 2;
+                if ((int64_t)sk * a.M * a.N > d->ws_floats) sk = (int)(d->ws_floats / ((int64_t)a.M * a.N));
+            }
+        }
+        if (sk < 1) sk = 1;
+        if (sk > a.nkt) sk = a.nkt;
+        a.kt_per_split = cdiv(a.nkt, sk);
+        a.splitk = cdiv(a.nkt, a.kt_per_split);
+        a.ws = d->ws;
+        MF_CHECK_ARG(a.splitk == 1 || (a.ws != nullptr && (int64_t)a.splitk * a.M * a.N <= d->ws_floats),
+                     "mf_gemm_conv: split-K=%d needs a workspace of %lld floats", a.splitk, (long long)a.splitk * a.M * a.N);
+        a.tiles_n = cdiv(a.N, tc.bn);
+        a.nblk = (int)tiles;
+        dim3 hgrid((unsigned)tiles, 1, (unsigned)a.splitk);
+        hipStream_t hs = (hipStream_t)stream;
+        if (tile == 16) launch_halo<8, 160, 4, 1, 4>(a, hgrid, hs);
+        else if (tile == 17) launch_halo<8, 128, 2, 2, 4>(a, hgrid, hs);
+        else launch_halo<8, 128, 2, 2, 6>(a, hgrid, hs);
+        MF_CHECK_LAUNCH("mf_gemm_conv(halo)");
+        if (a.splitk > 1) {
+            const int64_t total = (int64_t)a.M * a.N / (a.vec_ok ? 8 : 1);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, hs, a);
+            MF_CHECK_LAUNCH("mf_gemm_conv(split-K reduce)");
+        }
+        return MF_OK;
+    }
     const int bk = 128 / es;
     a.nkt = cdiv(a.K, bk);
     const int64_t tiles_mn = (int64_t)cdiv(a.M, tc.bm) * cdiv(a.N, tc.bn) * a.nz;

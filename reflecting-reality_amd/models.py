@@ -955,7 +955,7 @@ class AutoencoderKL(HipModel):
     def _moments(self, x: torch.Tensor) -> torch.Tensor:
         c = self.config
         n = len(c["block_out_channels"])
-        h = from_nchw(x.to(self.device).float(), self.prec, self.cin_pad)
+        h = from_nchw(hip.h2d(x, self.device).float(), self.prec, self.cin_pad)
         h = ops.conv2d(h, self.P["encoder.conv_in"])
         for i in range(n):
             for j in range(c["layers_per_block"]):

@@ -278,11 +278,11 @@ class StableDiffusionBrushNetPipeline:
         sf = float(self.vae.config["scaling_factor"])
         halves = [hip.vae_sample(moments, conditioning_noise[i * batch:(i + 1) * batch].contiguous(), lat_c, sf)
                   for i in range(dup)]
-        mask_l = hip.nearest_resize(original_mask.to(self.device), hl, wl)                         # :1189-1195
+        mask_l = hip.nearest_resize(hip.h2d(original_mask, self.device), hl, wl)                         # :1189-1195
         parts = [mask_l]
         if self.depth_conditioning_mode == "concat":
             d = self.prepare_image(depth, width, height, batch, num_images_per_prompt)
-            parts.append(hip.nearest_resize(d.to(self.device), hl, wl))                            # :1198-1202
+            parts.append(hip.nearest_resize(hip.h2d(d, self.device), hl, wl))                            # :1198-1202
         extra = torch.cat(parts, 1)
         return torch.cat([torch.cat([h, extra], 1) for h in halves], 0).contiguous()
 

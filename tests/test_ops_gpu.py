@@ -57,6 +57,36 @@ def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     check(f"conv3x3[{prec_name},tile{tile}]", nchw(y), ref, atol, rtol)
 
 
+@pytest.mark.parametrize("tile", [16, 17, 18])
+@pytest.mark.parametrize("case", ["plain", "tailN", "cat", "splitk", "epilogue", "big"])
+def test_conv3x3_halo_tiles(tile, case):
+    """conv3x3_halo_kernel (input patch resident in LDS, weights streamed per tap) against F.conv2d."""
+    prec = ops.Precision.get("bf16")
+    g = torch.Generator().manual_seed(11)
+    b, h, w_, c0, c1, n = {"plain": (2, 16, 32, 64, 0, 160), "tailN": (1, 8, 16, 32, 0, 200), "cat": (2, 16, 16, 64, 32, 128),
+                           "splitk": (1, 16, 16, 256, 0, 160), "epilogue": (2, 8, 32, 96, 0, 320),
+                           "big": (2, 64, 64, 320, 0, 320)}[case]
+    x = rb(torch.randn(b, c0, h, w_, generator=g))
+    x1 = rb(torch.randn(b, c1, h, w_, generator=g)) if c1 else None
+    w = rb(torch.randn(n, c0 + c1, 3, 3, generator=g) * 0.03)
+    bias = torch.randn(n, generator=g)
+    cw = ops.ConvWeight(w, bias, prec, DEV)
+    xin = torch.cat([x, x1], 1) if c1 else x
+    ref = F.conv2d(xin, w, bias, padding=1)
+    kw = {}
+    if case == "epilogue":
+        temb = torch.randn(b, n, generator=g)
+        r0 = rb(torch.randn(b, n, h, w_, generator=g))
+        ref = F.silu(0.5 * (ref + temb[:, :, None, None]) + r0)
+        kw = dict(temb=temb.to(DEV), res0=nhwc(r0, prec.act), alpha=0.5, act=hip.ACT_SILU)
+    y = ops.conv2d(nhwc(x, prec.act), cw, x1=nhwc(x1, prec.act) if c1 else None, tile=tile,
+                   splitk=3 if case == "splitk" else 1, **kw)
+    check(f"conv3x3_halo[tile{tile},{case}]", nchw(y), ref, 2e-2, 1e-2)
+    if case == "plain":     # a call the halo kernel cannot serve is refused, not silently rerouted
+        with pytest.raises(hip.MfhipError):
+            ops.conv2d(nhwc(x, prec.act), cw, stride=2, tile=tile)
+
+
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
 def test_conv_epilogue_temb_res_alpha_silu(prec_name, atol, rtol):
     prec = ops.Precision.get(prec_name)
