@@ -31,7 +31,7 @@ struct AttnArgs {
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
 template <int HD, bool DB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const AttnArgs p) {
     constexpr int DK = (HD + 15) / 16 * 16;   // QK^T reduction length, padded to the MFMA k-step
     constexpr int KS = DK / 16;
     constexpr int DV = (HD + 31) / 32 * 32;   // O^T rows, padded to the MFMA tile
@@ -57,6 +57,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
     // zero the whole staging area once: pad columns / rows must never hold NaN bit patterns
     for (int i = tid * 16; i < NBUF * BUF_BYTES; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+    // Head dims that leave pad rows in the 32-row V^T tiles (40, 80, 8) get a row of ones there: O^T row HD then
+    // accumulates sum_k P[k][q] on the matrix pipe, rescaled with O like every other row, and the VALU row sum goes away.
+    constexpr bool ONES = DV > HD;
+    constexpr int L_D = HD / 32, L_RR = HD % 32, L_E = (L_RR & 3) + 4 * (L_RR >> 3), L_H = (L_RR >> 2) & 1;
+    if (ONES) {
+        __syncthreads();
+        for (int i = tid; i < NBUF * 32; i += 256)           // 64 keys = 128 B = 32 dwords per buffer
+            *reinterpret_cast<uint32_t*>(smem + (i >> 5) * BUF_BYTES + K_BYTES + HD * RBV + (i & 31) * 4) = 0x3F803F80u;
+    }
 
     // Q fragments (B operand of S^T = K.Q^T): lane (query r, half h) holds Q[q][16ks + 8h + j]
     bf16x8_t qf[KS];
@@ -169,9 +178,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         // ---- online softmax (per query = per lane; the two lane halves hold disjoint keys) ----
         float mx = -INFINITY;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[tt][e]);
+        for (int e = 0; e < 16; ++e) mx = fmaxf(fmaxf(mx, st[0][e]), st[1][e]);     // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx * p.c);
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);
@@ -183,13 +190,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             for (int e = 0; e < 16; ++e) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(st[tt][e], p.c, -m_new));
                 st[tt][e] = pv;
-                rs += pv;
+                if (!ONES) rs += pv;
             }
-        l = l * alpha + rs;
+        // the running max settles after the first few tiles: skip the O^T rescale when no lane's max moved
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+            l *= alpha;
 #pragma unroll
-        for (int d = 0; d < DT; ++d)
+            for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        }
+        if (!ONES) l += rs;
         // ---- P^T fragments: accumulator registers 8s..8s+7 of tile tt are k-step 2*tt+s ----
         bf16x8_t pf[4];
 #pragma unroll
@@ -217,7 +228,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
 
     // ---- epilogue: normalise, transpose through LDS, row-contiguous stores ----
-    l += __shfl_xor(l, 32, 64);
+    if (ONES) l = __shfl(L_H == 0 ? o[L_D][L_E] : 0.0f, (lane & 31) + 32 * L_H, 64);
+    else l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     char* Os = smem + wave * 32 * RBO;   // safe: the loop ended on a barrier
 #pragma unroll
