@@ -156,9 +156,22 @@ def main():
             d, m, u = pipe.brushnet(x2, 981, encoder_hidden_states=pe, brushnet_cond=cond, return_dict=False)
             pipe.unet(x2, 981, pe, down_block_add_samples=d, mid_block_add_sample=m, up_block_add_samples=u)
         n_launch, secs, flops = hip.profile_end()
+        # algorithmic bytes: activations read once, weights once, output written once (bf16 = 2 B)
+        alg_bytes = 0.0
+        for _, _, (m, n, k, kh, stride, ups, nz, _tile, _sk) in hip.LAST_PROFILE:
+            a_px = m * stride * stride / (4.0 if ups else 1.0)
+            alg_bytes += nz * 2.0 * (a_px * k / (kh * kh) + n * k + m * n)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_family.json")
+        if os.path.exists(pmc) and a.batch == 4 and a.size == 512 and a.precision == "bf16":
+            with open(pmc) as f:
+                pj = json.load(f)
+            traffic = pj["traffic_bytes_per_launch"]          # separate rocprofv3 --pmc passes (tools/pmc_step.sh)
+            traffic_src = "profiles/r01_pmc_gemm_family.json: " + pj["method"]
         roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel (all tile instantiations)",
                     "achieved": round(flops / secs / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(flops / secs / 1e12 / peak, 4), "traffic": None,
+                    "frac": round(flops / secs / 1e12 / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes / n_launch),
                     "launches_per_denoise_step": n_launch, "avg_launch_us": round(secs / n_launch * 1e6, 2),
                     "flop_per_denoise_step": flops,
                     "denoise_step": {"ms": round(step_s * 1e3, 3), "achieved": round(step_tflops, 2),

@@ -1,0 +1,10 @@
+#!/bin/bash
+# HBM-side traffic of the mf_gemm_conv family over one denoise step: two separate rocprofv3 --pmc passes
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"); summarise with
+# tools/pmc_step_summary.py.  Run from the repo root on the GPU box:  bash tools/pmc_step.sh
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_step_$c -o step -- python3 tools/profile_step.py --steps 1 > gpurun_out/pmc_step_$c.log 2>&1
+done
+python3 tools/pmc_step_summary.py gpurun_out/pmc_step_FETCH_SIZE gpurun_out/pmc_step_WRITE_SIZE > gpurun_out/pmc_gemm_family.json
+cat gpurun_out/pmc_gemm_family.json
