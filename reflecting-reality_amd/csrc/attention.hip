@@ -83,51 +83,55 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     const char* kbase = p.k + ((int64_t)b * p.skv * p.ldk + head * HD) * 2;
     const char* vbase = p.vt + ((int64_t)(b * p.heads + head) * HD) * p.ldvt * 2;
 
+    // Per-thread staging coordinates are loop invariant: source pointers advance by a constant per 64-key tile and
+    // the LDS destinations never change; only the last tile needs the key-bound predicates.
     uint4 kreg[KJ], vreg[VJ];
+    const char* kptr[KJ]; const char* vptr[VJ];
+    int kdst[KJ], vdst[VJ], krow[KJ], vkey[VJ];
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+        const int v = tid + 256 * j;
+        const int row = v / (HD / 8), cv = v - row * (HD / 8);
+        krow[j] = v < KVEC ? row : (1 << 28);                       // fails every bound test
+        kptr[j] = kbase + ((int64_t)row * p.ldk + cv * 8) * 2;
+        kdst[j] = row * RBK + cv * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < VJ; ++j) {
+        const int v = tid + 256 * j;
+        const int row = v >> 3, cv = v & 7;
+        vkey[j] = v < VVEC ? cv * 8 + 8 : (1 << 28);
+        vptr[j] = vbase + ((int64_t)row * p.ldvt + cv * 8) * 2;
+        // keys cv*8 .. cv*8+7 of a 16-key step; LDS order inside a step is [0-3, 8-11, 4-7, 12-15]
+        vdst[j] = K_BYTES + row * RBV + (cv >> 1) * 32 + (cv & 1) * 8;
+    }
+    const int64_t kstep = (int64_t)64 * p.ldk * 2;
     auto load_tile = [&](int kv0) {
+        const bool full = kv0 + 64 <= p.skv && kv0 + 64 <= (int)p.ldvt;
 #pragma unroll
         for (int j = 0; j < KJ; ++j) {
-            const int v = tid + 256 * j;
-            kreg[j] = make_uint4(0, 0, 0, 0);
-            if (v < KVEC) {
-                const int row = v / (HD / 8), cv = v - row * (HD / 8);
-                const int key = kv0 + row;
-                if (key < p.skv) kreg[j] = ldg16(kbase + ((int64_t)key * p.ldk + cv * 8) * 2);
-            }
+            if (full ? krow[j] < 64 : kv0 + krow[j] < p.skv) kreg[j] = ldg16(kptr[j]);
+            else kreg[j] = make_uint4(0, 0, 0, 0);
+            kptr[j] += kstep;
         }
 #pragma unroll
         for (int j = 0; j < VJ; ++j) {
-            const int v = tid + 256 * j;
-            vreg[j] = make_uint4(0, 0, 0, 0);
-            if (v < VVEC) {
-                const int row = v >> 3, cv = v & 7;
-                const int key0 = kv0 + cv * 8;
-                if (key0 + 8 <= p.ldvt) vreg[j] = ldg16(vbase + ((int64_t)row * p.ldvt + key0) * 2);
-            }
+            if (full ? vkey[j] <= 64 : kv0 + vkey[j] <= (int)p.ldvt) vreg[j] = ldg16(vptr[j]);
+            else vreg[j] = make_uint4(0, 0, 0, 0);
+            vptr[j] += 128;
         }
     };
     auto store_tile = [&](int buf) {
-        char* Ks = smem + buf * BUF_BYTES;
-        char* Vs = Ks + K_BYTES;
+        char* base = smem + buf * BUF_BYTES;
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            const int v = tid + 256 * j;
-            if (v < KVEC) {
-                const int row = v / (HD / 8), cv = v - row * (HD / 8);
-                *reinterpret_cast<uint4*>(Ks + row * RBK + cv * 16) = kreg[j];
-            }
-        }
+        for (int j = 0; j < KJ; ++j)
+            if (krow[j] < 64) *reinterpret_cast<uint4*>(base + kdst[j]) = kreg[j];
 #pragma unroll
-        for (int j = 0; j < VJ; ++j) {
-            const int v = tid + 256 * j;
-            if (v < VVEC) {
-                const int row = v >> 3, cv = v & 7;
-                // keys cv*8 .. cv*8+7 of a 16-key step; LDS order inside a step is [0-3, 8-11, 4-7, 12-15]
-                char* dst = Vs + row * RBV + (cv >> 1) * 32 + (cv & 1) * 8;
-                *reinterpret_cast<uint2*>(dst) = make_uint2(vreg[j].x, vreg[j].y);
-                *reinterpret_cast<uint2*>(dst + 16) = make_uint2(vreg[j].z, vreg[j].w);
+        for (int j = 0; j < VJ; ++j)
+            if (vkey[j] <= 64) {
+                *reinterpret_cast<uint2*>(base + vdst[j]) = make_uint2(vreg[j].x, vreg[j].y);
+                *reinterpret_cast<uint2*>(base + vdst[j] + 16) = make_uint2(vreg[j].z, vreg[j].w);
             }
-        }
     };
 
     f32x16_t o[DT];
@@ -156,14 +160,13 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
 
         // ---- S^T = K . Q^T : two 32-key tiles ----
         f32x16_t st[2];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { st[0][e] = 0.0f; st[1][e] = 0.0f; }
+        const f32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // inline-constant src2, no register zeroing
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const uint4 a = *reinterpret_cast<const uint4*>(Ks + (32 * tt + r) * RBK + (16 * ks + 8 * h) * 2);
-                st[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), qf[ks], st[tt], 0, 0, 0);
+                st[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), qf[ks], ks == 0 ? zero16 : st[tt], 0, 0, 0);
             }
         }
         if (kv0 + 64 > p.skv) {
@@ -208,10 +211,10 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 uint4 u;
-                u.x = (uint32_t)f32_to_bf16(st[tt][8 * s + 0]) | ((uint32_t)f32_to_bf16(st[tt][8 * s + 1]) << 16);
-                u.y = (uint32_t)f32_to_bf16(st[tt][8 * s + 2]) | ((uint32_t)f32_to_bf16(st[tt][8 * s + 3]) << 16);
-                u.z = (uint32_t)f32_to_bf16(st[tt][8 * s + 4]) | ((uint32_t)f32_to_bf16(st[tt][8 * s + 5]) << 16);
-                u.w = (uint32_t)f32_to_bf16(st[tt][8 * s + 6]) | ((uint32_t)f32_to_bf16(st[tt][8 * s + 7]) << 16);
+                u.x = pack_bf16x2(st[tt][8 * s + 0], st[tt][8 * s + 1]);
+                u.y = pack_bf16x2(st[tt][8 * s + 2], st[tt][8 * s + 3]);
+                u.z = pack_bf16x2(st[tt][8 * s + 4], st[tt][8 * s + 5]);
+                u.w = pack_bf16x2(st[tt][8 * s + 6], st[tt][8 * s + 7]);
                 pf[2 * tt + s] = __builtin_bit_cast(bf16x8_t, u);
             }
         // ---- O^T += V^T . P^T ----
@@ -237,8 +240,8 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 u;
-            u.x = (uint32_t)f32_to_bf16(o[d][4 * g + 0] * inv) | ((uint32_t)f32_to_bf16(o[d][4 * g + 1] * inv) << 16);
-            u.y = (uint32_t)f32_to_bf16(o[d][4 * g + 2] * inv) | ((uint32_t)f32_to_bf16(o[d][4 * g + 3] * inv) << 16);
+            u.x = pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
+            u.y = pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 2) = u;
         }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed

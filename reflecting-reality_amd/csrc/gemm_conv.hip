@@ -125,8 +125,8 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
             *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(g[0], g[1], g[2], g[3]);
         } else {
             uint2 u;
-            u.x = (uint32_t)f32_to_bf16(g[0]) | ((uint32_t)f32_to_bf16(g[1]) << 16);
-            u.y = (uint32_t)f32_to_bf16(g[2]) | ((uint32_t)f32_to_bf16(g[3]) << 16);
+            u.x = pack_bf16x2(g[0], g[1]);
+            u.y = pack_bf16x2(g[2], g[3]);
             *reinterpret_cast<uint2*>(p.out + o * 2) = u;
         }
         return;
@@ -137,10 +137,10 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
         *reinterpret_cast<float4*>(p.out + o * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
         uint4 u;
-        u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-        u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-        u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+        u.x = pack_bf16x2(v[0], v[1]);
+        u.y = pack_bf16x2(v[2], v[3]);
+        u.z = pack_bf16x2(v[4], v[5]);
+        u.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>(p.out + o * 2) = u;
     }
 }
@@ -150,10 +150,10 @@ __device__ __forceinline__ uint4 ld8f_to_bf16(const char* p) {
     const float4 lo = *reinterpret_cast<const float4*>(p);
     const float4 hi = *reinterpret_cast<const float4*>(p + 16);
     uint4 r;
-    r.x = (uint32_t)f32_to_bf16(lo.x) | ((uint32_t)f32_to_bf16(lo.y) << 16);
-    r.y = (uint32_t)f32_to_bf16(lo.z) | ((uint32_t)f32_to_bf16(lo.w) << 16);
-    r.z = (uint32_t)f32_to_bf16(hi.x) | ((uint32_t)f32_to_bf16(hi.y) << 16);
-    r.w = (uint32_t)f32_to_bf16(hi.z) | ((uint32_t)f32_to_bf16(hi.w) << 16);
+    r.x = pack_bf16x2(lo.x, lo.y);
+    r.y = pack_bf16x2(lo.z, lo.w);
+    r.z = pack_bf16x2(hi.x, hi.y);
+    r.w = pack_bf16x2(hi.z, hi.w);
     return r;
 }
 

@@ -36,6 +36,15 @@ __device__ __forceinline__ bf16_raw f32_to_bf16(float f) {
     return __builtin_bit_cast(bf16_raw, b);
 }
 
+// two fp32 -> packed bf16x2 (RNE) in ONE v_cvt_pk_bf16_f32; (uint32)f32_to_bf16(a) | f32_to_bf16(b) << 16 costs two
+// conversions plus an SDWA or
+typedef __attribute__((ext_vector_type(2))) float mf_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 mf_bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    const mf_f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mf_bf16x2_t));
+}
+
 // dtype-generic scalar load/store (dt is wave-uniform at every call site)
 __device__ __forceinline__ float load_as_f32(const void* p, int dt, int64_t i) {
     return dt == MF_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_raw*)p)[i]);

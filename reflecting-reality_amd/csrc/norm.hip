@@ -35,8 +35,8 @@ __device__ __forceinline__ void store4(char* p, int dt, int64_t idx, float4 v) {
         *reinterpret_cast<float4*>(p + idx * 4) = v;
     } else {
         uint2 u;
-        u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-        u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+        u.x = pack_bf16x2(v.x, v.y);
+        u.y = pack_bf16x2(v.z, v.w);
         *reinterpret_cast<uint2*>(p + idx * 2) = u;
     }
 }
@@ -60,10 +60,10 @@ __device__ __forceinline__ void store8(char* p, int dt, int64_t idx, const float
         *reinterpret_cast<float4*>(p + idx * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
         uint4 u;
-        u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-        u.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-        u.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+        u.x = pack_bf16x2(v[0], v[1]);
+        u.y = pack_bf16x2(v[2], v[3]);
+        u.z = pack_bf16x2(v[4], v[5]);
+        u.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>(p + idx * 2) = u;
     }
 }
