@@ -918,6 +918,277 @@ void conv3x3_halo_kernel(const GemmArgs p) {
     }
 }
 
+// =====================================================================================================
+// conv3x3_pingpong_kernel: the halo idea on a 256 x 160 tile with ONE 8-wave block per CU and a two-group ping-pong
+// schedule (cdna_hip_programming.md, 8-wave GEMM template).  The per-CU DMA path (vector-memory issue -> TA/TCP ->
+// LDS) costs ~30 % of the 128 x 160 kernels whatever the L2 hit rate ("What bounds the convs"); this tile
+// moves 2.9x fewer DMA'd bytes per flop: 16 x 16 output pixels share one 18 x 18 x 64-channel patch (full 128-byte rows)
+// per 9 taps, and 256 pixels share every 160 x 64 weight stage.
+//
+// Waves 0-3 (group 0) and 4-7 (group 1) sit pairwise on the four SIMDs.  A tile (one tap x 64 channels) is two
+// sub-tiles of two k-steps; time is cut into intervals by s_barrier:
+//     interval 2s   : group 0 multiplies sub-tile s from registers | group 1 reads the fragments of sub-tile s
+//     interval 2s+1 : group 0 reads the fragments of sub-tile s+1  | group 1 multiplies sub-tile s
+// so each SIMD's matrix pipe always has exactly one wave in its MFMA phase (10 MFMAs), and every wave does its DMA
+// issue, LDS reads and bookkeeping while its SIMD partner multiplies.  One sub-tile's fragments (12 x 16 B) live in
+// registers (a whole tile's 96 VGPRs beside the 80 accumulators spilled).  Ring: stage t is read in intervals 4t-1 ..
+// 4t+2; a group refills it with its share of W(t+3) when it starts reading tile t+1, and every weight wave makes
+// sure its share of W(T) has landed at the end of interval 4T-2: 7-8 intervals of slack.  Weight DMAs come from waves
+// 0-6 (3 x 1 KiB each per stage); wave 7 fetches the patches (41 x 1 KiB per chunk, 4 per read phase of taps 0..5 so
+// the address arithmetic is spread out) and therefore only ever waits for a patch at a chunk boundary.
+template <int BN, int SW>
+__global__ __launch_bounds__(512, 2)
+void conv3x3_pingpong_kernel(const GemmArgs p) {
+    constexpr int TH = 16, TW = 16, PW = TW + 2, PH = TH + 2, PPIX = PH * PW;
+    constexpr int NW = 8, AW = 7, NWW = 7;
+    constexpr int NT = BN / 32, KS = 4;
+    constexpr int A_INSTR = (PPIX + 7) / 8;                     // 8 rows x 128 B per wave-instruction
+    constexpr int A_PER_TAP = (A_INSTR + 5) / 6;                // issued during taps 0..5 of the previous chunk
+    constexpr int W_INSTR = (BN + 7) / 8, WP = (W_INSTR + NWW - 1) / NWW;
+    constexpr int A_BYTES = A_INSTR * 1024, W_BYTES = WP * NWW * 1024;
+    constexpr int WN = BN, EP_RS = (WN + 4) * 4;
+    constexpr int SMEM = 2 * A_BYTES + SW * W_BYTES;
+    constexpr int SR = 16;
+    static_assert(BN % 32 == 0 && SW == 3, "tile");
+    static_assert(NW * SR * EP_RS <= SMEM && SMEM <= 160 * 1024, "LDS budget");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+
+    int bid = blockIdx.x;
+    {
+        const int q = p.nblk >> 3, r = p.nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tile_m = bid / p.tiles_n;
+    const int tile_n = bid - tile_m * p.tiles_n;
+    const int n0 = tile_n * BN;
+    const int tiles_x = p.Win / TW;
+    const int tiles_img = (p.Hin / TH) * tiles_x;
+    const int img = tile_m / tiles_img;
+    const int tr = tile_m - img * tiles_img;
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr - (tr / tiles_x) * tiles_x) * TW;
+    const int ksplit = blockIdx.z;
+
+    const int c_begin = ksplit * p.kt_per_split;              // 64-channel chunks of this split
+    int c_end = c_begin + p.kt_per_split;
+    if (c_end > p.nkt) c_end = p.nkt;
+    const int nchunks = c_end - c_begin;
+    const int nt = nchunks * 9;
+
+    const int npix = (p.M / p.HoWo) * p.Hin * p.Win;
+    const srd_t srdA0 = make_srd(p.a0, (unsigned)((npix - 1) * p.ld0b + p.C0 * 2));
+    const srd_t srdA1 = make_srd(p.a1 ? p.a1 : p.a0, (unsigned)((npix - 1) * p.ld1b + (p.Ctot - p.C0) * 2));
+    const srd_t srdW = make_srd(p.w, (unsigned)(((int64_t)(p.N - 1) * p.ldw + p.K) * 2));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+
+    // ---- weight DMA (waves 0..6) ----------------------------------------------------------------
+    unsigned woff[WP];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+        const int r = (wave + NWW * i) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        const int n = n0 + r;
+        woff[i] = (wave != AW && r < BN && n < p.N) ? (unsigned)(((int64_t)n * p.ldw) * 2 + lc * 16) : 0x80000000u;
+    }
+    int wi_tap = 0;
+    unsigned wi_k = (unsigned)c_begin * 128u;
+    auto issue_W = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            dma16_buf(woff[i] + wi_k, srdW, lds0 + 2 * A_BYTES + stage * W_BYTES + (wave + NWW * i) * 1024);
+        wi_k += (unsigned)p.Ctot * 2u;
+        if (++wi_tap == 9) { wi_tap = 0; wi_k -= (unsigned)p.Ctot * 18u - 128u; }
+    };
+    // ---- patch DMA (wave 7): instruction q of the patch of the chunk starting at channel c ---------------
+    // The pixel index of every (instruction, lane) of a patch is chunk invariant: a table in LDS (built once by the
+    // whole block) keeps wave 7's read phases down to one ds_read + 4 VALU per DMA instruction.
+    int* pix_tab = reinterpret_cast<int*>(smem + SMEM);
+    for (int e = tid; e < A_INSTR * 64; e += 512) {
+        const int pr = (e >> 6) * 8 + ((e & 63) >> 3);
+        const int py = pr / PW, px = pr - py * PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        const bool ok = pr < PPIX && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+        pix_tab[e] = ok ? (img * p.Hin + iy) * p.Win + ix : -1;
+    }
+    __syncthreads();
+    auto issue_A_range = [&](int buf, int cstart, int q_lo, int q_hi) {
+        const bool seg = cstart >= p.C0;
+        const int cin = seg ? cstart - p.C0 : cstart;
+        const int ldb = seg ? p.ld1b : p.ld0b;
+        const srd_t srd = seg ? srdA1 : srdA0;
+        for (int q = q_lo; q < q_hi; ++q) {
+            const int pix = pix_tab[q * 64 + lane];
+            const int lc = (lane & 7) ^ ((q * 4 + (lane >> 4)) & 7);          // (pr >> 1) & 7 with pr = 8 q + lane / 8
+            const unsigned off = pix >= 0 ? (unsigned)(pix * ldb + (cin + lc * 8) * 2) : 0x80000000u;
+            dma16_buf(off, srd, lds0 + buf * A_BYTES + q * 1024);
+        }
+    };
+
+    f32x16_t acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const int pr00 = (2 * wave + (frow >> 4)) * PW + (((frow & 15) + 14 * (frow >> 4)) & 15);
+    const int bkey = (frow >> 1) & 7;
+    const char* Wfrag = smem + 2 * A_BYTES + frow * 128;
+
+    uint4 fa[2], fb[2][NT];
+    auto ldfrag = [&](int abuf, int wstage, int tapoff, int half) {
+        const int pr = pr00 + tapoff;
+        const char* Ap = smem + abuf * A_BYTES + pr * 128;
+        const int akey = (pr >> 1) & 7;
+        const char* Wb = Wfrag + wstage * W_BYTES;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int c = 4 * half + 2 * k2 + fh;             // 16-byte chunk = k-step (2 half + k2), lane half fh
+            fa[k2] = *reinterpret_cast<const uint4*>(Ap + ((c ^ akey) << 4));
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                fb[k2][j] = *reinterpret_cast<const uint4*>(Wb + j * 32 * 128 + ((c ^ bkey) << 4));
+        }
+    };
+    auto mma = [&]() {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[k2]),
+                                                                 __builtin_bit_cast(bf16x8_t, fb[k2][j]), acc[j], 0, 0, 0);
+    };
+
+    if (nt > 0) {
+        const bool is_aw = wave == AW;
+        constexpr int A_PER_PHASE = (A_INSTR + 11) / 12;       // patch instructions per read phase over taps 0..5
+        // prologue: patch 0, stages 0..2; group 0 reads sub-tile 0 in "interval -1"
+        if (is_aw) {
+            issue_A_range(0, c_begin * 64, 0, A_INSTR);
+            wait_vmcnt<0>();
+        } else {
+            for (int s0 = 0; s0 < SW; ++s0)
+                if (s0 < nt) issue_W(s0);
+            if (nt >= 3) wait_vmcnt<2 * WP>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        // per-group state of the sub-tile it reads next (group 0 starts with sub-tile 1 = tile 0 / half 1, group 1 with 0)
+        int r_t = 0, r_half = 0, r_tap = 0, r_tapoff = 0, r_dx = 0, r_abuf = 0, r_slot = 0, r_chunk = 0;
+        auto read_phase = [&]() {
+            if (r_t < nt) {
+                ldfrag(r_abuf, r_slot, r_tapoff, r_half);
+                if (!is_aw) {
+                    // starting tile r_t: tile r_t - 1 has been read by both groups, its stage takes W(r_t - 1 + SW)
+                    if (r_half == 0 && r_t >= 1 && r_t - 1 + SW < nt) issue_W(r_slot == 0 ? SW - 1 : r_slot - 1);
+                } else if (r_chunk + 1 < nchunks && r_tap < 6) {
+                    const int q_lo = (2 * r_tap + r_half) * A_PER_PHASE;
+                    int q_hi = q_lo + A_PER_PHASE;
+                    if (q_hi > A_INSTR) q_hi = A_INSTR;
+                    issue_A_range((r_chunk & 1) ^ 1, (c_begin + r_chunk + 1) * 64, q_lo, q_hi);
+                }
+            }
+            if (r_half == 0) {
+                r_half = 1;
+            } else {
+                r_half = 0;
+                ++r_t;
+                r_slot = r_slot == SW - 1 ? 0 : r_slot + 1;
+                ++r_tap; ++r_dx; ++r_tapoff;
+                if (r_dx == 3) { r_dx = 0; r_tapoff += PW - 3; }
+                if (r_tap == 9) { r_tap = 0; r_tapoff = 0; r_abuf ^= 1; ++r_chunk; }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): fragments are in registers, the stage may be refilled
+        };
+        auto end_even = [&](int s) {       // end of interval 2s
+            if (!is_aw) {
+                if (s & 1) {               // interval 4T-2, T = (s+1)/2: every wave's share of W(T) must be in before 4T-1
+                    if (((s + 1) >> 1) + 1 < nt) wait_vmcnt<WP>();
+                    else wait_vmcnt<0>();
+                }
+            } else if (r_tap == 0 && r_half == 0) {
+                wait_vmcnt<0>();           // wave 7 has just read the last sub-tile of a chunk: the next one opens the next patch
+            }
+            __builtin_amdgcn_s_barrier();
+        };
+        const int ns = 2 * nt;
+        if (grp == 0) {
+            read_phase();                                // sub-tile 0
+            for (int sidx = 0; sidx < ns; ++sidx) {
+                __builtin_amdgcn_sched_barrier(0);
+                mma();                                   // interval 2s
+                __builtin_amdgcn_sched_barrier(0);
+                end_even(sidx);
+                read_phase();                            // interval 2s+1: sub-tile s+1
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            for (int sidx = 0; sidx < ns; ++sidx) {
+                read_phase();                            // interval 2s
+                end_even(sidx);
+                __builtin_amdgcn_sched_barrier(0);
+                mma();                                   // interval 2s+1
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue (slab scheme of gemm_conv_kernel; rows go through the pixel map) ------------------------------
+    char* slab = smem + wave * (SR * EP_RS);
+    constexpr int CPR = WN / 8;
+    constexpr int ITEMS = SR * CPR;
+    float* ws = p.splitk > 1 ? p.ws + (int64_t)ksplit * (int64_t)p.M * p.N : nullptr;
+#pragma unroll
+    for (int half = 0; half < 32 / SR; ++half) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = half * (SR / 2); e < half * (SR / 2) + SR / 2; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh - half * SR;
+                *reinterpret_cast<float*>(slab + row * EP_RS + (j * 32 + frow) * 4) = acc[j][e];
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it0 = 0; it0 < ITEMS; it0 += 64) {
+            const int it = it0 + lane;
+            if (ITEMS % 64 != 0 && it >= ITEMS) continue;
+            const int row = it / CPR, ec = (it - row * CPR) * 8;
+            const int f = half * SR + row;
+            const int ty = 2 * wave + (f >> 4);
+            const int tx = ((f & 15) + 14 * (f >> 4)) & 15;
+            const int m = (img * p.Hin + y0 + ty) * p.Win + x0 + tx;
+            const int n = n0 + ec;
+            float v[8];
+            const float4 lo = *reinterpret_cast<const float4*>(slab + row * EP_RS + ec * 4);
+            const float4 hi = *reinterpret_cast<const float4*>(slab + row * EP_RS + ec * 4 + 16);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            if (n < p.N) {
+                if (ws) {
+                    if (n + 8 <= p.N && (p.N & 3) == 0) {
+                        *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n) = lo;
+                        *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n + 4) = hi;
+                    } else {
+                        for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
+                    }
+                } else if (p.vec_ok && n + 8 <= p.N) {
+                    epilogue_store8(p, 0, m, n, v);
+                } else {
+                    for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, 0, m, n + jj, v[jj]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int64_t mn = (int64_t)p.M * p.N;
     if (p.vec_ok) {           // N % 8 == 0: 8 channels per thread, 16/32-byte accesses everywhere
@@ -976,6 +1247,7 @@ const TileCfg kTiles[] = {
     {128, 160, 256, 4, 8},  // 16  conv3x3_halo_kernel: 8x16 output pixels x 160 channels, 4x1 waves
     {128, 128, 256, 4, 8},  // 17  conv3x3_halo_kernel: 8x16 x 128, 2x2 waves
     {128, 128, 256, 6, 8},  // 18  same with a 6-deep weight ring
+    {256, 160, 512, 3, 16}, // 19  conv3x3_pingpong_kernel: 16x16 pixels x 160 channels, 8 waves, one block per CU
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1033,6 +1305,19 @@ void launch_halo(const GemmArgs& a, dim3 grid, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL((conv3x3_halo_kernel<TH, BN, WMv, WNv, SW>), grid, dim3(NW * 64), smem, s, a);
+}
+
+template <int BN>
+void launch_pingpong(const GemmArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int smem = 2 * ((18 * 18 + 7) / 8) * 1024 + 3 * (((BN + 7) / 8 + 6) / 7) * 7 * 1024 + ((18 * 18 + 7) / 8) * 256;
+    static_assert(smem <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pingpong_kernel<BN, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_pingpong_kernel<BN, 3>), grid, dim3(512), smem, s, a);
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -1139,11 +1424,12 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         const int64_t ext_w = ((int64_t)(a.N - 1) * a.ldw + a.K) * 2;
         const bool ok = d->dtype == MF_BF16 && !a_f32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 &&
                         d->pad_l == 1 && !d->upsample && d->h_out == d->h_in && d->w_out == d->w_in && d->nz == 1 &&
-                        d->h_in % tc.halo == 0 && d->w_in % 16 == 0 && a.C0 % 32 == 0 && a.Ctot % 32 == 0 &&
+                        d->h_in % tc.halo == 0 && d->w_in % 16 == 0 && a.C0 % (tc.halo == 16 ? 64 : 32) == 0 &&
+                        a.Ctot % (tc.halo == 16 ? 64 : 32) == 0 &&
                         ext_a < (1ll << 31) - (1 << 20) && ext_w < (1ll << 31) - (1 << 20) && d->act != MF_ACT_GEGLU4 &&
                         d->o_zs_o == 0 && d->o_zs_i == 0;
         MF_CHECK_ARG(ok, "mf_gemm_conv: tile %d (3x3 halo kernel) does not apply to this call", tile);
-        a.nkt = a.Ctot / 32;
+        a.nkt = a.Ctot / (tc.halo == 16 ? 64 : 32);
         const int64_t tiles = (int64_t)(a.M / tc.bm) * cdiv(a.N, tc.bn);
         int sk = d->splitk;
         if (sk == 0) {
@@ -1165,7 +1451,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         a.nblk = (int)tiles;
         dim3 hgrid((unsigned)tiles, 1, (unsigned)a.splitk);
         hipStream_t hs = (hipStream_t)stream;
-        if (tile == 16) launch_halo<8, 160, 4, 1, 4>(a, hgrid, hs);
+        if (tile == 19) launch_pingpong<160>(a, hgrid, hs);
+        else if (tile == 16) launch_halo<8, 160, 4, 1, 4>(a, hgrid, hs);
         else if (tile == 17) launch_halo<8, 128, 2, 2, 4>(a, hgrid, hs);
         else launch_halo<8, 128, 2, 2, 6>(a, hgrid, hs);
         MF_CHECK_LAUNCH("mf_gemm_conv(halo)");

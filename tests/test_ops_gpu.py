@@ -57,15 +57,20 @@ def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     check(f"conv3x3[{prec_name},tile{tile}]", nchw(y), ref, atol, rtol)
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19])
 @pytest.mark.parametrize("case", ["plain", "tailN", "cat", "splitk", "epilogue", "big"])
 def test_conv3x3_halo_tiles(tile, case):
-    """conv3x3_halo_kernel (input patch resident in LDS, weights streamed per tap) against F.conv2d."""
+    """conv3x3_halo_kernel (input patch resident in LDS, weights streamed per tap) and the 8-wave ping-pong
+    256x160 variant (tile 19: 16x16 pixel tiles, 64-channel chunks) against F.conv2d."""
     prec = ops.Precision.get("bf16")
     g = torch.Generator().manual_seed(11)
     b, h, w_, c0, c1, n = {"plain": (2, 16, 32, 64, 0, 160), "tailN": (1, 8, 16, 32, 0, 200), "cat": (2, 16, 16, 64, 32, 128),
                            "splitk": (1, 16, 16, 256, 0, 160), "epilogue": (2, 8, 32, 96, 0, 320),
                            "big": (2, 64, 64, 320, 0, 320)}[case]
+    if tile == 19:      # 16-row tiles, 64-channel chunks
+        b, h, w_, c0, c1, n = {"plain": (2, 16, 32, 64, 0, 160), "tailN": (1, 16, 16, 64, 0, 200), "cat": (2, 16, 16, 64, 64, 128),
+                               "splitk": (1, 16, 16, 256, 0, 160), "epilogue": (2, 16, 32, 128, 0, 320),
+                               "big": (2, 64, 64, 320, 0, 320)}[case]
     x = rb(torch.randn(b, c0, h, w_, generator=g))
     x1 = rb(torch.randn(b, c1, h, w_, generator=g)) if c1 else None
     w = rb(torch.randn(n, c0 + c1, 3, 3, generator=g) * 0.03)
