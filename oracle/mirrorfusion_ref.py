@@ -576,13 +576,17 @@ def preprocess_image(img: torch.Tensor) -> torch.Tensor:
 
 
 def build_conditioning(vae_sd: SD, vae_cfg: dict, image: torch.Tensor, mask: torch.Tensor,
-                       depth: Optional[torch.Tensor], vae_noise: torch.Tensor, cfg_dup: bool = True
-                       ) -> torch.Tensor:
-    """pipeline_brushnet.py:1116-1202 for depth_conditioning_mode='concat'.
+                       depth: Optional[torch.Tensor], vae_noise: torch.Tensor, cfg_dup: bool = True,
+                       depth_mode: str = "concat", depth_noise: Optional[torch.Tensor] = None,
+                       normals: Optional[torch.Tensor] = None, normals_mode: Optional[str] = None,
+                       normals_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pipeline_brushnet.py:1116-1215.
 
-    image/mask: [B,3,H,W] in [0,1]; depth [B,1,H,W] in [-1,1]; vae_noise: posterior noise for the
-    CFG-duplicated batch [2B,4,h,w] (the reference draws it from the global RNG, :1188).
-    Returns conditioning_latents [2B, 4+1(+1), h, w].
+    image/mask: [B,3,H,W] in [0,1]; depth [B,1,H,W] in [-1,1]; normals [B,3,H,W]; *_noise: posterior noise for the
+    CFG-duplicated batch [2B,4,h,w] (the reference draws them from the global RNG in the order image (:1188),
+    depth (:1206), normals (:1214)).  depth_mode "concat": nearest-resized depth (+1 ch, :1198-1202); "latents":
+    depth repeated to 3 channels and VAE-encoded (+4 ch, :1203-1206); normals alike (:1208-1215, +3 / +4 ch).
+    Returns conditioning_latents [2B, 4+1+..., h, w].
     """
     img = preprocess_image(image.float())
     m = preprocess_image(mask.float())
@@ -593,12 +597,25 @@ def build_conditioning(vae_sd: SD, vae_cfg: dict, image: torch.Tensor, mask: tor
     cond = vae_sample(moments, vae_noise) * vae_cfg["scaling_factor"]                    # :1188
     mm = F.interpolate(original_mask, size=cond.shape[-2:])                              # :1189-1195
     cond = torch.cat([cond, mm], 1)
+    hw = cond.shape[-2:]
     if depth is not None:
         d = preprocess_image(depth.float())
         if cfg_dup:
             d = torch.cat([d] * 2)
-        d = F.interpolate(d, size=cond.shape[-2:])                                       # :1198-1202
-        cond = torch.cat([cond, d], 1)
+        if depth_mode == "concat":
+            cond = torch.cat([cond, F.interpolate(d, size=hw)], 1)                       # :1198-1202
+        else:
+            dm = vae_encode_moments(vae_sd, vae_cfg, d.repeat(1, 3, 1, 1))               # :1204-1205
+            cond = torch.cat([cond, vae_sample(dm, depth_noise) * vae_cfg["scaling_factor"]], 1)
+    if normals is not None and normals_mode is not None:
+        nrm = preprocess_image(normals.float())
+        if cfg_dup:
+            nrm = torch.cat([nrm] * 2)
+        if normals_mode == "concat":
+            cond = torch.cat([cond, F.interpolate(nrm, size=hw)], 1)                     # :1208-1212
+        else:
+            nm = vae_encode_moments(vae_sd, vae_cfg, nrm)                                # :1213-1215
+            cond = torch.cat([cond, vae_sample(nm, normals_noise) * vae_cfg["scaling_factor"]], 1)
     return cond
 
 

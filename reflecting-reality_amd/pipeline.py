@@ -110,10 +110,9 @@ class StableDiffusionBrushNetPipeline:
         if safety_checker is not None:
             raise NotImplementedError("the safety checker (a CLIP vision model) is outside the accelerated path; "
                                       "pass safety_checker=None as examples/brushnet/test_brushnet.py:150 does")
-        if normals_conditioning_mode not in (None,):
-            raise NotImplementedError("normals conditioning is not part of the BASELINE configs (SURVEY.md §8f-4)")
-        if depth_conditioning_mode not in (None, "concat"):
-            raise NotImplementedError("depth_conditioning_mode='latents' is a 'next' row (SURVEY.md §8f-4)")
+        for nm, mode in (("depth", depth_conditioning_mode), ("normals", normals_conditioning_mode)):
+            if mode not in (None, "concat", "latents"):
+                raise ValueError(f"{nm}_conditioning_mode must be None, 'concat' or 'latents', got {mode!r}")
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
         self.unet, self.brushnet, self.scheduler = unet, brushnet, scheduler
         self.safety_checker, self.feature_extractor, self.image_encoder = safety_checker, feature_extractor, image_encoder
@@ -194,6 +193,8 @@ class StableDiffusionBrushNetPipeline:
                 raise TypeError(f"`{nm}` must be passed (PIL image, numpy array, torch tensor or a list of those)")
         if self.depth_conditioning_mode is not None and depth is None:
             raise ValueError(f"depth_conditioning_mode={self.depth_conditioning_mode!r} needs a `depth` input")
+        if self.normals_conditioning_mode is not None and normals is None:
+            raise ValueError(f"normals_conditioning_mode={self.normals_conditioning_mode!r} needs a `normals` input")
         if not isinstance(brushnet_conditioning_scale, float):
             raise TypeError("For single brushnet: `brushnet_conditioning_scale` must be type `float`.")
         starts = control_guidance_start if isinstance(control_guidance_start, (tuple, list)) else [control_guidance_start]
@@ -259,32 +260,56 @@ class StableDiffusionBrushNetPipeline:
         return noise.contiguous(), noise
 
     def build_conditioning(self, image, mask, depth, height, width, batch, num_images_per_prompt, do_cfg,
-                           conditioning_noise=None):
-        """pipeline_brushnet.py:1116-1202: [masked-image latents | mask | depth] at latent resolution."""
+                           conditioning_noise=None, normals=None):
+        """pipeline_brushnet.py:1116-1215: [masked-image latents | mask | depth | normals] at latent resolution.
+        `conditioning_noise`: the VAE posterior noise of the CFG-duplicated batch — one tensor (image) or a sequence
+        (image, depth, normals) for the 'latents' modes; None draws them in the reference's order from the global RNG."""
         img = self.prepare_image(image, width, height, batch, num_images_per_prompt)
         m3 = self.prepare_image(mask, width, height, batch, num_images_per_prompt)
         original_mask = (m3.sum(1)[:, None, :, :] < 0).to(torch.float32)                           # :1139 (1 = keep)
         height, width = img.shape[-2:]
         hl, wl = height // self.vae_scale_factor, width // self.vae_scale_factor
         dup = 2 if do_cfg else 1
-        moments = self.vae._moments(img)                                                           # B images, once
         lat_c = self.vae.config["latent_channels"]
-        if conditioning_noise is None:
-            # reference: latent_dist.sample() on the CFG-duplicated batch, global RNG (:1188, vae.py:782-791)
-            conditioning_noise = torch.randn(dup * batch, lat_c, hl, wl, dtype=torch.float32)
-        conditioning_noise = conditioning_noise.to(self.device, torch.float32)
-        if conditioning_noise.shape[0] != dup * batch:
-            raise ValueError(f"conditioning_noise must have batch {dup * batch}")
         sf = float(self.vae.config["scaling_factor"])
-        halves = [hip.vae_sample(moments, conditioning_noise[i * batch:(i + 1) * batch].contiguous(), lat_c, sf)
-                  for i in range(dup)]
-        mask_l = hip.nearest_resize(hip.h2d(original_mask, self.device), hl, wl)                         # :1189-1195
-        parts = [mask_l]
-        if self.depth_conditioning_mode == "concat":
+        noises = list(conditioning_noise) if isinstance(conditioning_noise, (list, tuple)) else [conditioning_noise]
+        noises += [None] * (3 - len(noises))
+
+        def encode_sample(x_host, noise):
+            """vae.encode(x).latent_dist.sample() * scaling_factor for the CFG-duplicated batch: B images are encoded
+            once and sampled once per CFG half (the reference encodes the duplicated batch, :1188)."""
+            moments = self.vae._moments(x_host)
+            if noise is None:
+                noise = torch.randn(dup * batch, lat_c, hl, wl, dtype=torch.float32)   # global RNG, like vae.py:782-791
+            noise = noise.to(self.device, torch.float32)
+            if noise.shape[0] != dup * batch:
+                raise ValueError(f"conditioning_noise must have batch {dup * batch}")
+            return [hip.vae_sample(moments, noise[i * batch:(i + 1) * batch].contiguous(), lat_c, sf) for i in range(dup)]
+
+        halves = encode_sample(img, noises[0])
+        parts = [[h] for h in halves]
+        mask_l = hip.nearest_resize(hip.h2d(original_mask, self.device), hl, wl)                   # :1189-1195
+        for ps in parts:
+            ps.append(mask_l)
+        if self.depth_conditioning_mode is not None:
             d = self.prepare_image(depth, width, height, batch, num_images_per_prompt)
-            parts.append(hip.nearest_resize(hip.h2d(d, self.device), hl, wl))                            # :1198-1202
-        extra = torch.cat(parts, 1)
-        return torch.cat([torch.cat([h, extra], 1) for h in halves], 0).contiguous()
+            if self.depth_conditioning_mode == "concat":
+                dl = hip.nearest_resize(hip.h2d(d, self.device), hl, wl)                           # :1198-1202
+                for ps in parts:
+                    ps.append(dl)
+            else:
+                for ps, h in zip(parts, encode_sample(d.repeat(1, 3, 1, 1), noises[1])):           # :1203-1206
+                    ps.append(h)
+        if self.normals_conditioning_mode is not None:
+            nrm = self.prepare_image(normals, width, height, batch, num_images_per_prompt)
+            if self.normals_conditioning_mode == "concat":
+                nl = hip.nearest_resize(hip.h2d(nrm, self.device), hl, wl)                         # :1208-1212
+                for ps in parts:
+                    ps.append(nl)
+            else:
+                for ps, h in zip(parts, encode_sample(nrm, noises[2])):                            # :1213-1215
+                    ps.append(h)
+        return torch.cat([torch.cat(ps, 1) for ps in parts], 0).contiguous()
 
     # ---- the call --------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -303,8 +328,8 @@ class StableDiffusionBrushNetPipeline:
                  conditioning_noise: Optional[torch.Tensor] = None, _timing: Optional[dict] = None, **kwargs):
         callback = kwargs.pop("callback", None)
         callback_steps = kwargs.pop("callback_steps", None)
-        if ip_adapter_image is not None or ip_adapter_image_embeds is not None or normals is not None:
-            raise NotImplementedError("IP-Adapter / normals inputs are outside the BASELINE configs (SURVEY.md §2 #14)")
+        if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
+            raise NotImplementedError("IP-Adapter inputs are outside the BASELINE configs (SURVEY.md §2 #14)")
         if guess_mode or cross_attention_kwargs or clip_skip is not None or timesteps is not None:
             raise NotImplementedError("guess_mode / cross_attention_kwargs / clip_skip / custom timesteps are not built")
         if isinstance(control_guidance_start, list) or isinstance(control_guidance_end, list):
@@ -335,7 +360,7 @@ class StableDiffusionBrushNetPipeline:
                 ww, hh = first.size
             height, width = height or int(hh), width or int(ww)
         cond = self.build_conditioning(image, mask, depth, height, width, nb, num_images_per_prompt, do_cfg,
-                                       conditioning_noise)
+                                       conditioning_noise, normals)
 
         self.scheduler.set_timesteps(num_inference_steps, device=self.device)                       # :1171
         ts = self.scheduler.timesteps

@@ -62,6 +62,26 @@ def test_tiny_pipeline_matches_reference(name):
     report(f"{name} image", img, G[f"{name}_image"], **TOL)
 
 
+def test_alt_conditioning_modes_match_reference():
+    """depth_conditioning_mode='latents' + normals_conditioning_mode='concat' (pipeline_brushnet.py:1203-1215)."""
+    usd, bsd, vsd = sds("tiny")
+    G = golden("tiny_pipeline.npz")
+    inp = synth.pipeline_inputs(1, 16, 16, seed=1234, cross_dim=32, vae_scale=2)
+    normals = torch.rand(1, 3, 16, 16, generator=torch.Generator().manual_seed(4321)) * 2.0 - 1.0
+    cond = R.build_conditioning(vsd, R.TINY_VAE, inp["image"], inp["mask"], inp["depth"], torch.from_numpy(G["alt_vae_noise"]),
+                                depth_mode="latents", depth_noise=torch.from_numpy(G["alt_depth_noise"]), normals=normals,
+                                normals_mode="concat")
+    assert cond.shape == (2, 12, 8, 8)
+    report("alt conditioning", cond, G["alt_cond"], **TOL)
+    bcfg = R.brushnet_config(R.TINY_UNET, 12)
+    from reflecting_reality_amd.models import BrushNetModel
+    shapes = BrushNetModel(dict(bcfg), precision="fp32", device="cpu").param_shapes()
+    bsd12 = synth.state_dict_for(shapes, 11)
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    lat = R.denoise(usd, R.TINY_UNET, bsd12, bcfg, R.DDIMRef(**R.SD15_SCHED), inp["latents"], cond, pe, 2, 7.5, 1.0)
+    report("alt 2-step latents", lat, G["alt_latents"], **TOL)
+
+
 def test_scheduler_traces_match_reference():
     G = golden("schedulers.npz")
     for n in (4, 50):

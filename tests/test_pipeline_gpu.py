@@ -140,3 +140,35 @@ def test_tiny_pipeline_per_step(prec, tol, name):
         if tol is None:
             assert float((trace[i].cpu() - ref).abs().mean()) < 0.15 * float(ref.abs().mean())
     report(f"{name} image[{prec}]", res.images, G[f"{name}_image"], atol=tol or 0.0, fail=tol is not None)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", None)])
+def test_alt_conditioning_modes(prec, tol):
+    """depth VAE-encoded ('latents') + normals nearest-resized ('concat'): 12-channel BrushNet condition, 2 DDIM steps."""
+    from reflecting_reality_amd import models as M
+    unet, _, vae = build("tiny", prec)
+    bcfg = R.brushnet_config(R.TINY_UNET, 12)
+    bn = M.BrushNetModel(dict(bcfg), precision=prec, device=DEV)
+    bn.load_state_dict(synth.state_dict_for(bn.param_shapes(), 11))
+    G = golden("tiny_pipeline.npz")
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                           scheduler=DDIMScheduler(**SD_SCHED, clip_sample=False), safety_checker=None,
+                                           feature_extractor=None, requires_safety_checker=False,
+                                           depth_conditioning_mode="latents", normals_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(1, 16, 16, seed=1234, cross_dim=32, vae_scale=2)
+    normals = torch.rand(1, 3, 16, 16, generator=torch.Generator().manual_seed(4321)) * 2.0 - 1.0
+    noise = [torch.from_numpy(G["alt_vae_noise"]), torch.from_numpy(G["alt_depth_noise"])]
+    cond = pipe.build_conditioning(inp["image"], inp["mask"], inp["depth"], 16, 16, 1, 1, True, noise, normals)
+    assert tuple(cond.shape) == (2, 12, 8, 8)
+    report(f"alt conditioning[{prec}]", cond, G["alt_cond"], atol=2e-4 if prec == "fp32" else 5e-2)
+    lat = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+               image=inp["image"], mask=inp["mask"], depth=inp["depth"], normals=normals, num_inference_steps=2,
+               guidance_scale=7.5, latents=inp["latents"].clone(), output_type="latent", brushnet_conditioning_scale=1.0,
+               height=16, width=16, conditioning_noise=noise).images
+    err = report(f"alt 2-step latents[{prec}]", lat, G["alt_latents"], atol=tol or 1e9, fail=tol is not None)
+    if tol is None:
+        assert float((lat.float().cpu() - torch.from_numpy(G["alt_latents"])).abs().mean()) < 0.5, err
+    with pytest.raises(ValueError):          # the mode needs its input
+        pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
+             mask=inp["mask"], depth=inp["depth"], num_inference_steps=2, height=16, width=16)

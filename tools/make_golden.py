@@ -179,6 +179,44 @@ def tiny():
         pout[f"{name}_image"] = res.images.numpy()
     np.savez_compressed(os.path.join(GOLD, "tiny_pipeline.npz"), **pout)
 
+    # --- F5b: the other conditioning modes (pipeline_brushnet.py:1203-1215): depth VAE-encoded ("latents", +4 ch)
+    # and normals nearest-resized ("concat", +3 ch) -> a 12-channel BrushNet condition ---------------------------------
+    bn12 = BrushNetModel.from_unet(unet, conditioning_channels=12, load_weights_from_unet=False).eval()
+    bn12_sd, _ = load_synth(bn12, 11)
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=sched_cfg["beta_start"], beta_end=sched_cfg["beta_end"],
+                          beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn12,
+                                           scheduler=sched, safety_checker=None, feature_extractor=None,
+                                           requires_safety_checker=False, depth_conditioning_mode="latents",
+                                           normals_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(1, 16, 16, seed=1234, cross_dim=ucfg["cross_attention_dim"], vae_scale=2)
+    normals = torch.rand(1, 3, 16, 16, generator=torch.Generator().manual_seed(4321)) * 2.0 - 1.0
+    captured = {}
+    hook = bn12.register_forward_pre_hook(
+        lambda mod, args, kwargs: captured.update(cond=kwargs["brushnet_cond"].clone()), with_kwargs=True)
+    torch.manual_seed(777)
+    res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+               image=inp["image"], mask=inp["mask"], depth=inp["depth"], normals=normals, num_inference_steps=2,
+               guidance_scale=7.5, latents=inp["latents"].clone(), output_type="latent",
+               brushnet_conditioning_scale=1.0, height=16, width=16)
+    hook.remove()
+    torch.manual_seed(777)
+    vae_noise = torch.randn(2, 4, 8, 8)
+    depth_noise = torch.randn(2, 4, 8, 8)
+    ocond = R.build_conditioning(vae_sd, vcfg, inp["image"], inp["mask"], inp["depth"], vae_noise, depth_mode="latents",
+                                 depth_noise=depth_noise, normals=normals, normals_mode="concat")
+    print("[alt modes] conditioning oracle-vs-ref:", maxdiff(ocond, captured["cond"]), tuple(ocond.shape))
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    olat = R.denoise(unet_sd, ucfg, bn12_sd, R.brushnet_config(ucfg, 12), R.DDIMRef(**R.SD15_SCHED), inp["latents"], ocond,
+                     pe, 2, 7.5, 1.0)
+    print("[alt modes] 2-step latents oracle-vs-ref:", maxdiff(olat, res.images))
+    pout["alt_cond"] = captured["cond"].numpy()
+    pout["alt_vae_noise"] = vae_noise.numpy()
+    pout["alt_depth_noise"] = depth_noise.numpy()
+    pout["alt_latents"] = res.images.numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_pipeline.npz"), **pout)
+
     # --- F1: scheduler traces with the SD1.5 constants -------------------------------------------
     sout = {}
     for n in (4, 50):
