@@ -10,7 +10,7 @@ from oracle import mirrorfusion_ref as R  # noqa: E402
 from reflecting_reality_amd import (DDIMScheduler, PNDMScheduler, StableDiffusionBrushNetPipeline,  # noqa: E402
                                     UniPCMultistepScheduler, synth)  # noqa: E402
 from test_models_gpu import build  # noqa: E402
-from util import golden, report  # noqa: E402
+from util import golden, keys, report  # noqa: E402
 
 DEV = "cuda"
 SD_SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
@@ -172,3 +172,89 @@ def test_alt_conditioning_modes(prec, tol):
     with pytest.raises(ValueError):          # the mode needs its input
         pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
              mask=inp["mask"], depth=inp["depth"], num_inference_steps=2, height=16, width=16)
+
+
+def _tiny_pipe(prec="fp32"):
+    unet, bn, vae = build("tiny", prec)
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                           scheduler=DDIMScheduler(**SD_SCHED, clip_sample=False), safety_checker=None,
+                                           feature_extractor=None, requires_safety_checker=False,
+                                           depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    return pipe
+
+
+def _run(pipe, inp, steps, h, w, noise, **kw):
+    args = dict(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
+                mask=inp["mask"], depth=inp["depth"], num_inference_steps=steps, guidance_scale=7.5,
+                latents=inp["latents"].clone(), output_type="latent", height=h, width=w, conditioning_noise=noise)
+    args.update(kw)
+    return pipe(**args).images.float().cpu()
+
+
+def test_graph_eager_and_stream_overlap_agree():
+    """The captured hipGraph, the eager loop, and both with / without the BrushNet side stream run the same kernels on
+    the same data: bitwise-identical latents (every kernel is deterministic, no atomics)."""
+    pipe = _tiny_pipe()
+    inp = synth.pipeline_inputs(2, 16, 32, seed=7, cross_dim=32, vae_scale=2)
+    noise = torch.randn(4, 4, 8, 16, generator=torch.Generator().manual_seed(3))
+    outs = {}
+    for graph in (True, False):
+        for overlap in (True, False):
+            pipe.use_hip_graph, pipe.overlap_brushnet, pipe._graph_state = graph, overlap, None
+            outs[(graph, overlap)] = _run(pipe, inp, 5, 16, 32, noise)
+    pipe.use_hip_graph, pipe.overlap_brushnet, pipe._graph_state = True, True, None
+    ref = outs[(False, False)]
+    for k, v in outs.items():
+        assert torch.equal(v, ref), f"graph={k[0]} overlap={k[1]} differs from the plain eager loop by {(v - ref).abs().max()}"
+    # a second call with new inputs reuses the captured graph and its static buffers
+    inp2 = synth.pipeline_inputs(2, 16, 32, seed=8, cross_dim=32, vae_scale=2)
+    a = _run(pipe, inp2, 5, 16, 32, noise)
+    pipe.use_hip_graph = False
+    b = _run(pipe, inp2, 5, 16, 32, noise)
+    pipe.use_hip_graph = True
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["batch2_nonsquare", "no_cfg", "cond_scale_window", "images_per_prompt"])
+def test_pipeline_variants_against_oracle(case):
+    """Call-surface variants of pipeline_brushnet.py:848-1363 against the pinned oracle (fp32 mode, 1e-3)."""
+    pipe = _tiny_pipe()
+    usd, bsd, vsd = (synth.state_dict_for(keys("tiny")[m], s) for m, s in (("unet", 0), ("brushnet", 1), ("vae", 2)))
+    bcfg = R.brushnet_config(R.TINY_UNET, 6)
+    b, h, w, steps = (2, 16, 32, 3) if case != "images_per_prompt" else (1, 16, 16, 3)
+    inp = synth.pipeline_inputs(b, h, w, seed=21, cross_dim=32, vae_scale=2)
+    nimg = 2 if case == "images_per_prompt" else 1
+    nb = b * nimg
+    g = torch.Generator().manual_seed(5)
+    cfg = case != "no_cfg"
+    noise = torch.randn((2 if cfg else 1) * nb, 4, h // 2, w // 2, generator=g)
+    lat0 = torch.randn(nb, 4, h // 2, w // 2, generator=g)
+    kw = dict(latents=lat0.clone())
+    scale, window = 1.0, (0.0, 1.0)
+    if case == "no_cfg":
+        kw["guidance_scale"] = 1.0
+    if case == "cond_scale_window":
+        scale, window = 0.6, (0.0, 0.5)
+        kw.update(brushnet_conditioning_scale=0.6, control_guidance_start=0.0, control_guidance_end=0.5)
+    if case == "images_per_prompt":
+        kw["num_images_per_prompt"] = 2
+    got = _run(pipe, inp, steps, h, w, noise, **kw)
+    # oracle replay
+    rep = lambda t: t.repeat_interleave(nimg, dim=0)
+    cond = R.build_conditioning(vsd, R.TINY_VAE, rep(inp["image"]), rep(inp["mask"]), rep(inp["depth"]), noise, cfg_dup=cfg)
+    sched = R.DDIMRef(**R.SD15_SCHED)
+    sched.set_timesteps(steps)
+    pe_pos, pe_neg = rep(inp["prompt_embeds"]), rep(inp["negative_prompt_embeds"])
+    pe = torch.cat([pe_neg, pe_pos]) if cfg else pe_pos
+    lat = lat0.clone()
+    for i, t in enumerate(sched.timesteps):
+        keep = 1.0 - float(i / steps < window[0] or (i + 1) / steps > window[1])      # pipeline_brushnet.py:1236-1242
+        x = torch.cat([lat] * 2) if cfg else lat
+        d, m, u = R.brushnet_forward(bsd, bcfg, x, t, cond, scale * keep)
+        eps = R.unet_forward(usd, R.TINY_UNET, x, t, pe, d, m, u)
+        if cfg:
+            eu, ec = eps.chunk(2)
+            eps = eu + 7.5 * (ec - eu)
+        lat = sched.step(eps, t, lat)
+    report(f"variant {case}", got, lat, atol=1e-3)
