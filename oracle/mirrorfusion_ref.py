@@ -45,6 +45,22 @@ TINY_UNET = dict(
     flip_sin_to_cos=True, freq_shift=0)
 TINY_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(32, 64), layers_per_block=1,
                 norm_num_groups=32, scaling_factor=0.18215)
+# SDXL (stabilityai/stable-diffusion-xl-base-1.0 unet/config.json) and a tiny configuration of the same architecture:
+# linear proj_in/proj_out, per-level transformer depth and head count, text_time additional embedding
+SDXL_UNET = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=2,
+    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+    cross_attention_dim=2048, attention_head_dim=(5, 10, 20), transformer_layers_per_block=(1, 2, 10),
+    use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=256,
+    projection_class_embeddings_input_dim=2816, norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0)
+TINY_XL_UNET = dict(
+    in_channels=4, out_channels=4, block_out_channels=(32, 64, 64), layers_per_block=2,
+    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+    cross_attention_dim=48, attention_head_dim=(2, 4, 8), transformer_layers_per_block=(1, 2, 3),
+    use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=8,
+    projection_class_embeddings_input_dim=6 * 8 + 24, norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0)
 
 
 def brushnet_config(unet_cfg: dict, conditioning_channels: int = 6) -> dict:
@@ -79,8 +95,10 @@ def timestep_embedding(timesteps: torch.Tensor, dim: int, flip_sin_to_cos: bool,
     return emb
 
 
-def time_embed(sd: SD, cfg: dict, timestep, batch: int) -> torch.Tensor:
-    """Timesteps + TimestepEmbedding (embeddings.py:191-254; brushnet.py:750-772, unet_2d_condition.py:1154)."""
+def time_embed(sd: SD, cfg: dict, timestep, batch: int, added: Optional[dict] = None) -> torch.Tensor:
+    """Timesteps + TimestepEmbedding (embeddings.py:191-254; brushnet.py:750-772, unet_2d_condition.py:1154), plus the
+    SDXL 'text_time' additional embedding (unet_2d_condition.py:971-987, brushnet.py:789-805): Fourier features of the six
+    time ids concatenated to the pooled text embedding, through add_embedding, added to the time embedding."""
     t = torch.as_tensor(timestep)
     if t.dim() == 0:
         t = t[None]
@@ -89,7 +107,14 @@ def time_embed(sd: SD, cfg: dict, timestep, batch: int) -> torch.Tensor:
     e = timestep_embedding(t, c0, cfg["flip_sin_to_cos"], cfg["freq_shift"])
     e = F.linear(e, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
     e = F.silu(e)
-    return F.linear(e, sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    e = F.linear(e, sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    if cfg.get("addition_embed_type") == "text_time":
+        text_embeds, time_ids = added["text_embeds"], added["time_ids"]
+        te = timestep_embedding(time_ids.flatten(), cfg["addition_time_embed_dim"], cfg["flip_sin_to_cos"], cfg["freq_shift"])
+        a = torch.cat([text_embeds, te.reshape(text_embeds.shape[0], -1)], -1)
+        a = F.silu(F.linear(a, sd["add_embedding.linear_1.weight"], sd["add_embedding.linear_1.bias"]))
+        e = e + F.linear(a, sd["add_embedding.linear_2.weight"], sd["add_embedding.linear_2.bias"])
+    return e
 
 
 def resnet(sd: SD, p: str, x: torch.Tensor, temb: Optional[torch.Tensor], groups: int, eps: float) -> torch.Tensor:
@@ -143,14 +168,22 @@ def transformer_2d(sd: SD, p: str, x: torch.Tensor, ehs: torch.Tensor, heads: in
     b, c, hh, ww = x.shape
     res = x
     h = F.group_norm(x, groups, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
-    h = F.conv2d(h, sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
-    h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
+    linear = sd[p + "proj_in.weight"].dim() == 2                   # use_linear_projection (transformer_2d.py:376-385)
+    if linear:
+        h = F.linear(h.permute(0, 2, 3, 1).reshape(b, hh * ww, c), sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
+    else:
+        h = F.conv2d(h, sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
+        h = h.permute(0, 2, 3, 1).reshape(b, hh * ww, c)
     i = 0
     while f"{p}transformer_blocks.{i}.norm1.weight" in sd:
         h = basic_transformer_block(sd, f"{p}transformer_blocks.{i}.", h, ehs, heads)
         i += 1
-    h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2).contiguous()
-    h = F.conv2d(h, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    if linear:                                                     # transformer_2d.py:418-427
+        h = F.linear(h, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+        h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2).contiguous()
+    else:
+        h = h.reshape(b, hh, ww, c).permute(0, 3, 1, 2).contiguous()
+        h = F.conv2d(h, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
     return h + res
 
 
@@ -171,11 +204,12 @@ def upsample(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
 # BrushNet (models/brushnet.py:678-925)
 # ---------------------------------------------------------------------------------------------
 def brushnet_forward(sd: SD, cfg: dict, sample: torch.Tensor, timestep, brushnet_cond: torch.Tensor,
-                     conditioning_scale: float = 1.0) -> Tuple[List[torch.Tensor], torch.Tensor, List[torch.Tensor]]:
+                     conditioning_scale: float = 1.0, added: Optional[dict] = None
+                     ) -> Tuple[List[torch.Tensor], torch.Tensor, List[torch.Tensor]]:
     g, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     nlev = len(cfg["block_out_channels"])
     lpb = cfg["layers_per_block"]
-    emb = time_embed(sd, cfg, timestep, sample.shape[0])
+    emb = time_embed(sd, cfg, timestep, sample.shape[0], added)
     x = torch.cat([sample, brushnet_cond], 1)                                          # :810
     x = F.conv2d(x, sd["conv_in_condition.weight"], sd["conv_in_condition.bias"], padding=1)
     down_res = [x]
@@ -212,14 +246,14 @@ def brushnet_forward(sd: SD, cfg: dict, sample: torch.Tensor, timestep, brushnet
 # ---------------------------------------------------------------------------------------------
 def unet_forward(sd: SD, cfg: dict, sample: torch.Tensor, timestep, ehs: torch.Tensor,
                  down_add: Optional[Sequence[torch.Tensor]] = None, mid_add: Optional[torch.Tensor] = None,
-                 up_add: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+                 up_add: Optional[Sequence[torch.Tensor]] = None, added: Optional[dict] = None) -> torch.Tensor:
     g, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     nlev = len(cfg["block_out_channels"])
     lpb = cfg["layers_per_block"]
     is_brushnet = down_add is not None and mid_add is not None and up_add is not None      # :1202
     down_add = list(down_add) if is_brushnet else None
     up_add = list(up_add) if is_brushnet else None
-    emb = time_embed(sd, cfg, timestep, sample.shape[0])
+    emb = time_embed(sd, cfg, timestep, sample.shape[0], added)
     x = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
     skips = [x]                                                                            # :1215 (captured pre-add)
     if is_brushnet:
@@ -621,14 +655,15 @@ def build_conditioning(vae_sd: SD, vae_cfg: dict, image: torch.Tensor, mask: tor
 
 def denoise(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, scheduler, latents: torch.Tensor,
             cond_latents: torch.Tensor, prompt_embeds_2b: torch.Tensor, num_steps: int, guidance_scale: float = 7.5,
-            conditioning_scale: float = 1.0, trace: Optional[list] = None) -> torch.Tensor:
-    """The hot loop (pipeline_brushnet.py:1250-1332) with CFG; prompt_embeds_2b = cat([negative, positive])."""
+            conditioning_scale: float = 1.0, trace: Optional[list] = None, added: Optional[dict] = None) -> torch.Tensor:
+    """The hot loop (pipeline_brushnet.py:1250-1332, pipeline_brushnet_sd_xl.py:1398-1500) with CFG;
+    prompt_embeds_2b = cat([negative, positive]); `added` = SDXL's added_cond_kwargs for the duplicated batch."""
     scheduler.set_timesteps(num_steps)
     latents = latents * scheduler.init_noise_sigma
     for t in scheduler.timesteps:
         x2 = torch.cat([latents] * 2)
-        down, mid, up = brushnet_forward(bn_sd, bn_cfg, x2, t, cond_latents, conditioning_scale)
-        eps = unet_forward(unet_sd, unet_cfg, x2, t, prompt_embeds_2b, down, mid, up)
+        down, mid, up = brushnet_forward(bn_sd, bn_cfg, x2, t, cond_latents, conditioning_scale, added)
+        eps = unet_forward(unet_sd, unet_cfg, x2, t, prompt_embeds_2b, down, mid, up, added)
         eu, ec = eps.chunk(2)
         eps = eu + guidance_scale * (ec - eu)                                            # :1310-1312
         latents = scheduler.step(eps, t, latents)                                        # :1315

@@ -10,7 +10,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
 from reflecting_reality_amd.models import AutoencoderKL, BrushNetModel, UNet2DConditionModel  # noqa: E402,F401
-from reflecting_reality_amd.pipeline import StableDiffusionBrushNetPipeline  # noqa: E402,F401
+from reflecting_reality_amd.pipeline import StableDiffusionBrushNetPipeline, StableDiffusionXLBrushNetPipeline  # noqa: E402,F401
 from reflecting_reality_amd.schedulers import DDIMScheduler, PNDMScheduler, UniPCMultistepScheduler  # noqa: E402,F401
 
 __version__ = "0.27.0.dev0+mi355x"

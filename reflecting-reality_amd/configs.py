@@ -23,6 +23,25 @@ TINY_UNET = dict(
 TINY_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(32, 64), layers_per_block=1,
                 norm_num_groups=32, scaling_factor=0.18215)
 
+# SDXL (stabilityai/stable-diffusion-xl-base-1.0 unet/config.json) and a tiny configuration of the
+# same architecture: linear proj_in/proj_out, per-level transformer depth and head count, text_time embedding
+SDXL_UNET = dict(
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=2,
+    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+    cross_attention_dim=2048, attention_head_dim=(5, 10, 20), transformer_layers_per_block=(1, 2, 10),
+    use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=256,
+    projection_class_embeddings_input_dim=2816, norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0)
+SDXL_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
+                layers_per_block=2, norm_num_groups=32, scaling_factor=0.13025)
+TINY_XL_UNET = dict(
+    in_channels=4, out_channels=4, block_out_channels=(32, 64, 64), layers_per_block=2,
+    down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+    up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+    cross_attention_dim=48, attention_head_dim=(2, 4, 8), transformer_layers_per_block=(1, 2, 3),
+    use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=8,
+    projection_class_embeddings_input_dim=6 * 8 + 24, norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0)
+
 
 def brushnet_config(unet_cfg: dict, conditioning_channels: int = 6) -> dict:
     n = len(unet_cfg["block_out_channels"])

@@ -191,9 +191,10 @@ def _resnet_shapes(out, p, cin, cout, temb_ch):
         out[p + "conv_shortcut.weight"] = (cout, cin, 1, 1); out[p + "conv_shortcut.bias"] = (cout,)
 
 
-def _transformer_shapes(out, p, c, cross, depth=1):
+def _transformer_shapes(out, p, c, cross, depth=1, linear=False):
+    proj = (c, c) if linear else (c, c, 1, 1)                    # use_linear_projection (transformer_2d.py:376-385)
     out[p + "norm.weight"] = (c,); out[p + "norm.bias"] = (c,)
-    out[p + "proj_in.weight"] = (c, c, 1, 1); out[p + "proj_in.bias"] = (c,)
+    out[p + "proj_in.weight"] = proj; out[p + "proj_in.bias"] = (c,)
     for i in range(depth):
         b = f"{p}transformer_blocks.{i}."
         for n in ("norm1", "norm2", "norm3"):
@@ -205,7 +206,15 @@ def _transformer_shapes(out, p, c, cross, depth=1):
             out[b + a + ".to_out.0.weight"] = (c, c); out[b + a + ".to_out.0.bias"] = (c,)
         out[b + "ff.net.0.proj.weight"] = (8 * c, c); out[b + "ff.net.0.proj.bias"] = (8 * c,)
         out[b + "ff.net.2.weight"] = (c, 4 * c); out[b + "ff.net.2.bias"] = (c,)
-    out[p + "proj_out.weight"] = (c, c, 1, 1); out[p + "proj_out.bias"] = (c,)
+    out[p + "proj_out.weight"] = proj; out[p + "proj_out.bias"] = (c,)
+
+
+def _add_embedding_shapes(out, cfg, temb):
+    """SDXL's text_time embedding (unet_2d_condition.py:~560, brushnet.py:303-305)."""
+    if cfg.get("addition_embed_type") == "text_time":
+        d = cfg["projection_class_embeddings_input_dim"]
+        out["add_embedding.linear_1.weight"] = (temb, d); out["add_embedding.linear_1.bias"] = (temb,)
+        out["add_embedding.linear_2.weight"] = (temb, temb); out["add_embedding.linear_2.bias"] = (temb,)
 
 
 class _UNetCore(HipModel):
@@ -229,17 +238,20 @@ class _UNetCore(HipModel):
         c.setdefault("act_fn", "silu")
         c.setdefault("use_linear_projection", False)
         c.setdefault("resnet_time_scale_shift", "default")
+        c.setdefault("addition_embed_type", None)
+        c.setdefault("addition_time_embed_dim", None)
+        c.setdefault("projection_class_embeddings_input_dim", None)
         c["block_out_channels"] = tuple(c["block_out_channels"])
         unsupported = []
         if c["act_fn"] not in ("silu", "swish"): unsupported.append("act_fn")
-        if c["use_linear_projection"]: unsupported.append("use_linear_projection")
+        if c["addition_embed_type"] not in (None, "text_time"): unsupported.append("addition_embed_type")
         if c["resnet_time_scale_shift"] != "default": unsupported.append("resnet_time_scale_shift")
         if c["mid_block_scale_factor"] != 1: unsupported.append("mid_block_scale_factor")
         if c["downsample_padding"] != 1: unsupported.append("downsample_padding")
-        for k in ("class_embed_type", "addition_embed_type", "encoder_hid_dim_type", "num_class_embeds"):
+        for k in ("class_embed_type", "encoder_hid_dim_type", "num_class_embeds"):
             if c.get(k) is not None: unsupported.append(k)
         if unsupported:
-            raise NotImplementedError(f"{type(self).__name__}: config options outside the SD1.5 hot path: {unsupported}")
+            raise NotImplementedError(f"{type(self).__name__}: config options outside the SD1.5 / SDXL hot path: {unsupported}")
 
     def _heads(self, level: int) -> int:
         c = self.config
@@ -251,6 +263,10 @@ class _UNetCore(HipModel):
         f32 = Precision.get("fp32")
         self.te1 = self._conv(sd, "time_embedding.linear_1", f32)
         self.te2 = self._conv(sd, "time_embedding.linear_2", f32)
+        self.add1 = self.add2 = None
+        if self.config["addition_embed_type"] == "text_time":
+            self.add1 = self._conv(sd, "add_embedding.linear_1", f32)
+            self.add2 = self._conv(sd, "add_embedding.linear_2", f32)
         # all time_emb_proj layers as ONE [sum(Cout), temb] GEMM; each resnet reads a column slice
         names = [k[: -len(".time_emb_proj.weight")] for k in self.param_shapes() if k.endswith(".time_emb_proj.weight")]
         self.temb_slices = {}
@@ -293,8 +309,9 @@ class _UNetCore(HipModel):
         self.tdepth[p] = i
 
     # ---- forward pieces ---------------------------------------------------------------------------
-    def _time_embedding(self, timestep, batch: int) -> torch.Tensor:
-        """Timesteps + TimestepEmbedding + every resnet's time_emb_proj(SiLU(emb)) -> [batch, sum(Cout)] fp32.
+    def _time_embedding(self, timestep, batch: int, added_cond_kwargs=None) -> torch.Tensor:
+        """Timesteps + TimestepEmbedding (+ SDXL's text_time add_embedding, unet_2d_condition.py:971-987) + every
+        resnet's time_emb_proj(SiLU(emb)) -> [batch, sum(Cout)] fp32.
         (embeddings.py:27-67,225-254; resnet.py:369-376).  Always fp32, like the reference."""
         if not torch.is_tensor(timestep):
             t = torch.full((batch,), float(timestep), dtype=F32, device=self.device)
@@ -306,7 +323,24 @@ class _UNetCore(HipModel):
         c0 = self.config["block_out_channels"][0]
         e = hip.timestep_embedding(t, c0, self.config["flip_sin_to_cos"], float(self.config["freq_shift"]))
         e = ops.linear(e, self.te1, act=hip.ACT_SILU, out_dtype=F32)
-        e = ops.linear(e, self.te2, act=hip.ACT_SILU, out_dtype=F32)   # SiLU(emb): every consumer applies it first
+        if self.add1 is None:
+            if added_cond_kwargs:
+                raise NotImplementedError("added_cond_kwargs without addition_embed_type='text_time'")
+            e = ops.linear(e, self.te2, act=hip.ACT_SILU, out_dtype=F32)   # SiLU(emb): every consumer applies it first
+            return ops.linear(e, self.temb_proj, out_dtype=F32)
+        for k in ("text_embeds", "time_ids"):
+            if not added_cond_kwargs or k not in added_cond_kwargs:
+                raise ValueError(f"{self.__class__} has the config param `addition_embed_type` set to 'text_time' which "
+                                 f"requires the keyword argument `{k}` to be passed in `added_cond_kwargs`")
+        text = added_cond_kwargs["text_embeds"].to(self.device, F32)
+        tid = added_cond_kwargs["time_ids"].to(self.device, F32).reshape(-1).contiguous()
+        te = hip.timestep_embedding(tid, self.config["addition_time_embed_dim"], self.config["flip_sin_to_cos"],
+                                    float(self.config["freq_shift"])).view(text.shape[0], -1)
+        a = torch.cat([text, te], -1).contiguous()                       # tiny: [batch, 2816]
+        a = ops.linear(a, self.add1, act=hip.ACT_SILU, out_dtype=F32)
+        # emb = time_embedding(t) + add_embedding(...): the second GEMM adds the first one's output as a residual
+        e = ops.linear(e, self.te2, out_dtype=F32)
+        e = ops.linear(a, self.add2, res0=e, act=hip.ACT_SILU, out_dtype=F32)
         return ops.linear(e, self.temb_proj, out_dtype=F32)
 
     def _temb(self, temb_all: Optional[torch.Tensor], p: str) -> Optional[torch.Tensor]:
@@ -459,7 +493,8 @@ class BrushNetModel(_UNetCore):
                                   "layers_per_block", "downsample_padding", "mid_block_scale_factor", "act_fn",
                                   "norm_num_groups", "norm_eps", "cross_attention_dim", "attention_head_dim",
                                   "num_attention_heads", "use_linear_projection", "resnet_time_scale_shift",
-                                  "transformer_layers_per_block")}
+                                  "transformer_layers_per_block", "addition_embed_type", "addition_time_embed_dim",
+                                  "projection_class_embeddings_input_dim")}
         cfg.update(conditioning_channels=conditioning_channels, down_block_types=("DownBlock2D",) * n,
                    mid_block_type="MidBlock2D", up_block_types=("UpBlock2D",) * n,
                    brushnet_conditioning_channel_order=brushnet_conditioning_channel_order,
@@ -492,6 +527,7 @@ class BrushNetModel(_UNetCore):
         out["conv_in_condition.weight"] = (boc[0], cin, 3, 3); out["conv_in_condition.bias"] = (boc[0],)
         out["time_embedding.linear_1.weight"] = (temb, boc[0]); out["time_embedding.linear_1.bias"] = (temb,)
         out["time_embedding.linear_2.weight"] = (temb, temb); out["time_embedding.linear_2.bias"] = (temb,)
+        _add_embedding_shapes(out, c, temb)
         lpb = c["layers_per_block"]
         n = len(boc)
         zero = [boc[0]]
@@ -560,11 +596,11 @@ class BrushNetModel(_UNetCore):
             raise RuntimeError("BrushNetModel has no parameters loaded")
         if guess_mode:
             raise NotImplementedError("guess_mode logspace scaling (brushnet.py:896-902) is off in every MirrorFusion config")
-        if class_labels is not None or timestep_cond is not None or attention_mask is not None or added_cond_kwargs:
-            raise NotImplementedError("class/timestep_cond/attention_mask/added_cond inputs are outside the SD1.5 hot path")
+        if class_labels is not None or timestep_cond is not None or attention_mask is not None:
+            raise NotImplementedError("class/timestep_cond/attention_mask inputs are outside the SD1.5 / SDXL hot path")
         side = self.side_stream
         if side is None:
-            d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, None)
+            d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, None, added_cond_kwargs)
         else:
             main = torch.cuda.current_stream(self.device)
             _RESIDUAL_EVENTS.clear()
@@ -577,20 +613,20 @@ class BrushNetModel(_UNetCore):
                 _RESIDUAL_EVENTS[t.data_ptr()] = ev
 
             with torch.cuda.stream(side):
-                d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, publish)
+                d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs)
         if not return_dict:
             return d, m, u
         return BrushNetOutput(down_block_res_samples=d, mid_block_res_sample=m, up_block_res_samples=u)
 
     side_stream: Optional["torch.cuda.Stream"] = None
 
-    def _forward_impl(self, sample, timestep, brushnet_cond, conditioning_scale, publish):
+    def _forward_impl(self, sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs=None):
         """Each zero-conv (brushnet.py:889-894) runs right after the feature it reads is produced — the same
         arithmetic as the reference's end-of-forward loops, but residual k is final as early as possible."""
         c = self.config
         bsz = sample.shape[0]
         s = float(conditioning_scale)
-        temb = self._time_embedding(timestep, bsz)
+        temb = self._time_embedding(timestep, bsz, added_cond_kwargs)
         x = hip.pack_nhwc(sample.to(self.device).float().contiguous(), brushnet_cond.to(self.device).float().contiguous(),
                           self.cin_pad, self.prec.act)                                            # :810 cat + pad
         x = ops.conv2d(x, self.P["conv_in_condition"])
@@ -664,6 +700,7 @@ class UNet2DConditionModel(_UNetCore):
         out["conv_in.weight"] = (boc[0], c["in_channels"], 3, 3); out["conv_in.bias"] = (boc[0],)
         out["time_embedding.linear_1.weight"] = (temb, boc[0]); out["time_embedding.linear_1.bias"] = (temb,)
         out["time_embedding.linear_2.weight"] = (temb, temb); out["time_embedding.linear_2.bias"] = (temb,)
+        _add_embedding_shapes(out, c, temb)
         lpb = c["layers_per_block"]
         n = len(boc)
         skip = [boc[0]]
@@ -672,7 +709,7 @@ class UNet2DConditionModel(_UNetCore):
             for j in range(lpb):
                 _resnet_shapes(out, f"down_blocks.{i}.resnets.{j}.", ch if j == 0 else boc[i], boc[i], temb)
                 if bt == "CrossAttnDownBlock2D":
-                    _transformer_shapes(out, f"down_blocks.{i}.attentions.{j}.", boc[i], cross, depth[i])
+                    _transformer_shapes(out, f"down_blocks.{i}.attentions.{j}.", boc[i], cross, depth[i], c["use_linear_projection"])
                 skip.append(boc[i])
             ch = boc[i]
             if i != n - 1:
@@ -680,7 +717,7 @@ class UNet2DConditionModel(_UNetCore):
                 out[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (ch,)
                 skip.append(ch)
         _resnet_shapes(out, "mid_block.resnets.0.", boc[-1], boc[-1], temb)
-        _transformer_shapes(out, "mid_block.attentions.0.", boc[-1], cross, depth[-1])
+        _transformer_shapes(out, "mid_block.attentions.0.", boc[-1], cross, depth[-1], c["use_linear_projection"])
         _resnet_shapes(out, "mid_block.resnets.1.", boc[-1], boc[-1], temb)
         rev = list(reversed(boc))
         rdepth = list(reversed(depth))
@@ -691,7 +728,7 @@ class UNet2DConditionModel(_UNetCore):
                 sk = skip.pop()
                 _resnet_shapes(out, f"up_blocks.{i}.resnets.{j}.", (prev if j == 0 else oc) + sk, oc, temb)
                 if bt == "CrossAttnUpBlock2D":
-                    _transformer_shapes(out, f"up_blocks.{i}.attentions.{j}.", oc, cross, rdepth[i])
+                    _transformer_shapes(out, f"up_blocks.{i}.attentions.{j}.", oc, cross, rdepth[i], c["use_linear_projection"])
             prev = oc
             if i != n - 1:
                 out[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (oc, oc, 3, 3)
@@ -729,7 +766,7 @@ class UNet2DConditionModel(_UNetCore):
         pop(0) exactly like the reference does (the caller's lists are emptied)."""
         if not self._ready:
             raise RuntimeError("UNet2DConditionModel has no parameters loaded")
-        if any(v is not None for v in (class_labels, timestep_cond, attention_mask, added_cond_kwargs,
+        if any(v is not None for v in (class_labels, timestep_cond, attention_mask,
                                        down_block_additional_residuals, mid_block_additional_residual,
                                        down_intrablock_additional_residuals, encoder_attention_mask)) \
                 or (cross_attention_kwargs not in (None, {})):
@@ -740,7 +777,7 @@ class UNet2DConditionModel(_UNetCore):
         is_brushnet = down_block_add_samples is not None and mid_block_add_sample is not None \
             and up_block_add_samples is not None                                                    # :1202
         bsz = sample.shape[0]
-        temb = self._time_embedding(timestep, bsz)
+        temb = self._time_embedding(timestep, bsz, added_cond_kwargs)
         ehs = self._bind_prompt(encoder_hidden_states)
         x = from_nchw(sample.to(self.device), self.prec, self.cin_pad)
         x = ops.conv2d(x, self.P["conv_in"])

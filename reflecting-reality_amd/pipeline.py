@@ -127,6 +127,7 @@ class StableDiffusionBrushNetPipeline:
         self.use_hip_graph = True        # capture the denoise step into a hipGraph when the scheduler allows it
         self.overlap_brushnet = True     # BrushNet on a second HIP stream, ordered against the UNet by per-residual events
         self._side_stream = None
+        self._added_cond = None          # SDXL: added_cond_kwargs of the (CFG-duplicated) batch, set by the XL subclass
         self._graph_state = None
 
     # ---- DiffusionPipeline surface ----------------------------------------------------------------
@@ -389,9 +390,11 @@ class StableDiffusionBrushNetPipeline:
                 x_in = self.scheduler.scale_model_input(x_in, t)
                 cond_scale = float(brushnet_conditioning_scale) * keep[i]
                 down, mid, up = self.brushnet(x_in, t, encoder_hidden_states=pe, brushnet_cond=cond,
-                                              conditioning_scale=cond_scale, return_dict=False)      # :1277
+                                              conditioning_scale=cond_scale, added_cond_kwargs=self._added_cond,
+                                              return_dict=False)                                     # :1277
                 eps = self.unet(x_in, t, encoder_hidden_states=pe, down_block_add_samples=down,
-                                mid_block_add_sample=mid, up_block_add_samples=up, return_dict=False)[0]   # :1296
+                                mid_block_add_sample=mid, up_block_add_samples=up, added_cond_kwargs=self._added_cond,
+                                return_dict=False)[0]                                                # :1296
                 if do_cfg:
                     eu, ec = eps[:nb], eps[nb:]
                     if fused_ddim:
@@ -448,14 +451,22 @@ class StableDiffusionBrushNetPipeline:
         ptype = 0 if sched.config["prediction_type"] == "epsilon" else 1
         # The captured graph (and every buffer it reads) is kept across calls with the same shapes and scalars:
         # new inputs are copied INTO the static buffers, so repeated calls pay no capture / instantiate cost.
+        added = self._added_cond
         key = (tuple(latents.shape), tuple(pe.shape), tuple(cond.shape), float(guidance_scale), cond_scale, ptype, clip,
-               str(dev), id(self.unet), id(self.brushnet))
+               str(dev), id(self.unet), id(self.brushnet),
+               tuple((k, tuple(v.shape)) for k, v in sorted(added.items())) if added else None)
         st = self._graph_state if self._graph_state is not None and self._graph_state["key"] == key else None
         if st is None:
             st = dict(key=key, graph=None, lat=torch.empty_like(latents), pe=torch.empty_like(pe),
                       cond=torch.empty_like(cond), t_cur=torch.empty(1, dtype=torch.float32, device=dev),
                       coef_cur=torch.empty(4, dtype=torch.float32, device=dev))
+            if added:
+                st["added"] = {k: torch.empty(v.shape, dtype=torch.float32, device=dev) for k, v in added.items()}
             self._graph_state = st
+        if added:
+            for k, v in added.items():
+                st["added"][k].copy_(v)
+            added = st["added"]
         lat, t_cur, coef_cur = st["lat"], st["t_cur"], st["coef_cur"]
         lat.copy_(latents)
         st["pe"].copy_(pe)
@@ -465,9 +476,10 @@ class StableDiffusionBrushNetPipeline:
         def one_step():
             x_in = torch.cat([lat] * 2)
             down, mid, up = self.brushnet(x_in, t_cur, encoder_hidden_states=pe, brushnet_cond=cond,
-                                          conditioning_scale=cond_scale, return_dict=False)
+                                          conditioning_scale=cond_scale, added_cond_kwargs=added, return_dict=False)
             eps = self.unet(x_in, t_cur, encoder_hidden_states=pe, down_block_add_samples=down,
-                            mid_block_add_sample=mid, up_block_add_samples=up, return_dict=False)[0]
+                            mid_block_add_sample=mid, up_block_add_samples=up, added_cond_kwargs=added,
+                            return_dict=False)[0]
             hip.cfg_ddim_step_dev(eps[:nb], eps[nb:], float(guidance_scale), lat, coef_cur, ptype, clip, out=lat)
 
         for i in range(len(ts)):
@@ -505,3 +517,92 @@ class StableDiffusionBrushNetPipeline:
         if "generator" in params:
             extra["generator"] = generator
         return self.scheduler.step(noise_pred, t, latents, **extra, return_dict=False)[0]
+
+
+class StableDiffusionXLBrushNetPipeline(StableDiffusionBrushNetPipeline):
+    """pipelines/brushnet/pipeline_brushnet_sd_xl.py:936-1535 on the same engine: the SDXL UNet / BrushNet-XL add the
+    'text_time' embedding (pooled text embedding + Fourier features of original size / crop / target size) to the time
+    embedding; conditioning is [masked-image latents | mask] (5 channels, :1301-1310); everything else is the
+    SD1.5 loop.  Text encoders are outside the accelerated path: pass prompt_embeds and pooled_prompt_embeds."""
+
+    def __init__(self, vae, text_encoder, text_encoder_2, tokenizer, tokenizer_2, unet, brushnet, scheduler,
+                 force_zeros_for_empty_prompt: bool = True, add_watermarker=None, feature_extractor=None,
+                 image_encoder=None):
+        super().__init__(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet, brushnet=brushnet,
+                         scheduler=scheduler, safety_checker=None, feature_extractor=feature_extractor,
+                         image_encoder=image_encoder, requires_safety_checker=False)
+        if add_watermarker:
+            raise NotImplementedError("the invisible watermark is outside the accelerated path")
+        self.text_encoder_2, self.tokenizer_2 = text_encoder_2, tokenizer_2
+        self.config.update(force_zeros_for_empty_prompt=force_zeros_for_empty_prompt)
+
+    def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, text_encoder_projection_dim):
+        """pipeline_brushnet_sd_xl.py:_get_add_time_ids, including its consistency check against add_embedding."""
+        ids = list(original_size) + list(crops_coords_top_left) + list(target_size)
+        passed = self.unet.config["addition_time_embed_dim"] * len(ids) + text_encoder_projection_dim
+        expected = self.unet.config["projection_class_embeddings_input_dim"]
+        if expected != passed:
+            raise ValueError(f"Model expects an added time embedding vector of length {expected}, but a vector of {passed} "
+                             "was created. The model has an incorrect config. Please check "
+                             "`unet.config.time_embedding_type` and `text_encoder_2.config.projection_dim`.")
+        return torch.tensor([ids], dtype=torch.float32)
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, prompt_2=None, image=None, mask=None, height=None, width=None,
+                 num_inference_steps: int = 50, denoising_end=None, guidance_scale: float = 5.0, negative_prompt=None,
+                 negative_prompt_2=None, num_images_per_prompt: int = 1, eta: float = 0.0, generator=None, latents=None,
+                 prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None,
+                 negative_pooled_prompt_embeds=None, output_type="pil", return_dict: bool = True,
+                 cross_attention_kwargs=None, guidance_rescale: float = 0.0, brushnet_conditioning_scale=1.0,
+                 guess_mode: bool = False, control_guidance_start=0.0, control_guidance_end=1.0, original_size=None,
+                 crops_coords_top_left=(0, 0), target_size=None, negative_original_size=None,
+                 negative_crops_coords_top_left=(0, 0), negative_target_size=None, clip_skip=None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",), conditioning_noise=None,
+                 **kwargs):
+        if prompt is not None or prompt_2 is not None or negative_prompt is not None or negative_prompt_2 is not None:
+            raise NotImplementedError("the two CLIP text encoders are outside the accelerated path: pass prompt_embeds, "
+                                      "negative_prompt_embeds, pooled_prompt_embeds and negative_pooled_prompt_embeds")
+        if denoising_end is not None or guidance_rescale:
+            raise NotImplementedError("denoising_end / guidance_rescale (pipeline_brushnet_sd_xl.py:1376-1391,1478-1480)")
+        if prompt_embeds is None or pooled_prompt_embeds is None:
+            raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed. Make sure to "
+                             "generate `pooled_prompt_embeds` from the same text encoder that was used to generate `prompt_embeds`.")
+        do_cfg = guidance_scale > 1
+        if do_cfg and (negative_prompt_embeds is None or negative_pooled_prompt_embeds is None):
+            raise ValueError("If `negative_prompt_embeds` are provided, `negative_pooled_prompt_embeds` also have to be passed.")
+        ih, iw = self.image_processor.preprocess(image).shape[-2:]
+        height, width = height or ih, width or iw
+        original_size = original_size or (ih, iw)                                                   # :1330-1334
+        target_size = target_size or (height, width)
+        b = prompt_embeds.shape[0]
+        nb = b * num_images_per_prompt
+        pooled = pooled_prompt_embeds.float().repeat(1, num_images_per_prompt).view(nb, -1)         # encode_prompt :483-486
+        proj_dim = int(pooled.shape[-1])
+        ids = self._get_add_time_ids(original_size, crops_coords_top_left, target_size, proj_dim)
+        if negative_original_size is not None and negative_target_size is not None:
+            nids = self._get_add_time_ids(negative_original_size, negative_crops_coords_top_left, negative_target_size, proj_dim)
+        else:
+            nids = ids
+        if do_cfg:
+            npooled = negative_pooled_prompt_embeds.float().repeat(1, num_images_per_prompt).view(nb, -1)
+            text = torch.cat([npooled, pooled], 0)
+            ids = torch.cat([nids, ids], 0)
+        else:
+            text = pooled
+        ids = ids.repeat(nb, 1)                                              # :1372 (sic: interleaves neg/pos rows)
+        self._added_cond = dict(text_embeds=text.to(self.device), time_ids=ids.to(self.device))
+        try:
+            return super().__call__(image=image, mask=mask, height=height, width=width,
+                                    num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                                    num_images_per_prompt=num_images_per_prompt, eta=eta, generator=generator,
+                                    latents=latents, prompt_embeds=prompt_embeds,
+                                    negative_prompt_embeds=negative_prompt_embeds, output_type=output_type,
+                                    return_dict=return_dict, cross_attention_kwargs=cross_attention_kwargs,
+                                    brushnet_conditioning_scale=brushnet_conditioning_scale, guess_mode=guess_mode,
+                                    control_guidance_start=control_guidance_start,
+                                    control_guidance_end=control_guidance_end, clip_skip=clip_skip,
+                                    callback_on_step_end=callback_on_step_end,
+                                    callback_on_step_end_tensor_inputs=list(callback_on_step_end_tensor_inputs),
+                                    conditioning_noise=conditioning_noise, **kwargs)
+        finally:
+            self._added_cond = None

@@ -19,11 +19,12 @@ SD = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_sch
 
 
 @pytest.mark.parametrize("size,ucfg,vcfg", [("tiny", configs.TINY_UNET, configs.TINY_VAE),
-                                            ("sd15", configs.SD15_UNET, configs.SD15_VAE)])
+                                            ("sd15", configs.SD15_UNET, configs.SD15_VAE),
+                                            ("tiny_xl", configs.TINY_XL_UNET, configs.TINY_VAE)])
 def test_param_tables_match_reference_state_dicts(size, ucfg, vcfg):
     ref = keys(size)
     models = dict(unet=UNet2DConditionModel(dict(ucfg), device="cpu"),
-                  brushnet=BrushNetModel(dict(configs.brushnet_config(ucfg, 6)), device="cpu"),
+                  brushnet=BrushNetModel(dict(configs.brushnet_config(ucfg, 5 if size == "tiny_xl" else 6)), device="cpu"),
                   vae=AutoencoderKL(dict(vcfg), device="cpu"))
     for name, m in models.items():
         mine = {k: tuple(v) for k, v in m.param_shapes().items()}

@@ -82,6 +82,37 @@ def test_alt_conditioning_modes_match_reference():
     report("alt 2-step latents", lat, G["alt_latents"], **TOL)
 
 
+def test_tiny_xl_matches_reference():
+    """SDXL architecture (linear projections, per-level depth/heads, text_time embedding) + the XL pipeline loop
+    (pipeline_brushnet_sd_xl.py:1301-1500) on a tiny configuration."""
+    shapes = keys("tiny_xl")
+    usd, bsd, vsd = (synth.state_dict_for(shapes[m], s) for m, s in (("unet", 20), ("brushnet", 21), ("vae", 2)))
+    G = golden("tiny_xl.npz")
+    ucfg, bcfg = R.TINY_XL_UNET, R.brushnet_config(R.TINY_XL_UNET, 5)
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    cond = torch.randn(2, 5, 8, 8, generator=g)
+    ehs = torch.randn(2, 77, ucfg["cross_attention_dim"], generator=g)
+    added = dict(text_embeds=torch.randn(2, 24, generator=g),
+                 time_ids=torch.tensor([[16., 16., 0., 0., 16., 16.], [32., 24., 4., 2., 16., 16.]]))
+    d, m, u = R.brushnet_forward(bsd, bcfg, x, 401, cond, 0.9, added)
+    for i, t in enumerate(d):
+        report(f"xl bn_down_{i}", t, G[f"bn_down_{i}"], **TOL)
+    report("xl bn_mid", m, G["bn_mid"], **TOL)
+    for i, t in enumerate(u):
+        report(f"xl bn_up_{i}", t, G[f"bn_up_{i}"], **TOL)
+    report("xl unet eps", R.unet_forward(usd, ucfg, x, 401, ehs, d, m, u, added), G["unet_eps_inj"], **TOL)
+    inp = synth.pipeline_inputs(1, 16, 16, seed=99, cross_dim=ucfg["cross_attention_dim"], vae_scale=2)
+    gp = torch.Generator().manual_seed(100)
+    pooled, npooled = torch.randn(1, 24, generator=gp), torch.randn(1, 24, generator=gp)
+    c2 = R.build_conditioning(vsd, R.TINY_VAE, inp["image"], inp["mask"], None, torch.from_numpy(G["pipe_vae_noise"]))
+    report("xl conditioning", c2, G["pipe_cond"], **TOL)
+    oadded = dict(text_embeds=torch.cat([npooled, pooled]), time_ids=torch.tensor([[24., 20., 2., 1., 16., 16.]]).repeat(2, 1))
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    lat = R.denoise(usd, ucfg, bsd, bcfg, R.DDIMRef(**R.SD15_SCHED), inp["latents"], c2, pe, 3, 5.0, 1.0, None, oadded)
+    report("xl 3-step latents", lat, G["pipe_latents"], **TOL)
+
+
 def test_scheduler_traces_match_reference():
     G = golden("schedulers.npz")
     for n in (4, 50):

@@ -38,12 +38,14 @@ torch.set_grad_enabled(False)
 
 
 def build_unet(cfg):
+    extra = {k: cfg[k] for k in ("transformer_layers_per_block", "use_linear_projection", "addition_embed_type",
+                                 "addition_time_embed_dim", "projection_class_embeddings_input_dim") if k in cfg}
     return UNet2DConditionModel(
         sample_size=8, in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
         down_block_types=cfg["down_block_types"], up_block_types=cfg["up_block_types"],
         block_out_channels=cfg["block_out_channels"], layers_per_block=cfg["layers_per_block"],
         cross_attention_dim=cfg["cross_attention_dim"], attention_head_dim=cfg["attention_head_dim"],
-        norm_num_groups=cfg["norm_num_groups"]).eval()
+        norm_num_groups=cfg["norm_num_groups"], **extra).eval()
 
 
 def build_vae(cfg):
@@ -246,6 +248,79 @@ def tiny():
     print("tiny fixtures written")
 
 
+def tiny_xl():
+    """SDXL architecture (linear projections, per-level depth / heads, text_time embedding) on a tiny configuration:
+    BrushNet-XL residuals, UNet-XL with injection, and a 3-step StableDiffusionXLBrushNetPipeline run."""
+    from diffusers.pipelines.brushnet.pipeline_brushnet_sd_xl import StableDiffusionXLBrushNetPipeline
+    ucfg, vcfg = R.TINY_XL_UNET, R.TINY_VAE
+    unet = build_unet(ucfg)
+    unet_sd, unet_shapes = load_synth(unet, 20)
+    brushnet = BrushNetModel.from_unet(unet, conditioning_channels=5, load_weights_from_unet=False).eval()
+    bn_sd, bn_shapes = load_synth(brushnet, 21)
+    vae = build_vae(vcfg)
+    vae_sd, vae_shapes = load_synth(vae, 2)
+    bcfg = R.brushnet_config(ucfg, 5)
+    with open(os.path.join(GOLD, "keys_tiny_xl.json"), "w") as f:
+        json.dump(dict(unet=unet_shapes, brushnet=bn_shapes, vae=vae_shapes), f, indent=0, sort_keys=True)
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    cond = torch.randn(2, 5, 8, 8, generator=g)
+    ehs = torch.randn(2, 77, ucfg["cross_attention_dim"], generator=g)
+    added = dict(text_embeds=torch.randn(2, 24, generator=g),
+                 time_ids=torch.tensor([[16., 16., 0., 0., 16., 16.], [32., 24., 4., 2., 16., 16.]]))
+    t = 401
+    out = {}
+    down, mid, up = brushnet(x, t, encoder_hidden_states=ehs, brushnet_cond=cond, conditioning_scale=0.9,
+                             added_cond_kwargs=added, return_dict=False)
+    od, om, ou = R.brushnet_forward(bn_sd, bcfg, x, t, cond, 0.9, added)
+    print("[xl] brushnet oracle-vs-ref:", max(maxdiff(a, b) for a, b in zip(down + [mid] + up, od + [om] + ou)))
+    for i, d in enumerate(down):
+        out[f"bn_down_{i}"] = d.numpy()
+    out["bn_mid"] = mid.numpy()
+    for i, u in enumerate(up):
+        out[f"bn_up_{i}"] = u.numpy()
+    eps = unet(x, t, encoder_hidden_states=ehs, added_cond_kwargs=added, down_block_add_samples=list(down),
+               mid_block_add_sample=mid, up_block_add_samples=list(up), return_dict=False)[0]
+    oeps = R.unet_forward(unet_sd, ucfg, x, t, ehs, od, om, ou, added)
+    print("[xl] unet+inj oracle-vs-ref:", maxdiff(eps, oeps))
+    out["unet_eps_inj"] = eps.numpy()
+    # --- pipeline: 3 DDIM steps, CFG 5.0, 16x16 image (latents 8x8) -------------------------------------------
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionXLBrushNetPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None,
+                                             tokenizer_2=None, unet=unet, brushnet=brushnet, scheduler=sched,
+                                             force_zeros_for_empty_prompt=True, add_watermarker=False)
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(1, 16, 16, seed=99, cross_dim=ucfg["cross_attention_dim"], vae_scale=2)
+    gp = torch.Generator().manual_seed(100)
+    pooled, npooled = torch.randn(1, 24, generator=gp), torch.randn(1, 24, generator=gp)
+    captured = {}
+    hook = brushnet.register_forward_pre_hook(
+        lambda mod, args, kwargs: captured.update(cond=kwargs["brushnet_cond"].clone(),
+                                                  tid=kwargs["added_cond_kwargs"]["time_ids"].clone()), with_kwargs=True)
+    torch.manual_seed(778)
+    res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+               pooled_prompt_embeds=pooled, negative_pooled_prompt_embeds=npooled, image=inp["image"], mask=inp["mask"],
+               num_inference_steps=3, guidance_scale=5.0, latents=inp["latents"].clone(), output_type="latent",
+               brushnet_conditioning_scale=1.0, height=16, width=16, original_size=(24, 20), crops_coords_top_left=(2, 1),
+               target_size=(16, 16))
+    hook.remove()
+    torch.manual_seed(778)
+    vae_noise = torch.randn(2, 4, 8, 8)
+    ocond = R.build_conditioning(vae_sd, vcfg, inp["image"], inp["mask"], None, vae_noise)
+    print("[xl] conditioning oracle-vs-ref:", maxdiff(ocond, captured["cond"]), tuple(captured["tid"].shape), captured["tid"][0].tolist())
+    tid = torch.tensor([[24., 20., 2., 1., 16., 16.]]).repeat(2, 1)
+    oadded = dict(text_embeds=torch.cat([npooled, pooled]), time_ids=tid)
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    olat = R.denoise(unet_sd, ucfg, bn_sd, bcfg, R.DDIMRef(**R.SD15_SCHED), inp["latents"], ocond, pe, 3, 5.0, 1.0, None, oadded)
+    print("[xl] 3-step latents oracle-vs-ref:", maxdiff(olat, res.images))
+    out["pipe_cond"] = captured["cond"].numpy()
+    out["pipe_vae_noise"] = vae_noise.numpy()
+    out["pipe_latents"] = res.images.numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_xl.npz"), **out)
+    print("tiny xl fixtures written")
+
+
 def full():
     """F6/F7: full-size SD1.5-shape single step at 32x32 latents (1 image with CFG) + VAE decode/encode."""
     ucfg, vcfg = R.SD15_UNET, R.SD15_VAE
@@ -302,9 +377,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
+    ap.add_argument("--only-xl", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
+    if a.only_xl:
+        tiny_xl()
+        sys.exit(0)
     if not a.only_full:
         tiny()
+        tiny_xl()
     if a.full or a.only_full:
         full()
