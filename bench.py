@@ -31,17 +31,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_pipeline(precision, device, keep_cpu_sd=False):
+def build_pipeline(precision, device, keep_cpu_sd=False, model="sd15"):
     from reflecting_reality_amd import (AutoencoderKL, BrushNetModel, DDIMScheduler, StableDiffusionBrushNetPipeline,
-                                        UNet2DConditionModel, synth)
-    from reflecting_reality_amd.configs import SD15_SCHED, SD15_UNET, SD15_VAE, brushnet_config
+                                        StableDiffusionXLBrushNetPipeline, UNet2DConditionModel, synth)
+    from reflecting_reality_amd.configs import SD15_SCHED, SD15_UNET, SD15_VAE, SDXL_UNET, SDXL_VAE, brushnet_config
     t0 = time.time()
     sds = {}
+    if model == "sdxl":          # SURVEY.md §8 f-3 (config 5): secondary workload, same engine
+        SD15_UNET, SD15_VAE, cond_ch = SDXL_UNET, SDXL_VAE, 5
+    else:
+        cond_ch = 6
     unet = UNet2DConditionModel(dict(SD15_UNET), precision=precision, device=device)
     sd = synth.state_dict_for(unet.param_shapes(), 0)
     unet.load_state_dict(sd)
     sds["unet"] = sd
-    bn = BrushNetModel(dict(brushnet_config(SD15_UNET, 6)), precision=precision, device=device)
+    bn = BrushNetModel(dict(brushnet_config(SD15_UNET, cond_ch)), precision=precision, device=device)
     sd = synth.state_dict_for(bn.param_shapes(), 1)
     bn.load_state_dict(sd)
     sds["brushnet"] = sd
@@ -52,11 +56,15 @@ def build_pipeline(precision, device, keep_cpu_sd=False):
     for m in (unet, bn, vae):
         m._src = None
     sched = DDIMScheduler(**{k: v for k, v in SD15_SCHED.items() if k != "skip_prk_steps"})
-    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
-                                           scheduler=sched, safety_checker=None, feature_extractor=None,
-                                           requires_safety_checker=False, depth_conditioning_mode="concat")
+    if model == "sdxl":
+        pipe = StableDiffusionXLBrushNetPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None,
+                                                 tokenizer_2=None, unet=unet, brushnet=bn, scheduler=sched)
+    else:
+        pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                               scheduler=sched, safety_checker=None, feature_extractor=None,
+                                               requires_safety_checker=False, depth_conditioning_mode="concat")
     pipe.set_progress_bar_config(disable=True)
-    log(f"[bench] models built in {time.time() - t0:.1f}s (seeded random weights, SD1.5 shapes)")
+    log(f"[bench] models built in {time.time() - t0:.1f}s (seeded random weights, {model} shapes)")
     return pipe, (sds if keep_cpu_sd else None)
 
 
@@ -91,12 +99,17 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--size", type=int, default=None, help="image side (default 512; 1024 for --model sdxl)")
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl"],
+                    help="sd15 = BASELINE.json's north-star workload; sdxl = the §8 f-3 secondary workload")
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     a = ap.parse_args()
+    xl = a.model == "sdxl"
+    if a.size is None:
+        a.size = 1024 if xl else 512
 
     from reflecting_reality_amd import distributed as D, hip, synth
     rank, world, local = D.init_process_group()
@@ -109,13 +122,22 @@ def main():
     device = torch.device("cuda", local)
     hip.load()
 
-    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
-    pipe, sds = build_pipeline(a.precision, device, keep_cpu_sd=want_cpu)
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline and not xl
+    pipe, sds = build_pipeline(a.precision, device, keep_cpu_sd=want_cpu, model=a.model)
     # every rank works on its own images: rank-dependent seed, same shapes (weak scaling)
-    inp = synth.pipeline_inputs(a.batch, a.size, a.size, seed=1234 + rank)
+    inp = synth.pipeline_inputs(a.batch, a.size, a.size, seed=1234 + rank, cross_dim=2048 if xl else 768)
     timing = {}
+    if xl:
+        gp = torch.Generator().manual_seed(4321 + rank)
+        pooled, npooled = torch.randn(a.batch, 1280, generator=gp), torch.randn(a.batch, 1280, generator=gp)
 
     def one_pass():
+        if xl:
+            return pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+                        pooled_prompt_embeds=pooled, negative_pooled_prompt_embeds=npooled, image=inp["image"],
+                        mask=inp["mask"], num_inference_steps=a.denoise_steps, guidance_scale=7.5, latents=inp["latents"],
+                        output_type="pt", brushnet_conditioning_scale=1.0, height=a.size, width=a.size,
+                        conditioning_noise=inp["vae_noise"], _timing=timing).images
         return pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
                     image=inp["image"], mask=inp["mask"], depth=inp["depth"], num_inference_steps=a.denoise_steps,
                     guidance_scale=7.5, latents=inp["latents"], output_type="pt", brushnet_conditioning_scale=1.0,
@@ -138,23 +160,28 @@ def main():
 
     images = a.batch * a.steps * world
     value = images / elapsed
-    gflop = GFLOP_PER_IMAGE_STEP.get(a.size, 2489.2 * (a.size / 512.0) ** 2)
+    gflop = GFLOP_PER_IMAGE_STEP.get(a.size, 2489.2 * (a.size / 512.0) ** 2) if not xl else None
     peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
     step_s = denoise_ms * 1e-3 / (a.steps * a.denoise_steps)
-    step_tflops = a.batch * gflop * 1e9 / step_s / 1e12
+    step_tflops = a.batch * gflop * 1e9 / step_s / 1e12 if gflop else None
 
     roofline = None
     if rank == 0 and not a.no_profile:
         # live per-launch timing of the dominant kernel family (mf_gemm_conv: every conv / linear, ~90 % of the
         # algorithmic FLOPs) over ONE denoise step, HIP events on the launch stream
         x2 = torch.cat([inp["latents"].to(device)] * 2)
-        cond = torch.randn(2 * a.batch, 6, a.size // 8, a.size // 8, device=device)
+        cond = torch.randn(2 * a.batch, 5 if xl else 6, a.size // 8, a.size // 8, device=device)
         pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]]).to(device)
+        added = dict(text_embeds=torch.cat([npooled, pooled]).to(device),
+                     time_ids=torch.tensor([[a.size, a.size, 0, 0, a.size, a.size]], dtype=torch.float32,
+                                           device=device).repeat(2 * a.batch, 1)) if xl else None
         for rep in range(2):
             if rep == 1:
                 hip.profile_begin()
-            d, m, u = pipe.brushnet(x2, 981, encoder_hidden_states=pe, brushnet_cond=cond, return_dict=False)
-            pipe.unet(x2, 981, pe, down_block_add_samples=d, mid_block_add_sample=m, up_block_add_samples=u)
+            d, m, u = pipe.brushnet(x2, 981, encoder_hidden_states=pe, brushnet_cond=cond, added_cond_kwargs=added,
+                                    return_dict=False)
+            pipe.unet(x2, 981, pe, added_cond_kwargs=added, down_block_add_samples=d, mid_block_add_sample=m,
+                      up_block_add_samples=u)
         n_launch, secs, flops = hip.profile_end()
         # algorithmic bytes: activations read once, weights once, output written once (bf16 = 2 B)
         alg_bytes = 0.0
@@ -163,7 +190,7 @@ def main():
             alg_bytes += nz * 2.0 * (a_px * k / (kh * kh) + n * k + m * n)
         traffic, traffic_src = None, None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_family.json")
-        if os.path.exists(pmc) and a.batch == 4 and a.size == 512 and a.precision == "bf16":
+        if os.path.exists(pmc) and a.batch == 4 and a.size == 512 and a.precision == "bf16" and not xl:
             with open(pmc) as f:
                 pj = json.load(f)
             traffic = pj["traffic_bytes_per_launch"]          # separate rocprofv3 --pmc passes (tools/pmc_step.sh)
@@ -174,9 +201,12 @@ def main():
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes / n_launch),
                     "launches_per_denoise_step": n_launch, "avg_launch_us": round(secs / n_launch * 1e6, 2),
                     "flop_per_denoise_step": flops,
-                    "denoise_step": {"ms": round(step_s * 1e3, 3), "achieved": round(step_tflops, 2),
-                                     "frac": round(step_tflops / peak, 4),
-                                     "algorithmic_gflop_per_image_step": gflop}}
+                    "denoise_step": ({"ms": round(step_s * 1e3, 3), "achieved": round(step_tflops, 2),
+                                      "frac": round(step_tflops / peak, 4), "algorithmic_gflop_per_image_step": gflop}
+                                     if gflop else
+                                     {"ms": round(step_s * 1e3, 3), "achieved": round(flops / step_s / 1e12, 2),
+                                      "frac": round(flops / step_s / 1e12 / peak, 4),
+                                      "note": "conv/GEMM FLOPs only (attention not counted)"})}
 
     cpu = None
     if want_cpu:
@@ -194,11 +224,12 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "images/sec at 512x512, 50-step DDIM, SD1.5+BrushNet",
+            "metric": ("images/sec at 512x512, 50-step DDIM, SD1.5+BrushNet" if not xl else
+                       f"images/sec at {a.size}x{a.size}, {a.denoise_steps}-step DDIM, SDXL+BrushNet-XL (secondary workload)"),
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"SD1.5 + BrushNet(6 cond ch) depth-cond inpaint, batch {a.batch}x{a.size}x{a.size} per GPU, "
+            "config": {"workload": f"{'SDXL + BrushNet-XL(5 cond ch)' if xl else 'SD1.5 + BrushNet(6 cond ch) depth-cond'} inpaint, batch {a.batch}x{a.size}x{a.size} per GPU, "
                                    f"{a.denoise_steps}-step DDIM, CFG 7.5, VAE encode+decode included, random-init weights",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "height": a.size, "width": a.size,
                        "denoise_steps": a.denoise_steps, "parallelism": f"batch-shard x{world} (no collective)"},
