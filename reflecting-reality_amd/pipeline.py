@@ -376,13 +376,13 @@ class StableDiffusionBrushNetPipeline:
             _timing["denoise_start"] = torch.cuda.Event(enable_timing=True)
             _timing["denoise_end"] = torch.cuda.Event(enable_timing=True)
             _timing["denoise_start"].record()
-        use_graph = (self.use_hip_graph and fused_ddim and do_cfg and callback is None
+        use_graph = (self.use_hip_graph and do_cfg and callback is None and (fused_ddim or eta == 0.0)
                      and all(k == 1.0 for k in keep) and len(ts) > 2)
         with self.progress_bar(total=num_inference_steps) as bar:
             if use_graph:
                 latents = self._denoise_graph(latents, ts, pe, cond, nb, guidance_scale, float(brushnet_conditioning_scale),
                                               callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds,
-                                              negative_prompt_embeds, bar)
+                                              negative_prompt_embeds, bar, fused_ddim, eta, generator)
                 ts = []
             for i, t in enumerate(ts):                                                               # :1250 HOT LOOP
                 self._overlap(i > 0)                         # step 0 autotunes GEMM tiles: keep its timings undisturbed
@@ -438,17 +438,22 @@ class StableDiffusionBrushNetPipeline:
             self.brushnet.side_stream = None
 
     def _denoise_graph(self, latents, ts, pe, cond, nb, guidance_scale, cond_scale, callback_on_step_end,
-                       cb_inputs, prompt_embeds, negative_prompt_embeds, bar):
-        """The hot loop as ONE captured hipGraph replayed per timestep (BrushNet + UNet + CFG + DDIM update, ~700
-        kernels): launch overhead disappears and the host only refreshes two tiny device buffers (timestep,
-        scheduler coefficients) between replays.  The first step runs eagerly: it autotunes GEMM tiles, binds the
-        prompt (cross-attention K/V cache) and sizes every scratch buffer before anything is captured."""
+                       cb_inputs, prompt_embeds, negative_prompt_embeds, bar, fused_ddim=True, eta=0.0, generator=None):
+        """The hot loop as ONE captured hipGraph replayed per timestep (BrushNet + UNet + CFG [+ DDIM update], ~800
+        kernels on two streams): launch overhead disappears and the host only refreshes two tiny device buffers
+        (timestep, scheduler coefficients) between replays.  DDIM's update is inside the graph; multistep schedulers
+        (PNDM, UniPC: host-side state and per-step scalar coefficients) get the guided noise prediction from the graph
+        and step eagerly (a handful of mf_axpby_n launches).  The first step runs eagerly: it autotunes GEMM tiles,
+        binds the prompt (cross-attention K/V cache) and sizes every scratch buffer before anything is captured."""
         sched = self.scheduler
         dev = latents.device
-        coefs = torch.tensor([sched.step_coefficients(int(t))[:4] for t in ts], dtype=torch.float32).to(dev)
         tvals = ts.to(torch.float32).to(dev)
-        clip = float(sched.config["clip_sample_range"]) if sched.config["clip_sample"] else 0.0
-        ptype = 0 if sched.config["prediction_type"] == "epsilon" else 1
+        if fused_ddim:
+            coefs = torch.tensor([sched.step_coefficients(int(t))[:4] for t in ts], dtype=torch.float32).to(dev)
+            clip = float(sched.config["clip_sample_range"]) if sched.config["clip_sample"] else 0.0
+            ptype = 0 if sched.config["prediction_type"] == "epsilon" else 1
+        else:
+            coefs, clip, ptype = None, 0.0, type(sched).__name__
         # The captured graph (and every buffer it reads) is kept across calls with the same shapes and scalars:
         # new inputs are copied INTO the static buffers, so repeated calls pay no capture / instantiate cost.
         added = self._added_cond
@@ -462,6 +467,8 @@ class StableDiffusionBrushNetPipeline:
                       coef_cur=torch.empty(4, dtype=torch.float32, device=dev))
             if added:
                 st["added"] = {k: torch.empty(v.shape, dtype=torch.float32, device=dev) for k, v in added.items()}
+            if not fused_ddim:
+                st["eps"] = torch.empty_like(latents)            # guided noise prediction handed to scheduler.step
             self._graph_state = st
         if added:
             for k, v in added.items():
@@ -480,11 +487,15 @@ class StableDiffusionBrushNetPipeline:
             eps = self.unet(x_in, t_cur, encoder_hidden_states=pe, down_block_add_samples=down,
                             mid_block_add_sample=mid, up_block_add_samples=up, added_cond_kwargs=added,
                             return_dict=False)[0]
-            hip.cfg_ddim_step_dev(eps[:nb], eps[nb:], float(guidance_scale), lat, coef_cur, ptype, clip, out=lat)
+            if fused_ddim:
+                hip.cfg_ddim_step_dev(eps[:nb], eps[nb:], float(guidance_scale), lat, coef_cur, ptype, clip, out=lat)
+            else:
+                st["eps"].copy_(hip.cfg_combine(eps[:nb], eps[nb:], float(guidance_scale)))         # :1310-1312
 
         for i in range(len(ts)):
             t_cur.copy_(tvals[i:i + 1])
-            coef_cur.copy_(coefs[i])
+            if fused_ddim:
+                coef_cur.copy_(coefs[i])
             if i == 0:
                 one_step()                                   # eager: tunes GEMMs, (re)binds the prompt K/V, sizes scratch
             else:
@@ -499,6 +510,10 @@ class StableDiffusionBrushNetPipeline:
                         self._overlap(False)
                     st["graph"] = graph                      # capture does not execute: replay below runs this step
                 st["graph"].replay()
+            if not fused_ddim:
+                # multistep schedulers keep references to their inputs (ets, last_sample): hand them copies, not the
+                # graph's static buffers
+                lat.copy_(self._sched_step(st["eps"].clone(), ts[i], lat.clone(), eta, generator))   # :1315
             if callback_on_step_end is not None:
                 avail = dict(latents=lat, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
                 outs = callback_on_step_end(self, i, ts[i], {k: avail[k] for k in cb_inputs}) or {}

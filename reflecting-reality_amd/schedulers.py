@@ -340,7 +340,13 @@ class UniPCMultistepScheduler(_SchedulerBase):
         sig = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sigmas = np.interp(ts, np.arange(0, len(sig)), sig)
         last = ((1 - self.alphas_cumprod[0]) / self.alphas_cumprod[0]) ** 0.5
-        self.sigmas = torch.from_numpy(np.concatenate([sigmas, [last]]).astype(np.float32))
+        new_sigmas = torch.from_numpy(np.concatenate([sigmas, [last]]).astype(np.float32))
+        # the scalar coefficients depend only on (sigma table, step index, order): memoised across calls so that the
+        # host arithmetic (0-dim tensor math + a small linear solve, ~0.9 ms per step) leaves the critical path
+        if getattr(self, "_coef_cache", None) is None or self.sigmas.shape != new_sigmas.shape \
+                or not torch.equal(self.sigmas, new_sigmas):
+            self._coef_cache = {}
+        self.sigmas = new_sigmas
         self.timesteps = torch.from_numpy(ts)
         self.num_inference_steps = len(ts)
         self.model_outputs = [None] * c["solver_order"]
@@ -399,15 +405,19 @@ class UniPCMultistepScheduler(_SchedulerBase):
             m_t = hip.axpby_n([x, eps], [float(a_c), float(-s_c)])
         if use_corrector:                                                       # UniC (:584-719)
             order = self.this_order
-            alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coefs(order, self._step_index, self._step_index - 1, 1)
-            rhos = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
-            m0 = self.model_outputs[-1]
-            k = -alpha_t * B_h
-            terms, coefs, cm0 = [self.last_sample, m_t], [float(sigma_t / sigma_s0), float(k * rhos[-1])], -alpha_t * h_phi_1 - k * rhos[-1]
-            for i in range(1, order):
-                w = k * rhos[i - 1] / rks[i - 1]
-                terms.append(self.model_outputs[-(i + 1)]); coefs.append(float(w)); cm0 = cm0 - w
-            terms.append(m0); coefs.append(float(cm0))
+            key = ("c", order, self._step_index)
+            coefs = self._coef_cache.get(key)
+            if coefs is None:
+                alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coefs(order, self._step_index, self._step_index - 1, 1)
+                rhos = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+                k = -alpha_t * B_h
+                coefs, cm0 = [float(sigma_t / sigma_s0), float(k * rhos[-1])], -alpha_t * h_phi_1 - k * rhos[-1]
+                for i in range(1, order):
+                    w = k * rhos[i - 1] / rks[i - 1]
+                    coefs.append(float(w)); cm0 = cm0 - w
+                coefs.append(float(cm0))
+                self._coef_cache[key] = coefs
+            terms = [self.last_sample, m_t] + [self.model_outputs[-(i + 1)] for i in range(1, order)] + [self.model_outputs[-1]]
             x = hip.axpby_n(terms, coefs)
         for i in range(c["solver_order"] - 1):
             self.model_outputs[i] = self.model_outputs[i + 1]
@@ -416,15 +426,20 @@ class UniPCMultistepScheduler(_SchedulerBase):
         self.this_order = min(this_order, self.lower_order_nums + 1)
         self.last_sample = x
         order = self.this_order                                                 # UniP (:455-582)
-        alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coefs(order, self._step_index + 1, self._step_index, 0)
-        terms, coefs, cm0 = [x], [float(sigma_t / sigma_s0)], -alpha_t * h_phi_1
-        if order > 1:
-            rhos_p = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
-            k = -alpha_t * B_h
-            for i in range(1, order):
-                w = k * rhos_p[i - 1] / rks[i - 1]
-                terms.append(self.model_outputs[-(i + 1)]); coefs.append(float(w)); cm0 = cm0 - w
-        terms.append(m_t); coefs.append(float(cm0))
+        key = ("p", order, self._step_index)
+        coefs = self._coef_cache.get(key)
+        if coefs is None:
+            alpha_t, sigma_t, sigma_s0, h_phi_1, B_h, rks, R, b = self._coefs(order, self._step_index + 1, self._step_index, 0)
+            coefs, cm0 = [float(sigma_t / sigma_s0)], -alpha_t * h_phi_1
+            if order > 1:
+                rhos_p = torch.tensor([0.5]) if order == 2 else torch.linalg.solve(R[:-1, :-1], b[:-1])
+                k = -alpha_t * B_h
+                for i in range(1, order):
+                    w = k * rhos_p[i - 1] / rks[i - 1]
+                    coefs.append(float(w)); cm0 = cm0 - w
+            coefs.append(float(cm0))
+            self._coef_cache[key] = coefs
+        terms = [x] + [self.model_outputs[-(i + 1)] for i in range(1, order)] + [m_t]
         prev = hip.axpby_n(terms, coefs)
         if self.lower_order_nums < c["solver_order"]:
             self.lower_order_nums += 1

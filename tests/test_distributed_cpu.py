@@ -25,12 +25,19 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:          # a fixed port collides with a lingering TIME_WAIT socket of a previous run
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_two_rank_gloo_sharding_and_timing(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", str(script)]
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     import json

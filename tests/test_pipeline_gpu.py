@@ -216,6 +216,23 @@ def test_graph_eager_and_stream_overlap_agree():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["pndm", "unipc"])
+def test_multistep_schedulers_graph_matches_eager(name):
+    """PNDM / UniPC: the captured model evaluation + eager scheduler step gives the eager loop's latents bit for bit."""
+    pipe = _tiny_pipe()
+    base = pipe.scheduler.config
+    inp = synth.pipeline_inputs(2, 16, 16, seed=17, cross_dim=32, vae_scale=2)
+    noise = torch.randn(4, 4, 8, 8, generator=torch.Generator().manual_seed(4))
+    outs = []
+    for graph in (True, False):
+        pipe.scheduler = (PNDMScheduler.from_config(base, skip_prk_steps=True) if name == "pndm"
+                          else UniPCMultistepScheduler.from_config(base))
+        pipe.use_hip_graph, pipe._graph_state = graph, None
+        outs.append(_run(pipe, inp, 6, 16, 16, noise))
+    pipe.use_hip_graph = True
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("case", ["batch2_nonsquare", "no_cfg", "cond_scale_window", "images_per_prompt"])
 def test_pipeline_variants_against_oracle(case):
     """Call-surface variants of pipeline_brushnet.py:848-1363 against the pinned oracle (fp32 mode, 1e-3)."""
