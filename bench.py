@@ -121,6 +121,9 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     hip.load()
+    # host preprocessing is a few 12 MB elementwise ops and copies: a small OpenMP team avoids the wake-up jitter of a
+    # 100+-core host (cpu_baseline sets its own thread count later)
+    torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)))
 
     want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline and not xl
     pipe, sds = build_pipeline(a.precision, device, keep_cpu_sd=want_cpu, model=a.model)
@@ -150,9 +153,15 @@ def main():
     t0 = time.perf_counter()
     denoise_ms = 0.0
     for _ in range(a.steps):
+        tp0 = time.perf_counter()
         img = one_pass()
         torch.cuda.synchronize()
-        denoise_ms += timing["denoise_start"].elapsed_time(timing["denoise_end"])
+        tp1 = time.perf_counter()
+        dms = timing["denoise_start"].elapsed_time(timing["denoise_end"])
+        denoise_ms += dms
+        log(f"[bench] pass {(tp1 - tp0) * 1e3:.1f} ms: before the denoise loop {(timing['host_before_denoise'] - tp0) * 1e3:.1f} ms "
+            f"(preprocess + upload + VAE encode), denoise {dms:.1f} ms, after it {(tp1 - timing['host_after_denoise']) * 1e3:.1f} ms "
+            f"(host view; VAE decode + postprocess)")
     D.barrier()
     torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=device)

@@ -118,8 +118,22 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
     if (p.act == MF_ACT_GEGLU4) {
         // weight rows are interleaved [4 values | 4 gates]: out[n/2 + j] = v[j] * gelu_erf(v[4 + j])  (activations.py:100-103)
         float g[4];
+        if (p.out_dt == MF_BF16) {
+            // bf16 output: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside the bf16 rounding) on
+            // v_rcp_f32 / v_exp_f32 -- about half the VALU work of erff, and this epilogue runs once per 5 K-tiles
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = v[j] * (0.5f * v[4 + j] * (1.0f + erff(v[4 + j] * 0.70710678118654752440f)));
+            for (int j = 0; j < 4; ++j) {
+                const float x = v[4 + j];
+                const float z = fabsf(x) * 0.70710678118654752440f;
+                const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+                const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+                const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+                g[j] = v[j] * (0.5f * x + 0.5f * fabsf(x) * e);              // 0.5 x (1 + sign(x) erf(|z|))
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = v[j] * (0.5f * v[4 + j] * (1.0f + erff(v[4 + j] * 0.70710678118654752440f)));
+        }
         const int64_t o = zo + (int64_t)m * p.ldc + (n >> 1);
         if (p.out_dt == MF_F32) {
             *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(g[0], g[1], g[2], g[3]);

@@ -1,6 +1,7 @@
 // GroupNorm(+SiLU), LayerNorm and row softmax for NHWC / token-major activations on gfx950.
 // All three are HBM-bound: one read + one write of the tensor (GroupNorm reads it twice: stats,
 // then apply), fp32 statistics, vectorised 4-channel accesses, no atomics (bitwise reproducible).
+#include <stdlib.h>
 #include "mf_common.h"
 
 namespace {
@@ -265,6 +266,61 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
     }
 }
 
+// Half a wave per row (two rows per wave, 8 per block), 8-channel (16-byte) vectors: C % 8 == 0, C <= 2048.
+// For the transformer widths of the path (320 / 640 / 1280) this moves twice the bytes per instruction of the
+// 4-channel kernel below and halves the dependent shuffle chain (5 steps inside 32 lanes).
+__global__ __launch_bounds__(256) void layernorm8_kernel(const char* x, int in_dt, char* out, int out_dt,
+                                                         const float* gamma, const float* beta, int64_t rows, int C,
+                                                         float eps) {
+    const int l32 = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const bool live = row < rows;                       // keep every lane alive for the shuffles
+    constexpr int MAXV = 8;
+    float v[MAXV][8];
+    const int c8n = C >> 3;
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c8 = l32 + 32 * j;
+        if (live && c8 < c8n) {
+            load8(x, in_dt, row * C + c8 * 8, v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[j][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 32);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        if (l32 + 32 * j < c8n) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) q += __shfl_xor(q, off, 32);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c8 = l32 + 32 * j;
+        if (c8 < c8n) {
+            const int c = c8 * 8;
+            float g[8], bb[8], y[8];
+            load8(reinterpret_cast<const char*>(gamma), MF_F32, c, g);
+            load8(reinterpret_cast<const char*>(beta), MF_F32, c, bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = (v[j][e] - mean) * rstd * g[e] + bb[e];
+            store8(out, out_dt, row * C + c, y);
+        }
+    }
+}
+
 // One wave per row, up to 8 x 256 channels.
 __global__ __launch_bounds__(256) void layernorm_kernel(const char* x, int in_dt, char* out, int out_dt,
                                                         const float* gamma, const float* beta, int64_t rows, int C,
@@ -397,8 +453,13 @@ extern "C" int mf_layernorm(const void* x, int32_t in_dtype, void* out, int32_t 
     MF_CHECK_ARG(x && out && gamma && beta, "mf_layernorm: null pointer");
     MF_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= 2048, "mf_layernorm: C=%d must be a multiple of 4 and <= 2048", c);
     if (rows <= 0) return MF_OK;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const char*)x, in_dtype, (char*)out, out_dtype, gamma, beta, rows, c, eps);
+    static const bool ln4 = getenv("MFHIP_LN4") != nullptr;     // A/B switch: the 4-channel kernel
+    if (!ln4 && c % 8 == 0 && mf_aligned16(x) && mf_aligned16(out) && mf_aligned16(gamma) && mf_aligned16(beta))
+        hipLaunchKernelGGL(layernorm8_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const char*)x, in_dtype, (char*)out, out_dtype, gamma, beta, rows, c, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const char*)x, in_dtype, (char*)out, out_dtype, gamma, beta, rows, c, eps);
     MF_CHECK_LAUNCH("mf_layernorm");
     return MF_OK;
 }

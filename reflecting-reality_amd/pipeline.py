@@ -14,6 +14,8 @@ the pipeline a transformers `text_encoder` + `tokenizer` pair.
 """
 from __future__ import annotations
 
+import time
+
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Union
 
@@ -373,6 +375,7 @@ class StableDiffusionBrushNetPipeline:
         fused_ddim = isinstance(self.scheduler, DDIMScheduler) and eta == 0.0
         num_warmup = len(ts) - num_inference_steps * self.scheduler.order
         if _timing is not None:          # HIP events on the launch stream around the denoise loop (bench.py)
+            _timing["host_before_denoise"] = time.perf_counter()
             _timing["denoise_start"] = torch.cuda.Event(enable_timing=True)
             _timing["denoise_end"] = torch.cuda.Event(enable_timing=True)
             _timing["denoise_start"].record()
@@ -417,6 +420,7 @@ class StableDiffusionBrushNetPipeline:
         self._overlap(False)
         if _timing is not None:
             _timing["denoise_end"].record()
+            _timing["host_after_denoise"] = time.perf_counter()
         if output_type != "latent":
             sf = float(self.vae.config["scaling_factor"])
             z = hip.axpby_n([latents.contiguous()], [1.0 / sf])                                     # :1342

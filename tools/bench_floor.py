@@ -18,3 +18,8 @@ for (b_, hw, c) in ((8, 4096, 320), (8, 1024, 640), (8, 256, 1280), (8, 64, 1280
     g = torch.ones(c, device="cuda"); be = torch.zeros(c, device="cuda")
     t = timed(lambda: hip.groupnorm(x, g, be, groups=32, eps=1e-5, silu=True, out_dtype=torch.bfloat16))
     print(f"groupnorm B={b_} HW={hw} C={c}: {t:7.1f} us ({6 * x.numel() / t / 1e6:5.2f} TB/s for read+read+write)")
+for (rows, c) in ((32768, 320), (8192, 640), (2048, 1280)):
+    x = torch.randn(rows, c, device="cuda").bfloat16()
+    g = torch.ones(c, device="cuda"); be = torch.zeros(c, device="cuda")
+    t = timed(lambda: hip.layernorm(x, g, be, 1e-5, torch.bfloat16))
+    print(f"layernorm rows={rows} C={c}: {t:7.1f} us ({4 * rows * c / t / 1e6:5.2f} TB/s for read+write)")
