@@ -363,3 +363,50 @@ def test_linear_geglu_fused(prec_name, atol, rtol):
     y = ops.linear_geglu(x.to(DEV, prec.act), ops.geglu_weight(w, b, prec, DEV))
     assert y.shape == (300, 256)
     check(f"linear_geglu[{prec_name}]", y, ref, atol, rtol)
+
+
+def test_c_abi_error_paths_and_edge_cases():
+    """The C ABI refuses what it cannot serve (error code + message, nothing launched) and handles degenerate sizes."""
+    import ctypes as C
+    lib = hip.load()
+    prec = ops.Precision.get("bf16")
+    x = torch.randn(2, 8, 8, 32, device=DEV).bfloat16()
+    cw = ops.ConvWeight(torch.randn(16, 32, 3, 3) * 0.05, torch.randn(16), prec, DEV)
+    # channel mismatch, non-contiguous input, misaligned operand, unknown attention head dim
+    with pytest.raises(hip.MfhipError, match="channels"):
+        ops.conv2d(x[..., :24].contiguous(), cw)
+    with pytest.raises(hip.MfhipError, match="contiguous"):
+        ops.conv2d(x.permute(0, 2, 1, 3), cw)
+    out = torch.empty(2, 8, 8, 16, device=DEV, dtype=torch.bfloat16)
+    big = torch.zeros(2 * 8 * 8 * 32 + 8, device=DEV, dtype=torch.bfloat16)
+    mis = big[1:1 + 2 * 8 * 8 * 32].view(2, 8, 8, 32)                      # 2-byte offset: not 16-byte aligned
+    with pytest.raises(hip.MfhipError, match="aligned"):
+        hip.gemm_conv(mis, cw.w, out, dtype=torch.bfloat16, c0=32, lda0=32, batch=2, h_in=8, w_in=8, h_out=8, w_out=8,
+                      kh=3, kw=3, pad_t=1, pad_l=1, n=16, bias=cw.bias)
+    q = torch.randn(1, 16, 8 * 24, device=DEV).bfloat16()
+    with pytest.raises(hip.MfhipError, match="head_dim"):
+        hip.attention_bf16(q, q, torch.zeros(1, 8 * 24, 16, device=DEV).bfloat16(), torch.empty_like(q), ldq=192, ldk=192,
+                           ldvt=16, ldo=192, batch=1, heads=8, sq=16, skv=16, head_dim=24, scale=0.2)
+    with pytest.raises(hip.MfhipError, match="groups"):
+        hip.groupnorm(x, torch.ones(32, device=DEV), torch.zeros(32, device=DEV), groups=5, eps=1e-5, silu=False,
+                      out_dtype=torch.bfloat16)
+    assert lib.mf_gemm_conv(None, None) != 0 and b"null" in lib.mf_last_error()
+    # degenerate sizes: one pixel, one output channel group, K smaller than a tile; and a 1-row LayerNorm
+    g = torch.Generator().manual_seed(9)
+    x1 = rb(torch.randn(1, 8, 1, 1, generator=g))
+    w1 = rb(torch.randn(8, 8, 3, 3, generator=g) * 0.1)
+    y = ops.conv2d(nhwc(x1, prec.act), ops.ConvWeight(w1, None, prec, DEV))
+    check("conv 1x1 image", nchw(y), F.conv2d(x1, w1, None, padding=1), 2e-2, 1e-2)
+    ln = hip.layernorm(torch.ones(1, 8, device=DEV), torch.ones(8, device=DEV), torch.zeros(8, device=DEV), 1e-5, torch.float32)
+    assert torch.allclose(ln.cpu(), torch.zeros(1, 8), atol=1e-3)
+    # determinism: the same launch twice is bit-identical (no atomics anywhere, split-K slabs reduced in a fixed order)
+    xb = torch.randn(2, 16, 16, 256, device=DEV).bfloat16()
+    cwb = ops.ConvWeight(torch.randn(64, 256, 3, 3) * 0.02, torch.randn(64), prec, DEV)
+    a = ops.conv2d(xb, cwb, splitk=4, tile=1)
+    b = ops.conv2d(xb, cwb, splitk=4, tile=1)
+    assert torch.equal(a, b)
+    gn1 = hip.groupnorm(xb, torch.ones(256, device=DEV), torch.zeros(256, device=DEV), groups=32, eps=1e-5, silu=True,
+                        out_dtype=torch.bfloat16)
+    gn2 = hip.groupnorm(xb, torch.ones(256, device=DEV), torch.zeros(256, device=DEV), groups=32, eps=1e-5, silu=True,
+                        out_dtype=torch.bfloat16)
+    assert torch.equal(gn1, gn2)
