@@ -356,14 +356,40 @@ class _UNetCore(HipModel):
         g = self.config["norm_num_groups"]
         eps = self.config["norm_eps"] if eps is None else eps
         P = self.P
+        join = None
+        if p + "conv_shortcut" in P:
+            # the 1x1 shortcut only needs the block input: on the auxiliary stream it overlaps norm1 / conv1 / norm2
+            sc, join = self._on_aux(lambda: ops.conv2d(x, P[p + "conv_shortcut"], padding=0, x1=x1))
+        else:
+            sc = x
         h = hip.groupnorm(x, *P[p + "norm1"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act, x1=x1)
         h = ops.conv2d(h, P[p + "conv1"], temb=self._temb(temb_all, p))
         h = hip.groupnorm(h, *P[p + "norm2"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act)
-        if p + "conv_shortcut" in P:
-            sc = ops.conv2d(x, P[p + "conv_shortcut"], padding=0, x1=x1)
-        else:
-            sc = x
+        if join is not None:
+            join()
         return ops.conv2d(h, P[p + "conv2"], res0=sc, res1=inj)
+
+    aux_stream: Optional["torch.cuda.Stream"] = None
+
+    def _on_aux(self, fn):
+        """Run `fn` (launches whose inputs are ready now and whose result is needed later) on this model's auxiliary
+        HIP stream; returns (result, join) where join() orders the current stream after it.  Without an auxiliary
+        stream (the default outside the pipeline's denoise loops) fn runs inline."""
+        aux = self.aux_stream
+        if aux is None:
+            return fn(), None
+        cur = torch.cuda.current_stream(self.device)
+        aux.wait_stream(cur)
+        with torch.cuda.stream(aux):
+            out = fn()
+            done = torch.cuda.Event()
+            done.record(aux)
+        for t in (out if isinstance(out, (tuple, list)) else (out,)):
+            t.record_stream(cur)
+
+        def join():
+            cur.wait_event(done)
+        return out, join
 
     def _attention(self, b: str, x: torch.Tensor, ctx: Optional[torch.Tensor], heads: int, residual: torch.Tensor
                    ) -> torch.Tensor:
@@ -375,9 +401,12 @@ class _UNetCore(HipModel):
         d = c // heads
         if ctx is None:
             skv = x.shape[1]
+            # V^T on the auxiliary stream while q | k is projected on this one
+            vt, join = self._on_aux(lambda: ops.linear_t(x, P[b + "to_v"], (skv + 7) // 8 * 8, out=self._vt_buffer(x, c, skv)))
             qk = ops.linear(x, P[b + "to_qk"])
             q, k = qk[..., :c], qk[..., c:]
-            vt = ops.linear_t(x, P[b + "to_v"], (skv + 7) // 8 * 8, out=self._vt_buffer(x, c, skv))
+            if join is not None:
+                join()
         else:
             skv = ctx.shape[1]
             q = ops.linear(x, P[b + "to_q"])

@@ -129,6 +129,8 @@ class StableDiffusionBrushNetPipeline:
         self.use_hip_graph = True        # capture the denoise step into a hipGraph when the scheduler allows it
         self.overlap_brushnet = True     # BrushNet on a second HIP stream, ordered against the UNet by per-residual events
         self._side_stream = None
+        self.overlap_aux = False         # UNet shortcut convs / V projections on a third stream: measured 0.8 % slower
+                                         # (18.15 vs 18.0 ms per step, tools/bench_aux.py), so off by default
         self._added_cond = None          # SDXL: added_cond_kwargs of the (CFG-duplicated) batch, set by the XL subclass
         self._graph_state = None
 
@@ -437,9 +439,15 @@ class StableDiffusionBrushNetPipeline:
         if on and self.overlap_brushnet and self.device.type == "cuda":
             if self._side_stream is None or self._side_stream.device != self.device:
                 self._side_stream = torch.cuda.Stream(device=self.device)
+                self._aux_stream = torch.cuda.Stream(device=self.device)
             self.brushnet.side_stream = self._side_stream
+            # an auxiliary stream for UNet launches off its critical path (shortcut convs, V projections).  BrushNet
+            # keeps a single stream: a fork of the already forked side stream segfaults in hipStreamEndCapture
+            # (ROCm 7.2), and its shortcut convs already overlap the UNet
+            self.unet.aux_stream = self._aux_stream if self.overlap_aux else None
         else:
             self.brushnet.side_stream = None
+            self.unet.aux_stream = self.brushnet.aux_stream = None
 
     def _denoise_graph(self, latents, ts, pe, cond, nb, guidance_scale, cond_scale, callback_on_step_end,
                        cb_inputs, prompt_embeds, negative_prompt_embeds, bar, fused_ddim=True, eta=0.0, generator=None):
