@@ -219,8 +219,8 @@ constexpr int min_waves(int bm, int bn, int stages, int nthr) {
     return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, min_waves(BM, BN, STAGES, WAVES_M* WAVES_N * 64))
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES, bool DXR = false>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, min_waves(BM + (DXR ? 32 : 0), BN, STAGES, WAVES_M* WAVES_N * 64))
 void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;
     constexpr int ES = (DT == MF_F32) ? 4 : 2;   // element size of the compute dtype
@@ -503,7 +503,126 @@ void gemm_conv_kernel(const GemmArgs p) {
 
     // ---- main loop ------------------------------------------------------------------------
     if (nt > 0) {
-        if constexpr (!A_F32) {
+        if constexpr (DXR) {
+            // 3x3 / stride 1 convolution with dx-tap reuse of the A tile.  K runs (ky, 128-byte-row chunk, kx): the
+            // three kx taps of a (ky, chunk) group read the SAME input pixels shifted by one, so a group stages ONE A
+            // window and the MFMAs of tap kx read it at row offset kx.  The window is the tile's image rows (BM / W
+            // of them when W <= BM, a BM-pixel piece of one row otherwise) each framed by its left and right
+            // neighbour pixel: W + 2 (or BM + 2) LDS rows per image row, the frame pixels outside the image being
+            // hardware zeros of the DMA range check — the horizontal padding needs no per-fragment masking.
+            // A-side DMAs drop to ~40 % of the per-tap scheme; the vector-memory path, not the bytes in L2, is what
+            // bounds these kernels.  LDS: [A window x 2][W tile x 2].
+            static_assert(!A_F32 && STAGES == 2, "dx reuse: DMA staging, double buffered");
+            constexpr int AROWS = BM + RPP, A3_IT = AROWS / RPP;
+            constexpr int AB = AROWS * 128, WB = BN * 128;
+            const int nck = p.Ctot / BK;                           // K chunks per tap
+            const int weff = p.Wo < BM ? p.Wo : BM;                // pixels of one image row inside the tile
+            const int wfr = weff + 2;                              // ... plus the frame
+            const int nrows_img = p.M / p.Wo;                      // image rows in the whole batch
+            const int gy0 = m0 / p.Wo, gx0 = p.Wo < BM ? 0 : m0 - gy0 * p.Wo;
+            int ay[A3_IT], apix[A3_IT];
+#pragma unroll
+            for (int i = 0; i < A3_IT; ++i) {
+                const int r = lrow + i * RPP;                      // LDS row of the window
+                const int ir = r / wfr, c = r - ir * wfr;
+                const int gy = gy0 + ir, x = gx0 + c - 1;
+                if (ir * weff < BM && gy < nrows_img && (unsigned)x < (unsigned)p.Wo) {
+                    const int b = gy / p.Ho;
+                    ay[i] = gy - b * p.Ho;
+                    apix[i] = gy * p.Wo + x;                       // pixel index at ky = 1
+                } else {
+                    ay[i] = -(1 << 28);
+                    apix[i] = 0;
+                }
+            }
+            unsigned w3[B_IT];
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int n = n0 + lrow + i * RPP;
+                w3[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + chunk * VEC) * ES) : 0x80000000u;
+            }
+            const int nb = p.M / p.HoWo;
+            const srd_t sA0 = make_srd(a0, (unsigned)((nb * p.Hin * p.Win - 1) * p.ld0b + p.C0 * AES));
+            const srd_t sA1 = make_srd(a1, (unsigned)((nb * p.Hin * p.Win - 1) * p.ld1b + (p.Ctot - p.C0) * AES));
+            const srd_t sW = make_srd(wbase, (unsigned)(((int64_t)(p.N - 1) * p.ldw + p.K) * ES));
+            const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem) + wave * 1024;
+            // issue state: group (ky, global chunk) and kx of the next tile to stage; kt_begin is a multiple of 3
+            int i_ky = (kt_begin / 3) / nck, i_cg = (kt_begin / 3) - i_ky * nck, i_kx = 0, i_grp = 0;
+            auto issue3 = [&](int wstage) {
+                if (i_kx == 0) {
+                    const int c = i_cg * BK;
+                    const bool seg = c >= p.C0;
+                    const int ldb = seg ? p.ld1b : p.ld0b;
+                    const int ccb = ((seg ? c - p.C0 : c) + chunk * VEC) * AES;
+                    const srd_t srd = seg ? sA1 : sA0;
+                    const unsigned la = ldsb + (i_grp & 1) * AB;
+#pragma unroll
+                    for (int i = 0; i < A3_IT; ++i) {
+                        const int iy = ay[i] + i_ky - 1;
+                        const bool ok = (unsigned)iy < (unsigned)p.Hin;
+                        const unsigned off = ok ? (unsigned)((apix[i] + (i_ky - 1) * p.Win) * ldb + ccb) : 0x80000000u;
+                        dma16_buf(off, srd, la + i * RPP * 128);
+                    }
+                }
+                const unsigned wk = (unsigned)(((i_ky * 3 + i_kx) * p.Ctot + i_cg * BK) * ES);
+                const unsigned lb = ldsb + 2 * AB + wstage * WB;
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) dma16_buf(w3[i] + wk, sW, lb + i * RPP * 128);
+                if (++i_kx == 3) {
+                    i_kx = 0; ++i_grp;
+                    if (++i_cg == nck) { i_cg = 0; ++i_ky; }
+                }
+            };
+            int arow0[MT];                                         // window row of this lane's output pixel at kx = 0
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = wm * WM + i * 32 + frow;
+                const int ir = m / weff;
+                arow0[i] = ir * wfr + (m - ir * weff);
+            }
+            auto compute3 = [&](int abuf, int wstage, int kx) {
+                const char* Ab = smem + abuf * AB;
+                const char* Bs = smem + 2 * AB + wstage * WB + (wn * WN + frow) * 128;
+                int aoffs[MT], akey[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int r = arow0[i] + kx;
+                    aoffs[i] = r * 128;
+                    akey[i] = (r >> 1) & 7;
+                }
+                uint4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+                auto ldfrag = [&](int ks, uint4 (&fa)[MT], uint4 (&fb)[NT]) {
+                    const int cb = (((2 * ks + fh) ^ fkey) << 4);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        fa[i] = *reinterpret_cast<const uint4*>(Ab + aoffs[i] + (((2 * ks + fh) ^ akey[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const uint4*>(Bs + j * 32 * 128 + cb);
+                };
+                ldfrag(0, fa0, fb0);
+                ldfrag(1, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                ldfrag(2, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                ldfrag(3, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa0, fb0);
+                mma(fa1, fb1);
+            };
+            issue3(0);
+            int c_kx = 0, c_grp = 0;
+            for (int t = 0; t < nt; ++t) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                if (t + 1 < nt) issue3((t + 1) & 1);
+                compute3(c_grp & 1, t & 1, c_kx);
+                if (++c_kx == 3) { c_kx = 0; ++c_grp; }
+            }
+        } else if constexpr (!A_F32) {
             // LDS ring, STAGES-1 tiles in flight while tile t is multiplied.  Only a COUNTED vmcnt (all but the newer
             // tiles' G = A_IT + B_IT DMAs each) and a raw s_barrier order the ring.  RAW: a tile is read only after
             // every wave's vmcnt + the barrier; WAR: stage (t + PF) % STAGES was last read in compute(t - 1), which
@@ -1240,7 +1359,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-struct TileCfg { int bm, bn, threads, stages, halo; };   // halo: rows of output pixels per tile of conv3x3_halo_kernel (0 = implicit GEMM)
+struct TileCfg { int bm, bn, threads, stages, halo, dxr; };   // halo: rows of output pixels per tile of conv3x3_halo_kernel (0 = implicit GEMM)
 // keep in sync with launch_tile()
 const TileCfg kTiles[] = {
     {128, 128, 256, 2},  // 1
@@ -1262,19 +1381,25 @@ const TileCfg kTiles[] = {
     {128, 128, 256, 4, 8},  // 17  conv3x3_halo_kernel: 8x16 x 128, 2x2 waves
     {128, 128, 256, 6, 8},  // 18  same with a 6-deep weight ring
     {256, 160, 512, 3, 16}, // 19  conv3x3_pingpong_kernel: 16x16 pixels x 160 channels, 8 waves, one block per CU
+    {128, 160, 256, 2, 0, 1},  // 20  gemm_conv_kernel with dx-tap reuse of the A window (3x3 / stride 1 convs), 4x1 waves
+    {128, 128, 256, 2, 0, 1},  // 21  same, 2x2 waves
+    {64, 128, 256, 2, 0, 1},   // 22
+    {128, 64, 256, 2, 0, 1},   // 23
+    {192, 128, 256, 2, 0, 1},  // 24
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST>
+template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int smem = ST * (BM + BN) * 128;
+    constexpr int smem = DX ? 2 * (BM + WMv * WNv * 8) * 128 + 2 * BN * 128 : ST * (BM + BN) * 128;
+    static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST>), grid, dim3(WMv * WNv * 64), smem, s, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX>), grid, dim3(WMv * WNv * 64), smem, s, a);
 }
 
 template <int DT, bool AF>
@@ -1301,6 +1426,11 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
             case 13: launch_one<DT, 192, 128, 2, 2, false, 2>(a, grid, s); break;
             case 14: launch_one<DT, 128, 160, 4, 1, false, 2>(a, grid, s); break;
             case 15: launch_one<DT, 128, 192, 2, 2, false, 2>(a, grid, s); break;
+            case 20: launch_one<DT, 128, 160, 4, 1, false, 2, true>(a, grid, s); break;
+            case 21: launch_one<DT, 128, 128, 2, 2, false, 2, true>(a, grid, s); break;
+            case 22: launch_one<DT, 64, 128, 2, 2, false, 2, true>(a, grid, s); break;
+            case 23: launch_one<DT, 128, 64, 2, 2, false, 2, true>(a, grid, s); break;
+            case 24: launch_one<DT, 192, 128, 2, 2, false, 2, true>(a, grid, s); break;
             default: break;
         }
     }
@@ -1343,7 +1473,7 @@ int pick_tile(int M, int N, int nz, int splitk) {
     for (int t = 1; t <= kNumTiles; ++t) {
         const TileCfg& c = kTiles[t - 1];
         const double tiles = (double)cdiv(M, c.bm) * cdiv(N, c.bn) * nz * (splitk > 1 ? splitk : 1);
-        if (c.stages != 2 || c.halo) continue;                            // the ring / halo variants are picked by the host autotuner
+        if (c.stages != 2 || c.halo || c.dxr) continue;                            // the ring / halo variants are picked by the host autotuner
         const int bpc = (2 * (c.bm + c.bn) * 128 <= 80 * 1024) ? 2 : 1;   // blocks per CU that fit in LDS
         const double rounds = (double)(int64_t)((tiles + 256.0 * bpc - 1) / (256.0 * bpc));
         double per_cu = tiles / 256.0;
@@ -1481,6 +1611,17 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     }
     const int bk = 128 / es;
     a.nkt = cdiv(a.K, bk);
+    if (tc.dxr) {
+        const int64_t npix = (int64_t)d->batch * d->h_in * d->w_in;
+        const int64_t ext_a = (npix - 1) * (int64_t)(a.ld0b > a.ld1b ? a.ld0b : a.ld1b) + (int64_t)a.Ctot * aes;
+        const int64_t ext_w = ((int64_t)(a.N - 1) * a.ldw + a.K) * es;
+        const bool ok = !a_f32 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && !d->upsample &&
+                        d->h_out == d->h_in && d->w_out == d->w_in && d->nz == 1 && a.C0 % bk == 0 && a.Ctot % bk == 0 &&
+                        ext_a < (1ll << 31) - (1 << 20) && ext_w < (1ll << 31) - (1 << 20) &&
+                        ((d->w_in <= tc.bm && tc.bm % d->w_in == 0 && (tc.bm / d->w_in) * (d->w_in + 2) <= tc.bm + tc.threads / 8) ||
+                         (d->w_in > tc.bm && d->w_in % tc.bm == 0));
+        MF_CHECK_ARG(ok, "mf_gemm_conv: tile %d (dx-tap reuse) does not apply to this call", tile);
+    }
     const int64_t tiles_mn = (int64_t)cdiv(a.M, tc.bm) * cdiv(a.N, tc.bn) * a.nz;
     int splitk = d->splitk;
     if (splitk == 0) {
@@ -1497,6 +1638,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.splitk = splitk > 1 ? splitk : 1;
     if (a.splitk > a.nkt) a.splitk = a.nkt;
     a.kt_per_split = cdiv(a.nkt, a.splitk);
+    if (tc.dxr) a.kt_per_split = (a.kt_per_split + 2) / 3 * 3;       // whole (ky, chunk) groups of three taps
     a.splitk = cdiv(a.nkt, a.kt_per_split);   // no empty splits
     a.ws = d->ws;
     MF_CHECK_ARG(a.splitk == 1 || (a.ws != nullptr && (int64_t)a.splitk * a.nz * a.M * a.N <= d->ws_floats),

@@ -57,7 +57,7 @@ def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     check(f"conv3x3[{prec_name},tile{tile}]", nchw(y), ref, atol, rtol)
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18, 19])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24])
 @pytest.mark.parametrize("case", ["plain", "tailN", "cat", "splitk", "epilogue", "big"])
 def test_conv3x3_halo_tiles(tile, case):
     """conv3x3_halo_kernel (input patch resident in LDS, weights streamed per tap) and the 8-wave ping-pong
@@ -67,7 +67,7 @@ def test_conv3x3_halo_tiles(tile, case):
     b, h, w_, c0, c1, n = {"plain": (2, 16, 32, 64, 0, 160), "tailN": (1, 8, 16, 32, 0, 200), "cat": (2, 16, 16, 64, 32, 128),
                            "splitk": (1, 16, 16, 256, 0, 160), "epilogue": (2, 8, 32, 96, 0, 320),
                            "big": (2, 64, 64, 320, 0, 320)}[case]
-    if tile == 19:      # 16-row tiles, 64-channel chunks
+    if tile >= 19:      # 64-channel chunks (tile 19 also needs 16-row tiles)
         b, h, w_, c0, c1, n = {"plain": (2, 16, 32, 64, 0, 160), "tailN": (1, 16, 16, 64, 0, 200), "cat": (2, 16, 16, 64, 64, 128),
                                "splitk": (1, 16, 16, 256, 0, 160), "epilogue": (2, 16, 32, 128, 0, 320),
                                "big": (2, 64, 64, 320, 0, 320)}[case]
@@ -87,6 +87,12 @@ def test_conv3x3_halo_tiles(tile, case):
     y = ops.conv2d(nhwc(x, prec.act), cw, x1=nhwc(x1, prec.act) if c1 else None, tile=tile,
                    splitk=3 if case == "splitk" else 1, **kw)
     check(f"conv3x3_halo[tile{tile},{case}]", nchw(y), ref, 2e-2, 1e-2)
+    if tile >= 20 and case in ("plain", "epilogue"):          # dx-tap reuse also runs in the fp32 parity mode, any image size
+        p32 = ops.Precision.get("fp32")
+        x32 = torch.randn(3, 64, 7, 16, generator=g)              # M = 336: a ragged last tile, image rows of 16 pixels
+        w32 = torch.randn(40, 64, 3, 3, generator=g) * 0.05
+        y32 = ops.conv2d(nhwc(x32, p32.act), ops.ConvWeight(w32, bias[:40], p32, DEV), tile=tile, splitk=2 if case == "epilogue" else 1)
+        check(f"conv3x3_dxr_fp32[tile{tile}]", nchw(y32), F.conv2d(x32, w32, bias[:40], padding=1), 2e-4, 2e-4)
     if case == "plain":     # a call the halo kernel cannot serve is refused, not silently rerouted
         with pytest.raises(hip.MfhipError):
             ops.conv2d(nhwc(x, prec.act), cw, stride=2, tile=tile)

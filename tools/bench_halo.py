@@ -11,7 +11,7 @@ for (b, h, w, ci, co) in [(8, 64, 64, 320, 320), (8, 64, 64, 640, 320), (8, 32, 
     wt = ops.ConvWeight(torch.randn(co, ci, 3, 3) * 0.02, torch.randn(co), prec, "cuda")
     flops = 2.0 * b * h * w * co * ci * 9
     r = []
-    for t in (1, 14, 16, 18, 19):
+    for t in (1, 14, 16, 18, 20, 21):
         us = timed(lambda: ops.conv2d(x, wt, padding=1, tile=t, splitk=1))
         r.append(f"tile{t}: {us:7.1f} us {flops / us / 1e6:5.0f} TF/s")
     print(f"M={b*h*w} N={co} K={ci*9}: " + " | ".join(r), flush=True)
