@@ -416,3 +416,39 @@ def test_c_abi_error_paths_and_edge_cases():
     gn2 = hip.groupnorm(xb, torch.ones(256, device=DEV), torch.zeros(256, device=DEV), groups=32, eps=1e-5, silu=True,
                         out_dtype=torch.bfloat16)
     assert torch.equal(gn1, gn2)
+
+
+def test_reference_layer_known_answers_on_the_hip_path():
+    """The reference's own ResnetBlock2D / Upsample2D / Downsample2D KATs (tests/models/test_layers_utils.py) through
+    the C ABI in the fp32 parity mode: GroupNorm+SiLU, conv with fused time-embedding / shortcut / residual epilogues,
+    nearest-2x upsampling folded into the conv gather, stride-2 conv."""
+    import kat_layers as K
+    prec = ops.Precision.get("fp32")
+    dev = DEV
+
+    def cw(sd, name):
+        return ops.ConvWeight(sd[name + ".weight"], sd[name + ".bias"], prec, dev)
+
+    for name, shortcut in (("resnet_default", False), ("resnet_shortcut", True)):
+        sd, x, temb = K.resnet_case(shortcut)
+        xh = nhwc(x, prec.act)
+        ones, zeros = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+        t = ops.linear(F.silu(temb).to(dev), cw(sd, "time_emb_proj"), out_dtype=torch.float32)
+        h = hip.groupnorm(xh, ones, zeros, groups=32, eps=1e-6, silu=True, out_dtype=prec.act)
+        h = ops.conv2d(h, cw(sd, "conv1"), temb=t)
+        h = hip.groupnorm(h, ones, zeros, groups=32, eps=1e-6, silu=True, out_dtype=prec.act)
+        sc = ops.conv2d(xh, cw(sd, "conv_shortcut"), padding=0) if shortcut else xh
+        K.check_slice(name, nchw(ops.conv2d(h, cw(sd, "conv2"), res0=sc)))
+    sd, x = K.sampler_case("up")
+    K.check_slice("upsample_conv", nchw(ops.conv2d(nhwc(x, prec.act), cw(sd, "conv"), upsample=True)))
+    sd, x = K.sampler_case("down")
+    K.check_slice("downsample_conv", nchw(ops.conv2d(nhwc(x, prec.act), cw(sd, "conv"), stride=2, padding=1)))
+    # Transformer2DModel with cross-attention through the model code (GroupNorm, proj_in, LN, attention, GEGLU, proj_out)
+    from reflecting_reality_amd import models as M
+    sd, x, ctx = K.transformer_case()
+    m = M.UNet2DConditionModel.__new__(M.UNet2DConditionModel)
+    m.prec, m.device, m.config = prec, torch.device(dev), {"norm_num_groups": 32}
+    m.P, m.tdepth, m._cross_kv, m._ehs_gen = {}, {}, {}, 0
+    m._prepare_transformer(sd, "")
+    out = m._transformer("", nhwc(x, prec.act), ctx.to(dev), 2)
+    K.check_slice("transformer_cross", nchw(out))

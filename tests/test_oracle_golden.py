@@ -113,6 +113,20 @@ def test_tiny_xl_matches_reference():
     report("xl 3-step latents", lat, G["pipe_latents"], **TOL)
 
 
+def test_reference_layer_known_answers():
+    """ResnetBlock2D / Upsample2D / Downsample2D KATs of the reference's tests/models/test_layers_utils.py."""
+    import kat_layers as K
+    for name, shortcut in (("resnet_default", False), ("resnet_shortcut", True)):
+        sd, x, temb = K.resnet_case(shortcut)
+        K.check_slice(name, R.resnet(sd, "", x, temb, 32, 1e-6))
+    sd, x = K.sampler_case("up")
+    K.check_slice("upsample_conv", R.upsample(sd, "", x))
+    sd, x = K.sampler_case("down")
+    K.check_slice("downsample_conv", R.downsample(sd, "", x))
+    sd, x, ctx = K.transformer_case()
+    K.check_slice("transformer_cross", R.transformer_2d(sd, "", x, ctx, 2, 32))
+
+
 def test_scheduler_traces_match_reference():
     G = golden("schedulers.npz")
     for n in (4, 50):
