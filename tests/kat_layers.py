@@ -74,3 +74,39 @@ def transformer_case():
     sd["proj_out.weight"], sd["proj_out.bias"] = pout.weight.data, pout.bias.data
     context = torch.randn(1, 4, 64)
     return sd, sample, context
+
+EXPECT["down_block"] = [-0.0232, -0.9869, 0.8054, -0.0637, -0.1688, -1.4264, 0.4470, -1.3394, 0.0904]
+EXPECT["up_block"] = [-0.2041, -0.4165, -0.3022, 0.0041, -0.6628, -0.7053, 0.1928, -0.0325, 0.0523]
+
+
+def _resnet_sd(sd, p, cin, cout):
+    """ResnetBlock2D.__init__ order: conv1, time_emb_proj, conv2, conv_shortcut (if cin != cout)."""
+    c1, lin, c2 = nn.Conv2d(cin, cout, 3, padding=1), nn.Linear(128, cout), nn.Conv2d(cout, cout, 3, padding=1)
+    sd[p + "norm1.weight"], sd[p + "norm1.bias"] = torch.ones(cin), torch.zeros(cin)
+    sd[p + "norm2.weight"], sd[p + "norm2.bias"] = torch.ones(cout), torch.zeros(cout)
+    sd[p + "conv1.weight"], sd[p + "conv1.bias"] = c1.weight.data, c1.bias.data
+    sd[p + "time_emb_proj.weight"], sd[p + "time_emb_proj.bias"] = lin.weight.data, lin.bias.data
+    sd[p + "conv2.weight"], sd[p + "conv2.bias"] = c2.weight.data, c2.bias.data
+    if cin != cout:
+        sc = nn.Conv2d(cin, cout, 1)
+        sd[p + "conv_shortcut.weight"], sd[p + "conv_shortcut.bias"] = sc.weight.data, sc.bias.data
+
+
+def block_case(kind: str):
+    """DownBlock2DTests / UpBlock2DTests (tests/models/unets/test_unet_2d_blocks.py:23-29,200-210 with the dummy inputs
+    of test_unet_blocks_common.py:46-78): hidden [4,32,32,32] and temb [4,128] from seed 0; the up block's skip tensor
+    re-seeds the global generator with 1 before the block is built."""
+    torch.manual_seed(0)
+    hidden, temb = torch.randn(4, 32, 32, 32), torch.randn(4, 128)
+    sd = {}
+    if kind == "down":
+        _resnet_sd(sd, "resnets.0.", 32, 32)
+        conv = nn.Conv2d(32, 32, 3, stride=2, padding=1)
+        skip = None
+    else:
+        torch.manual_seed(1)
+        skip = torch.randn(4, 32, 32, 32)
+        _resnet_sd(sd, "resnets.0.", 64, 32)
+        conv = nn.Conv2d(32, 32, 3, padding=1)
+    sd["sampler.conv.weight"], sd["sampler.conv.bias"] = conv.weight.data, conv.bias.data
+    return sd, hidden, temb, skip

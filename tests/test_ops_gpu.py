@@ -443,6 +443,22 @@ def test_reference_layer_known_answers_on_the_hip_path():
     K.check_slice("upsample_conv", nchw(ops.conv2d(nhwc(x, prec.act), cw(sd, "conv"), upsample=True)))
     sd, x = K.sampler_case("down")
     K.check_slice("downsample_conv", nchw(ops.conv2d(nhwc(x, prec.act), cw(sd, "conv"), stride=2, padding=1)))
+    # DownBlock2D / UpBlock2D: the never-materialised cat([h, skip]) feeds GroupNorm, conv1 and the 1x1 shortcut
+    for kind in ("down", "up"):
+        sd, x, temb, skip = K.block_case(kind)
+        xh, sk = nhwc(x, prec.act), (nhwc(skip, prec.act) if skip is not None else None)
+        cin = 64 if kind == "up" else 32
+        t = ops.linear(F.silu(temb).to(dev), cw(sd, "resnets.0.time_emb_proj"), out_dtype=torch.float32)
+        h = hip.groupnorm(xh, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), groups=32, eps=1e-6, silu=True,
+                          out_dtype=prec.act, x1=sk)
+        h = ops.conv2d(h, cw(sd, "resnets.0.conv1"), temb=t)
+        h = hip.groupnorm(h, torch.ones(32, device=dev), torch.zeros(32, device=dev), groups=32, eps=1e-6, silu=True,
+                          out_dtype=prec.act)
+        sc = ops.conv2d(xh, cw(sd, "resnets.0.conv_shortcut"), padding=0, x1=sk) if kind == "up" else xh
+        h = ops.conv2d(h, cw(sd, "resnets.0.conv2"), res0=sc)
+        out = ops.conv2d(h, cw(sd, "sampler.conv"), stride=2, padding=1) if kind == "down" else \
+            ops.conv2d(h, cw(sd, "sampler.conv"), upsample=True)
+        K.check_slice(f"{kind}_block", nchw(out))
     # Transformer2DModel with cross-attention through the model code (GroupNorm, proj_in, LN, attention, GEGLU, proj_out)
     from reflecting_reality_amd import models as M
     sd, x, ctx = K.transformer_case()

@@ -125,6 +125,10 @@ def test_reference_layer_known_answers():
     K.check_slice("downsample_conv", R.downsample(sd, "", x))
     sd, x, ctx = K.transformer_case()
     K.check_slice("transformer_cross", R.transformer_2d(sd, "", x, ctx, 2, 32))
+    sd, x, temb, _ = K.block_case("down")                        # DownBlock2D = resnet + stride-2 conv
+    K.check_slice("down_block", R.downsample(sd, "sampler.", R.resnet(sd, "resnets.0.", x, temb, 32, 1e-6)))
+    sd, x, temb, skip = K.block_case("up")                       # UpBlock2D = resnet over cat([h, skip]) + nearest-2x conv
+    K.check_slice("up_block", R.upsample(sd, "sampler.", R.resnet(sd, "resnets.0.", torch.cat([x, skip], 1), temb, 32, 1e-6)))
 
 
 def test_scheduler_traces_match_reference():
