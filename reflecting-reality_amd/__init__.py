@@ -14,7 +14,7 @@ __version__ = "0.1.0"
 _LAZY = {
     "BrushNetModel": "models", "UNet2DConditionModel": "models", "AutoencoderKL": "models",
     "BrushNetOutput": "models", "DDIMScheduler": "schedulers", "PNDMScheduler": "schedulers", "UniPCMultistepScheduler": "schedulers",
-    "StableDiffusionBrushNetPipeline": "pipeline", "StableDiffusionXLBrushNetPipeline": "pipeline", "StableDiffusionPipelineOutput": "pipeline",
+    "MfhipAttnProcessor": "attn_processor", "StableDiffusionBrushNetPipeline": "pipeline", "StableDiffusionXLBrushNetPipeline": "pipeline", "StableDiffusionPipelineOutput": "pipeline",
     "VaeImageProcessor": "pipeline", "Precision": "ops",
 }
 

@@ -162,6 +162,15 @@ class HipModel:
         model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
         return model
 
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("training (backward + optimizer) is SURVEY.md §8 f-2: not built; the HIP path is "
+                                      "forward only")
+        return self
+
+    def enable_gradient_checkpointing(self):
+        raise NotImplementedError("gradient checkpointing belongs to the training path (SURVEY.md §8 f-2)")
+
     def save_pretrained(self, path: str, **unused):
         from safetensors.torch import save_file
         os.makedirs(path, exist_ok=True)

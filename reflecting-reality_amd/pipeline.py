@@ -134,6 +134,71 @@ class StableDiffusionBrushNetPipeline:
         self._added_cond = None          # SDXL: added_cond_kwargs of the (CFG-duplicated) batch, set by the XL subclass
         self._graph_state = None
 
+    # ---- loading / saving (pipelines/pipeline_utils.py:148-296 save_pretrained, :465-919 from_pretrained) ---------
+    _scheduler_classes = ("DDIMScheduler", "PNDMScheduler", "UniPCMultistepScheduler")
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, torch_dtype=None, device="cuda", **kwargs):
+        """The reference's calling convention (examples/brushnet/test_brushnet.py:146-155): `__init__` parameters without
+        a default are modules — taken from kwargs, else loaded from the sub-folder `model_index.json` names (`brushnet`
+        is never in an SD1.5 index, so it must be passed, like in the reference); parameters with a default
+        (`depth_conditioning_mode`, ...) are plain kwargs.  `unet=None` means "load it from the base directory".
+        Text encoder / tokenizer are outside the accelerated path: passed-in objects are kept, nothing is loaded."""
+        import json
+        import os
+        from . import schedulers as S
+        root = pretrained_model_name_or_path
+        index = {}
+        if os.path.exists(os.path.join(root, "model_index.json")):
+            with open(os.path.join(root, "model_index.json")) as f:
+                index = json.load(f)
+        mods = {}
+        for name, klass in (("vae", AutoencoderKL), ("unet", UNet2DConditionModel), ("brushnet", BrushNetModel)):
+            obj = kwargs.pop(name, None)
+            if obj is None:
+                if not os.path.isdir(os.path.join(root, name)):
+                    raise ValueError(f"Pipeline {cls.__name__} expected {{'{name}'}}, but it was neither passed nor "
+                                     f"found under {root!r}.")
+                obj = klass.from_pretrained(root, subfolder=name, torch_dtype=torch_dtype, device=device)
+            mods[name] = obj
+        sched = kwargs.pop("scheduler", None)
+        if sched is None:
+            with open(os.path.join(root, "scheduler", "scheduler_config.json")) as f:
+                scfg = json.load(f)
+            sname = scfg.get("_class_name") or (index.get("scheduler") or [None, "PNDMScheduler"])[1]
+            if sname not in cls._scheduler_classes:
+                raise NotImplementedError(f"scheduler {sname} is outside the MirrorFusion path (have {cls._scheduler_classes})")
+            sched = getattr(S, sname).from_config(scfg)
+        if kwargs.pop("safety_checker", None) is not None:
+            raise NotImplementedError("the safety checker is outside the accelerated path; pass safety_checker=None")
+        kwargs.pop("low_cpu_mem_usage", None)
+        return cls(vae=mods["vae"], text_encoder=kwargs.pop("text_encoder", None), tokenizer=kwargs.pop("tokenizer", None),
+                   unet=mods["unet"], brushnet=mods["brushnet"], scheduler=sched, safety_checker=None,
+                   feature_extractor=kwargs.pop("feature_extractor", None),
+                   requires_safety_checker=kwargs.pop("requires_safety_checker", False),
+                   depth_conditioning_mode=kwargs.pop("depth_conditioning_mode", None),
+                   normals_conditioning_mode=kwargs.pop("normals_conditioning_mode", None))
+
+    def save_pretrained(self, save_directory: str, **unused):
+        """`model_index.json` + one sub-folder per module in the reference's on-disk format (config.json +
+        diffusion_pytorch_model.safetensors with the reference's key names; scheduler/scheduler_config.json)."""
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        index = {"_class_name": type(self).__name__, "_diffusers_version": "0.27.0.dev0"}
+        for name in ("vae", "unet", "brushnet"):
+            m = getattr(self, name)
+            m.save_pretrained(os.path.join(save_directory, name))
+            index[name] = ["diffusers", m._class_name]
+        self.scheduler.save_config(os.path.join(save_directory, "scheduler"))
+        index["scheduler"] = ["diffusers", type(self.scheduler).__name__]
+        for name in ("text_encoder", "tokenizer", "safety_checker", "feature_extractor"):
+            index[name] = [None, None]
+        index.update(requires_safety_checker=False, depth_conditioning_mode=self.depth_conditioning_mode,
+                     normals_conditioning_mode=self.normals_conditioning_mode)
+        with open(os.path.join(save_directory, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2)
+
     # ---- DiffusionPipeline surface ----------------------------------------------------------------
     @property
     def device(self):

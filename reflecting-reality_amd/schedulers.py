@@ -70,6 +70,31 @@ class _SchedulerBase:
     def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
         return sample
 
+    config_name = "scheduler_config.json"
+
+    def save_config(self, path: str):
+        """configuration_utils.py save_config: `scheduler_config.json` with `_class_name` (explicitly set keys only
+        are what a later from_config into another class keeps; the rest is re-defaulted there)."""
+        import json
+        import os
+        os.makedirs(path, exist_ok=True)
+        cfg = {k: v for k, v in dict(self.config).items() if not k.startswith("_")}
+        cfg["_class_name"] = type(self).__name__
+        cfg["_diffusers_version"] = "0.27.0.dev0"
+        with open(os.path.join(path, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2, sort_keys=True)
+
+    save_pretrained = save_config
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder=None, **kwargs):
+        import json
+        import os
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, cls.config_name)) as f:
+            cfg = json.load(f)
+        return cls.from_config(cfg, **kwargs)
+
     def __len__(self):
         return self.config["num_train_timesteps"]
 

@@ -184,3 +184,48 @@ def test_compat_diffusers_alias_exposes_the_hot_path_names():
         sys.modules.pop("diffusers", None)
         if saved is not None:
             sys.modules["diffusers"] = saved
+
+
+def test_pipeline_save_and_from_pretrained_roundtrip(tmp_path):
+    """pipeline_utils.py save_pretrained / from_pretrained conventions on the reference's on-disk format."""
+    import json
+    from reflecting_reality_amd.schedulers import UniPCMultistepScheduler as U
+    shapes = keys("tiny")
+    mk = lambda klass, cfg, name, seed: klass(dict(cfg), precision="fp32", device="cpu").load_state_dict(
+        synth.state_dict_for(shapes[name], seed))
+    unet = mk(UNet2DConditionModel, configs.TINY_UNET, "unet", 0)
+    bn = mk(BrushNetModel, configs.brushnet_config(configs.TINY_UNET, 6), "brushnet", 1)
+    vae = mk(AutoencoderKL, configs.TINY_VAE, "vae", 2)
+    sched = PNDMScheduler(**{k: v for k, v in configs.SD15_SCHED.items() if k != "clip_sample"})
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                           scheduler=sched, depth_conditioning_mode="concat")
+    pipe.save_pretrained(str(tmp_path))
+    idx = json.load(open(tmp_path / "model_index.json"))
+    assert idx["unet"] == ["diffusers", "UNet2DConditionModel"] and idx["scheduler"] == ["diffusers", "PNDMScheduler"]
+    for sub in ("unet", "brushnet", "vae"):
+        assert (tmp_path / sub / "config.json").exists() and (tmp_path / sub / "diffusion_pytorch_model.safetensors").exists()
+    # the scheduler config the way the SD1.5 hub repo ships it: no `timestep_spacing` key (it predates the option)
+    (tmp_path / "scheduler" / "scheduler_config.json").write_text(json.dumps({
+        "_class_name": "PNDMScheduler", "_diffusers_version": "0.6.0", "beta_end": 0.012, "beta_schedule": "scaled_linear",
+        "beta_start": 0.00085, "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True,
+        "steps_offset": 1, "trained_betas": None, "clip_sample": False}))
+    # brushnet passed explicitly (test_brushnet.py:139-155), everything else from the directory
+    bn2 = BrushNetModel.from_pretrained(str(tmp_path), subfolder="brushnet", torch_dtype=torch.float32, device="cpu")
+    back = StableDiffusionBrushNetPipeline.from_pretrained(str(tmp_path), brushnet=bn2, torch_dtype=torch.float32,
+                                                           device="cpu", safety_checker=None,
+                                                           depth_conditioning_mode="concat", low_cpu_mem_usage=False)
+    assert type(back.scheduler).__name__ == "PNDMScheduler" and back.scheduler.config["steps_offset"] == 1
+    assert back.depth_conditioning_mode == "concat" and back.brushnet is bn2
+    for a, b in ((unet, back.unet), (vae, back.vae), (bn, back.brushnet)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert sa.keys() == sb.keys() and all(torch.equal(sa[k], sb[k]) for k in sa)
+    # the scheduler swap of test_brushnet.py:158 on the loaded pipeline
+    back.scheduler = U.from_config(back.scheduler.config)
+    back.scheduler.set_timesteps(50)
+    assert back.scheduler.timesteps[:3].tolist() == [999, 979, 959]
+    with pytest.raises(ValueError):             # a module that is neither passed nor on disk
+        import shutil
+        shutil.rmtree(tmp_path / "brushnet")
+        StableDiffusionBrushNetPipeline.from_pretrained(str(tmp_path), device="cpu")
+    with pytest.raises(NotImplementedError):
+        unet.train()

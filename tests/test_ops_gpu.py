@@ -468,3 +468,36 @@ def test_reference_layer_known_answers_on_the_hip_path():
     m._prepare_transformer(sd, "")
     out = m._transformer("", nhwc(x, prec.act), ctx.to(dev), 2)
     K.check_slice("transformer_cross", nchw(out))
+
+
+@pytest.mark.parametrize("dtype,heads,d,cross,tol", [(torch.bfloat16, 8, 40, False, 3e-2), (torch.bfloat16, 8, 40, True, 3e-2),
+                                                     (torch.float32, 2, 24, True, 2e-4)])
+def test_attn_processor_on_the_reference_operator_abi(dtype, heads, d, cross, tol):
+    """MfhipAttnProcessor called the way `Attention.forward` calls its processor (attention_processor.py:490-531),
+    against the reference processor's arithmetic (AttnProcessor2_0: torch SDPA) on the same torch layers."""
+    from reflecting_reality_amd import MfhipAttnProcessor
+    torch.manual_seed(3)
+    c, cd = heads * d, 48
+
+    class Attn(torch.nn.Module):                       # the attributes a processor reads (attention_processor.py:80-215)
+        def __init__(self):
+            super().__init__()
+            self.heads, self.spatial_norm, self.group_norm, self.norm_cross = heads, None, None, None
+            self.residual_connection, self.rescale_output_factor = False, 1.0
+            self.to_q = torch.nn.Linear(c, c, bias=False)
+            self.to_k = torch.nn.Linear(cd if cross else c, c, bias=False)
+            self.to_v = torch.nn.Linear(cd if cross else c, c, bias=False)
+            self.to_out = torch.nn.ModuleList([torch.nn.Linear(c, c), torch.nn.Dropout(0.0)])
+
+    attn = Attn().to(DEV, dtype)
+    x = torch.randn(2, 136, c, device=DEV, dtype=dtype)
+    ctx = torch.randn(2, 77, cd, device=DEV, dtype=dtype) if cross else None
+    got = MfhipAttnProcessor()(attn, x, encoder_hidden_states=ctx)
+    src = ctx if cross else x
+    q, k, v = attn.to_q(x), attn.to_k(src), attn.to_v(src)
+    sp = lambda t: t.view(2, -1, heads, d).transpose(1, 2).float()
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(2, -1, c)
+    ref = attn.to_out[0](ref.to(dtype)).float()
+    check(f"attn processor[{dtype},{'cross' if cross else 'self'}]", got, ref.cpu(), tol, tol)
+    with pytest.raises(NotImplementedError):
+        MfhipAttnProcessor()(attn, x, attention_mask=torch.zeros(1, device=DEV))
