@@ -10,8 +10,10 @@
 // S^T accumulator, converted pairwise to bf16, is *already* the B operand of the second product
 // O^T = V^T.P^T (accumulator rows -> k index, no LDS round trip).  V arrives pre-transposed
 // ([head*d][keys], produced that way by the to_v GEMM with swapped operands) so both K and V^T
-// fragments are single 16-byte LDS reads; the k-permutation implied by the accumulator layout
-// (k = 16s + 8(j>>2) + 4h + (j&3)) is applied when the V^T tile is written to LDS.
+// fragments are single 16-byte LDS reads.  K and V^T tiles are staged by LDS-DMA (buffer_load ... lds, double
+// buffered, no staging registers or ds_writes); the k-permutation implied by the accumulator layout
+// (k = 16s + 8(j>>2) + 4h + (j&3)) is applied to the ROWS of the K tile (row R holds key R with bits 2 and 3
+// swapped — a per-lane source offset), so P^T comes out in natural key order and V^T is staged as it lies in memory.
 // The softmax rescale factor is per query = per lane, so rescaling O^T is a plain register multiply.
 // O^T is transposed once through LDS at the end so the global stores are row-contiguous.
 #include <stdlib.h>
@@ -24,7 +26,7 @@ struct AttnArgs {
     const char* k; int64_t ldk;
     const char* vt; int64_t ldvt;
     char* out; int64_t ldo;
-    int heads, sq, skv;
+    int heads, sq, skv, batch;
     float c;   // softmax scale * log2(e)
 };
 
@@ -39,14 +41,17 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     constexpr int RBK = DK * 2 + 16;          // K tile row stride (odd multiple of 16 B: conflict-free b128 reads)
     constexpr int RBV = 144;                  // V^T tile row stride: 64 keys * 2 B + 16
     constexpr int RBO = DV * 2 + 16;          // epilogue transpose row stride
-    constexpr int KVEC = 64 * (HD / 8);       // 16-B vectors per K tile
-    constexpr int VVEC = HD * 8;              // 16-B vectors per V^T tile
-    constexpr int KJ = (KVEC + 255) / 256, VJ = (VVEC + 255) / 256;
-    constexpr int K_BYTES = 64 * RBK, V_BYTES = DV * RBV;
+    constexpr int KCPR = RBK / 16, VCPR = RBV / 16;          // 16-byte chunks per LDS row (data + pad)
+    constexpr int KI = KCPR;                                  // wave-instructions per K tile: 64 rows x KCPR chunks / 64 lanes
+    constexpr int VI = (HD * VCPR + 63) / 64;                 // ... per V^T tile (rows < HD; the tail spills zeros into pad rows)
+    constexpr int KPW = (KI + 3) / 4, VPW = (VI + 3) / 4;     // per wave
+    constexpr int K_BYTES = 64 * RBK;
+    constexpr int V_BYTES = (DV * RBV > VI * 1024 ? DV * RBV : VI * 1024);
     constexpr int O_BYTES = 4 * 32 * RBO;
     constexpr int BUF_BYTES = K_BYTES + V_BYTES;            // one K + V^T tile
-    constexpr int NBUF = DB ? 2 : 1;
+    constexpr int NBUF = 2;
     constexpr int LDS_BYTES = (NBUF * BUF_BYTES) > O_BYTES ? (NBUF * BUF_BYTES) : O_BYTES;
+    static_assert(DB, "K / V^T tiles are double buffered");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,11 +65,12 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     // Head dims that leave pad rows in the 32-row V^T tiles (40, 80, 8) get a row of ones there: O^T row HD then
     // accumulates sum_k P[k][q] on the matrix pipe, rescaled with O like every other row, and the VALU row sum goes away.
     constexpr bool ONES = DV > HD;
-    constexpr int L_D = HD / 32, L_RR = HD % 32, L_E = (L_RR & 3) + 4 * (L_RR >> 3), L_H = (L_RR >> 2) & 1;
+    constexpr int ONES_ROW = DV - 1;                          // the last pad row: the V^T DMA's zero spill never reaches it
+    constexpr int L_D = ONES_ROW / 32, L_RR = ONES_ROW % 32, L_E = (L_RR & 3) + 4 * (L_RR >> 3), L_H = (L_RR >> 2) & 1;
     if (ONES) {
         __syncthreads();
         for (int i = tid; i < NBUF * 32; i += 256)           // 64 keys = 128 B = 32 dwords per buffer
-            *reinterpret_cast<uint32_t*>(smem + (i >> 5) * BUF_BYTES + K_BYTES + HD * RBV + (i & 31) * 4) = 0x3F803F80u;
+            *reinterpret_cast<uint32_t*>(smem + (i >> 5) * BUF_BYTES + K_BYTES + ONES_ROW * RBV + (i & 31) * 4) = 0x3F803F80u;
     }
 
     // Q fragments (B operand of S^T = K.Q^T): lane (query r, half h) holds Q[q][16ks + 8h + j]
@@ -83,55 +89,47 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     const char* kbase = p.k + ((int64_t)b * p.skv * p.ldk + head * HD) * 2;
     const char* vbase = p.vt + ((int64_t)(b * p.heads + head) * HD) * p.ldvt * 2;
 
-    // Per-thread staging coordinates are loop invariant: source pointers advance by a constant per 64-key tile and
-    // the LDS destinations never change; only the last tile needs the key-bound predicates.
-    uint4 kreg[KJ], vreg[VJ];
-    const char* kptr[KJ]; const char* vptr[VJ];
-    int kdst[KJ], vdst[VJ], krow[KJ], vkey[VJ];
+    // LDS-DMA staging.  A wave-instruction fills 64 consecutive 16-byte chunks of the (padded) LDS tile; lane chunk g
+    // of the K tile is (row R = g / KCPR, chunk c = g % KCPR) and reads key row perm(R) of this head (pad chunks and
+    // rows past the tensor: offset >= num_records -> zeros); the V^T tile is (row = g / VCPR, c) -> 8 keys of channel
+    // `row`.  Offsets advance by a constant per 64-key tile.  Keys past skv inside the last tile read whatever follows
+    // in memory (the next batch's rows, finite, or zeros past the tensor): their scores are masked to -inf below and
+    // their probabilities are exact zeros.
+    const int64_t k_left = ((int64_t)(p.batch - b) * p.skv * p.ldk - head * HD) * 2;
+    const int64_t v_left = ((int64_t)((p.batch - b) * p.heads - head) * HD * p.ldvt) * 2;
+    const srd_t srdK = make_srd(kbase, (unsigned)(k_left < 0x7fffffff ? k_left : 0x7fffffff));
+    const srd_t srdV = make_srd(vbase, (unsigned)(v_left < 0x7fffffff ? v_left : 0x7fffffff));
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned koff[KPW], voff[VPW];
 #pragma unroll
-    for (int j = 0; j < KJ; ++j) {
-        const int v = tid + 256 * j;
-        const int row = v / (HD / 8), cv = v - row * (HD / 8);
-        krow[j] = v < KVEC ? row : (1 << 28);                       // fails every bound test
-        kptr[j] = kbase + ((int64_t)row * p.ldk + cv * 8) * 2;
-        kdst[j] = row * RBK + cv * 16;
+    for (int i = 0; i < KPW; ++i) {
+        const int g = (wv + 4 * i) * 64 + lane;
+        const int R = g / KCPR, c = g - R * KCPR;
+        const int kr = (R & ~12) | ((R & 4) << 1) | ((R & 8) >> 1);
+        const int64_t off = ((int64_t)kr * p.ldk + c * 8) * 2;
+        koff[i] = (c < HD / 8 && off < 0x7fffffff) ? (unsigned)off : 0x80000000u;
     }
 #pragma unroll
-    for (int j = 0; j < VJ; ++j) {
-        const int v = tid + 256 * j;
-        const int row = v >> 3, cv = v & 7;
-        vkey[j] = v < VVEC ? cv * 8 + 8 : (1 << 28);
-        vptr[j] = vbase + ((int64_t)row * p.ldvt + cv * 8) * 2;
-        // keys cv*8 .. cv*8+7 of a 16-key step; LDS order inside a step is [0-3, 8-11, 4-7, 12-15]
-        vdst[j] = K_BYTES + row * RBV + (cv >> 1) * 32 + (cv & 1) * 8;
+    for (int i = 0; i < VPW; ++i) {
+        const int g = (wv + 4 * i) * 64 + lane;
+        const int row = g / VCPR, c = g - row * VCPR;
+        const int64_t off = ((int64_t)row * p.ldvt + c * 8) * 2;
+        voff[i] = (row < HD && c < 8 && off < 0x7fffffff) ? (unsigned)off : 0x80000000u;
     }
-    const int64_t kstep = (int64_t)64 * p.ldk * 2;
-    auto load_tile = [&](int kv0) {
-        const bool full = kv0 + 64 <= p.skv && kv0 + 64 <= (int)p.ldvt;
+    const unsigned kstep = (unsigned)(64 * p.ldk * 2);
+    auto issue_tile = [&](int buf) {
+        const unsigned lk = lds0 + buf * BUF_BYTES;
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
-            if (full ? krow[j] < 64 : kv0 + krow[j] < p.skv) kreg[j] = ldg16(kptr[j]);
-            else kreg[j] = make_uint4(0, 0, 0, 0);
-            kptr[j] += kstep;
+        for (int i = 0; i < KPW; ++i) {
+            if (wv + 4 * i < KI) dma16_buf(koff[i], srdK, lk + (wv + 4 * i) * 1024);
+            koff[i] += kstep;          // an out-of-range lane stays out of range: 0x80000000 + n * kstep < 2^32 for every tile
         }
 #pragma unroll
-        for (int j = 0; j < VJ; ++j) {
-            if (full ? vkey[j] <= 64 : kv0 + vkey[j] <= (int)p.ldvt) vreg[j] = ldg16(vptr[j]);
-            else vreg[j] = make_uint4(0, 0, 0, 0);
-            vptr[j] += 128;
+        for (int i = 0; i < VPW; ++i) {
+            if (wv + 4 * i < VI) dma16_buf(voff[i], srdV, lk + K_BYTES + (wv + 4 * i) * 1024);
+            voff[i] += 128;
         }
-    };
-    auto store_tile = [&](int buf) {
-        char* base = smem + buf * BUF_BYTES;
-#pragma unroll
-        for (int j = 0; j < KJ; ++j)
-            if (krow[j] < 64) *reinterpret_cast<uint4*>(base + kdst[j]) = kreg[j];
-#pragma unroll
-        for (int j = 0; j < VJ; ++j)
-            if (vkey[j] <= 64) {
-                *reinterpret_cast<uint2*>(base + vdst[j]) = make_uint2(vreg[j].x, vreg[j].y);
-                *reinterpret_cast<uint2*>(base + vdst[j] + 16) = make_uint2(vreg[j].z, vreg[j].w);
-            }
     };
 
     f32x16_t o[DT];
@@ -142,21 +140,16 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     float m = -INFINITY, l = 0.0f;
 
     const int ntiles = (p.skv + 63) / 64;
-    load_tile(0);
-    __syncthreads();   // zero-fill done
-    if (DB) {
-        store_tile(0);
-        __syncthreads();
-    }
+    __syncthreads();   // zero-fill (and the ones rows) done
+    issue_tile(0);
+    wait_vmcnt<0>();
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
-        const char* Ks = smem + (DB ? (t & 1) : 0) * BUF_BYTES;
+        const char* Ks = smem + (t & 1) * BUF_BYTES;
         const char* Vs = Ks + K_BYTES;
-        if (!DB) {
-            store_tile(0);
-            __syncthreads();
-        }
-        if (t + 1 < ntiles) load_tile(kv0 + 64);       // global loads fly under this tile's MFMAs
+        // the other buffer was last read in iteration t-1, which every wave finished before the barrier that ended it
+        if (t + 1 < ntiles) issue_tile((t + 1) & 1);       // the DMA flies under this tile's MFMAs and softmax
 
         // ---- S^T = K . Q^T : two 32-key tiles ----
         f32x16_t st[2];
@@ -174,7 +167,7 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int key = kv0 + 32 * tt + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int key = kv0 + 32 * tt + (e & 3) + 4 * (e >> 2 & 1) + 16 * (e >> 3) + 8 * h;   // row with bits 2, 3 swapped
                     if (key >= p.skv) st[tt][e] = -INFINITY;
                 }
         }
@@ -225,13 +218,12 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
                 const uint4 a = *reinterpret_cast<const uint4*>(Vs + (32 * d + r) * RBV + (16 * kst + 8 * h) * 2);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kst], o[d], 0, 0, 0);
             }
-        // the other buffer was last read in iteration t-1, which every wave finished before the previous barrier
-        if (DB && t + 1 < ntiles) store_tile((t + 1) & 1);
-        __syncthreads();
+        wait_vmcnt<0>();      // this wave's share of tile t+1 has landed ...
+        __syncthreads();      // ... and so has everybody else's; every wave is done reading tile t
     }
 
     // ---- epilogue: normalise, transpose through LDS, row-contiguous stores ----
-    if (ONES) l = __shfl(L_H == 0 ? o[L_D][L_E] : 0.0f, (lane & 31) + 32 * L_H, 64);
+    if (ONES) l = __shfl(o[L_D][L_E], (lane & 31) + 32 * L_H, 64);      // the half-wave that holds accumulator row ONES_ROW
     else l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     char* Os = smem + wave * 32 * RBO;   // safe: the loop ended on a barrier
@@ -259,10 +251,8 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
 
 template <int HD>
 void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
-    static const bool db = getenv("MFHIP_ATTN_SINGLE_BUFFER") == nullptr;
     dim3 grid((a.sq + 127) / 128, a.heads, batch);
-    if (db) hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace
@@ -280,7 +270,7 @@ extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int6
     }
     AttnArgs a{};
     a.q = (const char*)q; a.ldq = ldq; a.k = (const char*)k; a.ldk = ldk; a.vt = (const char*)vt; a.ldvt = ldvt;
-    a.out = (char*)out; a.ldo = ldo; a.heads = heads; a.sq = sq; a.skv = skv;
+    a.out = (char*)out; a.ldo = ldo; a.heads = heads; a.sq = sq; a.skv = skv; a.batch = batch;
     a.c = scale * 1.44269504088896340736f;
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {

@@ -58,5 +58,31 @@ __device__ __forceinline__ void store_from_f32(void* p, int dt, int64_t i, float
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
 
+// ---- LDS-DMA helpers shared by the GEMM / conv and attention kernels ---------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(4))) int srd_t;   // buffer resource descriptor (4 SGPRs)
+
+__device__ __forceinline__ srd_t make_srd(const char* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    srd_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));     // stride 0 (raw buffer)
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);                      // num_records: loads at offset >= this return 0
+    r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ void dma16_buf(unsigned voff, srd_t srd, unsigned lds_off) {
+    // buffer_load ... lds: per-lane 32-bit byte offset into the descriptor, hardware range check (an offset past
+    // num_records writes zeros: that IS the conv zero padding / tile tail), wave-uniform LDS destination in M0.
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 ::"v"(voff), "s"(srd), "s"(lds_off) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 static inline int mf_dtype_size(int dt) { return dt == MF_F32 ? 4 : 2; }
 static inline bool mf_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
