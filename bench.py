@@ -70,7 +70,7 @@ def build_pipeline(precision, device, keep_cpu_sd=False, model="sd15"):
 
 def cpu_baseline(sds, size, threads):
     """The CPU oracle (a port of the reference's arithmetic, pinned bit-exact to it) on the host cores, on a bounded
-    sample: ONE image, ONE denoise step (BrushNet + UNet, CFG batch of 2) + VAE encode + decode at `size`, extrapolated
+    sample: ONE image, ONE denoise step (BrushNet + UNet, CFG batch of 2; best of three) + VAE encode + decode at `size`, extrapolated
     to the 50-step pipeline (per-step cost is constant)."""
     from oracle import mirrorfusion_ref as R
     torch.set_num_threads(threads)
@@ -81,11 +81,13 @@ def cpu_baseline(sds, size, threads):
     ehs = torch.randn(2, 77, 768, generator=g)
     bcfg = R.brushnet_config(R.SD15_UNET, 6)
     with torch.no_grad():
-        t0 = time.time()
-        x2 = torch.cat([lat] * 2)
-        d, m, u = R.brushnet_forward(sds["brushnet"], bcfg, x2, 981, cond, 1.0)
-        R.unet_forward(sds["unet"], R.SD15_UNET, x2, 981, ehs, d, m, u)
-        t_step = time.time() - t0
+        t_step = float("inf")
+        for _ in range(3):           # best of three: the first pass pays thread-pool start-up and first-touch page faults
+            t0 = time.time()
+            x2 = torch.cat([lat] * 2)
+            d, m, u = R.brushnet_forward(sds["brushnet"], bcfg, x2, 981, cond, 1.0)
+            R.unet_forward(sds["unet"], R.SD15_UNET, x2, 981, ehs, d, m, u)
+            t_step = min(t_step, time.time() - t0)
         t0 = time.time()
         R.vae_decode(sds["vae"], R.SD15_VAE, lat)
         R.vae_encode_moments(sds["vae"], R.SD15_VAE, torch.randn(1, 3, size, size, generator=g))
