@@ -39,7 +39,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 6
+#define MF_ABI_VERSION 7
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -191,6 +191,10 @@ int mf_cfg_combine(const float* eps_u, const float* eps_c, float g, float* eps, 
 /* generic y = sum_i c[i]*x[i] (i < nin <= 6) — PNDM/PLMS linear multistep and _get_prev_sample
  * (scheduling_pndm.py:370-382,436-446) */
 int mf_axpby_n(const float* const* xs, const float* coefs, int32_t nin, float* y, int64_t n, void* stream);
+/* training loss (examples/brushnet/train_brushnet_mirror.py:1433-1449): per_sample[r] = mean_i (pred[r][i] -
+ * target[r][i])^2 * (weights ? weights[r] : 1) and loss[0] = mean_r per_sample[r]; fp32 in, double accumulation */
+int mf_mse_loss(const float* pred, const float* target, const float* weights, float* per_sample, float* loss,
+                int32_t rows, int64_t n, void* stream);
 /* DiagonalGaussianDistribution.sample * scaling (vae.py:769-791, pipeline_brushnet.py:1188):
  * moments NHWC [b][hw][ld] (mean = ch 0..c-1, logvar = ch c..2c-1) -> z NCHW fp32 [b][c][hw] */
 int mf_vae_sample(const void* moments, int32_t m_dtype, int64_t ld, const float* noise, float* z, int32_t c,

@@ -670,3 +670,37 @@ def denoise(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, scheduler, lat
         if trace is not None:
             trace.append(latents.clone())
     return latents
+
+
+# ---------------------------------------------------------------------------------------------
+# training step, forward half (examples/brushnet/train_brushnet_mirror.py)
+# ---------------------------------------------------------------------------------------------
+def training_loss(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, sched_cfg: dict, latents: torch.Tensor,
+                  noise: torch.Tensor, timesteps: torch.Tensor, ehs: torch.Tensor, cond_latents: torch.Tensor,
+                  snr_gamma: Optional[float] = None):
+    """train_brushnet_mirror.py:1407-1449 (+ MirrorFusionModel.forward :858-888, DDPM add_noise
+    scheduling_ddpm.py:501-525, get_velocity :527-546, compute_snr training_utils.py:50-73).
+    Returns (loss, model_pred)."""
+    ac = _alphas_cumprod(sched_cfg)
+    sa = (ac[timesteps] ** 0.5).flatten()[:, None, None, None]
+    sb = ((1 - ac[timesteps]) ** 0.5).flatten()[:, None, None, None]
+    noisy = sa * latents + sb * noise                                                     # :1416
+    down, mid, up = brushnet_forward(bn_sd, bn_cfg, noisy, timesteps, cond_latents, 1.0)  # :860-866
+    pred = unet_forward(unet_sd, unet_cfg, noisy, timesteps, ehs, down, mid, up)          # :874-886
+    ptype = sched_cfg.get("prediction_type", "epsilon")
+    if ptype == "epsilon":
+        target = noise
+    elif ptype == "v_prediction":
+        target = sa * noise - sb * latents
+    else:
+        raise ValueError(f"Unknown prediction type {ptype}")
+    if snr_gamma is None:
+        return F.mse_loss(pred.float(), target.float(), reduction="mean"), pred           # :1434
+    alpha = (ac ** 0.5)[timesteps].float()
+    sigma = ((1.0 - ac) ** 0.5)[timesteps].float()
+    snr = (alpha / sigma) ** 2
+    w = torch.stack([snr, snr_gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0]   # :1441-1443
+    w = w / snr if ptype == "epsilon" else w / (snr + 1)
+    loss = F.mse_loss(pred.float(), target.float(), reduction="none")
+    loss = loss.mean(dim=list(range(1, len(loss.shape)))) * w
+    return loss.mean(), pred

@@ -11,7 +11,7 @@ if _ROOT not in sys.path:
 
 from reflecting_reality_amd.models import AutoencoderKL, BrushNetModel, UNet2DConditionModel  # noqa: E402,F401
 from reflecting_reality_amd.pipeline import StableDiffusionBrushNetPipeline, StableDiffusionXLBrushNetPipeline  # noqa: E402,F401
-from reflecting_reality_amd.schedulers import DDIMScheduler, PNDMScheduler, UniPCMultistepScheduler  # noqa: E402,F401
+from reflecting_reality_amd.schedulers import DDIMScheduler, DDPMScheduler, PNDMScheduler, UniPCMultistepScheduler  # noqa: E402,F401
 from reflecting_reality_amd.attn_processor import MfhipAttnProcessor  # noqa: E402,F401
 
 __version__ = "0.27.0.dev0+mi355x"

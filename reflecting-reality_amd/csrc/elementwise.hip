@@ -145,6 +145,38 @@ __global__ void axpby_kernel(AxpbyArgs a, float* y, int64_t n) {
     }
 }
 
+// Training loss (train_brushnet_mirror.py:1433-1449): per-sample mean((pred - target)^2) * weight, then the
+// mean over samples.  One block per sample, fp32 products accumulated in double, fixed reduction order.
+__global__ void mse_rows_kernel(const float* pred, const float* target, const float* weights, float* per_row,
+                                int64_t n) {
+    __shared__ double part[256];
+    const float* p = pred + (int64_t)blockIdx.x * n;
+    const float* t = target + (int64_t)blockIdx.x * n;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = p[i] - t[i];
+        acc += (double)(d * d);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float m = (float)(part[0] / (double)n);
+        per_row[blockIdx.x] = weights ? m * weights[blockIdx.x] : m;
+    }
+}
+
+__global__ void mean_rows_kernel(const float* per_row, float* loss, int rows) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double acc = 0.0;
+        for (int i = 0; i < rows; ++i) acc += (double)per_row[i];
+        loss[0] = (float)(acc / (double)rows);
+    }
+}
+
 __global__ void vae_sample_kernel(const char* mom, int dt, int64_t ld, const float* noise, float* z, int c, int batch,
                                   int hw, float scaling) {
     const int64_t total = (int64_t)batch * c * hw;
@@ -273,6 +305,16 @@ extern "C" int mf_axpby_n(const float* const* xs, const float* coefs, int32_t ni
     for (int i = 0; i < nin; ++i) { a.x[i] = xs[i]; a.c[i] = coefs[i]; }
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, y, n);
     MF_CHECK_LAUNCH("mf_axpby_n");
+    return MF_OK;
+}
+
+extern "C" int mf_mse_loss(const float* pred, const float* target, const float* weights, float* per_sample,
+                           float* loss, int32_t rows, int64_t n, void* stream) {
+    MF_CHECK_ARG(pred && target && per_sample && loss && rows > 0 && n > 0, "mf_mse_loss: bad arguments");
+    hipLaunchKernelGGL(mse_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, pred, target, weights,
+                       per_sample, n);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, per_sample, loss, rows);
+    MF_CHECK_LAUNCH("mf_mse_loss");
     return MF_OK;
 }
 

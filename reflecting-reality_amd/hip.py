@@ -16,7 +16,7 @@ from . import _build
 
 MF_F32, MF_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MfhipError(RuntimeError):
@@ -71,7 +71,7 @@ EXPORTS = [
     "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape",
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
-    "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_vae_sample", "mf_nearest_resize",
+    "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -500,6 +500,27 @@ def axpby_n(xs, coefs) -> torch.Tensor:
     out = torch.empty_like(xs[0])
     _check(load().mf_axpby_n(arr, cf, n, C.c_void_p(out.data_ptr()), C.c_int64(out.numel()), _stream()), "mf_axpby_n")
     return out
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor, weights: Optional[torch.Tensor] = None):
+    """(loss[1], per_sample[B]) with per_sample[b] = mean((pred[b] - target[b])**2) * weights[b]; fp32 tensors."""
+    _req_cuda(pred, target)
+    if pred.shape != target.shape or pred.dtype != torch.float32 or target.dtype != torch.float32:
+        raise ValueError("mse_loss: pred and target must be fp32 tensors of the same shape")
+    pred, target = pred.contiguous(), target.contiguous()
+    rows = pred.shape[0]
+    per = torch.empty(rows, dtype=torch.float32, device=pred.device)
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    w = None
+    if weights is not None:
+        w = weights.to(pred.device, torch.float32).contiguous()
+        if w.numel() != rows:
+            raise ValueError("mse_loss: one weight per sample")
+    _check(load().mf_mse_loss(C.c_void_p(pred.data_ptr()), C.c_void_p(target.data_ptr()),
+                              C.c_void_p(w.data_ptr() if w is not None else None), C.c_void_p(per.data_ptr()),
+                              C.c_void_p(loss.data_ptr()), C.c_int32(rows), C.c_int64(pred.numel() // rows), _stream()),
+           "mf_mse_loss")
+    return loss, per
 
 
 def vae_sample(moments: torch.Tensor, noise: torch.Tensor, c: int, scaling: float) -> torch.Tensor:

@@ -52,7 +52,7 @@ class _SchedulerBase:
         self.betas = _betas(cfg)
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
-        self.final_alpha_cumprod = torch.tensor(1.0) if cfg["set_alpha_to_one"] else self.alphas_cumprod[0]
+        self.final_alpha_cumprod = torch.tensor(1.0) if cfg.get("set_alpha_to_one", True) else self.alphas_cumprod[0]
         self.init_noise_sigma = 1.0
         self.num_inference_steps: Optional[int] = None
         self.timesteps = torch.from_numpy(np.arange(0, cfg["num_train_timesteps"])[::-1].copy().astype(np.int64))
@@ -112,6 +112,34 @@ class _SchedulerBase:
             outs.append(hip.axpby_n([original_samples[i].float().contiguous(), noise[i].float().contiguous()],
                                     [float(sa[k]), float(sb[k])]))
         return torch.stack(outs)
+
+    def get_velocity(self, sample: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """scheduling_ddpm.py:527-546: v = sqrt(a_t) eps - sqrt(1 - a_t) x, per-sample t."""
+        ts = timesteps.cpu().long().reshape(-1)
+        a = self.alphas_cumprod[ts]
+        sa, sb = a ** 0.5, (1 - a) ** 0.5
+        outs = []
+        for i in range(sample.shape[0]):
+            k = i if ts.numel() > 1 else 0
+            outs.append(hip.axpby_n([noise[i].float().contiguous(), sample[i].float().contiguous()],
+                                    [float(sa[k]), -float(sb[k])]))
+        return torch.stack(outs)
+
+
+class DDPMScheduler(_SchedulerBase):
+    """The training script's noise scheduler (train_brushnet_mirror.py:957): only the forward-process half
+    (`add_noise`, `get_velocity`, `alphas_cumprod`) is used there; sampling with it is not part of the path."""
+    _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                     trained_betas=None, variance_type="fixed_small", clip_sample=True, prediction_type="epsilon",
+                     thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0,
+                     sample_max_value=1.0, timestep_spacing="leading", steps_offset=0,
+                     rescale_betas_zero_snr=False)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        raise NotImplementedError("DDPMScheduler here is the training-side noise scheduler; sample with DDIM/PNDM/UniPC")
+
+    def step(self, *args, **kwargs):
+        raise NotImplementedError("DDPMScheduler here is the training-side noise scheduler; sample with DDIM/PNDM/UniPC")
 
 
 class DDIMScheduler(_SchedulerBase):

@@ -224,3 +224,26 @@ def test_sd15_full_size_brushnet_matches_reference():
         for i, t in enumerate(ts):
             report(f"{nm}_{i}", strided_sample(t, G[f"{nm}_{i}_stats"][2]), G[f"{nm}_{i}_sample"], **TOL)
             assert abs(float(t.double().sum()) - G[f"{nm}_{i}_stats"][0]) < 1e-3 * max(1.0, G[f"{nm}_{i}_stats"][1])
+
+
+def _train_inputs():
+    g = torch.Generator().manual_seed(2024)
+    return (torch.randn(3, 4, 8, 8, generator=g) * 0.8, torch.randn(3, 4, 8, 8, generator=g),
+            torch.randn(3, 5, 8, 8, generator=g), torch.randn(3, 77, 32, generator=g))
+
+
+@pytest.mark.parametrize("ptype", ["epsilon", "v_prediction"])
+def test_training_loss_matches_reference(ptype):
+    """Forward half of the training step (train_brushnet_mirror.py:1407-1449): per-sample timesteps, both
+    prediction types, plain and min-SNR-weighted MSE."""
+    usd = synth.state_dict_for(keys("tiny")["unet"], 0)
+    bsd = synth.state_dict_for(keys("tiny_train")["brushnet"], 21)
+    G = golden("tiny_train.npz")
+    latents, noise, cond, ehs = _train_inputs()
+    ts = torch.from_numpy(G["timesteps"])
+    cfg = dict(R.SD15_SCHED, prediction_type=ptype)
+    for gamma, tag in ((None, "none"), (5.0, "snr5")):
+        loss, pred = R.training_loss(usd, R.TINY_UNET, bsd, R.brushnet_config(R.TINY_UNET, 5), cfg, latents, noise, ts,
+                                     ehs, cond, gamma)
+        report(f"train pred {ptype}", pred, G[f"{ptype}_pred"], **TOL)
+        assert abs(float(loss) - float(G[f"{ptype}_loss_{tag}"])) < 1e-6

@@ -248,6 +248,58 @@ def tiny():
     print("tiny fixtures written")
 
 
+def tiny_train():
+    """Forward half of the training step (examples/brushnet/train_brushnet_mirror.py:1407-1449).  The script itself
+    is not importable here (autoroot / cudf / h5py), so the same library calls it makes are issued in its order:
+    DDPMScheduler.add_noise / get_velocity, MirrorFusionModel.forward's BrushNet -> UNet composition (:858-888),
+    diffusers.training_utils.compute_snr and F.mse_loss."""
+    import torch.nn.functional as F
+    from diffusers import DDPMScheduler
+    from diffusers.training_utils import compute_snr
+    ucfg, vcfg = R.TINY_UNET, R.TINY_VAE
+    (unet, unet_sd, _), _, _ = models(ucfg, vcfg, 0)
+    bn = BrushNetModel.from_unet(unet, conditioning_channels=5, load_weights_from_unet=False).eval()
+    bn_sd, bn_shapes = load_synth(bn, 21)
+    bcfg = R.brushnet_config(ucfg, 5)
+    g = torch.Generator().manual_seed(2024)
+    bsz = 3
+    latents = torch.randn(bsz, 4, 8, 8, generator=g) * 0.8
+    noise = torch.randn(bsz, 4, 8, 8, generator=g)
+    cond = torch.randn(bsz, 5, 8, 8, generator=g)
+    ehs = torch.randn(bsz, 77, ucfg["cross_attention_dim"], generator=g)
+    timesteps = torch.tensor([17, 480, 965]).long()
+    out = dict(timesteps=timesteps.numpy())
+    with open(os.path.join(GOLD, "keys_tiny_train.json"), "w") as f:
+        json.dump(dict(brushnet=bn_shapes), f, indent=0, sort_keys=True)
+    for ptype in ("epsilon", "v_prediction"):
+        sched_cfg = dict(R.SD15_SCHED, prediction_type=ptype)
+        ns = DDPMScheduler(num_train_timesteps=1000, beta_start=sched_cfg["beta_start"], beta_end=sched_cfg["beta_end"],
+                           beta_schedule="scaled_linear", prediction_type=ptype)
+        noisy = ns.add_noise(latents, noise, timesteps)                                              # :1416
+        down, mid, up = bn(noisy, timesteps, encoder_hidden_states=ehs, brushnet_cond=cond, return_dict=False)
+        pred = unet(noisy, timesteps, encoder_hidden_states=ehs, down_block_add_samples=list(down),
+                    mid_block_add_sample=mid, up_block_add_samples=list(up), return_dict=False)[0]
+        target = noise if ptype == "epsilon" else ns.get_velocity(latents, noise, timesteps)         # :1427-1430
+        out[f"{ptype}_noisy"] = noisy.numpy()
+        out[f"{ptype}_pred"] = pred.numpy()
+        for gamma in (None, 5.0):
+            if gamma is None:
+                loss = F.mse_loss(pred.float(), target.float(), reduction="mean")                    # :1434
+            else:
+                snr = compute_snr(ns, timesteps)                                                     # :1440-1449
+                w = torch.stack([snr, gamma * torch.ones_like(timesteps)], dim=1).min(dim=1)[0]
+                w = w / snr if ptype == "epsilon" else w / (snr + 1)
+                loss = F.mse_loss(pred.float(), target.float(), reduction="none")
+                loss = (loss.mean(dim=list(range(1, len(loss.shape)))) * w).mean()
+            oloss, opred = R.training_loss(unet_sd, ucfg, bn_sd, bcfg, sched_cfg, latents, noise, timesteps, ehs, cond,
+                                           gamma)
+            print(f"[train {ptype} gamma={gamma}] loss ref={float(loss):.8f} oracle-vs-ref: loss",
+                  abs(float(loss) - float(oloss)), "pred", maxdiff(pred, opred))
+            out[f"{ptype}_loss_{'none' if gamma is None else 'snr5'}"] = np.float32(float(loss))
+    np.savez_compressed(os.path.join(GOLD, "tiny_train.npz"), **out)
+    print("tiny training-step fixture written")
+
+
 def tiny_xl():
     """SDXL architecture (linear projections, per-level depth / heads, text_time embedding) on a tiny configuration:
     BrushNet-XL residuals, UNet-XL with injection, and a 3-step StableDiffusionXLBrushNetPipeline run."""
@@ -378,13 +430,18 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--only-xl", action="store_true")
+    ap.add_argument("--only-train", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     if a.only_xl:
         tiny_xl()
         sys.exit(0)
+    if a.only_train:
+        tiny_train()
+        sys.exit(0)
     if not a.only_full:
         tiny()
+        tiny_train()
         tiny_xl()
     if a.full or a.only_full:
         full()
