@@ -247,3 +247,23 @@ def test_training_loss_matches_reference(ptype):
                                      ehs, cond, gamma)
         report(f"train pred {ptype}", pred, G[f"{ptype}_pred"], **TOL)
         assert abs(float(loss) - float(G[f"{ptype}_loss_{tag}"])) < 1e-6
+
+
+def test_full_size_layers_match_reference():
+    """F6: ResnetBlock2D 320@64x64 and 2560->1280@16x16 (shortcut), Transformer2DModel 320 ch / 4096 tokens,
+    self-attention S=4096 d=40 — the reference modules' outputs at the production sizes."""
+    from layer_cases import cases
+    G = golden("sd15_layers.npz")
+    C = cases()
+    outs = {}
+    for name in ("resnet_320_64", "resnet_2560_1280_16"):
+        sd, x, temb = C[name]
+        outs[name] = R.resnet(sd, "", x, temb, 32, 1e-5)
+    sd, x, ehs = C["transformer_320_4096"]
+    outs["transformer_320_4096"] = R.transformer_2d(sd, "", x, ehs, 8, 32)
+    sd, tok, _ = C["attention_4096_40"]
+    outs["attention_4096_40"] = R.attention(sd, "", tok, None, 8)
+    for name, y in outs.items():
+        st = G[name + "_stats"]
+        report(name, strided_sample(y, st[2]), G[name + "_sample"], **TOL)
+        assert abs(float(y.double().sum()) - st[0]) <= 1e-6 * st[1] + 1e-6

@@ -300,6 +300,53 @@ def tiny_train():
     print("tiny training-step fixture written")
 
 
+def layers_full():
+    """F6: single layers at the production sizes of the SD1.5 path, from the reference's own modules
+    (ResnetBlock2D 320->320 @64x64, ResnetBlock2D 2560->1280 @16x16 with the 1x1 shortcut, Transformer2DModel 320 ch /
+    4096 tokens / 8 heads with 77x768 cross-attention, Attention self-attention S=4096 d=40); strided samples + sums."""
+    from diffusers.models.attention_processor import Attention
+    from diffusers.models.resnet import ResnetBlock2D
+    from diffusers.models.transformers.transformer_2d import Transformer2DModel
+    g = torch.Generator().manual_seed(606)
+    out = {}
+    shapes_all = {}
+
+    def put(name, t):
+        s = summarize(t)
+        out[name + "_sample"] = s["sample"]
+        out[name + "_stats"] = np.array([s["sum"], s["abssum"], s["sample_stride"]])
+
+    for name, cin, cout, hw, seed in (("resnet_320_64", 320, 320, 64, 61), ("resnet_2560_1280_16", 2560, 1280, 16, 62)):
+        m = ResnetBlock2D(in_channels=cin, out_channels=cout, temb_channels=1280, groups=32, eps=1e-5).eval()
+        sd, shapes = load_synth(m, seed)
+        shapes_all[name] = shapes
+        x = torch.randn(1, cin, hw, hw, generator=g)
+        temb = torch.randn(1, 1280, generator=g)
+        y = m(x, temb)
+        print(f"[{name}] oracle-vs-ref:", maxdiff(y, R.resnet(sd, "", x, temb, 32, 1e-5)), "absmax", float(y.abs().max()))
+        put(name, y)
+    m = Transformer2DModel(num_attention_heads=8, attention_head_dim=40, in_channels=320, num_layers=1,
+                           cross_attention_dim=768, norm_num_groups=32).eval()
+    sd, shapes = load_synth(m, 63)
+    shapes_all["transformer_320_4096"] = shapes
+    x = torch.randn(1, 320, 64, 64, generator=g)
+    ehs = torch.randn(1, 77, 768, generator=g)
+    y = m(x, encoder_hidden_states=ehs, return_dict=False)[0]
+    print("[transformer_320_4096] oracle-vs-ref:", maxdiff(y, R.transformer_2d(sd, "", x, ehs, 8, 32)), "absmax", float(y.abs().max()))
+    put("transformer_320_4096", y)
+    a = Attention(query_dim=320, heads=8, dim_head=40, bias=False).eval()
+    sd, shapes = load_synth(a, 64)
+    shapes_all["attention_4096_40"] = shapes
+    tok = torch.randn(1, 4096, 320, generator=g)
+    y = a(tok)
+    print("[attention_4096_40] oracle-vs-ref:", maxdiff(y, R.attention(sd, "", tok, None, 8)), "absmax", float(y.abs().max()))
+    put("attention_4096_40", y)
+    with open(os.path.join(GOLD, "keys_sd15_layers.json"), "w") as f:
+        json.dump(shapes_all, f, indent=0, sort_keys=True)
+    np.savez_compressed(os.path.join(GOLD, "sd15_layers.npz"), **out)
+    print("full-size layer fixtures written")
+
+
 def tiny_xl():
     """SDXL architecture (linear projections, per-level depth / heads, text_time embedding) on a tiny configuration:
     BrushNet-XL residuals, UNet-XL with injection, and a 3-step StableDiffusionXLBrushNetPipeline run."""
@@ -431,6 +478,7 @@ if __name__ == "__main__":
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--only-xl", action="store_true")
     ap.add_argument("--only-train", action="store_true")
+    ap.add_argument("--only-layers", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     if a.only_xl:
@@ -439,9 +487,13 @@ if __name__ == "__main__":
     if a.only_train:
         tiny_train()
         sys.exit(0)
+    if a.only_layers:
+        layers_full()
+        sys.exit(0)
     if not a.only_full:
         tiny()
         tiny_train()
+        layers_full()
         tiny_xl()
     if a.full or a.only_full:
         full()
