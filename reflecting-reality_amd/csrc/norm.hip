@@ -18,7 +18,8 @@ struct GnArgs {
     int silu;
     char* out; int out_dt;
     float* ws;   // [batch][G][nchunks][2] = (mean, M2) of each chunk
-    float* ws_ab;   // [batch][2][C] per-channel scale / shift
+    float* ws_ab;   // [batch][2][C] per-channel scale / shift (separate-finalize path)
+    int fuse_finalize;
 };
 
 __device__ __forceinline__ float4 load4(const char* p, int dt, int64_t idx) {
@@ -163,11 +164,12 @@ __global__ __launch_bounds__(GN_BLK) void gn_stats_kernel(const GnArgs p) {
 // Pass 1b, grid (batch): combine the chunk statistics of every group in a fixed order (double) and write the
 // per-channel affine y = x*a[c] + b[c].  (An in-kernel "last block finalizes" variant needs agent-scope fences,
 // whose L2 writeback/invalidate on this multi-XCD part cost more than this launch: measured 95 us vs 34 us.)
-__global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
-    __shared__ float gm[64], gr[64];
-    const int b = blockIdx.x, t = threadIdx.x;
-    // chunk k holds (mean_k, M2_k) over n_k elements: mean = sum n_k mean_k / N, M2 = sum M2_k + n_k (mean_k - mean)^2.
-    // 8 lanes per group, each over chunks j, j+8, ...; fixed-order butterflies (xor partners add the same two values).
+// (mean, rstd) of every group of sample b from the per-chunk (mean_k, M2_k) of pass 1, by all threads of the block:
+// chunk k holds (mean_k, M2_k) over n_k elements: mean = sum n_k mean_k / N, M2 = sum M2_k + n_k (mean_k - mean)^2.
+// 8 lanes per group, each over chunks j, j+8, ...; fixed-order butterflies (xor partners add the same two values), so
+// every block that evaluates it gets the same bits.
+__device__ __forceinline__ void gn_group_mean_rstd(const GnArgs& p, int b, float* gm, float* gr) {
+    const int t = threadIdx.x;
     for (int g0 = 0; g0 < p.G; g0 += (int)blockDim.x >> 3) {
         const int g = g0 + (t >> 3), j = t & 7;
         const bool on = g < p.G;
@@ -203,6 +205,12 @@ __global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
             gr[g] = (float)(1.0 / sqrt(m2 / n + (double)p.eps));
         }
     }
+}
+
+__global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
+    __shared__ float gm[64], gr[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    gn_group_mean_rstd(p, b, gm, gr);
     __syncthreads();
     float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
     for (int c = t; c < p.C; c += blockDim.x) {
@@ -218,6 +226,11 @@ template <int VW>
 __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int rows_per_block) {
     const int b = blockIdx.y, t = threadIdx.x;
     const int lcol = t % p.tpr, trow = t / p.tpr;
+    __shared__ float gm[64], gr[64];
+    if (p.fuse_finalize) {       // every block combines the chunk statistics itself: one launch (and its gap) less
+        gn_group_mean_rstd(p, b, gm, gr);
+        __syncthreads();
+    }
     if (trow >= p.rif) return;
     const int r0 = blockIdx.x * rows_per_block;
     int r1 = r0 + rows_per_block;
@@ -231,8 +244,19 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
         if (c < p.C0) { base = p.x0; ld = p.C0; cc = c; }
         else { base = p.x1; ld = p.C1; cc = c - p.C0; }
         float sa[VW], sb[VW];
-        loadv<VW>(reinterpret_cast<const char*>(ab + c), MF_F32, sa);
-        loadv<VW>(reinterpret_cast<const char*>(ab + p.C + c), MF_F32, sb);
+        if (p.fuse_finalize) {
+            loadv<VW>(reinterpret_cast<const char*>(p.gamma + c), MF_F32, sa);
+            loadv<VW>(reinterpret_cast<const char*>(p.beta + c), MF_F32, sb);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const int g = (c + e) / p.cpg;
+                sa[e] = gr[g] * sa[e];
+                sb[e] = sb[e] - gm[g] * sa[e];
+            }
+        } else {
+            loadv<VW>(reinterpret_cast<const char*>(ab + c), MF_F32, sa);
+            loadv<VW>(reinterpret_cast<const char*>(ab + p.C + c), MF_F32, sb);
+        }
         const int64_t step = (int64_t)p.rif * ld * esz, ostep = (int64_t)p.rif * p.C * osz;
         const char* ptr = base + (((int64_t)b * p.HW + r0 + trow) * ld + cc) * esz;
         char* optr = p.out + (((int64_t)b * p.HW + r0 + trow) * p.C + c) * osz;
@@ -420,6 +444,9 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ws = d->ws;
     a.ws_ab = d->ws + (int64_t)d->batch * d->groups * GN_MAX_CHUNKS * 2;
     MF_CHECK_ARG(d->groups <= 64, "mf_groupnorm: at most 64 groups");
+    static const bool gn3 = getenv("MFHIP_GN3") != nullptr;     // A/B switch: separate finalize launch
+    // measured (tools/bench_gn.py): -1.5...2 us per GroupNorm up to 32x32, +1 us at 64x64 (64 chunks combined by 256 blocks)
+    a.fuse_finalize = !gn3 && d->hw <= 1024 && mf_aligned16(d->gamma) && mf_aligned16(d->beta);
     const int vw = (d->c0 % 8 == 0 && d->c1 % 8 == 0) ? 8 : 4;
     a.cvn = C / vw;
     a.tpr = a.cvn < GN_BLK ? a.cvn : GN_BLK;
@@ -436,12 +463,12 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     if (vw == 8) {
         hipLaunchKernelGGL(gn_stats_kernel<8>, dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
         MF_CHECK_LAUNCH("mf_groupnorm(stats)");
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
+        if (!a.fuse_finalize) hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
         hipLaunchKernelGGL(gn_apply_kernel<8>, dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<4>, dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
         MF_CHECK_LAUNCH("mf_groupnorm(stats)");
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
+        if (!a.fuse_finalize) hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
         hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
     }
     MF_CHECK_LAUNCH("mf_groupnorm(apply)");
