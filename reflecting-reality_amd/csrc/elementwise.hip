@@ -57,6 +57,20 @@ __global__ void add_kernel(const char* a, int adt, const char* b, int bdt, char*
         store_from_f32(o, odt, i, load_as_f32(a, adt, i) + load_as_f32(b, bdt, i));
 }
 
+// all three tensors bf16, 16-byte aligned, n % 8 == 0: 8 elements per thread
+__global__ void add_bf16x8_kernel(const uint4* a, const uint4* b, uint4* o, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 x = a[i], y = b[i];
+        auto add2 = [](unsigned p, unsigned q) {
+            return pack_bf16x2(__uint_as_float(p << 16) + __uint_as_float(q << 16),
+                               __uint_as_float(p & 0xffff0000u) + __uint_as_float(q & 0xffff0000u));
+        };
+        uint4 r;
+        r.x = add2(x.x, y.x); r.y = add2(x.y, y.y); r.z = add2(x.z, y.z); r.w = add2(x.w, y.w);
+        o[i] = r;
+    }
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __global__ void geglu_kernel(const char* h, int in_dt, char* out, int out_dt, int64_t rows, int c) {
@@ -236,8 +250,13 @@ extern "C" int mf_add(const void* a, int32_t a_dtype, const void* b, int32_t b_d
                       int64_t n, void* stream) {
     MF_CHECK_ARG(a && b && out && n >= 0, "mf_add: bad arguments");
     if (n == 0) return MF_OK;
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const char*)a, a_dtype,
-                       (const char*)b, b_dtype, (char*)out, out_dtype, n);
+    if (a_dtype == MF_BF16 && b_dtype == MF_BF16 && out_dtype == MF_BF16 && n % 8 == 0 && mf_aligned16(a) && mf_aligned16(b) &&
+        mf_aligned16(out))
+        hipLaunchKernelGGL(add_bf16x8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a,
+                           (const uint4*)b, (uint4*)out, n / 8);
+    else
+        hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const char*)a, a_dtype,
+                           (const char*)b, b_dtype, (char*)out, out_dtype, n);
     MF_CHECK_LAUNCH("mf_add");
     return MF_OK;
 }

@@ -501,3 +501,17 @@ def test_attn_processor_on_the_reference_operator_abi(dtype, heads, d, cross, to
     check(f"attn processor[{dtype},{'cross' if cross else 'self'}]", got, ref.cpu(), tol, tol)
     with pytest.raises(NotImplementedError):
         MfhipAttnProcessor()(attn, x, attention_mask=torch.zeros(1, device=DEV))
+
+
+def test_add_vector_and_scalar_paths():
+    """mf_add: the 8-wide bf16 kernel (aligned, n % 8 == 0) and the generic one give the fp32 sum rounded once."""
+    g = torch.Generator().manual_seed(11)
+    for n in (8, 4096 * 320, 1000):                      # 1000 % 8 == 0 too; odd sizes below
+        a = torch.randn(n, generator=g).bfloat16()
+        b = torch.randn(n, generator=g).bfloat16()
+        ref = (a.float() + b.float()).bfloat16()
+        assert torch.equal(hip.add(a.to(DEV), b.to(DEV), torch.bfloat16).cpu(), ref)
+    a = torch.randn(1003, generator=g).bfloat16()
+    b = torch.randn(1003, generator=g)
+    assert torch.equal(hip.add(a.to(DEV), b.to(DEV), torch.float32).cpu(), a.float() + b)      # mixed dtypes: generic kernel
+    assert torch.equal(hip.add(a.to(DEV), a.to(DEV), torch.bfloat16).cpu(), (a.float() * 2).bfloat16())   # n % 8 != 0
