@@ -267,3 +267,28 @@ def test_full_size_layers_match_reference():
         st = G[name + "_stats"]
         report(name, strided_sample(y, st[2]), G[name + "_sample"], **TOL)
         assert abs(float(y.double().sum()) - st[0]) <= 1e-6 * st[1] + 1e-6
+
+
+def test_baseline_config0_oracle_matches_reference_pipeline():
+    """BASELINE.json configs[0] at full size (1 x 256 x 256, 4 DDIM steps, CFG 7.5): the oracle's conditioning build +
+    first denoise step against the reference pipeline's recorded latents.  (All four steps and the decoded image are
+    compared when the fixture is generated - tools/make_golden.py prints 0.0 for each - and by the GPU suite; one step
+    keeps this CPU test to about half a minute.)"""
+    k = keys("sd15")
+    usd, bsd, vsd = (synth.state_dict_for(k[m], s) for m, s in (("unet", 0), ("brushnet", 1), ("vae", 2)))
+    G = golden("sd15_config0.npz")
+    inp = synth.pipeline_inputs(1, 256, 256, seed=1234)
+    cond = R.build_conditioning(vsd, R.SD15_VAE, inp["image"], inp["mask"], inp["depth"], torch.from_numpy(G["vae_noise"]))
+    assert cond.shape == (2, 6, 32, 32)
+    sched = R.DDIMRef(**R.SD15_SCHED)
+    sched.set_timesteps(4)
+    assert sched.timesteps.tolist() == G["timesteps"].tolist()
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    t = sched.timesteps[0]
+    x2 = torch.cat([inp["latents"]] * 2)
+    bcfg = R.brushnet_config(R.SD15_UNET, 6)
+    down, mid, up = R.brushnet_forward(bsd, bcfg, x2, t, cond, 1.0)
+    eps = R.unet_forward(usd, R.SD15_UNET, x2, t, pe, down, mid, up)
+    eu, ec = eps.chunk(2)
+    lat = sched.step(eu + 7.5 * (ec - eu), t, inp["latents"])
+    report("config0 latents after step 0", lat, G["latents_0"], **TOL)

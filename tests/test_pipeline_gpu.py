@@ -10,7 +10,7 @@ from oracle import mirrorfusion_ref as R  # noqa: E402
 from reflecting_reality_amd import (DDIMScheduler, PNDMScheduler, StableDiffusionBrushNetPipeline,  # noqa: E402
                                     UniPCMultistepScheduler, synth)  # noqa: E402
 from test_models_gpu import build  # noqa: E402
-from util import golden, keys, report  # noqa: E402
+from util import golden, keys, report, strided_sample  # noqa: E402
 
 DEV = "cuda"
 SD_SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
@@ -275,3 +275,38 @@ def test_pipeline_variants_against_oracle(case):
             eps = eu + 7.5 * (ec - eu)
         lat = sched.step(eps, t, lat)
     report(f"variant {case}", got, lat, atol=1e-3)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", None)])
+def test_baseline_config0_full_size_pipeline(prec, tol):
+    """BASELINE.json configs[0]: full-size SD1.5 + BrushNet, 1 x 256 x 256, 4 DDIM steps, CFG 7.5 through
+    StableDiffusionBrushNetPipeline.__call__, against the per-step latents and the image the REFERENCE pipeline
+    produced for the same seeded inputs (tests/golden/sd15_config0.npz).  fp32 mode: the north-star bar, 1e-3 latent
+    L-inf after every step; bf16 mode is reported and held to a loose bound (no NaN, same image within 0.1)."""
+    unet, bn, vae = build("sd15", prec)
+    G = golden("sd15_config0.npz")
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                           scheduler=DDIMScheduler(clip_sample=False, **SD_SCHED), safety_checker=None,
+                                           feature_extractor=None, requires_safety_checker=False,
+                                           depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(1, 256, 256, seed=1234)
+    trace = []
+
+    def cb(p, i, t, kw):
+        trace.append(kw["latents"].clone())
+        return {}
+
+    res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+               image=inp["image"], mask=inp["mask"], depth=inp["depth"], num_inference_steps=4, guidance_scale=7.5,
+               latents=inp["latents"].clone(), output_type="pt", brushnet_conditioning_scale=1.0,
+               callback_on_step_end=cb, height=256, width=256, conditioning_noise=torch.from_numpy(G["vae_noise"]))
+    assert pipe.scheduler.timesteps.tolist() == G["timesteps"].tolist() == [751, 501, 251, 1]
+    assert len(trace) == 4
+    for i, l in enumerate(trace):
+        err = report(f"config0 latents after step {i} [{prec}]", l, G[f"latents_{i}"], atol=tol if tol else 1e9, fail=tol is not None)
+        assert err == err                                     # not NaN
+    st = G["image_stats"]
+    img = res.images
+    assert tuple(img.shape) == (1, 3, 256, 256)
+    report(f"config0 image [{prec}]", strided_sample(img, st[2], 1024), G["image_sample"], atol=2e-3 if prec == "fp32" else 0.1)

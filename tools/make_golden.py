@@ -471,6 +471,43 @@ def full():
     np.savez_compressed(os.path.join(GOLD, "sd15_step.npz"), **out)
     print("full-size fixtures written")
 
+    # --- BASELINE.json configs[0]: SD1.5 + BrushNet depth-cond inpaint, 1 x 256 x 256, 4 DDIM steps, CFG 7.5, fp32,
+    # through the reference pipeline's __call__ (the reference's own CPU-runnable case) -------------------------------
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=brushnet,
+                                           scheduler=sched, safety_checker=None, feature_extractor=None,
+                                           requires_safety_checker=False, depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(1, 256, 256, seed=1234)
+    trace = []
+
+    def cb(p_, i, t_, kw_):
+        trace.append(kw_["latents"].clone())
+        return {}
+
+    torch.manual_seed(777)                    # the VAE posterior noise comes from the global RNG (:1188)
+    res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
+               image=inp["image"], mask=inp["mask"], depth=inp["depth"], num_inference_steps=4, guidance_scale=7.5,
+               latents=inp["latents"].clone(), output_type="pt", brushnet_conditioning_scale=1.0,
+               callback_on_step_end=cb, height=256, width=256)
+    torch.manual_seed(777)
+    vae_noise = torch.randn(2, 4, 32, 32)
+    ocond = R.build_conditioning(vae_sd, vcfg, inp["image"], inp["mask"], inp["depth"], vae_noise)
+    otrace = []
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    olat = R.denoise(unet_sd, ucfg, bn_sd, bcfg, R.DDIMRef(**R.SD15_SCHED), inp["latents"], ocond, pe, 4, 7.5, 1.0, otrace)
+    print("[config0] per-step latents oracle-vs-ref:", [round(maxdiff(a, b), 8) for a, b in zip(trace, otrace)])
+    oimg = (R.vae_decode(vae_sd, vcfg, olat / vcfg["scaling_factor"]) / 2 + 0.5).clamp(0, 1)
+    print("[config0] image oracle-vs-ref:", maxdiff(oimg, res.images))
+    c0 = dict(vae_noise=vae_noise.numpy(), timesteps=pipe.scheduler.timesteps.numpy())
+    for i, l in enumerate(trace):
+        c0[f"latents_{i}"] = l.numpy()
+    s_ = summarize(res.images, 1024)
+    c0["image_sample"], c0["image_stats"] = s_["sample"], np.array([s_["sum"], s_["abssum"], s_["sample_stride"]])
+    np.savez_compressed(os.path.join(GOLD, "sd15_config0.npz"), **c0)
+    print("configs[0] fixture written")
+
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
