@@ -310,3 +310,32 @@ def test_baseline_config0_full_size_pipeline(prec, tol):
     img = res.images
     assert tuple(img.shape) == (1, 3, 256, 256)
     report(f"config0 image [{prec}]", strided_sample(img, st[2], 1024), G["image_sample"], atol=2e-3 if prec == "fp32" else 0.1)
+
+
+def test_full_size_batch_shard_equivalence_and_determinism():
+    """BASELINE configs[1]/[2] sizes (batch 4 x 512 x 512, full-size models) through size-independent properties:
+    (1) batch sharding (each rank runs its own images, no collective) gives every image the latents it
+    gets in the full batch — shards [0:2] and [2:4] against the batch of 4, fp32 mode, 1e-3; (2) two identical calls
+    are bit-identical (captured hipGraph, two streams, no atomics)."""
+    unet, bn, vae = build("sd15", "fp32")
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                           scheduler=DDIMScheduler(clip_sample=False, **SD_SCHED), safety_checker=None,
+                                           feature_extractor=None, requires_safety_checker=False,
+                                           depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+
+    def run(sl):
+        nz = inp["vae_noise"]
+        noise = torch.cat([nz[:4][sl], nz[4:][sl]])                 # uncond half, then cond half
+        return pipe(prompt_embeds=inp["prompt_embeds"][sl], negative_prompt_embeds=inp["negative_prompt_embeds"][sl],
+                    image=inp["image"][sl], mask=inp["mask"][sl], depth=inp["depth"][sl], num_inference_steps=3,
+                    guidance_scale=7.5, latents=inp["latents"][sl].clone(), output_type="latent", height=512, width=512,
+                    conditioning_noise=noise).images
+
+    full = run(slice(0, 4))
+    again = run(slice(0, 4))
+    assert torch.isfinite(full).all()
+    assert torch.equal(full, again), "two identical calls must be bit-identical"
+    for sl in (slice(0, 2), slice(2, 4)):
+        report(f"shard {sl.start}:{sl.stop} vs batch of 4", run(sl), full[sl].cpu(), atol=1e-3)
