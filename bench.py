@@ -117,14 +117,20 @@ def main():
         a.size = 1024 if xl else 512
 
     from reflecting_reality_amd import distributed as D, hip, synth
-    rank, world, local = D.init_process_group()
+    # MF_BENCH_BACKEND=gloo: test hook for boxes with fewer GPUs than ranks (ranks then share devices, timings mean
+    # nothing); the driver's multi-GPU runs use the default, "nccl" = RCCL, one rank per GPU
+    backend = os.environ.get("MF_BENCH_BACKEND") or None
+    rank, world, local = D.init_process_group(backend)
     if world != a.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {a.gpus}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
         a.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    reduce_device = "cpu" if backend == "gloo" else device
     hip.load()
     # host preprocessing is a few 12 MB elementwise ops and copies: a small OpenMP team avoids the wake-up jitter of a
     # 100+-core host (cpu_baseline sets its own thread count later)
@@ -175,7 +181,7 @@ def main():
             f"(host view; VAE decode + postprocess)")
     D.barrier()
     torch.cuda.synchronize()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=device)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=reduce_device)
     assert torch.isfinite(img).all(), "non-finite output image"
 
     images = a.batch * a.steps * world
