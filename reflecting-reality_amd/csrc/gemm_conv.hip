@@ -49,7 +49,7 @@ struct GemmArgs {
     const char* res1; int res1_dt; int64_t ld_res1;
     float alpha; int act;
     char* out; int out_dt; int64_t ldc;
-    int tiles_n, nblk, vec_ok, fast;
+    int tiles_n, nblk, vec_ok, fast, dbg_no_res_pre;
 };
 
 // Scalar epilogue for one output element (tails, misaligned outputs, split-K reduce).
@@ -78,7 +78,16 @@ __device__ __forceinline__ void load8_as_f32(const char* p, int dt, int64_t idx,
 }
 
 // Vector epilogue: 8 consecutive output channels of one pixel.
-__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, int m, int n, float* v) {
+__device__ __forceinline__ void unpack8_bf16(const uint4& u, float* o) {
+    o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+    o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+    o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+    o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+// `pre`: the bf16 residual vectors of this item were fetched ahead of the LDS transposition (q0 / q1).
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, int m, int n, float* v, bool pre = false,
+                                                const uint4& q0 = uint4{0, 0, 0, 0}, const uint4& q1 = uint4{0, 0, 0, 0}) {
     if (p.bias) {
         if (p.bias_mode) {
             const float b = p.bias[m];
@@ -101,13 +110,15 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
     if (p.res0) {
         float r[8];
-        load8_as_f32(p.res0, p.res0_dt, (int64_t)m * p.ld_res0 + n, r);
+        if (pre) unpack8_bf16(q0, r);
+        else load8_as_f32(p.res0, p.res0_dt, (int64_t)m * p.ld_res0 + n, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
     if (p.res1) {
         float r[8];
-        load8_as_f32(p.res1, p.res1_dt, (int64_t)m * p.ld_res1 + n, r);
+        if (pre) unpack8_bf16(q1, r);
+        else load8_as_f32(p.res1, p.res1_dt, (int64_t)m * p.ld_res1 + n, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
@@ -651,9 +662,29 @@ void gemm_conv_kernel(const GemmArgs p) {
     constexpr int ITEMS = SR * CPR;                  // (row, group) items per slab
     float* ws = p.splitk > 1 ? p.ws + ((int64_t)ksplit * p.nz + z) * (int64_t)p.M * p.N : nullptr;
     const int64_t zo = zq * p.o_zs_o + zr * p.o_zs_i;
+    // bf16 residuals of a slab's items are fetched BEFORE its LDS transposition: loads and stores share vmcnt and
+    // return in order, so a load issued after the previous item's store waits for that store's round trip
+    const bool res_pre = !ws && p.vec_ok && (p.res0 || p.res1) && (!p.res0 || p.res0_dt == MF_BF16) &&
+                         (!p.res1 || p.res1_dt == MF_BF16) && !p.dbg_no_res_pre;
+    constexpr int NIT = (ITEMS + 63) / 64;
 #pragma unroll
     for (int ih = 0; ih < MT * (32 / SR); ++ih) {
         const int i = ih / (32 / SR), half = ih % (32 / SR);     // accumulator rows [half*SR, half*SR + SR) of tile i
+        uint4 q0[NIT], q1[NIT];
+        if (res_pre) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int it = k * 64 + lane;
+                const int row = it / CPR, ec = (it - row * CPR) * 8;
+                const int m = m0 + wm * WM + i * 32 + half * SR + row;
+                const int n = n0 + wn * WN + ec;
+                q0[k] = uint4{0, 0, 0, 0}; q1[k] = uint4{0, 0, 0, 0};
+                if ((ITEMS % 64 == 0 || it < ITEMS) && m < p.M && n + 8 <= p.N) {
+                    if (p.res0) q0[k] = *reinterpret_cast<const uint4*>(p.res0 + ((int64_t)m * p.ld_res0 + n) * 2);
+                    if (p.res1) q1[k] = *reinterpret_cast<const uint4*>(p.res1 + ((int64_t)m * p.ld_res1 + n) * 2);
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -683,7 +714,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                         for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
                     }
                 } else if (p.vec_ok && n + 8 <= p.N) {
-                    epilogue_store8(p, zo, m, n, v);
+                    epilogue_store8(p, zo, m, n, v, res_pre, q0[it0 / 64], q1[it0 / 64]);
                 } else {
                     for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj]);
                 }
@@ -1630,6 +1661,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     const int64_t nblk = (int64_t)cdiv(a.M, tc.bm) * a.tiles_n;
     MF_CHECK_ARG(nblk < (1ll << 31) && (int64_t)a.nz * a.splitk < 65536, "mf_gemm_conv: grid too large");
     a.nblk = (int)nblk;
+    { static const bool off = getenv("MFHIP_NO_RES_PRE") != nullptr; a.dbg_no_res_pre = off; }     // A/B switch
     dim3 grid((unsigned)nblk, 1, (unsigned)(a.nz * a.splitk));
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MF_BF16) {
