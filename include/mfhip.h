@@ -27,6 +27,13 @@ extern "C" {
 
 #define MF_F32 0
 #define MF_BF16 1
+/* compute-only codes for mf_gemm_desc.dtype ("split" precision: the mode that meets the reference's fp32 results to
+ * 1e-3 on the latents AND runs on the 16-bit matrix pipe).  Operands are fp32 in memory; every value x is split into
+ * two 16-bit halves x = hi + lo (hi = x rounded toward zero to 11 / 8 significant bits, lo = x - hi, exact in fp32,
+ * rounded to 16 bits) and a product is three MFMAs: hi*hi + hi*lo + lo*hi, fp32 accumulate.  MF_F16X3: fp16 halves
+ * (22 significant bits, |x| < 65504); MF_BF16X3: bf16 halves (16 bits, fp32 range). */
+#define MF_F16X3 2
+#define MF_BF16X3 3
 
 #define MF_OK 0
 #define MF_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -39,7 +46,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 7
+#define MF_ABI_VERSION 8
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -65,7 +72,8 @@ int mf_sizeof_groupnorm_desc(void);
  * and, in batched form, the QK^T / PV products of attention_processor.py:577-622.
  * ------------------------------------------------------------------------------------------ */
 typedef struct mf_gemm_desc {
-    /* compute dtype: MF_BF16 (bf16 MFMA 32x32x16, fp32 accumulate) or MF_F32 (fp32 MFMA 32x32x2) */
+    /* compute dtype: MF_BF16 (bf16 MFMA 32x32x16, fp32 accumulate), MF_F32 (fp32 MFMA 32x32x2) or a split code
+     * MF_F16X3 / MF_BF16X3 (fp32 operands, three 16-bit MFMAs per product; a_dtype must be MF_F32) */
     int32_t dtype;
     /* A operand */
     const void* a0;       /* segment 0, NHWC */
@@ -77,9 +85,13 @@ typedef struct mf_gemm_desc {
     int32_t h_out, w_out;
     int32_t kh, kw, stride, pad_t, pad_l;
     int32_t upsample;     /* 1: nearest-neighbour 2x before the convolution */
-    /* W operand, [n][k] row-major, row stride ldw elements, dtype == dtype */
+    /* W operand, [n][k] row-major, row stride ldw elements, dtype == dtype (fp32 for the split codes).
+     * w_split = 1 (split codes only): W was split ahead of time — per block of 32 k the row holds the 32 high halves
+     * then the 32 low halves (16-bit each: the same 128 bytes as 32 floats), rows zero-padded to a multiple of 32 k,
+     * ldw counted in 4-byte units.  w_split = 0: raw fp32, split on the fly (activation x activation products). */
     const void* w;
     int64_t ldw;
+    int32_t w_split;
     int32_t n;            /* output channels */
     /* strided batching (attention): blockIdx.z = z, offset = (z / zdiv)*zs_o + (z % zdiv)*zs_i */
     int32_t nz, zdiv;
@@ -111,6 +123,9 @@ int mf_gemm_conv(const mf_gemm_desc* d, void* stream);
 /* number of instantiated tile configurations and their (BM, BN) */
 int mf_gemm_num_tiles(void);
 int mf_gemm_tile_shape(int tile, int* bm, int* bn);
+/* bumped whenever tile indices are renumbered or change meaning (appending tiles keeps it): a host-side cache of tuned
+ * tile indices is only valid for the version it was recorded under */
+int mf_gemm_tile_table_version(void);
 
 /* --------------------------------------------------------------------------------------------
  * mf_groupnorm — GroupNorm over NHWC (optionally over the channel-concat of two tensors),
@@ -149,6 +164,15 @@ int mf_softmax_rows(const float* scores, void* out, int32_t out_dtype, int64_t r
 int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                       void* out, int64_t ldo, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
                       int32_t head_dim, float scale, void* stream);
+
+/* The same kernel in split precision (the parity mode's attention): every operand is given as two fp16 planes
+ * (hi, lo) of identical layout with hi + lo = the fp32 value to 22 bits (mf_split_halves makes them), each product is
+ * three fp16 MFMAs, P is split in registers, out is fp32 [B][Sq][ldo].  head_dim 8 / 40 / 64 / 80. */
+int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ldq, const void* k_hi, const void* k_lo, int64_t ldk,
+                       const void* vt_hi, const void* vt_lo, int64_t ldvt, float* out, int64_t ldo, int32_t batch,
+                       int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream);
+/* x (n fp32, n % 4 == 0) -> fp16 planes hi = x rounded toward zero, lo = (x - hi) rounded toward zero */
+int mf_split_halves(const float* x, void* hi, void* lo, int64_t n, void* stream);
 
 /* ---- elementwise / layout -------------------------------------------------------------- */
 /* NCHW fp32 -> NHWC (dtype), channels zero-padded to c_pad; two sources concatenated along C

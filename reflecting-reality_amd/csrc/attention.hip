@@ -1,4 +1,6 @@
-// Flash-style fused attention for gfx950, bf16 operands / fp32 softmax + accumulation.
+// Flash-style fused attention for gfx950, bf16 operands / fp32 softmax + accumulation, plus the same kernel in
+// split precision (SP: every operand given as two fp16 planes hi + lo = the fp32 value to 22 bits, three MFMAs per
+// product, P split in registers, fp32 output) — the parity mode runs THIS kernel, not a separate code path.
 //
 // Replaces F.scaled_dot_product_attention (reference models/attention_processor.py:1266-1268) for
 // the SD1.5 head dims (40 / 80 / 160; also 8 and 64 for tiny test configs).
@@ -25,6 +27,7 @@ struct AttnArgs {
     const char* q; int64_t ldq;
     const char* k; int64_t ldk;
     const char* vt; int64_t ldvt;
+    const char* q2; const char* k2; const char* vt2;   // SP: the low-half planes (same layout as q / k / vt)
     char* out; int64_t ldo;
     int heads, sq, skv, batch;
     float c;   // softmax scale * log2(e)
@@ -32,15 +35,22 @@ struct AttnArgs {
 
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <int HD, bool DB>
-__global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const AttnArgs p) {
+__device__ __forceinline__ f32x16_t mfma16(const uint4& a, const uint4& b, const f32x16_t& c, bool f16) {
+    return f16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0)
+               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+template <int HD, bool DB, bool SP = false>
+__global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2)) void attn_fwd_kernel(const AttnArgs p) {
+    constexpr int NP = SP ? 2 : 1;            // operand planes (hi, lo)
+    constexpr int OES = SP ? 4 : 2;           // output element size
     constexpr int DK = (HD + 15) / 16 * 16;   // QK^T reduction length, padded to the MFMA k-step
     constexpr int KS = DK / 16;
     constexpr int DV = (HD + 31) / 32 * 32;   // O^T rows, padded to the MFMA tile
     constexpr int DT = DV / 32;
     constexpr int RBK = DK * 2 + 16;          // K tile row stride (odd multiple of 16 B: conflict-free b128 reads)
     constexpr int RBV = 144;                  // V^T tile row stride: 64 keys * 2 B + 16
-    constexpr int RBO = DV * 2 + 16;          // epilogue transpose row stride
+    constexpr int RBO = DV * OES + 16;        // epilogue transpose row stride
     constexpr int KCPR = RBK / 16, VCPR = RBV / 16;          // 16-byte chunks per LDS row (data + pad)
     constexpr int KI = KCPR;                                  // wave-instructions per K tile: 64 rows x KCPR chunks / 64 lanes
     constexpr int VI = (HD * VCPR + 63) / 64;                 // ... per V^T tile (rows < HD; the tail spills zeros into pad rows)
@@ -48,10 +58,12 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     constexpr int K_BYTES = 64 * RBK;
     constexpr int V_BYTES = (DV * RBV > VI * 1024 ? DV * RBV : VI * 1024);
     constexpr int O_BYTES = 4 * 32 * RBO;
-    constexpr int BUF_BYTES = K_BYTES + V_BYTES;            // one K + V^T tile
+    constexpr int BUF_BYTES = NP * (K_BYTES + V_BYTES);     // one K + V^T tile: [K planes][V^T planes]
+    constexpr int V0 = NP * K_BYTES;                        // offset of the first V^T plane inside a buffer
     constexpr int NBUF = 2;
     constexpr int LDS_BYTES = (NBUF * BUF_BYTES) > O_BYTES ? (NBUF * BUF_BYTES) : O_BYTES;
     static_assert(DB, "K / V^T tiles are double buffered");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,24 +82,25 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     if (ONES) {
         __syncthreads();
         for (int i = tid; i < NBUF * 32; i += 256)           // 64 keys = 128 B = 32 dwords per buffer
-            *reinterpret_cast<uint32_t*>(smem + (i >> 5) * BUF_BYTES + K_BYTES + ONES_ROW * RBV + (i & 31) * 4) = 0x3F803F80u;
+            *reinterpret_cast<uint32_t*>(smem + (i >> 5) * BUF_BYTES + V0 + ONES_ROW * RBV + (i & 31) * 4) = SP ? 0x3C003C00u : 0x3F803F80u;   // 1.0 (hi plane only)
     }
 
     // Q fragments (B operand of S^T = K.Q^T): lane (query r, half h) holds Q[q][16ks + 8h + j]
-    bf16x8_t qf[KS];
-    {
-        const char* qrow = p.q + (((int64_t)b * p.sq + (qi < p.sq ? qi : 0)) * p.ldq + head * HD) * 2;
+    uint4 qf[NP][KS];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        const char* qrow = (pl ? p.q2 : p.q) + (((int64_t)b * p.sq + (qi < p.sq ? qi : 0)) * p.ldq + head * HD) * 2;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int kk = 16 * ks + 8 * h;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (kk < HD && qi < p.sq) v = ldg16(qrow + kk * 2);
-            qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+            qf[pl][ks] = v;
         }
     }
 
-    const char* kbase = p.k + ((int64_t)b * p.skv * p.ldk + head * HD) * 2;
-    const char* vbase = p.vt + ((int64_t)(b * p.heads + head) * HD) * p.ldvt * 2;
+    const int64_t kb_off = ((int64_t)b * p.skv * p.ldk + head * HD) * 2;
+    const int64_t vb_off = ((int64_t)(b * p.heads + head) * HD) * p.ldvt * 2;
 
     // LDS-DMA staging.  A wave-instruction fills 64 consecutive 16-byte chunks of the (padded) LDS tile; lane chunk g
     // of the K tile is (row R = g / KCPR, chunk c = g % KCPR) and reads key row perm(R) of this head (pad chunks and
@@ -97,8 +110,12 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     // their probabilities are exact zeros.
     const int64_t k_left = ((int64_t)(p.batch - b) * p.skv * p.ldk - head * HD) * 2;
     const int64_t v_left = ((int64_t)((p.batch - b) * p.heads - head) * HD * p.ldvt) * 2;
-    const srd_t srdK = make_srd(kbase, (unsigned)(k_left < 0x7fffffff ? k_left : 0x7fffffff));
-    const srd_t srdV = make_srd(vbase, (unsigned)(v_left < 0x7fffffff ? v_left : 0x7fffffff));
+    srd_t srdK[NP], srdV[NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        srdK[pl] = make_srd((pl ? p.k2 : p.k) + kb_off, (unsigned)(k_left < 0x7fffffff ? k_left : 0x7fffffff));
+        srdV[pl] = make_srd((pl ? p.vt2 : p.vt) + vb_off, (unsigned)(v_left < 0x7fffffff ? v_left : 0x7fffffff));
+    }
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     unsigned koff[KPW], voff[VPW];
@@ -122,12 +139,16 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
         const unsigned lk = lds0 + buf * BUF_BYTES;
 #pragma unroll
         for (int i = 0; i < KPW; ++i) {
-            if (wv + 4 * i < KI) dma16_buf(koff[i], srdK, lk + (wv + 4 * i) * 1024);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                if (wv + 4 * i < KI) dma16_buf(koff[i], srdK[pl], lk + pl * K_BYTES + (wv + 4 * i) * 1024);
             koff[i] += kstep;          // an out-of-range lane stays out of range: 0x80000000 + n * kstep < 2^32 for every tile
         }
 #pragma unroll
         for (int i = 0; i < VPW; ++i) {
-            if (wv + 4 * i < VI) dma16_buf(voff[i], srdV, lk + K_BYTES + (wv + 4 * i) * 1024);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                if (wv + 4 * i < VI) dma16_buf(voff[i], srdV[pl], lk + V0 + pl * V_BYTES + (wv + 4 * i) * 1024);
             voff[i] += 128;
         }
     };
@@ -147,7 +168,7 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
         const char* Ks = smem + (t & 1) * BUF_BYTES;
-        const char* Vs = Ks + K_BYTES;
+        const char* Vs = Ks + V0;
         // the other buffer was last read in iteration t-1, which every wave finished before the barrier that ended it
         if (t + 1 < ntiles) issue_tile((t + 1) & 1);       // the DMA flies under this tile's MFMAs and softmax
 
@@ -159,7 +180,14 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const uint4 a = *reinterpret_cast<const uint4*>(Ks + (32 * tt + r) * RBK + (16 * ks + 8 * h) * 2);
-                st[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), qf[ks], ks == 0 ? zero16 : st[tt], 0, 0, 0);
+                if constexpr (SP) {
+                    const uint4 a2 = *reinterpret_cast<const uint4*>(Ks + K_BYTES + (32 * tt + r) * RBK + (16 * ks + 8 * h) * 2);
+                    st[tt] = mfma16(a2, qf[0][ks], ks == 0 ? zero16 : st[tt], true);      // the small terms first
+                    st[tt] = mfma16(a, qf[1][ks], st[tt], true);
+                    st[tt] = mfma16(a, qf[0][ks], st[tt], true);
+                } else {
+                    st[tt] = mfma16(a, qf[0][ks], ks == 0 ? zero16 : st[tt], false);
+                }
             }
         }
         if (kv0 + 64 > p.skv) {
@@ -198,17 +226,33 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
         }
         if (!ONES) l += rs;
         // ---- P^T fragments: accumulator registers 8s..8s+7 of tile tt are k-step 2*tt+s ----
-        bf16x8_t pf[4];
+        uint4 pf[NP][4];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                uint4 u;
-                u.x = pack_bf16x2(st[tt][8 * s + 0], st[tt][8 * s + 1]);
-                u.y = pack_bf16x2(st[tt][8 * s + 2], st[tt][8 * s + 3]);
-                u.z = pack_bf16x2(st[tt][8 * s + 4], st[tt][8 * s + 5]);
-                u.w = pack_bf16x2(st[tt][8 * s + 6], st[tt][8 * s + 7]);
-                pf[2 * tt + s] = __builtin_bit_cast(bf16x8_t, u);
+                if constexpr (SP) {
+                    // P = hi + lo in fp16 halves (hi toward zero, lo = P - hi exact in fp32); P <= 1, and fp16
+                    // subnormals survive both v_cvt_pkrtz_f16_f32 and the matrix pipe (tools/micro/f16_denorm.hip)
+                    unsigned hw[4], lw[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = st[tt][8 * s + 2 * e], a1 = st[tt][8 * s + 2 * e + 1];
+                        const auto hh = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+                        const auto ll = __builtin_amdgcn_cvt_pkrtz(a0 - (float)hh[0], a1 - (float)hh[1]);
+                        hw[e] = __builtin_bit_cast(unsigned, hh);
+                        lw[e] = __builtin_bit_cast(unsigned, ll);
+                    }
+                    pf[0][2 * tt + s] = uint4{hw[0], hw[1], hw[2], hw[3]};
+                    pf[1][2 * tt + s] = uint4{lw[0], lw[1], lw[2], lw[3]};
+                } else {
+                    uint4 u;
+                    u.x = pack_bf16x2(st[tt][8 * s + 0], st[tt][8 * s + 1]);
+                    u.y = pack_bf16x2(st[tt][8 * s + 2], st[tt][8 * s + 3]);
+                    u.z = pack_bf16x2(st[tt][8 * s + 4], st[tt][8 * s + 5]);
+                    u.w = pack_bf16x2(st[tt][8 * s + 6], st[tt][8 * s + 7]);
+                    pf[0][2 * tt + s] = u;
+                }
             }
         // ---- O^T += V^T . P^T ----
 #pragma unroll
@@ -216,7 +260,14 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 const uint4 a = *reinterpret_cast<const uint4*>(Vs + (32 * d + r) * RBV + (16 * kst + 8 * h) * 2);
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kst], o[d], 0, 0, 0);
+                if constexpr (SP) {
+                    const uint4 a2 = *reinterpret_cast<const uint4*>(Vs + V_BYTES + (32 * d + r) * RBV + (16 * kst + 8 * h) * 2);
+                    o[d] = mfma16(a2, pf[0][kst], o[d], true);
+                    o[d] = mfma16(a, pf[1][kst], o[d], true);
+                    o[d] = mfma16(a, pf[0][kst], o[d], true);
+                } else {
+                    o[d] = mfma16(a, pf[0][kst], o[d], false);
+                }
             }
         wait_vmcnt<0>();      // this wave's share of tile t+1 has landed ...
         __syncthreads();      // ... and so has everybody else's; every wave is done reading tile t
@@ -231,28 +282,46 @@ __global__ __launch_bounds__(256, HD <= 80 ? 3 : 2) void attn_fwd_kernel(const A
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            uint2 u;
-            u.x = pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
-            u.y = pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 2) = u;
+            if constexpr (SP) {
+                *reinterpret_cast<float4*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 4) =
+                    make_float4(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+            } else {
+                uint2 u;
+                u.x = pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
+                u.y = pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 2) = u;
+            }
         }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
     __builtin_amdgcn_wave_barrier();
-    constexpr int OV = 32 * (HD / 8);
+    constexpr int EPV = 16 / OES;         // elements per 16-byte vector of the output
+    constexpr int OV = 32 * (HD / EPV);
     for (int v = lane; v < OV; v += 64) {
-        const int row = v / (HD / 8), cv = v - row * (HD / 8);
+        const int row = v / (HD / EPV), cv = v - row * (HD / EPV);
         const int qq = q0 + row;
         if (qq < p.sq) {
             const uint4 val = *reinterpret_cast<const uint4*>(Os + row * RBO + cv * 16);
-            *reinterpret_cast<uint4*>(p.out + (((int64_t)b * p.sq + qq) * p.ldo + head * HD + cv * 8) * 2) = val;
+            *reinterpret_cast<uint4*>(p.out + (((int64_t)b * p.sq + qq) * p.ldo + head * HD + cv * EPV) * OES) = val;
         }
     }
 }
 
-template <int HD>
+template <int HD, bool SP = false>
 void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
     dim3 grid((a.sq + 127) / 128, a.heads, batch);
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, true, SP>), grid, dim3(256), 0, s, a);
+}
+
+// fp32 [rows][ld] (first `cols` columns) -> two fp16 planes of the same layout: hi toward zero, lo = x - hi
+__global__ __launch_bounds__(256) void split_halves_kernel(const float* x, unsigned short* hi, unsigned short* lo, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const auto h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+        const auto l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
+        const auto l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
+        reinterpret_cast<uint2*>(hi)[i] = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+        reinterpret_cast<uint2*>(lo)[i] = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+    }
 }
 
 }  // namespace
@@ -284,5 +353,52 @@ extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int6
             return MF_EINVAL;
     }
     MF_CHECK_LAUNCH("mf_attention_bf16");
+    return MF_OK;
+}
+
+extern "C" int mf_split_halves(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+    MF_CHECK_ARG(x && hi && lo && n >= 0 && n % 4 == 0, "mf_split_halves: null pointer or n not a multiple of 4");
+    if (!mf_aligned16(x) || (((uintptr_t)hi) & 7) || (((uintptr_t)lo) & 7)) {
+        mf_set_error("mf_split_halves: x must be 16-byte and hi / lo 8-byte aligned");
+        return MF_EALIGN;
+    }
+    if (n == 0) return MF_OK;
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_halves_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned short*)hi, (unsigned short*)lo, n / 4);
+    MF_CHECK_LAUNCH("mf_split_halves");
+    return MF_OK;
+}
+
+extern "C" int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ldq, const void* k_hi, const void* k_lo, int64_t ldk,
+                                  const void* vt_hi, const void* vt_lo, int64_t ldvt, float* out, int64_t ldo, int32_t batch,
+                                  int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream) {
+    MF_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out, "mf_attention_f16x3: null pointer");
+    MF_CHECK_ARG(batch >= 1 && heads >= 1 && sq >= 1 && skv >= 1, "mf_attention_f16x3: bad sizes");
+    MF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= skv,
+                 "mf_attention_f16x3: leading dims must be multiples of 8 (ldo: 4) and ldvt >= skv");
+    if (!mf_aligned16(q_hi) || !mf_aligned16(q_lo) || !mf_aligned16(k_hi) || !mf_aligned16(k_lo) || !mf_aligned16(vt_hi) ||
+        !mf_aligned16(vt_lo) || !mf_aligned16(out)) {
+        mf_set_error("mf_attention_f16x3: pointers must be 16-byte aligned");
+        return MF_EALIGN;
+    }
+    AttnArgs a{};
+    a.q = (const char*)q_hi; a.q2 = (const char*)q_lo; a.ldq = ldq;
+    a.k = (const char*)k_hi; a.k2 = (const char*)k_lo; a.ldk = ldk;
+    a.vt = (const char*)vt_hi; a.vt2 = (const char*)vt_lo; a.ldvt = ldvt;
+    a.out = (char*)out; a.ldo = ldo; a.heads = heads; a.sq = sq; a.skv = skv; a.batch = batch;
+    a.c = scale * 1.44269504088896340736f;
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 8: launch_attn<8, true>(a, batch, s); break;
+        case 40: launch_attn<40, true>(a, batch, s); break;
+        case 64: launch_attn<64, true>(a, batch, s); break;
+        case 80: launch_attn<80, true>(a, batch, s); break;
+        default:
+            mf_set_error("mf_attention_f16x3: unsupported head_dim %d (have 8, 40, 64, 80)", head_dim);
+            return MF_EINVAL;
+    }
+    MF_CHECK_LAUNCH("mf_attention_f16x3");
     return MF_OK;
 }

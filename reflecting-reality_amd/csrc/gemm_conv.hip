@@ -205,11 +205,17 @@ constexpr int min_waves(int bm, int bn, int stages, int nthr) {
     return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES, bool DXR = false>
+// DT: MF_BF16, MF_F32, or a split code (MF_F16X3 / MF_BF16X3: fp32 operands staged exactly like MF_F32, every 8-wide
+// fragment split in registers into 16-bit (hi, lo) halves, three 32x32x16 MFMAs per product).  WPK (split codes only):
+// the W operand was split ahead of time ([32 hi | 32 lo] 16-bit values per block of 32 k — the same 128 bytes as 32
+// floats, so its staging is byte-identical too) and needs no conversion.
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES, bool DXR = false, bool WPK = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, min_waves(BM + (DXR ? 32 : 0), BN, STAGES, WAVES_M* WAVES_N * 64))
 void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;
-    constexpr int ES = (DT == MF_F32) ? 4 : 2;   // element size of the compute dtype
+    constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3);
+    static_assert(!WPK || SPLIT, "a pre-split W operand only exists for the split codes");
+    constexpr int ES = (DT == MF_BF16) ? 2 : 4;   // element size of the operands in memory / LDS
     constexpr int AES = A_F32 ? 4 : ES;          // element size of the A storage dtype
     constexpr int VEC = 16 / ES;                 // elements per 16-byte LDS chunk
     constexpr int BK = 128 / ES;                 // K elements per tile (128 bytes per row)
@@ -328,7 +334,9 @@ void gemm_conv_kernel(const GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            const char* src = (kvalid && w_row[i]) ? w_row[i] + (int64_t)kk * ES : zero;
+            // a pre-split W row is zero-padded to whole blocks of 32 k: chunk -> k is not monotonic there, every chunk of
+            // an existing K tile is readable
+            const char* src = ((kvalid || WPK) && w_row[i]) ? w_row[i] + (int64_t)kk * ES : zero;
             dma16(src, Bs + i * RPP * 128);
         }
         advance_k();
@@ -440,6 +448,69 @@ void gemm_conv_kernel(const GemmArgs p) {
     const int fh = lane >> 5;                // which half of the k-step this lane holds
     const int fkey = (frow >> 1) & 7;        // swizzle key (tile bases are multiples of 32 rows)
 
+    // ---- split codes: fp32 -> (hi, lo) 16-bit halves in registers ---------------------------------------------
+    // c0, c1: 8 consecutive fp32 (k = 16 ks + 8 fh + 0..7 of this lane's row).  hi = x toward zero, lo = x - hi (exact in
+    // fp32) toward zero; the error of hi + lo against x is below 2^-22 |x| (fp16 halves) / 2^-16 |x| (bf16 halves).
+    auto split8 = [&](const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
+        const float x[8] = {__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), __uint_as_float(c0.w),
+                            __uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z), __uint_as_float(c1.w)};
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (DT == MF_F16X3) {
+                const auto hh = __builtin_amdgcn_cvt_pkrtz(x[2 * e], x[2 * e + 1]);          // v_cvt_pkrtz_f16_f32
+                const auto ll = __builtin_amdgcn_cvt_pkrtz(x[2 * e] - (float)hh[0], x[2 * e + 1] - (float)hh[1]);
+                h[e] = __builtin_bit_cast(unsigned, hh);
+                l[e] = __builtin_bit_cast(unsigned, ll);
+            } else {
+                const unsigned ua = __float_as_uint(x[2 * e]), ub = __float_as_uint(x[2 * e + 1]);
+                h[e] = (ua >> 16) | (ub & 0xffff0000u);                                       // truncated bf16 pair
+                l[e] = pack_bf16x2(x[2 * e] - __uint_as_float(ua & 0xffff0000u), x[2 * e + 1] - __uint_as_float(ub & 0xffff0000u));
+            }
+        }
+        hi = uint4{h[0], h[1], h[2], h[3]};
+        lo = uint4{l[0], l[1], l[2], l[3]};
+    };
+    auto mma16 = [&](const uint4& a, const uint4& b, f32x16_t& c) {
+        if constexpr (DT == MF_F16X3)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+        else
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    };
+    // One K tile (32 k = two 16-wide MFMA steps) of a split code.  Ap[i] / Ak[i]: LDS row base and swizzle key of this
+    // lane's row of A tile i; Bp: row base of W tile 0 (tile j at + j * 32 rows), key fkey.
+    auto compute_split = [&](const char* const (&Ap)[MT], const int (&Ak)[MT], const char* Bp) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint4 c0 = *reinterpret_cast<const uint4*>(Ap[i] + (((4 * ks + 2 * fh) ^ Ak[i]) << 4));
+                const uint4 c1 = *reinterpret_cast<const uint4*>(Ap[i] + (((4 * ks + 2 * fh + 1) ^ Ak[i]) << 4));
+                split8(c0, c1, ah[i], al[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (WPK) {
+                    bh[j] = *reinterpret_cast<const uint4*>(Bp + j * 32 * 128 + (((2 * ks + fh) ^ fkey) << 4));
+                    bl[j] = *reinterpret_cast<const uint4*>(Bp + j * 32 * 128 + (((4 + 2 * ks + fh) ^ fkey) << 4));
+                } else {
+                    const uint4 c0 = *reinterpret_cast<const uint4*>(Bp + j * 32 * 128 + (((4 * ks + 2 * fh) ^ fkey) << 4));
+                    const uint4 c1 = *reinterpret_cast<const uint4*>(Bp + j * 32 * 128 + (((4 * ks + 2 * fh + 1) ^ fkey) << 4));
+                    split8(c0, c1, bh[j], bl[j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    mma16(al[i], bh[j], acc[i][j]);      // the small terms first
+                    mma16(ah[i], bl[j], acc[i][j]);
+                    mma16(ah[i], bh[j], acc[i][j]);
+                }
+        }
+    };
+
     auto mma = [&](const uint4 (&fa)[MT], const uint4 (&fb)[NT]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -462,6 +533,13 @@ void gemm_conv_kernel(const GemmArgs p) {
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE_BYTES + (wm * WM + frow) * 128;
         const char* Bs = smem + stage * STAGE_BYTES + BM * 128 + (wn * WN + frow) * 128;
+        if constexpr (SPLIT) {
+            const char* Ap[MT]; int Ak[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { Ap[i] = As + i * 32 * 128; Ak[i] = fkey; }
+            compute_split(Ap, Ak, Bs);
+            return;
+        }
         uint4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
         auto ldfrag = [&](int ks, uint4 (&fa)[MT], uint4 (&fb)[NT]) {
             const int coff = (((2 * ks + fh) ^ fkey) << 4);
@@ -575,6 +653,13 @@ void gemm_conv_kernel(const GemmArgs p) {
                     const int r = arow0[i] + kx;
                     aoffs[i] = r * 128;
                     akey[i] = (r >> 1) & 7;
+                }
+                if constexpr (SPLIT) {
+                    const char* Ap[MT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) Ap[i] = Ab + aoffs[i];
+                    compute_split(Ap, akey, Bs);
+                    return;
                 }
                 uint4 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
                 auto ldfrag = [&](int ks, uint4 (&fa)[MT], uint4 (&fb)[NT]) {
@@ -1395,23 +1480,47 @@ const TileCfg kTiles[] = {
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false>
+template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     constexpr int smem = DX ? 2 * (BM + WMv * WNv * 8) * 128 + 2 * BN * 128 : ST * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX>), grid, dim3(WMv * WNv * 64), smem, s, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK>), grid, dim3(WMv * WNv * 64), smem, s, a);
+}
+
+// Split codes: the tiles whose register budget holds the split fragments (see kTiles).  Returns false for a tile that
+// is not instantiated for them.
+template <int DT, bool WPK>
+bool launch_tile_split(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    switch (tile) {
+        case 1: launch_one<DT, 128, 128, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
+        case 2: launch_one<DT, 128, 64, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
+        case 3: launch_one<DT, 64, 64, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
+        case 6: launch_one<DT, 64, 128, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
+        default: break;
+    }
+    if constexpr (WPK) {
+        switch (tile) {
+            case 7: launch_one<DT, 128, 128, 2, 2, false, 3, false, true>(a, grid, s); return true;
+            case 14: launch_one<DT, 128, 160, 4, 1, false, 2, false, true>(a, grid, s); return true;
+            case 20: launch_one<DT, 128, 160, 4, 1, false, 2, true, true>(a, grid, s); return true;
+            case 21: launch_one<DT, 128, 128, 2, 2, false, 2, true, true>(a, grid, s); return true;
+            case 22: launch_one<DT, 64, 128, 2, 2, false, 2, true, true>(a, grid, s); return true;
+            default: break;
+        }
+    }
+    return false;
 }
 
 template <int DT, bool AF>
 void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
-    if (AF && tile > 12) tile = 1;        // the fp32->bf16 converting path is register staged (2 stages)
-    if (AF && tile > 6) tile -= 6;
+    // AF (fp32 activations converted to bf16 on load) is register staged with 2 stages: mf_gemm_conv has already
+    // resolved the tile to 1..6, so the grid it computed matches the kernel's BM x BN
     switch (tile) {
         case 1: launch_one<DT, 128, 128, 2, 2, AF, 2>(a, grid, s); break;
         case 2: launch_one<DT, 128, 64, 2, 2, AF, 2>(a, grid, s); break;
@@ -1473,11 +1582,12 @@ void launch_pingpong(const GemmArgs& a, dim3 grid, hipStream_t s) {
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Heuristic tile choice (mf_gemm_desc.tile overrides it; the Python host autotunes per shape).
-int pick_tile(int M, int N, int nz, int splitk) {
+int pick_tile(int M, int N, int nz, int splitk, int max_tile = kNumTiles, bool split = false) {
     int best = 1;
     double best_cost = 1e300;
-    for (int t = 1; t <= kNumTiles; ++t) {
+    for (int t = 1; t <= max_tile; ++t) {
         const TileCfg& c = kTiles[t - 1];
+        if (split && t != 1 && t != 2 && t != 3 && t != 6) continue;     // instantiated for every split variant
         const double tiles = (double)cdiv(M, c.bm) * cdiv(N, c.bn) * nz * (splitk > 1 ? splitk : 1);
         if (c.stages != 2 || c.halo || c.dxr) continue;                            // the ring / halo variants are picked by the host autotuner
         const int bpc = (2 * (c.bm + c.bn) * 128 <= 80 * 1024) ? 2 : 1;   // blocks per CU that fit in LDS
@@ -1496,6 +1606,7 @@ int pick_tile(int M, int N, int nz, int splitk) {
 }  // namespace
 
 extern "C" int mf_gemm_num_tiles(void) { return kNumTiles; }
+extern "C" int mf_gemm_tile_table_version(void) { return 1; }
 extern "C" int mf_gemm_tile_shape(int tile, int* bm, int* bn) {
     if (tile < 1 || tile > kNumTiles) return MF_EINVAL;
     *bm = kTiles[tile - 1].bm;
@@ -1505,11 +1616,16 @@ extern "C" int mf_gemm_tile_shape(int tile, int* bm, int* bn) {
 
 extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(d != nullptr, "mf_gemm_conv: null descriptor");
-    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_BF16, "mf_gemm_conv: bad dtype %d", d->dtype);
+    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_BF16 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X3,
+                 "mf_gemm_conv: bad dtype %d", d->dtype);
+    const bool split = d->dtype == MF_F16X3 || d->dtype == MF_BF16X3;
+    MF_CHECK_ARG(!split || d->a_dtype == MF_F32, "mf_gemm_conv: the split codes take fp32 activations");
+    MF_CHECK_ARG(d->w_split == 0 || (d->w_split == 1 && split && d->ldw % 32 == 0),
+                 "mf_gemm_conv: w_split needs a split compute code and rows padded to a multiple of 32 k");
     const int es = mf_dtype_size(d->dtype);
     const int vec = 16 / es;
     MF_CHECK_ARG(d->a0 && d->w && d->out, "mf_gemm_conv: null a0/w/out");
-    MF_CHECK_ARG(d->a_dtype == d->dtype || (d->a_dtype == MF_F32 && d->dtype == MF_BF16),
+    MF_CHECK_ARG(d->a_dtype == d->dtype || (d->a_dtype == MF_F32 && d->dtype != MF_F32),
                  "mf_gemm_conv: a_dtype %d incompatible with compute dtype %d", d->a_dtype, d->dtype);
     MF_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && (d->a1 != nullptr) == (d->c1 > 0), "mf_gemm_conv: bad c0/c1/a1");
     MF_CHECK_ARG(d->c0 % vec == 0 && d->c1 % vec == 0, "mf_gemm_conv: channels (%d,%d) must be multiples of %d",
@@ -1565,7 +1681,14 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
                (!d->res1 || (mf_aligned16(d->res1) && d->ld_res1 % 8 == 0));
 
     int tile = d->tile;
-    if (tile <= 0 || tile > kNumTiles) tile = pick_tile(a.M, a.N, a.nz, d->splitk);
+    if (tile <= 0 || tile > kNumTiles) tile = pick_tile(a.M, a.N, a.nz, d->splitk, a_f32 ? 6 : kNumTiles, split);
+    if (a_f32) {
+        // the converting path only exists for the 2-stage tiles 1..6; 7..12 are the same shapes with a deeper ring.
+        // Resolve the EFFECTIVE tile before the grid is derived from it (a 192x128 grid on a 128x128 kernel would leave
+        // rows unwritten); anything else does not apply and is refused, never rerouted.
+        if (tile >= 7 && tile <= 12) tile -= 6;
+        MF_CHECK_ARG(tile <= 6, "mf_gemm_conv: tile %d does not apply to fp32 activations with bf16 compute (tiles 1-12 do)", tile);
+    }
     const TileCfg& tc = kTiles[tile - 1];
     if (tc.halo) {
         // conv3x3_halo_kernel: bf16, 3x3 / stride 1 / pad 1, whole TH x 16 tiles, 32-channel chunks
@@ -1664,7 +1787,12 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     { static const bool off = getenv("MFHIP_NO_RES_PRE") != nullptr; a.dbg_no_res_pre = off; }     // A/B switch
     dim3 grid((unsigned)nblk, 1, (unsigned)(a.nz * a.splitk));
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == MF_BF16) {
+    if (split) {
+        const bool ok = d->dtype == MF_F16X3
+                            ? (d->w_split ? launch_tile_split<MF_F16X3, true>(tile, a, grid, s) : launch_tile_split<MF_F16X3, false>(tile, a, grid, s))
+                            : (d->w_split ? launch_tile_split<MF_BF16X3, true>(tile, a, grid, s) : launch_tile_split<MF_BF16X3, false>(tile, a, grid, s));
+        MF_CHECK_ARG(ok, "mf_gemm_conv: tile %d is not instantiated for the split codes (w_split=%d)", tile, d->w_split);
+    } else if (d->dtype == MF_BF16) {
         if (a_f32) launch_tile<MF_BF16, true>(tile, a, grid, s);
         else launch_tile<MF_BF16, false>(tile, a, grid, s);
     } else {

@@ -14,9 +14,9 @@ import torch
 
 from . import _build
 
-MF_F32, MF_BF16 = 0, 1
+MF_F32, MF_BF16, MF_F16X3, MF_BF16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MfhipError(RuntimeError):
@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("h_out", C.c_int32), ("w_out", C.c_int32),
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
         ("upsample", C.c_int32),
-        ("w", C.c_void_p), ("ldw", C.c_int64),
+        ("w", C.c_void_p), ("ldw", C.c_int64), ("w_split", C.c_int32),
         ("n", C.c_int32),
         ("nz", C.c_int32), ("zdiv", C.c_int32),
         ("a_zs_o", C.c_int64), ("a_zs_i", C.c_int64), ("w_zs_o", C.c_int64), ("w_zs_i", C.c_int64),
@@ -68,8 +68,9 @@ class GroupNormDesc(C.Structure):
 # every symbol include/mfhip.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
     "mf_abi_version", "mf_last_error", "mf_sizeof_gemm_desc", "mf_sizeof_groupnorm_desc",
-    "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape",
+    "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape", "mf_gemm_tile_table_version",
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
+    "mf_attention_f16x3", "mf_split_halves",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
 ]
@@ -199,40 +200,72 @@ LAST_PROFILE = []
 # for grids that cannot fill 256 CUs) the first time a GEMM shape is seen and remembers the winner.  Winners
 # are persisted in tune_cache.json next to this file so later processes (and graph capture) start tuned.
 AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
+# The package ships a cache tuned on MI355X (read-only); new winners go to a per-user file (MFHIP_TUNE_CACHE, default
+# ~/.cache/mfhip/tune_cache.json) that is overlaid on it.  Both carry the library's tile-table version: when tiles are
+# renumbered (mf_gemm_tile_table_version changes) stale indices are dropped instead of being trusted.
 _TUNE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tune_cache.json")
 _tune: Optional[dict] = None
-_tune_dirty = False
+_tune_new: dict = {}
+
+
+def tune_user_path() -> str:
+    return os.environ.get("MFHIP_TUNE_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "mfhip", "tune_cache.json")
+
+
+def _tune_read(path: str, version: int) -> dict:
+    import json
+    try:
+        with open(path) as f:
+            raw = json.load(f)
+        if not isinstance(raw, dict) or raw.get("_meta", {}).get("tile_table") != version:
+            return {}
+        return {k: tuple(v) for k, v in raw.get("entries", {}).items()}
+    except (OSError, ValueError, TypeError, AttributeError):
+        return {}
 
 
 def _tune_load() -> dict:
     global _tune
     if _tune is None:
-        _tune = {}
-        try:
-            import json
-            with open(_TUNE_PATH) as f:
-                _tune = {k: tuple(v) for k, v in json.load(f).items()}
-        except Exception:
-            _tune = {}
+        version = load().mf_gemm_tile_table_version()
+        _tune = _tune_read(_TUNE_PATH, version)
+        _tune.update(_tune_read(tune_user_path(), version))
     return _tune
 
 
-def tune_save() -> None:
-    global _tune_dirty
-    if _tune is not None and _tune_dirty:
-        import json
-        try:
-            with open(_TUNE_PATH, "w") as f:
-                json.dump({k: list(v) for k, v in sorted(_tune.items())}, f, indent=0)
-            _tune_dirty = False
-        except OSError:
-            pass
+def tune_save(path: Optional[str] = None) -> None:
+    """Persist the winners found by this process (merged over what the user file already holds): written to a temporary
+    file and renamed, so a concurrent reader never sees half a file."""
+    if not _tune_new:
+        return
+    import json
+    import tempfile
+    path = path or tune_user_path()
+    version = load().mf_gemm_tile_table_version()
+    merged = _tune_read(path, version)
+    merged.update(_tune_new)
+    try:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        fd, tmp = tempfile.mkstemp(dir=os.path.dirname(path) or ".", suffix=".tmp")
+        with os.fdopen(fd, "w") as f:
+            json.dump({"_meta": {"tile_table": version}, "entries": {k: list(v) for k, v in sorted(merged.items())}}, f, indent=0)
+        os.replace(tmp, path)
+    except OSError:
+        pass
+
+
+def _tune_forget(ks: str) -> None:
+    _tune_load().pop(ks, None)
+    _tune_new.pop(ks, None)
+
+
+def _tune_key(key: tuple) -> str:
+    return ",".join(str(int(x)) for x in key)
 
 
 def _tuned_config(d: "GemmDesc", key: tuple):
-    global _tune_dirty
     cache = _tune_load()
-    ks = ",".join(str(int(x)) for x in key)
+    ks = _tune_key(key)
     hit = cache.get(ks)
     if hit is not None:
         return hit
@@ -271,11 +304,11 @@ def _tuned_config(d: "GemmDesc", key: tuple):
         if dt < best_t:
             best, best_t = (t, s), dt
     cache[ks] = best
-    _tune_dirty = True
+    _tune_new[ks] = best
     return best
 
 
-def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype: torch.dtype,
+def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_split: int = 0,
               c0: int, lda0: int, batch: int, h_in: int, w_in: int, h_out: int, w_out: int,
               kh: int = 1, kw: int = 1, stride: int = 1, pad_t: int = 0, pad_l: int = 0, upsample: bool = False,
               a1: Optional[torch.Tensor] = None, c1: int = 0, lda1: int = 0,
@@ -287,18 +320,24 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype: to
               alpha: float = 1.0, act: int = ACT_NONE,
               nz: int = 1, zdiv: int = 1, a_zs=(0, 0), w_zs=(0, 0), o_zs=(0, 0),
               splitk: int = 0, tile: int = 0) -> torch.Tensor:
-    """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements."""
+    """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements.  `dtype`: a torch
+    dtype (bf16 / fp32 compute) or an MF_* compute code (the split codes take fp32 a0 and, with w_split=1, a weight
+    from ops.split_pack)."""
     _req_cuda(a0, a1, w, out, bias, temb, res0, res1)
     d = GemmDesc()
-    d.dtype = dt_code(dtype)
+    code = dtype if isinstance(dtype, int) else dt_code(dtype)
+    d.dtype = code
     d.a0, d.a1 = _ptr(a0), _ptr(a1)
     d.c0, d.c1, d.lda0, d.lda1 = c0, c1, lda0, lda1
     d.a_dtype = dt_code(a0.dtype)
     d.batch, d.h_in, d.w_in, d.h_out, d.w_out = batch, h_in, w_in, h_out, w_out
     d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.upsample = kh, kw, stride, pad_t, pad_l, int(upsample)
-    if w.dtype != dtype:
-        raise MfhipError(f"weight dtype {w.dtype} != compute dtype {dtype}")
+    want_w = ({MF_F16X3: torch.float16, MF_BF16X3: torch.bfloat16}[code] if w_split else
+              torch.bfloat16 if code == MF_BF16 else torch.float32)
+    if w.dtype != want_w:
+        raise MfhipError(f"weight dtype {w.dtype} != {want_w} expected by compute code {code} (w_split={w_split})")
     d.w = _ptr(w)
+    d.w_split = w_split
     d.ldw = ldw if ldw is not None else kh * kw * (c0 + c1)
     d.n = n
     d.nz, d.zdiv = nz, zdiv
@@ -320,9 +359,11 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype: to
     ws = scratch("splitk", SPLITK_WS_FLOATS, out.device)
     d.splitk, d.ws, d.ws_floats = splitk, ws.data_ptr(), ws.numel()
     d.tile = tile
+    tkey = None
     if tile == 0 and splitk in (0, 1) and AUTOTUNE:
-        d.tile, d.splitk = _tuned_config(d, (dt_code(dtype), d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh,
-                                             stride, int(upsample), int(c1 > 0), nz, int(splitk == 1), act, h_out, w_out))
+        tkey = (code, d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), int(c1 > 0),
+                nz, int(splitk == 1), act, h_out, w_out) + ((w_split,) if code >= MF_F16X3 else ())
+        d.tile, d.splitk = _tuned_config(d, tkey)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -331,7 +372,13 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype: to
         PROFILE.append((e0, e1, 2.0 * batch * h_out * w_out * n * kh * kw * (c0 + c1) * nz,
                         (batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), nz, d.tile, d.splitk)))
         return out
-    _check(load().mf_gemm_conv(C.byref(d), _stream()), "mf_gemm_conv")
+    rc = load().mf_gemm_conv(C.byref(d), _stream())
+    if rc != 0 and tkey is not None and d.tile != 0:
+        # a cached (tile, split-K) the library no longer accepts for this call: forget it and let the heuristic choose
+        _tune_forget(_tune_key(tkey))
+        d.tile, d.splitk = 0, splitk
+        rc = load().mf_gemm_conv(C.byref(d), _stream())
+    _check(rc, "mf_gemm_conv")
     return out
 
 
@@ -392,6 +439,30 @@ def attention_bf16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torc
                                     C.c_void_p(vt.data_ptr()), C.c_int64(ldvt), C.c_void_p(out.data_ptr()),
                                     C.c_int64(ldo), batch, heads, sq, skv, head_dim, C.c_float(scale), _stream()),
            "mf_attention_bf16")
+    return out
+
+
+def split_halves(x: torch.Tensor):
+    """fp32 tensor -> (hi, lo) fp16 tensors of the same shape with hi + lo = x to 22 bits."""
+    _req_cuda(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise MfhipError("split_halves: contiguous fp32 input")
+    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _check(load().mf_split_halves(C.c_void_p(x.data_ptr()), C.c_void_p(hi.data_ptr()), C.c_void_p(lo.data_ptr()),
+                                  C.c_int64(x.numel()), _stream()), "mf_split_halves")
+    return hi, lo
+
+
+def attention_f16x3(q, k, vt, out: torch.Tensor, *, ldq: int, ldk: int, ldvt: int, ldo: int, batch: int, heads: int,
+                    sq: int, skv: int, head_dim: int, scale: float) -> torch.Tensor:
+    """q / k / vt: (hi, lo) pairs from split_halves; out fp32."""
+    _req_cuda(*q, *k, *vt, out)
+    _check(load().mf_attention_f16x3(C.c_void_p(q[0].data_ptr()), C.c_void_p(q[1].data_ptr()), C.c_int64(ldq),
+                                     C.c_void_p(k[0].data_ptr()), C.c_void_p(k[1].data_ptr()), C.c_int64(ldk),
+                                     C.c_void_p(vt[0].data_ptr()), C.c_void_p(vt[1].data_ptr()), C.c_int64(ldvt),
+                                     C.c_void_p(out.data_ptr()), C.c_int64(ldo), batch, heads, sq, skv, head_dim,
+                                     C.c_float(scale), _stream()), "mf_attention_f16x3")
     return out
 
 

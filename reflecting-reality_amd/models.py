@@ -95,6 +95,7 @@ class HipModel:
         self.device = torch.device(device)
         self._src: Optional[Dict[str, torch.Tensor]] = None   # fp32 master copy (CPU), for save_pretrained
         self._ready = False
+        self._weights_gen = 0       # bumped whenever the device weights are rebuilt (captured hipGraphs key on it)
 
     # -- dtype / device surface the callers touch ----------------------------------------------
     @property
@@ -137,6 +138,7 @@ class HipModel:
                 raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(shp)}")
         self._src = {k: sd[k].detach().to("cpu", F32) for k in shapes if k in sd}
         self._prepare(self._src)
+        self._weights_gen += 1
         self._ready = True
         return self
 
@@ -157,7 +159,9 @@ class HipModel:
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, cls.config_name)) as f:
             config = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
-        prec = precision or (torch_dtype if torch_dtype in (torch.bfloat16, torch.float32) else "bf16")
+        # torch_dtype=None -> the fast mode; torch.float16 (what test_brushnet.py:124 selects by default) raises in
+        # Precision.get instead of being run silently as something else
+        prec = precision or (torch_dtype if torch_dtype is not None else "bf16")
         model = cls(config, precision=prec, device=device)
         model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
         return model
@@ -183,7 +187,9 @@ class HipModel:
 
     # -- helpers shared by the three models -------------------------------------------------------
     def _conv(self, sd, name, prec=None, cin_pad=None) -> ConvWeight:
-        return ConvWeight(sd[name + ".weight"], sd.get(name + ".bias"), prec or self.prec, self.device, cin_pad)
+        # to_v is consumed by ops.linear_t with the weight as the A operand: never pre-split
+        return ConvWeight(sd[name + ".weight"], sd.get(name + ".bias"), prec or self.prec, self.device, cin_pad,
+                          raw=name.endswith(".to_v"))
 
     def _norm(self, sd, name):
         return (sd[name + ".weight"].to(self.device, F32).contiguous(), sd[name + ".bias"].to(self.device, F32).contiguous())
@@ -883,9 +889,9 @@ class DiagonalGaussianDistribution:
     def sample(self, generator: Optional[torch.Generator] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
         b, h, w, _ = self._m.shape
         if noise is None:
-            # the reference draws on the parameter device with the global RNG (vae.py:782-791); draw on the CPU
-            # so results do not depend on the device RNG implementation
-            noise = torch.randn(b, self._c, h, w, generator=generator, dtype=F32)
+            # vae.py:782-791 (randn_tensor): on the generator's device; without one, the host's global RNG
+            from .rng import randn_tensor
+            noise = randn_tensor((b, self._c, h, w), generator, self._m.device)
         return hip.vae_sample(self._m, noise.to(self._m.device), self._c, 1.0)
 
     def mode(self) -> torch.Tensor:

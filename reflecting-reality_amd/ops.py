@@ -1,8 +1,12 @@
 """Layer-level operators of the MirrorFusion hot path on top of the libmfhip C ABI.
 
 Tensors are NHWC ([B, H, W, C]; the same memory as token-major [B, H*W, C]).  ``Precision`` picks the
-compute mode of a whole model: "bf16" (bf16 MFMA operands, fp32 accumulate/statistics — the fast
-path) or "fp32" (fp32 MFMA — the parity path checked at 1e-3 against the fp32 CPU oracle).
+compute mode of a whole model:
+  "bf16"   bf16 MFMA operands and activation storage, fp32 accumulate / statistics — the fast path;
+  "fp32"   fp32 MFMA (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate) — the exact parity path;
+  "f16x3"  fp32 storage, every GEMM operand split into two fp16 halves and multiplied with three fp16 MFMAs
+           (22 significant bits): the parity mode that runs on the fast matrix pipe.  "split" / "parity" are
+           aliases.  "bf16x3" is the same scheme on bf16 halves (16 bits, fp32 exponent range).
 """
 from __future__ import annotations
 
@@ -16,23 +20,37 @@ from . import hip
 
 @dataclass(frozen=True)
 class Precision:
-    name: str                     # "bf16" | "fp32"
-    compute: torch.dtype          # MFMA operand dtype
+    name: str                     # "bf16" | "fp32" | "f16x3" | "bf16x3"
+    compute: torch.dtype          # dtype of the GEMM operands in memory
     act: torch.dtype              # activation storage dtype
+    code: int = -1                # mf_gemm_desc.dtype (MF_BF16 / MF_F32 / MF_F16X3 / MF_BF16X3)
 
     @staticmethod
     def get(name: Union[str, "Precision", torch.dtype]) -> "Precision":
         if isinstance(name, Precision):
             return name
         if name in ("bf16", torch.bfloat16):
-            return Precision("bf16", torch.bfloat16, torch.bfloat16)
+            return Precision("bf16", torch.bfloat16, torch.bfloat16, hip.MF_BF16)
         if name in ("fp32", "f32", torch.float32):
-            return Precision("fp32", torch.float32, torch.float32)
-        raise ValueError(f"unsupported precision {name!r} (use 'bf16' or 'fp32')")
+            return Precision("fp32", torch.float32, torch.float32, hip.MF_F32)
+        if name in ("f16x3", "split", "parity"):
+            return Precision("f16x3", torch.float32, torch.float32, hip.MF_F16X3)
+        if name == "bf16x3":
+            return Precision("bf16x3", torch.float32, torch.float32, hip.MF_BF16X3)
+        if name == torch.float16:
+            # the reference's scripts default to fp16 (examples/brushnet/test_brushnet.py:124); the HIP path has no fp16
+            # storage mode and will not silently substitute another one
+            raise ValueError("torch_dtype=torch.float16 is not built: use torch.bfloat16 (the fast mode), torch.float32 "
+                             "or precision='f16x3' (fp32 storage, fp16 matrix pipe)")
+        raise ValueError(f"unsupported precision {name!r} (use 'bf16', 'fp32', 'f16x3' or 'bf16x3')")
 
     @property
     def vec(self) -> int:         # elements per 16-byte vector: channel counts must be multiples of this
         return 8 if self.compute == torch.bfloat16 else 4
+
+    @property
+    def split(self) -> bool:
+        return self.code in (hip.MF_F16X3, hip.MF_BF16X3)
 
 
 def _round_up(x: int, m: int) -> int:
@@ -43,7 +61,7 @@ class ConvWeight:
     """Conv2d / Linear parameters re-laid-out once for the implicit-GEMM kernel: [N][kh][kw][Cin_pad]."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], prec: Precision, device,
-                 cin_pad: Optional[int] = None):
+                 cin_pad: Optional[int] = None, raw: bool = False):
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
         n, cin, kh, kw = weight.shape
@@ -51,10 +69,32 @@ class ConvWeight:
         w = weight.detach().to(device=device, dtype=torch.float32).permute(0, 2, 3, 1)   # [N, kh, kw, Cin]
         if cp != cin:
             w = torch.nn.functional.pad(w, (0, cp - cin))
-        self.w = w.reshape(n, kh * kw * cp).to(prec.compute).contiguous()
+        w = w.reshape(n, kh * kw * cp)
+        self.w_split, self.ldw = 0, kh * kw * cp
+        if prec.split and not raw:
+            # split ahead of time: per block of 32 k, [32 high halves | 32 low halves] (the same 128 bytes as 32
+            # floats); rows zero-padded to whole blocks.  `raw` keeps fp32 (the weight is the A operand: linear_t)
+            self.w, self.ldw = split_pack(w, prec.code)
+            self.w_split = 1
+        else:
+            self.w = w.to(prec.compute).contiguous()
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.n, self.cin, self.cin_pad, self.kh, self.kw = n, cin, cp, kh, kw
         self.prec = prec
+
+
+def split_pack(w: torch.Tensor, code: int):
+    """fp32 [N, K] -> (packed 16-bit tensor [N, 2*Kp], Kp) in mf_gemm_desc's w_split layout: hi = round(w) to the
+    16-bit type, lo = round(w - hi); per block of 32 k the 32 hi values precede the 32 lo values."""
+    n, k = w.shape
+    kp = _round_up(k, 32)
+    if kp != k:
+        w = torch.nn.functional.pad(w, (0, kp - k))
+    half = torch.float16 if code == hip.MF_F16X3 else torch.bfloat16
+    hi = w.to(half)
+    lo = (w - hi.float()).to(half)
+    packed = torch.cat([hi.view(n, kp // 32, 32), lo.view(n, kp // 32, 32)], dim=2).reshape(n, 2 * kp).contiguous()
+    return packed, kp
 
 
 def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
@@ -76,7 +116,7 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
     ho = (hu + pt + pb - cw.kh) // stride + 1
     wo = (wu + pl + pr - cw.kw) // stride + 1
     out = torch.empty(b, ho, wo, cw.n, dtype=out_dtype or cw.prec.act, device=x.device)
-    hip.gemm_conv(x, cw.w, out, dtype=cw.prec.compute, c0=c0, lda0=c0, a1=x1, c1=c1, lda1=c1,
+    hip.gemm_conv(x, cw.w, out, dtype=cw.prec.code, w_split=cw.w_split, ldw=cw.ldw, c0=c0, lda0=c0, a1=x1, c1=c1, lda1=c1,
                   batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, kh=cw.kh, kw=cw.kw, stride=stride,
                   pad_t=pt, pad_l=pl, upsample=upsample, n=cw.n, bias=cw.bias,
                   temb=temb, ld_temb=(temb.stride(0) if temb is not None else 0),
@@ -95,8 +135,8 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
     m = x.numel() // k
     if out is None:
         out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
-    hip.gemm_conv(x, lw.w, out, dtype=lw.prec.compute, c0=k, lda0=k, batch=m, h_in=1, w_in=1, h_out=1, w_out=1,
-                  n=lw.n, bias=lw.bias, res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
+    hip.gemm_conv(x, lw.w, out, dtype=lw.prec.code, w_split=lw.w_split, ldw=lw.ldw, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
+                  h_out=1, w_out=1, n=lw.n, bias=lw.bias, res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
     return out
 
 
@@ -116,8 +156,8 @@ def linear_geglu(x: torch.Tensor, lw: ConvWeight, tile: int = 0) -> torch.Tensor
     m = x.numel() // k
     inner = lw.n // 2
     out = torch.empty(*x.shape[:-1], inner, dtype=lw.prec.act, device=x.device)
-    hip.gemm_conv(x, lw.w, out, dtype=lw.prec.compute, c0=k, lda0=k, batch=m, h_in=1, w_in=1, h_out=1, w_out=1,
-                  n=lw.n, ldc=inner, bias=lw.bias, act=hip.ACT_GEGLU4, splitk=1, tile=tile)
+    hip.gemm_conv(x, lw.w, out, dtype=lw.prec.code, w_split=lw.w_split, ldw=lw.ldw, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
+                  h_out=1, w_out=1, n=lw.n, ldc=inner, bias=lw.bias, act=hip.ACT_GEGLU4, splitk=1, tile=tile)
     return out
 
 
@@ -129,9 +169,11 @@ def linear_t(x: torch.Tensor, lw: ConvWeight, ld_out: int, out: Optional[torch.T
     x: [B, S, K]; returns [B, n, ld_out] with columns [S, ld_out) left untouched (callers zero them once).
     """
     b, s, k = x.shape
+    if lw.w_split:
+        raise hip.MfhipError("linear_t: the weight is the A operand here, build it with ConvWeight(..., raw=True)")
     if out is None:
         out = torch.zeros(b, lw.n, ld_out, dtype=lw.prec.act, device=x.device)
-    hip.gemm_conv(lw.w, x, out, dtype=lw.prec.compute, c0=k, lda0=k, batch=lw.n, h_in=1, w_in=1, h_out=1, w_out=1,
+    hip.gemm_conv(lw.w, x, out, dtype=lw.prec.code, c0=k, lda0=k, batch=lw.n, h_in=1, w_in=1, h_out=1, w_out=1,
                   ldw=k, n=s, ldc=ld_out, bias=lw.bias, bias_mode=1, nz=b, zdiv=1,
                   a_zs=(0, 0), w_zs=(s * k, 0), o_zs=(lw.n * ld_out, 0))
     return out
@@ -148,18 +190,19 @@ def attention_unfused(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads:
     d = c // heads
     ldv = vt.shape[-1]
     scores = torch.empty(b * heads, sq, ldv, dtype=torch.float32, device=q.device)
-    hip.gemm_conv(q, k, scores, dtype=prec.compute, c0=d, lda0=c, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1,
+    hip.gemm_conv(q, k, scores, dtype=prec.code, c0=d, lda0=c, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1,
                   ldw=c, n=skv, ldc=ldv, alpha=scale, nz=b * heads, zdiv=heads,
                   a_zs=(sq * c, d), w_zs=(k.shape[1] * c, d), o_zs=(heads * sq * ldv, sq * ldv), splitk=1)
     p = hip.softmax_rows(scores, skv, prec.act)
     out = torch.empty(b, sq, c, dtype=prec.act, device=q.device)
-    hip.gemm_conv(p, vt, out, dtype=prec.compute, c0=ldv, lda0=ldv, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1,
+    hip.gemm_conv(p, vt, out, dtype=prec.code, c0=ldv, lda0=ldv, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1,
                   ldw=ldv, n=d, ldc=c, nz=b * heads, zdiv=heads,
                   a_zs=(heads * sq * ldv, sq * ldv), w_zs=(c * ldv, d * ldv), o_zs=(sq * c, d), splitk=1)
     return out
 
 
 FLASH_HEAD_DIMS = (8, 40, 64, 80, 160)
+FLASH_SPLIT_HEAD_DIMS = (8, 40, 64, 80)          # 160 (two split K / V^T planes, double buffered) does not fit in LDS
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, skv: int, scale: float,
@@ -172,6 +215,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sk
         out = torch.empty(b, sq, c, dtype=torch.bfloat16, device=q.device)
         return hip.attention_bf16(q, k, vt, out, ldq=q.stride(1), ldk=k.stride(1), ldvt=vt.shape[-1], ldo=c, batch=b,
                                   heads=heads, sq=sq, skv=skv, head_dim=d, scale=scale)
+    if prec.code == hip.MF_F16X3 and d in FLASH_SPLIT_HEAD_DIMS and vt.shape[-1] % 8 == 0:
+        # the parity mode runs the same flash kernel: operands as (hi, lo) fp16 planes, fp32 output.  q and k may be
+        # column slices of one fused projection: split the parent once and slice the planes
+        if q.stride(1) != c and q.storage_offset() + c == k.storage_offset() and q.stride(1) == k.stride(1) == 2 * c:
+            qk = q.as_strided((b, sq, 2 * c), (sq * 2 * c, 2 * c, 1), q.storage_offset())
+            ph, pl = hip.split_halves(qk)
+            qs, ks = (ph[..., :c], pl[..., :c]), (ph[..., c:], pl[..., c:])
+        else:
+            qs, ks = hip.split_halves(q.contiguous()), hip.split_halves(k.contiguous())
+        vs = hip.split_halves(vt)
+        out = torch.empty(b, sq, c, dtype=torch.float32, device=q.device)
+        return hip.attention_f16x3(qs, ks, vs, out, ldq=qs[0].stride(1), ldk=ks[0].stride(1), ldvt=vt.shape[-1], ldo=c,
+                                   batch=b, heads=heads, sq=sq, skv=skv, head_dim=d, scale=scale)
     if q.stride(1) != c or k.stride(1) != c:
         q, k = q.contiguous(), k.contiguous()
     return attention_unfused(q, k, vt, heads, skv, scale, prec)

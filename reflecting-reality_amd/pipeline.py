@@ -24,6 +24,7 @@ import torch
 
 from . import hip
 from .models import AutoencoderKL, BrushNetModel, UNet2DConditionModel
+from .rng import randn_tensor
 from .schedulers import DDIMScheduler
 
 try:
@@ -316,12 +317,9 @@ class StableDiffusionBrushNetPipeline:
         shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
-                             f"effective batch size of {batch_size}.")
+                             f"effective batch size of {batch_size}. Make sure the batch size matches the length of the generators.")
         if latents is None:
-            if isinstance(generator, list):
-                noise = torch.cat([torch.randn((1,) + shape[1:], generator=g, dtype=torch.float32) for g in generator])
-            else:
-                noise = torch.randn(shape, generator=generator, dtype=torch.float32)   # host draw: device-independent
+            noise = randn_tensor(shape, generator, self.device)      # on the generator's device, like randn_tensor
         else:
             noise = latents
         noise = noise.to(self.device, torch.float32)
@@ -532,10 +530,12 @@ class StableDiffusionBrushNetPipeline:
         else:
             coefs, clip, ptype = None, 0.0, type(sched).__name__
         # The captured graph (and every buffer it reads) is kept across calls with the same shapes and scalars:
-        # new inputs are copied INTO the static buffers, so repeated calls pay no capture / instantiate cost.
+        # new inputs are copied INTO the static buffers, so repeated calls pay no capture / instantiate cost.  The key
+        # carries each model's weights generation: load_state_dict / .to() rebuild every weight tensor (and the UNet's
+        # cross-attention K/V cache), so a graph captured before that points at freed buffers and must not be replayed.
         added = self._added_cond
         key = (tuple(latents.shape), tuple(pe.shape), tuple(cond.shape), float(guidance_scale), cond_scale, ptype, clip,
-               str(dev), id(self.unet), id(self.brushnet),
+               str(dev), id(self.unet), self.unet._weights_gen, id(self.brushnet), self.brushnet._weights_gen,
                tuple((k, tuple(v.shape)) for k, v in sorted(added.items())) if added else None)
         st = self._graph_state if self._graph_state is not None and self._graph_state["key"] == key else None
         if st is None:

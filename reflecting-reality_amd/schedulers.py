@@ -212,7 +212,8 @@ class DDIMScheduler(_SchedulerBase):
                                      pred_type=ptype, clip=clip)
         if eta > 0:
             if variance_noise is None:
-                variance_noise = torch.randn(model_output.shape, generator=generator, dtype=torch.float32)
+                from .rng import randn_tensor
+                variance_noise = randn_tensor(model_output.shape, generator, prev.device)   # scheduling_ddim.py:455-458
             prev = hip.axpby_n([prev, variance_noise.to(prev.device).float().contiguous()], [1.0, std])
         if not return_dict:
             return (prev,)

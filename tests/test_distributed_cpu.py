@@ -51,3 +51,30 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert res[0]["mine"] == [0, 1, 2, 3, 4] and res[1]["mine"] == [5, 6, 7, 8]      # contiguous, extra item to rank 0
     assert res[0]["total"] == res[1]["total"] == 9
     assert abs(res[0]["dt"] - res[1]["dt"]) < 1e-9 and res[0]["dt"] >= 0.1             # both report the slow rank's time
+
+
+def test_bench_self_launch_two_ranks_stub():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment starts its two ranks itself (child processes, before
+    anything touches a GPU) and rank 0 prints one JSON line with n_gpus = 2; the time is the slowest rank's."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for attempt in range(3):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                              "--batch", "4", "--stub"], capture_output=True, text=True, timeout=300, env=env)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    # rank 1 sleeps 40 ms per pass: 3 passes >= 120 ms, and value = images of BOTH ranks / that time
+    assert rec["ms_per_step"] >= 40.0
+    assert abs(rec["value"] - 4 * 3 * 2 / (rec["ms_per_step"] * 3e-3)) < 0.05 * rec["value"]
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], capture_output=True,
+                         text=True, timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (out.stderr + out.stdout)

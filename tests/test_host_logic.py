@@ -229,3 +229,72 @@ def test_pipeline_save_and_from_pretrained_roundtrip(tmp_path):
         StableDiffusionBrushNetPipeline.from_pretrained(str(tmp_path), device="cpu")
     with pytest.raises(NotImplementedError):
         unet.train()
+
+
+def test_split_pack_layout_and_precision():
+    """ops.split_pack: per block of 32 k the row holds [32 hi | 32 lo] 16-bit values, rows zero-padded to whole blocks;
+    hi + lo reproduces the fp32 weight to 22 (fp16 halves) / 16 (bf16 halves) bits."""
+    from reflecting_reality_amd import hip, ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(5, 72, generator=g) * 0.05
+    for code, half, bits in ((hip.MF_F16X3, torch.float16, 21), (hip.MF_BF16X3, torch.bfloat16, 15)):
+        packed, kp = ops.split_pack(w, code)
+        assert kp == 96 and packed.shape == (5, 192) and packed.dtype == half
+        blocks = packed.view(5, 3, 2, 32).float()
+        rec = (blocks[:, :, 0] + blocks[:, :, 1]).reshape(5, 96)
+        assert float(rec[:, 72:].abs().max()) == 0.0                          # zero padding
+        assert float((rec[:, :72] - w).abs().max()) <= float(w.abs().max()) * 2.0 ** -bits
+        assert torch.equal(blocks[:, :, 0].reshape(5, 96)[:, :72], w.to(half).float())
+    cw = ops.ConvWeight(w[:, :64].reshape(5, 64, 1, 1).contiguous(), None, ops.Precision.get("f16x3"), "cpu")
+    assert cw.w_split == 1 and cw.ldw == 64 and cw.w.shape == (5, 128)
+    raw = ops.ConvWeight(w[:, :64].contiguous(), None, ops.Precision.get("f16x3"), "cpu", raw=True)
+    assert raw.w_split == 0 and raw.w.dtype == torch.float32
+
+
+def test_precision_names_and_fp16_is_refused():
+    """torch_dtype=torch.float16 (the default of examples/brushnet/test_brushnet.py:124) must not silently run as another
+    precision."""
+    from reflecting_reality_amd import hip, ops
+    assert ops.Precision.get(torch.bfloat16).code == hip.MF_BF16 and ops.Precision.get("fp32").code == hip.MF_F32
+    for alias in ("f16x3", "split", "parity"):
+        p = ops.Precision.get(alias)
+        assert p.split and p.code == hip.MF_F16X3 and p.act == torch.float32 and p.vec == 4
+    with pytest.raises(ValueError, match="float16"):
+        ops.Precision.get(torch.float16)
+    with pytest.raises(ValueError, match="float16"):
+        UNet2DConditionModel(dict(configs.TINY_UNET), precision=torch.float16, device="cpu")
+
+
+def test_randn_tensor_follows_the_generator_device():
+    """utils/torch_utils.py randn_tensor semantics: CPU generator -> host draw; list -> one draw per sample."""
+    from reflecting_reality_amd.rng import randn_tensor
+    a = randn_tensor((2, 4, 8, 8), torch.Generator().manual_seed(5))
+    assert torch.equal(a, torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(5)))
+    gs = [torch.Generator().manual_seed(s) for s in (1, 2)]
+    b = randn_tensor((2, 4, 8, 8), gs)
+    assert torch.equal(b[1], torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(2))[0])
+    with pytest.raises(ValueError, match="list of generators"):
+        randn_tensor((3, 4, 8, 8), gs)
+
+
+def test_tune_cache_versioning_and_atomic_save(tmp_path, monkeypatch):
+    from reflecting_reality_amd import hip
+    ver = hip.load().mf_gemm_tile_table_version()
+    path = tmp_path / "sub" / "tune.json"
+    monkeypatch.setenv("MFHIP_TUNE_CACHE", str(path))
+    monkeypatch.setattr(hip, "_tune", None)
+    monkeypatch.setattr(hip, "_tune_new", {})
+    shipped = hip._tune_read(hip._TUNE_PATH, ver)
+    assert len(shipped) > 100, "the shipped cache must be readable under the library's tile-table version"
+    assert hip._tune_read(hip._TUNE_PATH, ver + 1) == {}                 # another numbering: dropped, not trusted
+    hip._tune_load()
+    hip._tune_new["1,1,64,64,64,1,1,0,0,1,0,0,1,1"] = (3, 1)
+    hip.tune_save()
+    with open(path) as f:
+        saved = json.load(f)
+    assert saved["_meta"] == {"tile_table": ver} and saved["entries"] == {"1,1,64,64,64,1,1,0,0,1,0,0,1,1": [3, 1]}
+    assert [p.name for p in path.parent.iterdir()] == ["tune.json"]        # no temp file left behind
+    path.write_text("{ truncated")                                          # a corrupt user file is ignored
+    assert hip._tune_read(str(path), ver) == {}
+    hip._tune_forget("1,1,64,64,64,1,1,0,0,1,0,0,1,1")
+    assert "1,1,64,64,64,1,1,0,0,1,0,0,1,1" not in hip._tune_new

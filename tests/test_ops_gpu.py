@@ -38,13 +38,19 @@ def check(name, got, ref, atol, rtol):
     assert bad == 0, f"{name}: {bad} elements out of tolerance, max err {err.max().item():.3e}"
 
 
-PRECS = [("fp32", 2e-4, 2e-4), ("bf16", 2e-2, 1e-2)]
+PRECS = [("fp32", 2e-4, 2e-4), ("f16x3", 2e-4, 2e-4), ("bf16", 2e-2, 1e-2)]
+SPLIT_TILES = (0, 1, 2, 3, 6, 7, 14)          # tiles instantiated for the split codes with a pre-split weight
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
 @pytest.mark.parametrize("tile", list(range(16)))
 def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     prec = ops.Precision.get(prec_name)
+    if prec.split and tile not in SPLIT_TILES:
+        x = torch.zeros(1, 8, 8, 32, device=DEV)
+        with pytest.raises(hip.MfhipError, match="not instantiated"):     # refused, never rerouted
+            ops.conv2d(x, ops.ConvWeight(torch.zeros(8, 32, 3, 3), None, prec, DEV), tile=tile)
+        return
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 40, 20, 12, generator=g)       # M = 480 (tails on every tile), Cin = 40
     w = torch.randn(72, 40, 3, 3, generator=g) * 0.05  # N = 72 (tail)
@@ -203,7 +209,7 @@ def test_linear_t(prec_name, atol, rtol):
     if prec_name == "bf16":
         x, w = rb(x), rb(w)
     ref = F.linear(x, w, b).transpose(1, 2)             # [3, 64, 77]
-    lw = ops.ConvWeight(w, b, prec, DEV)
+    lw = ops.ConvWeight(w, b, prec, DEV, raw=True)      # the weight is the A operand: never pre-split
     vt = ops.linear_t(x.to(DEV, prec.act), lw, 80)
     assert vt.shape == (3, 64, 80)
     check(f"linear_t[{prec_name}]", vt[:, :, :77], ref, atol, rtol)
@@ -227,7 +233,7 @@ def make_vt(v, ld, dtype):
     return vt
 
 
-@pytest.mark.parametrize("prec_name,atol,rtol", [("fp32", 2e-4, 2e-4), ("bf16", 2e-2, 2e-2)])
+@pytest.mark.parametrize("prec_name,atol,rtol", [("fp32", 2e-4, 2e-4), ("f16x3", 2e-4, 2e-4), ("bf16x3", 1e-3, 1e-3), ("bf16", 2e-2, 2e-2)])
 @pytest.mark.parametrize("heads,d,sq,skv", [(2, 40, 200, 200), (2, 8, 64, 77), (1, 512, 96, 96)])
 def test_attention_unfused(prec_name, atol, rtol, heads, d, sq, skv):
     prec = ops.Precision.get(prec_name)

@@ -10,7 +10,7 @@ from oracle import mirrorfusion_ref as R  # noqa: E402
 from reflecting_reality_amd import (DDIMScheduler, PNDMScheduler, StableDiffusionBrushNetPipeline,  # noqa: E402
                                     UniPCMultistepScheduler, synth)  # noqa: E402
 from test_models_gpu import build  # noqa: E402
-from util import golden, keys, report, strided_sample  # noqa: E402
+from util import check, golden, keys, report, report_env, strided_sample  # noqa: E402
 
 DEV = "cuda"
 SD_SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
@@ -103,11 +103,14 @@ def test_scheduler_traces(name, cls, extra, n):
     assert worst < 2e-5   # the stand-in model sin(3x + 0.01t) amplifies fp32 rounding between sinf implementations
 
 
-# fp32 mode: BASELINE.json's bound (latent L-inf <= 1e-3).  bf16 mode: bf16 MFMA operands put ~1e-2 absolute error
-# on each eps branch; guidance 7.5 multiplies the (cond - uncond) error by 7.5 and the 4-step schedule divides by
-# sqrt(alpha_t) ~ 0.2, so individual latents can be off by O(1) on this random-weight net; the test bounds the mean
-# error and reports the max (DESIGN.md "Precision modes").
-@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", None)])
+# fp32 and f16x3 modes: BASELINE.json's bound (latent L-inf <= 1e-3) on every step.  bf16 mode: bf16 operands put ~1e-2
+# absolute error on each eps branch, guidance 7.5 multiplies the (cond - uncond) error and the 4-step schedule divides
+# by sqrt(alpha_t) ~ 0.2 — the REFERENCE run in bf16 moves its own latents by 0.5 ... 2.6 on these cases
+# (tests/golden/bf16_envelope.json); the HIP bf16 path is asserted to stay inside util.ENV_K_* times that, per step.
+PREC_TOL = [("fp32", 1e-3), ("f16x3", 1e-3), ("bf16", None)]
+
+
+@pytest.mark.parametrize("prec,tol", PREC_TOL)
 @pytest.mark.parametrize("name", ["ddim", "pndm", "unipc"])
 def test_tiny_pipeline_per_step(prec, tol, name):
     """4-step tiny pipeline, CFG 7.5: conditioning latents, per-step latents and final image vs the reference."""
@@ -124,7 +127,7 @@ def test_tiny_pipeline_per_step(prec, tol, name):
     inp = synth.pipeline_inputs(1, 16, 16, seed=1234, cross_dim=32, vae_scale=2)
     noise = torch.from_numpy(G[f"{name}_vae_noise"])
     cond = pipe.build_conditioning(inp["image"], inp["mask"], inp["depth"], 16, 16, 1, 1, True, noise)
-    report(f"conditioning[{prec}]", cond, G[f"{name}_cond"], atol=2e-4 if prec == "fp32" else 5e-2)
+    check(f"conditioning[{prec}]", cond, G[f"{name}_cond"], prec, dict(atol=2e-4), f"tiny_pipeline/{name}/cond")
     trace = []
     res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
                image=inp["image"], mask=inp["mask"], depth=inp["depth"], num_inference_steps=4, guidance_scale=7.5,
@@ -136,13 +139,11 @@ def test_tiny_pipeline_per_step(prec, tol, name):
     assert len(trace) == nsteps
     for i in range(nsteps):
         ref = torch.from_numpy(G[f"{name}_latents_{i}"])
-        report(f"{name} latents step {i}[{prec}]", trace[i], ref, atol=tol or 0.0, fail=tol is not None)
-        if tol is None:
-            assert float((trace[i].cpu() - ref).abs().mean()) < 0.15 * float(ref.abs().mean())
-    report(f"{name} image[{prec}]", res.images, G[f"{name}_image"], atol=tol or 0.0, fail=tol is not None)
+        check(f"{name} latents step {i}[{prec}]", trace[i], ref, prec, dict(atol=tol), f"tiny_pipeline/{name}/latents_{i}")
+    check(f"{name} image[{prec}]", res.images, G[f"{name}_image"], prec, dict(atol=tol), f"tiny_pipeline/{name}/image")
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", None)])
+@pytest.mark.parametrize("prec,tol", PREC_TOL)
 def test_alt_conditioning_modes(prec, tol):
     """depth VAE-encoded ('latents') + normals nearest-resized ('concat'): 12-channel BrushNet condition, 2 DDIM steps."""
     from reflecting_reality_amd import models as M
@@ -161,14 +162,12 @@ def test_alt_conditioning_modes(prec, tol):
     noise = [torch.from_numpy(G["alt_vae_noise"]), torch.from_numpy(G["alt_depth_noise"])]
     cond = pipe.build_conditioning(inp["image"], inp["mask"], inp["depth"], 16, 16, 1, 1, True, noise, normals)
     assert tuple(cond.shape) == (2, 12, 8, 8)
-    report(f"alt conditioning[{prec}]", cond, G["alt_cond"], atol=2e-4 if prec == "fp32" else 5e-2)
+    check(f"alt conditioning[{prec}]", cond, G["alt_cond"], prec, dict(atol=2e-4), "tiny_pipeline/alt/cond")
     lat = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"],
                image=inp["image"], mask=inp["mask"], depth=inp["depth"], normals=normals, num_inference_steps=2,
                guidance_scale=7.5, latents=inp["latents"].clone(), output_type="latent", brushnet_conditioning_scale=1.0,
                height=16, width=16, conditioning_noise=noise).images
-    err = report(f"alt 2-step latents[{prec}]", lat, G["alt_latents"], atol=tol or 1e9, fail=tol is not None)
-    if tol is None:
-        assert float((lat.float().cpu() - torch.from_numpy(G["alt_latents"])).abs().mean()) < 0.5, err
+    check(f"alt 2-step latents[{prec}]", lat, G["alt_latents"], prec, dict(atol=tol), "tiny_pipeline/alt/latents")
     with pytest.raises(ValueError):          # the mode needs its input
         pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
              mask=inp["mask"], depth=inp["depth"], num_inference_steps=2, height=16, width=16)
@@ -277,12 +276,12 @@ def test_pipeline_variants_against_oracle(case):
     report(f"variant {case}", got, lat, atol=1e-3)
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("bf16", None)])
+@pytest.mark.parametrize("prec,tol", PREC_TOL)
 def test_baseline_config0_full_size_pipeline(prec, tol):
     """BASELINE.json configs[0]: full-size SD1.5 + BrushNet, 1 x 256 x 256, 4 DDIM steps, CFG 7.5 through
     StableDiffusionBrushNetPipeline.__call__, against the per-step latents and the image the REFERENCE pipeline
-    produced for the same seeded inputs (tests/golden/sd15_config0.npz).  fp32 mode: the north-star bar, 1e-3 latent
-    L-inf after every step; bf16 mode is reported and held to a loose bound (no NaN, same image within 0.1)."""
+    produced for the same seeded inputs (tests/golden/sd15_config0.npz).  fp32 and f16x3 modes: the north-star bar, 1e-3
+    latent L-inf after every step; bf16 mode: inside the reference's own bf16 envelope on this very case, per step."""
     unet, bn, vae = build("sd15", prec)
     G = golden("sd15_config0.npz")
     pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
@@ -304,12 +303,11 @@ def test_baseline_config0_full_size_pipeline(prec, tol):
     assert pipe.scheduler.timesteps.tolist() == G["timesteps"].tolist() == [751, 501, 251, 1]
     assert len(trace) == 4
     for i, l in enumerate(trace):
-        err = report(f"config0 latents after step {i} [{prec}]", l, G[f"latents_{i}"], atol=tol if tol else 1e9, fail=tol is not None)
-        assert err == err                                     # not NaN
+        check(f"config0 latents after step {i} [{prec}]", l, G[f"latents_{i}"], prec, dict(atol=tol), f"sd15_config0/latents_{i}")
     st = G["image_stats"]
     img = res.images
     assert tuple(img.shape) == (1, 3, 256, 256)
-    report(f"config0 image [{prec}]", strided_sample(img, st[2], 1024), G["image_sample"], atol=2e-3 if prec == "fp32" else 0.1)
+    check(f"config0 image [{prec}]", strided_sample(img, st[2], 1024), G["image_sample"], prec, dict(atol=2e-3), "sd15_config0/image")
 
 
 def test_full_size_batch_shard_equivalence_and_determinism():
@@ -339,3 +337,66 @@ def test_full_size_batch_shard_equivalence_and_determinism():
     assert torch.equal(full, again), "two identical calls must be bit-identical"
     for sl in (slice(0, 2), slice(2, 4)):
         report(f"shard {sl.start}:{sl.stop} vs batch of 4", run(sl), full[sl].cpu(), atol=1e-3)
+
+
+def test_graph_is_recaptured_after_weights_reload():
+    """load_state_dict rebuilds every weight tensor (and the UNet's K/V cache): the cached hipGraph of the previous
+    weights must not be replayed (its kernels would read freed buffers).  The graph key carries a weights generation."""
+    from reflecting_reality_amd import models as M
+    unet, bn, vae = build("tiny", "fp32")
+    bn2 = M.BrushNetModel(dict(R.brushnet_config(R.TINY_UNET, 6)), precision="fp32", device=DEV)
+    sd_a = synth.state_dict_for(keys("tiny")["brushnet"], 1)
+    sd_b = synth.state_dict_for(keys("tiny")["brushnet"], 5)
+    bn2.load_state_dict(sd_a)
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn2,
+                                           scheduler=DDIMScheduler(**SD_SCHED, clip_sample=False), safety_checker=None,
+                                           feature_extractor=None, requires_safety_checker=False,
+                                           depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(1, 16, 16, seed=31, cross_dim=32, vae_scale=2)
+    noise = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(9))
+    a = _run(pipe, inp, 5, 16, 16, noise)
+    gen0 = bn2._weights_gen
+    bn2.load_state_dict(sd_b)                            # e.g. the next checkpoint evaluated through the same pipeline
+    assert bn2._weights_gen == gen0 + 1
+    b = _run(pipe, inp, 5, 16, 16, noise)
+    pipe.use_hip_graph, pipe._graph_state = False, None
+    b_eager = _run(pipe, inp, 5, 16, 16, noise)
+    assert torch.equal(b, b_eager), "the graph of the old weights was replayed after load_state_dict"
+    assert not torch.equal(a, b)
+
+
+def test_cuda_generator_draws_on_the_device():
+    """examples/brushnet/test_brushnet.py:166 passes torch.Generator('cuda'): the initial latents are drawn on that
+    device (randn_tensor), not on the host."""
+    pipe = _tiny_pipe()
+    inp = synth.pipeline_inputs(2, 16, 16, seed=41, cross_dim=32, vae_scale=2)
+    noise = torch.randn(4, 4, 8, 8, generator=torch.Generator().manual_seed(2))
+    want = torch.randn(2, 4, 8, 8, generator=torch.Generator(DEV).manual_seed(123), device=DEV)
+    a = _run(pipe, inp, 3, 16, 16, noise, latents=None, generator=torch.Generator(DEV).manual_seed(123))
+    b = _run(pipe, inp, 3, 16, 16, noise, latents=want.cpu())
+    assert torch.equal(a, b)
+    # DDIM with eta > 0 draws its variance noise the same way
+    c = _run(pipe, inp, 3, 16, 16, noise, latents=want.cpu(), eta=0.5, generator=torch.Generator(DEV).manual_seed(7))
+    assert torch.isfinite(c).all() and not torch.equal(c, b)
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py --gpus 2 started as a plain command launches its own two ranks (here sharing the one device, gloo for
+    the barrier / max-over-ranks) and prints ONE JSON line with n_gpus = 2 and the images of both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MF_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--batch", "1", "--size", "256", "--denoise-steps", "3", "--no-cpu-baseline", "--no-profile"],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["steps"] == 1
+    assert abs(rec["value"] - 2 / (rec["ms_per_step"] * 1e-3)) < 0.02 * rec["value"]

@@ -39,8 +39,8 @@ def main():
     from reflecting_reality_amd import hip
     hip.tune_save()
     import shutil
-    if os.path.exists(hip._TUNE_PATH) and os.path.isdir("gpurun_out"):
-        shutil.copy(hip._TUNE_PATH, "gpurun_out/tune_cache.json")
+    if os.path.isdir("gpurun_out"):
+        hip.tune_save("gpurun_out/tune_cache_new.json")
     if a.vae:
         z = pipe.vae.decode(inp["latents"].to(dev), return_dict=False)[0]
         pipe.vae._moments(inp["image"])
