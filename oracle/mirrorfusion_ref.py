@@ -704,3 +704,45 @@ def training_loss(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, sched_cf
     loss = F.mse_loss(pred.float(), target.float(), reduction="none")
     loss = loss.mean(dim=list(range(1, len(loss.shape)))) * w
     return loss.mean(), pred
+
+
+# ---------------------------------------------------------------------------------------------
+# training step, backward half: autograd through the restatement above + clip + AdamW
+# (examples/brushnet/train_brushnet_mirror.py:1188-1200 optimizer, :1459-1466 backward / clip / step)
+# ---------------------------------------------------------------------------------------------
+def adamw_update(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
+                 betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+    """torch.optim.AdamW's single-tensor update (decoupled weight decay, bias correction, no amsgrad), in place."""
+    b1, b2 = betas
+    p.mul_(1.0 - lr * weight_decay)
+    m.mul_(b1).add_(g, alpha=1.0 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+    bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def training_steps(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, sched_cfg: dict, batches, lr: float = 1e-5,
+                   max_grad_norm: float = 1.0, snr_gamma: Optional[float] = None, train_unet: bool = False,
+                   betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+    """One optimizer step per batch (latents, noise, timesteps, ehs, cond): loss -> backward -> clip_grad_norm_(1.0) ->
+    AdamW, on copies of the state dicts.  Returns (new_bn_sd, new_unet_sd, records) where records[i] holds the loss,
+    the pre-clip gradient norm and the gradients of step i."""
+    bn = {k: v.clone().requires_grad_(True) for k, v in bn_sd.items()}
+    un = {k: v.clone().requires_grad_(train_unet) for k, v in unet_sd.items()}
+    params = list(bn.items()) + ([("unet." + k, v) for k, v in un.items()] if train_unet else [])
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in params}
+    records = []
+    for step, (latents, noise, timesteps, ehs, cond) in enumerate(batches, 1):
+        for _, v in params:
+            v.grad = None
+        loss, _ = training_loss(un, unet_cfg, bn, bn_cfg, sched_cfg, latents, noise, timesteps, ehs, cond, snr_gamma)
+        loss.backward()
+        grads = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v)) for k, v in params}
+        total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()      # clip_grad_norm_ (:1463)
+        coef = torch.clamp(max_grad_norm / (total + 1e-6), max=1.0)
+        with torch.no_grad():
+            for k, v in params:
+                adamw_update(v, grads[k] * coef, state[k][0], state[k][1], step, lr, betas, eps, weight_decay)
+        records.append(dict(loss=float(loss.detach()), grad_norm=float(total), grads=grads))
+    return ({k: v.detach() for k, v in bn.items()}, {k: v.detach() for k, v in un.items()}, records)

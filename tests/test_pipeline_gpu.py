@@ -400,3 +400,34 @@ def test_bench_two_ranks_on_one_device():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["steps"] == 1
     assert abs(rec["value"] - 2 / (rec["ms_per_step"] * 1e-3)) < 0.02 * rec["value"]
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-3), ("bf16", None)])
+def test_baseline_config1_batch4_512_against_reference(prec, tol):
+    """BASELINE.json configs[1] sizes — batch 4 x 512 x 512, the tile choices the autotuner makes at M = 32768 — through
+    the whole pipeline incl. the VAE decode at 64 x 64 latents (4096-token single-head d = 512 attention), against what
+    the REFERENCE pipeline produced for image 0 of the same inputs (tests/golden/sd15_config1_slice.npz: per-step
+    latents of 3 DDIM steps and the decoded image).  f16x3 (the timed parity mode): 1e-3; bf16 (the timed fast mode):
+    inside the reference's own bf16 envelope for this very case.  fp32 MFMA is covered at these sizes by
+    test_full_size_batch_shard_equivalence_and_determinism (shards equal the batch) + configs[0]."""
+    unet, bn, vae = build("sd15", prec)
+    G = golden("sd15_config1_slice.npz")
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                           scheduler=DDIMScheduler(clip_sample=False, **SD_SCHED), safety_checker=None,
+                                           feature_extractor=None, requires_safety_checker=False,
+                                           depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+    trace = []
+    res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
+               mask=inp["mask"], depth=inp["depth"], num_inference_steps=3, guidance_scale=7.5, latents=inp["latents"].clone(),
+               output_type="pt", height=512, width=512, conditioning_noise=inp["vae_noise"],
+               callback_on_step_end=lambda p, i, t, kw: trace.append(kw["latents"][:1].clone()) or {})
+    assert pipe.scheduler.timesteps.tolist() == G["timesteps"].tolist()
+    assert tuple(res.images.shape) == (4, 3, 512, 512) and torch.isfinite(res.images).all()
+    for i, l in enumerate(trace):
+        check(f"config1 image 0, latents after step {i} [{prec}]", l, G[f"latents_{i}"], prec, dict(atol=tol),
+              f"sd15_config1_slice/latents_{i}")
+    st = G["image_stats"]
+    check(f"config1 image 0, decoded [{prec}]", strided_sample(res.images[:1], st[2], 4096), G["image_sample"], prec,
+          dict(atol=2e-3), "sd15_config1_slice/image")

@@ -242,8 +242,37 @@ def full(out):
     out["sd15_config0/image"] = stats(sample_like(res.images, C["image_stats"][2], 1024), C["image_sample"])
 
 
+def config1_slice(out):
+    ucfg, vcfg = R.SD15_UNET, R.SD15_VAE
+    (unet, _, _), (brushnet, _, _), (vae, _, _) = MG.models(ucfg, vcfg, 0)
+    for m in (unet, brushnet, vae):
+        m.to(BF)
+    C = np.load(os.path.join(GOLD, "sd15_config1_slice.npz"))
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=brushnet,
+                                           scheduler=sched, safety_checker=None, feature_extractor=None,
+                                           requires_safety_checker=False, depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+    sl = slice(0, 1)
+    nz = inp["vae_noise"]
+    noise = torch.cat([nz[:4][sl], nz[4:][sl]])
+    trace = []
+    with fixed_noise([noise]):
+        res = pipe(prompt_embeds=inp["prompt_embeds"][sl].to(BF), negative_prompt_embeds=inp["negative_prompt_embeds"][sl].to(BF),
+                   image=inp["image"][sl], mask=inp["mask"][sl], depth=inp["depth"][sl], num_inference_steps=3,
+                   guidance_scale=7.5, latents=inp["latents"][sl].clone().to(BF), output_type="pt",
+                   brushnet_conditioning_scale=1.0,
+                   callback_on_step_end=lambda p, i, t, k: trace.append(k["latents"].clone()) or {}, height=512, width=512)
+    for i, l in enumerate(trace):
+        out[f"sd15_config1_slice/latents_{i}"] = stats(l, C[f"latents_{i}"])
+    out["sd15_config1_slice/image"] = stats(sample_like(res.images, C["image_stats"][2], 4096), C["image_sample"])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-config1", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     a = ap.parse_args()
@@ -254,11 +283,14 @@ if __name__ == "__main__":
             out = json.load(f)
     out["_about"] = ("|reference(bf16) - reference(fp32)| of the imported reference on the golden cases "
                      "(tools/make_bf16_envelope.py): linf / mean abs error, and the fp32 result's abs max / mean")
-    if not a.only_full:
+    if a.only_config1:
+        config1_slice(out)
+    elif not a.only_full:
         tiny(out)
         tiny_xl(out)
-    if a.full or a.only_full:
+    if (a.full or a.only_full) and not a.only_config1:
         full(out)
+        config1_slice(out)
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     for k, v in sorted(out.items()):

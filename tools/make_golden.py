@@ -299,6 +299,86 @@ def tiny_train():
     np.savez_compressed(os.path.join(GOLD, "tiny_train.npz"), **out)
     print("tiny training-step fixture written")
 
+    # ---- backward half (SURVEY.md §8 a-16 pin): two optimizer steps of the reference's own modules under torch
+    # autograd — loss.backward(), clip_grad_norm_(1.0), torch.optim.AdamW(lr 1e-5, betas 0.9/0.999, wd 1e-2, eps 1e-8)
+    # (train_brushnet_mirror.py:1188-1200,1459-1466) — BrushNet trainable, UNet frozen (the default) or trainable
+    # (--train_base_unet).  Stored: loss and pre-clip gradient norm per step, the step-1 gradients of named tensors and
+    # their total movement |w_2 - w_0| after the two steps. --------------------------------------------------------
+    from diffusers import DDPMScheduler as _DDPM
+    torch.set_grad_enabled(True)
+    tout = {}
+    named_bn = ["conv_in_condition.weight", "time_embedding.linear_1.weight", "down_blocks.0.resnets.0.conv1.weight",
+                "down_blocks.0.resnets.1.norm2.weight", "down_blocks.1.resnets.0.time_emb_proj.bias",
+                "down_blocks.0.downsamplers.0.conv.weight", "mid_block.resnets.0.conv2.bias",
+                "up_blocks.0.resnets.0.conv_shortcut.weight", "up_blocks.0.upsamplers.0.conv.weight", "up_blocks.1.resnets.2.norm1.bias",
+                "brushnet_down_blocks.0.weight", "brushnet_mid_block.bias", "brushnet_up_blocks.3.weight"]
+    named_un = ["conv_in.weight", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+                "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_v.weight",
+                "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+                "down_blocks.0.attentions.0.transformer_blocks.0.norm2.weight", "down_blocks.0.attentions.0.proj_out.bias",
+                "mid_block.attentions.0.norm.weight", "up_blocks.1.attentions.2.transformer_blocks.0.attn1.to_out.0.bias",
+                "up_blocks.1.resnets.0.conv1.weight", "conv_norm_out.bias", "conv_out.weight"]
+    g2 = torch.Generator().manual_seed(2025)
+    batches = [(latents, noise, timesteps, ehs, cond),
+               (torch.randn(bsz, 4, 8, 8, generator=g2) * 0.8, torch.randn(bsz, 4, 8, 8, generator=g2),
+                torch.tensor([702, 3, 250]).long(), torch.randn(bsz, 77, ucfg["cross_attention_dim"], generator=g2),
+                torch.randn(bsz, 5, 8, 8, generator=g2))]
+    for tag, train_unet, gamma in (("frozen", False, None), ("unet", True, 5.0)):
+        (unet2, unet_sd2, _), _, _ = models(ucfg, vcfg, 0)
+        bn2 = BrushNetModel.from_unet(unet2, conditioning_channels=5, load_weights_from_unet=False)
+        bn_sd2, _ = load_synth(bn2, 21)
+        bn2.train()
+        unet2.requires_grad_(train_unet)
+        if train_unet:
+            unet2.train()
+        plist = list(bn2.parameters()) + (list(unet2.parameters()) if train_unet else [])
+        opt = torch.optim.AdamW(plist, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+        ns = _DDPM(num_train_timesteps=1000, beta_start=R.SD15_SCHED["beta_start"], beta_end=R.SD15_SCHED["beta_end"],
+                   beta_schedule="scaled_linear")
+        w0 = {k: v.detach().clone() for k, v in bn2.state_dict().items()}
+        u0 = {k: v.detach().clone() for k, v in unet2.state_dict().items()}
+        for i, (lat_, noi_, ts_, ehs_, cond_) in enumerate(batches):
+            noisy = ns.add_noise(lat_, noi_, ts_)
+            down, mid, up = bn2(noisy, ts_, encoder_hidden_states=ehs_, brushnet_cond=cond_, return_dict=False)
+            pred = unet2(noisy, ts_, encoder_hidden_states=ehs_, down_block_add_samples=list(down), mid_block_add_sample=mid,
+                         up_block_add_samples=list(up), return_dict=False)[0]
+            if gamma is None:
+                loss = F.mse_loss(pred.float(), noi_.float(), reduction="mean")
+            else:
+                snr = compute_snr(ns, ts_)
+                w = torch.stack([snr, gamma * torch.ones_like(ts_)], dim=1).min(dim=1)[0] / snr
+                loss = (F.mse_loss(pred.float(), noi_.float(), reduction="none").mean(dim=[1, 2, 3]) * w).mean()
+            loss.backward()
+            gn = torch.nn.utils.clip_grad_norm_(plist, 1.0)                       # accelerator.clip_grad_norm_ (:1463)
+            tout[f"{tag}_loss_{i}"] = np.float32(float(loss))
+            tout[f"{tag}_grad_norm_{i}"] = np.float32(float(gn))
+            if i == 0:
+                coef = min(1.0, 1.0 / (float(gn) + 1e-6))
+                for k in named_bn:
+                    tout[f"{tag}_grad/{k}"] = (dict(bn2.named_parameters())[k].grad / coef).detach().numpy().copy()
+                if train_unet:
+                    for k in named_un:
+                        tout[f"{tag}_grad/unet.{k}"] = (dict(unet2.named_parameters())[k].grad / coef).detach().numpy().copy()
+            opt.step()
+            opt.zero_grad()
+        for k in named_bn:
+            tout[f"{tag}_dw/{k}"] = np.float32(float((bn2.state_dict()[k] - w0[k]).norm()))
+        if train_unet:
+            for k in named_un:
+                tout[f"{tag}_dw/unet.{k}"] = np.float32(float((unet2.state_dict()[k] - u0[k]).norm()))
+        # the oracle's autograd + hand-written AdamW on the same batches
+        nb, nu, rec = R.training_steps(unet_sd2, ucfg, bn_sd2, bcfg, dict(R.SD15_SCHED), batches, lr=1e-5, snr_gamma=gamma,
+                                       train_unet=train_unet)
+        print(f"[train backward {tag}] loss", [r["loss"] for r in rec], "ref", [float(tout[f"{tag}_loss_{i}"]) for i in range(2)],
+              "grad norm", [r["grad_norm"] for r in rec], "ref", [float(tout[f"{tag}_grad_norm_{i}"]) for i in range(2)])
+        print(f"[train backward {tag}] oracle-vs-ref: max grad diff",
+              max(maxdiff(rec[0]["grads"][k], torch.from_numpy(tout[f"{tag}_grad/{k}"])) for k in named_bn),
+              "max weight diff after 2 steps", max(maxdiff(nb[k], bn2.state_dict()[k]) for k in nb),
+              ("unet " + str(max(maxdiff(nu[k], unet2.state_dict()[k]) for k in nu))) if train_unet else "")
+    torch.set_grad_enabled(False)
+    np.savez_compressed(os.path.join(GOLD, "tiny_train_backward.npz"), **tout)
+    print("tiny training backward fixture written")
+
 
 def layers_full():
     """F6: single layers at the production sizes of the SD1.5 path, from the reference's own modules
@@ -509,8 +589,53 @@ def full():
     print("configs[0] fixture written")
 
 
+def config1_slice():
+    """BASELINE.json configs[1] sizes through the reference pipeline for ONE image of the batch: image 0 of the batch-4
+    x 512 x 512 synthetic inputs (seed 77), 3 DDIM steps, CFG 7.5, decoded (64 x 64 latents: the VAE's 4096-token
+    single-head d = 512 attention).  The GPU tests run the whole batch of 4 and compare image 0 with this."""
+    ucfg, vcfg = R.SD15_UNET, R.SD15_VAE
+    (unet, unet_sd, _), (brushnet, bn_sd, _), (vae, vae_sd, _) = models(ucfg, vcfg, 0)
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=brushnet,
+                                           scheduler=sched, safety_checker=None, feature_extractor=None,
+                                           requires_safety_checker=False, depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+    sl = slice(0, 1)
+    nz = inp["vae_noise"]
+    noise = torch.cat([nz[:4][sl], nz[4:][sl]])                 # uncond half, then cond half (what the HIP test passes)
+    import diffusers.models.autoencoders.vae as ref_vae
+    orig = ref_vae.randn_tensor
+    ref_vae.randn_tensor = lambda shape, generator=None, device=None, dtype=None, layout=None: noise.to(dtype)
+    trace = []
+    try:
+        res = pipe(prompt_embeds=inp["prompt_embeds"][sl], negative_prompt_embeds=inp["negative_prompt_embeds"][sl],
+                   image=inp["image"][sl], mask=inp["mask"][sl], depth=inp["depth"][sl], num_inference_steps=3,
+                   guidance_scale=7.5, latents=inp["latents"][sl].clone(), output_type="pt", brushnet_conditioning_scale=1.0,
+                   callback_on_step_end=lambda p_, i, t_, kw_: trace.append(kw_["latents"].clone()) or {}, height=512, width=512)
+    finally:
+        ref_vae.randn_tensor = orig
+    ocond = R.build_conditioning(vae_sd, vcfg, inp["image"][sl], inp["mask"][sl], inp["depth"][sl], noise)
+    pe = torch.cat([inp["negative_prompt_embeds"][sl], inp["prompt_embeds"][sl]])
+    otrace = []
+    olat = R.denoise(unet_sd, ucfg, bn_sd, R.brushnet_config(ucfg, 6), R.DDIMRef(**R.SD15_SCHED), inp["latents"][sl], ocond, pe,
+                     3, 7.5, 1.0, otrace)
+    print("[config1 slice] per-step latents oracle-vs-ref:", [round(maxdiff(a, b), 8) for a, b in zip(trace, otrace)])
+    oimg = (R.vae_decode(vae_sd, vcfg, olat / vcfg["scaling_factor"]) / 2 + 0.5).clamp(0, 1)
+    print("[config1 slice] image oracle-vs-ref:", maxdiff(oimg, res.images))
+    out = dict(timesteps=pipe.scheduler.timesteps.numpy())
+    for i, l in enumerate(trace):
+        out[f"latents_{i}"] = l.numpy()
+    s_ = summarize(res.images, 4096)
+    out["image_sample"], out["image_stats"] = s_["sample"], np.array([s_["sum"], s_["abssum"], s_["sample_stride"]])
+    np.savez_compressed(os.path.join(GOLD, "sd15_config1_slice.npz"), **out)
+    print("configs[1] slice fixture written")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--only-config1", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--only-xl", action="store_true")
@@ -518,6 +643,9 @@ if __name__ == "__main__":
     ap.add_argument("--only-layers", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
+    if a.only_config1:
+        config1_slice()
+        sys.exit(0)
     if a.only_xl:
         tiny_xl()
         sys.exit(0)
@@ -534,3 +662,4 @@ if __name__ == "__main__":
         tiny_xl()
     if a.full or a.only_full:
         full()
+        config1_slice()
