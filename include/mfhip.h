@@ -227,6 +227,87 @@ int mf_vae_sample(const void* moments, int32_t m_dtype, int64_t ld, const float*
 int mf_nearest_resize(const float* src, float* dst, int32_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
                       int32_t w_out, void* stream);
 
+/* ============================================================================================
+ * Training: the backward pass and the optimizer of examples/brushnet/train_brushnet_mirror.py:1459-1466
+ * (accelerator.backward -> ATen autograd in the reference; clip_grad_norm_ :1463; torch.optim.AdamW :1188-1200).
+ * All tensors fp32.  Data gradients of convolutions / linears need no entry of their own: they are mf_gemm_conv on the
+ * transposed (tap-flipped) weight that mf_transpose lays out; strided / upsampling convs add mf_zero_insert2x /
+ * mf_sumpool2x2.  Every reduction has a fixed order: gradients are bit-reproducible.
+ * ========================================================================================== */
+
+/* Weight gradient of mf_gemm_conv's convolution (same geometry fields): dw[n][(ky*kw + kx)*(c0+c1) + c] (+)= sum over
+ * output pixels m of dy[m][n] * A[pixel(m, ky, kx)][c].  dtype MF_F32 (fp32 MFMA) or MF_F16X3 (split precision).
+ * Replaces autograd's conv2d / linear weight gradients (torch/nn/grad.py conv2d_weight; linear: dy^T x). */
+typedef struct mf_wgrad_desc {
+    int32_t dtype;
+    const float* a0; const float* a1;   /* the forward input, NHWC, one or two channel segments */
+    int32_t c0, c1;
+    int64_t lda0, lda1;
+    int32_t batch, h_in, w_in, h_out, w_out, kh, kw, stride, pad_t, pad_l, upsample;
+    const float* dy; int64_t lddy;      /* gradient of the conv output, [batch*h_out*w_out][n] */
+    int32_t n;
+    float* dw; int64_t lddw;            /* [n][kh*kw*(c0+c1)] */
+    int32_t accumulate;                 /* 1: dw += ... */
+    int32_t splitm;                     /* slabs over the pixel dimension: 0 = heuristic */
+    float* ws; int64_t ws_floats;       /* splitm * n * kh*kw*(c0+c1) floats (mf_conv_wgrad_ws_floats) */
+} mf_wgrad_desc;
+int mf_sizeof_wgrad_desc(void);
+int64_t mf_conv_wgrad_ws_floats(const mf_wgrad_desc* d);
+int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream);
+
+/* y[z][c][r] = x[z][r][c] for nz matrices: element strides ldx / ldy between rows, zsx / zsy between matrices (signed:
+ * a negative zsy with y pointing at the last matrix writes the batch in reverse — the tap flip of a dgrad weight) */
+int mf_transpose(const float* x, float* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,
+                 int64_t zsy, void* stream);
+
+/* out[s][j] (+)= sum over the rows of segment s (rows_per_seg consecutive rows) of x[row][j], j < n: bias gradients
+ * (one segment), the time-embedding gradient of a resnet (one segment per image), dgamma / dbeta partials */
+int64_t mf_colsum_ws_floats(int32_t segs, int64_t rows_per_seg, int32_t n);
+int mf_colsum(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t segs, int64_t rows_per_seg, int32_t n,
+              int32_t accumulate, float* ws, void* stream);
+
+/* Backward of mf_groupnorm (GroupNorm + optional SiLU over one or two NHWC segments; native_group_norm_backward +
+ * silu_backward in the reference's autograd): dx per segment, per-image dgamma / dbeta partials [batch][c0+c1]
+ * (nullable; sum them with mf_colsum). */
+typedef struct mf_groupnorm_bwd_desc {
+    const float* x0; const float* x1; int32_t c0, c1;
+    const float* dy;
+    const float* gamma; const float* beta;
+    float* dx0; float* dx1;
+    float* dgamma_part; float* dbeta_part;
+    int32_t batch, hw, groups, silu;
+    float eps;
+} mf_groupnorm_bwd_desc;
+int mf_sizeof_groupnorm_bwd_desc(void);
+int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream);
+
+/* LayerNorm backward over [rows][c] (c <= 2048): dx, and per-64-row-block dgamma / dbeta partials
+ * [(rows+63)/64][c] (nullable) */
+int mf_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma_part, float* dbeta_part,
+                     int64_t rows, int32_t c, float eps, void* stream);
+/* ds = scale * p * (dp - sum_j dp*p) per row of [rows][ld] (valid length cols, pad written 0): softmax backward */
+int mf_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int32_t cols, int32_t ld, float scale, void* stream);
+int mf_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* h = [a | g] ([rows][2c]), out = a * gelu_erf(g): dh from dout ([rows][c]) */
+int mf_geglu_bwd(const float* h, const float* dout, float* dh, int64_t rows, int32_t c, void* stream);
+/* y[b][2h][2w][c]: x at the even positions, zeros elsewhere (a stride-2 conv's data gradient as a stride-1 conv) */
+int mf_zero_insert2x(const float* x, float* y, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* y[b][h][w][c] = sum of the 2x2 block of x[b][2h][2w][c]: backward of the nearest-2x upsample (upsampling.py:170-178) */
+int mf_sumpool2x2(const float* x, float* y, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* gradient of mf_mse_loss's loss[0] with respect to pred */
+int mf_mse_grad(const float* pred, const float* target, const float* weights, float* dpred, int32_t rows, int64_t n, void* stream);
+
+/* sum of squares of a flat gradient arena into out[0] (double, device), two fixed-order stages */
+int64_t mf_sumsq_ws_doubles(void);
+int mf_sumsq(const float* x, int64_t n, double* out, int32_t accumulate, double* ws, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (train_brushnet_mirror.py:1463): coef[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6)) stays on
+ * the device (mf_adamw reads it: no host synchronisation in the step); norm_out[0] (nullable) = sqrt(sumsq) */
+int mf_clip_coef(const double* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+/* torch.optim.AdamW (train_brushnet_mirror.py:1188-1200; no amsgrad) over flat arenas of n fp32: the gradient is read as
+ * g * grad_scale[0] (grad_scale nullable) */
+int mf_adamw(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int32_t step, const float* grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

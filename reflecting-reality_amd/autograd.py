@@ -1,0 +1,267 @@
+"""Reverse-mode differentiation of the HIP forward path: a tape of backward closures over the libmfhip kernels.
+
+The reference trains through ATen autograd (examples/brushnet/train_brushnet_mirror.py:1459 `accelerator.backward(loss)`).
+Here the forward kernels are hand-written, so their vector-Jacobian products are too: while `ops.TAPE` is set, every
+layer-level operator (ops.conv2d / linear / groupnorm / layernorm / attention / geglu / add ...) appends a closure that,
+given the gradient of its output, launches the backward kernels of csrc/train.hip (and mf_gemm_conv for the data
+gradients) and hands gradients on to its inputs.  Nothing here does arithmetic in PyTorch: torch owns the buffers.
+
+Gradients are keyed by the storage of the tensor they belong to, so the NCHW-shaped channels-last *views* that cross the
+BrushNet -> UNet boundary (models.to_nchw_view / from_nchw) carry their gradient back without any layout copy.
+Parameters live in flat fp32 arenas (weights, gradients, Adam moments): a `Param` is a pair of views.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import hip
+
+
+class Param:
+    """A tensor of a model's flat arenas: `data` (fp32 master weight, in the kernels' layout) and `grad` (same shape; None
+    when the parameter is frozen)."""
+    __slots__ = ("name", "data", "grad")
+
+    def __init__(self, name: str, data: torch.Tensor, grad: Optional[torch.Tensor]):
+        self.name, self.data, self.grad = name, data, grad
+
+
+def _key(t: torch.Tensor):
+    return t.untyped_storage().data_ptr()
+
+
+class Tape:
+    def __init__(self, code: int):
+        self.code = code                       # MF_F32 or MF_F16X3: the contraction mode of the backward GEMMs
+        self.ops: List[Callable[[], None]] = []
+        self.grads: Dict[int, torch.Tensor] = {}
+        self.stop = set()                      # storages that need no gradient (the batch's inputs)
+        self.on_param_grad: Optional[Callable[[Param], None]] = None   # gradient-bucket hook (distributed.GradBuckets)
+
+    # ---- bookkeeping ---------------------------------------------------------------------------------------
+    def no_grad(self, *ts: Optional[torch.Tensor]) -> None:
+        for t in ts:
+            if t is not None:
+                self.stop.add(_key(t))
+
+    def needs(self, t: Optional[torch.Tensor]) -> bool:
+        return t is not None and _key(t) not in self.stop
+
+    def record(self, fn: Callable[[], None]) -> None:
+        self.ops.append(fn)
+
+    def add(self, t: Optional[torch.Tensor], g: torch.Tensor) -> None:
+        """Accumulate g (laid out like t's storage: same numel) into t's gradient.  Never in place: the same g may be
+        handed to several consumers (a residual fan-out)."""
+        if not self.needs(t):
+            return
+        if t.numel() != g.numel():
+            raise hip.MfhipError(f"gradient of {tuple(t.shape)} has {g.numel()} elements")
+        k = _key(t)
+        old = self.grads.get(k)
+        self.grads[k] = g if old is None else hip.axpby_n([old, g.view(old.shape)], [1.0, 1.0])
+
+    def add_cols(self, view: torch.Tensor, g_rows: torch.Tensor, n: int, segs: int) -> None:
+        """view = parent[:, a:b] (a column slice of a 2-D fp32 tensor): add the per-segment column sums of g_rows
+        ([segs * rows_per_seg][n]) into the matching columns of the parent's dense gradient."""
+        if not self.needs(view):
+            return
+        k = _key(view)
+        dense = self.grads.get(k)
+        numel = view.untyped_storage().nbytes() // 4
+        if dense is None:
+            dense = torch.zeros(numel, dtype=torch.float32, device=view.device)
+            self.grads[k] = dense
+        tgt = dense.as_strided(view.shape, view.stride(), view.storage_offset())
+        hip.colsum(g_rows, n, segs=segs, out=tgt, ldo=view.stride(0), accumulate=True)
+
+    def take(self, t: torch.Tensor) -> Optional[torch.Tensor]:
+        g = self.grads.pop(_key(t), None)
+        return None if g is None else g.view(-1)
+
+    def param_grad_done(self, p: Optional[Param]) -> None:
+        if p is not None and p.grad is not None and self.on_param_grad is not None:
+            self.on_param_grad(p)
+
+    def backward(self) -> None:
+        for fn in reversed(self.ops):
+            fn()
+        self.ops.clear()
+        self.grads.clear()
+
+
+# =====================================================================================================================
+# backward closures
+# =====================================================================================================================
+def _dgrad_weight(cw, tape: Tape) -> torch.Tensor:
+    """[Ctot][taps (flipped)][N]: the weight of the data-gradient convolution, laid out by mf_transpose once per
+    optimizer step (the master weight changes every step)."""
+    gen = getattr(cw, "_wd_gen", None)
+    if gen != cw.generation() or getattr(cw, "_wd", None) is None:
+        taps, n, ct = cw.kh * cw.kw, cw.n, cw.cin_pad
+        wd = torch.empty(ct, taps * n, dtype=torch.float32, device=cw.w.device)
+        # per tap t: x_t[n][c] = w[n][t*ct + c] (ld taps*ct)  ->  y[c][(taps-1-t)*n + n'] (ld taps*n): zsy < 0 flips the taps
+        hip.transpose(cw.w, n, ct, nz=taps, ldx=taps * ct, ldy=taps * n, zsx=ct, zsy=-n, out=wd, y_offset=(taps - 1) * n)
+        cw._wd, cw._wd_gen = wd, cw.generation()
+    return cw._wd
+
+
+def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, stride, pad_t, pad_l, upsample, temb, res0, res1,
+                alpha, act) -> None:
+    """out = alpha * (conv(cat(x, x1)) + bias + temb[b]) + res0 + res1  (mf_gemm_conv; linear = 1x1 over batch rows)."""
+    if act != hip.ACT_NONE:
+        raise hip.MfhipError("training: fused activations are not differentiated; apply ops.silu / ops.geglu as their own op")
+    c0 = x.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    n = cw.n
+
+    def bwd():
+        g = tape.take(out)
+        if g is None:
+            return
+        g = g.view(-1, n)
+        tape.add(res0, g)
+        tape.add(res1, g)
+        gc = g if alpha == 1.0 else hip.axpby_n([g], [alpha])
+        if temb is not None:
+            tape.add_cols(temb, gc, n, batch)
+        if cw.p_bias is not None and cw.p_bias.grad is not None:
+            hip.colsum(gc, n, out=cw.p_bias.grad.view(1, n), accumulate=True)
+            tape.param_grad_done(cw.p_bias)
+        if cw.p_w is not None and cw.p_w.grad is not None:
+            hip.conv_wgrad(x, gc, cw.p_w.grad, code=tape.code, c0=c0, x1=x1, c1=c1, batch=batch, h_in=h_in, w_in=w_in, h_out=h_out,
+                           w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n)
+            tape.param_grad_done(cw.p_w)
+        if not (tape.needs(x) or tape.needs(x1)):
+            return
+        wd = _dgrad_weight(cw, tape)
+        taps = cw.kh * cw.kw
+        a, gh, gw = gc, h_out, w_out
+        if stride == 2:
+            a = hip.zero_insert2x(gc.view(batch, h_out, w_out, n))
+            gh, gw = 2 * h_out, 2 * w_out
+        elif stride != 1:
+            raise hip.MfhipError("training: only stride 1 / 2 convolutions are differentiated")
+        hu, wu = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
+        outs = []
+        off = 0
+        for seg, cs in ((x, c0), (x1, c1)):
+            if seg is None:
+                continue
+            if tape.needs(seg):
+                dx = torch.empty(batch, hu, wu, cs, dtype=torch.float32, device=x.device)
+                hip.gemm_conv(a, wd[off:off + cs], dx, dtype=tape.code, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw, h_out=hu,
+                              w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l, ldw=taps * n,
+                              n=cs)
+                outs.append((seg, hip.sumpool2x2(dx) if upsample else dx))
+            off += cs
+        for seg, dx in outs:
+            tape.add(seg, dx)
+
+    tape.record(bwd)
+
+
+def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, groups: int, eps: float, silu: bool) -> None:
+    def bwd():
+        g = tape.take(out)
+        if g is None:
+            return
+        want = p_gamma.grad is not None
+        dx0, dx1, dg, db = hip.groupnorm_bwd(x0, g.view(out.shape), p_gamma.data, p_beta.data, groups=groups, eps=eps, silu=silu,
+                                             x1=x1, want_param_grads=want)
+        if want:
+            c = dg.shape[1]
+            hip.colsum(dg, c, out=p_gamma.grad.view(1, c), accumulate=True)
+            hip.colsum(db, c, out=p_beta.grad.view(1, c), accumulate=True)
+            tape.param_grad_done(p_gamma)
+            tape.param_grad_done(p_beta)
+        tape.add(x0, dx0)
+        if x1 is not None:
+            tape.add(x1, dx1)
+
+    tape.record(bwd)
+
+
+def record_layernorm(tape: Tape, x, p_gamma: Param, p_beta: Param, out, eps: float) -> None:
+    def bwd():
+        g = tape.take(out)
+        if g is None:
+            return
+        want = p_gamma.grad is not None
+        dx, dg, db = hip.layernorm_bwd(x, g.view(x.shape), p_gamma.data, eps, want_param_grads=want)
+        if want:
+            c = dg.shape[1]
+            hip.colsum(dg, c, out=p_gamma.grad.view(1, c), accumulate=True)
+            hip.colsum(db, c, out=p_beta.grad.view(1, c), accumulate=True)
+            tape.param_grad_done(p_gamma)
+            tape.param_grad_done(p_beta)
+        tape.add(x, dx)
+
+    tape.record(bwd)
+
+
+def record_pointwise(tape: Tape, inputs, out, fn) -> None:
+    """out = f(inputs...) elementwise; fn(g) returns one gradient per input (or None)."""
+    def bwd():
+        g = tape.take(out)
+        if g is None:
+            return
+        for t, gi in zip(inputs, fn(g)):
+            if gi is not None:
+                tape.add(t, gi)
+
+    tape.record(bwd)
+
+
+def record_attention(tape: Tape, q, k, v, out, heads: int, skv: int, scale: float, forward_probs) -> None:
+    """out[b][i][h*d:] = softmax(q_h k_h^T * scale) v_h  with q [B, Sq, C], k / v [B, Skv, C] (contiguous fp32).
+    Backward recomputes P with the forward's kernels (`forward_probs`), then five strided-batched GEMMs and the
+    transposes that bring their operands into the kernel's NT form; P is never kept between forward and backward."""
+    b, sq, c = q.shape
+    d = c // heads
+    z = b * heads
+
+    def bwd():
+        g = tape.take(out)
+        if g is None:
+            return
+        g = g.view(b, sq, c)
+        code = tape.code
+        p = forward_probs()                                      # [z][sq][ld], pad columns zero
+        ld = p.shape[-1]
+        dev = q.device
+        # dP = dO v^T
+        dp = torch.empty(z, sq, ld, dtype=torch.float32, device=dev)
+        hip.gemm_conv(g, v, dp, dtype=code, c0=d, lda0=c, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1, ldw=c, n=skv, ldc=ld, nz=z,
+                      zdiv=heads, a_zs=(sq * c, d), w_zs=(skv * c, d), o_zs=(heads * sq * ld, sq * ld), splitk=1)
+        ds = hip.softmax_bwd(p, dp, skv, scale)                  # [z][sq][ld], pad columns zero
+        del dp
+        # dV = P^T dO   (A = P^T [skv][sq], W = dO^T [d][sq])
+        pt = hip.transpose(p, sq, skv, nz=z, ldx=ld, ldy=sq, zsx=sq * ld, zsy=skv * sq)            # [z][skv][sq]
+        del p
+        gt = hip.transpose(g, sq, c, nz=b, ldx=c, ldy=sq, zsx=sq * c, zsy=c * sq)                   # [b][c][sq]
+        dv = torch.empty(b, skv, c, dtype=torch.float32, device=dev)
+        hip.gemm_conv(pt, gt, dv, dtype=code, c0=sq, lda0=sq, batch=skv, h_in=1, w_in=1, h_out=1, w_out=1, ldw=sq, n=d, ldc=c, nz=z,
+                      zdiv=heads, a_zs=(heads * skv * sq, skv * sq), w_zs=(c * sq, d * sq), o_zs=(skv * c, d), splitk=1)
+        del pt, gt
+        # dQ = dS k   (W = k^T [d][ld], pad columns zero)
+        kt = torch.zeros(b, c, ld, dtype=torch.float32, device=dev)
+        hip.transpose(k, skv, c, nz=b, ldx=c, ldy=ld, zsx=skv * c, zsy=c * ld, out=kt)
+        dq = torch.empty(b, sq, c, dtype=torch.float32, device=dev)
+        hip.gemm_conv(ds, kt, dq, dtype=code, c0=ld, lda0=ld, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1, ldw=ld, n=d, ldc=c, nz=z,
+                      zdiv=heads, a_zs=(heads * sq * ld, sq * ld), w_zs=(c * ld, d * ld), o_zs=(sq * c, d), splitk=1)
+        del kt
+        # dK = dS^T q  (A = dS^T [skv][sq], W = q^T [d][sq])
+        dst = hip.transpose(ds, sq, skv, nz=z, ldx=ld, ldy=sq, zsx=sq * ld, zsy=skv * sq)           # [z][skv][sq]
+        del ds
+        qt = hip.transpose(q, sq, c, nz=b, ldx=c, ldy=sq, zsx=sq * c, zsy=c * sq)                   # [b][c][sq]
+        dk = torch.empty(b, skv, c, dtype=torch.float32, device=dev)
+        hip.gemm_conv(dst, qt, dk, dtype=code, c0=sq, lda0=sq, batch=skv, h_in=1, w_in=1, h_out=1, w_out=1, ldw=sq, n=d, ldc=c, nz=z,
+                      zdiv=heads, a_zs=(heads * skv * sq, skv * sq), w_zs=(c * sq, d * sq), o_zs=(skv * c, d), splitk=1)
+        tape.add(q, dq)
+        tape.add(k, dk)
+        tape.add(v, dv)
+
+    tape.record(bwd)

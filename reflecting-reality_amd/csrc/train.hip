@@ -1,0 +1,685 @@
+// Backward / optimizer kernels of the MirrorFusion training step for gfx950 (examples/brushnet/train_brushnet_mirror.py
+// :1459-1466: accelerator.backward, clip_grad_norm_(1.0), AdamW step).  The reference has no native code here: every
+// gradient is ATen autograd.  These kernels are the arithmetic of that backward pass, hand-written:
+//
+//   mf_conv_wgrad      dW[n][tap][c] = sum_m dY[m][n] * A[pix(m, tap)][c]      (MFMA; the one GEMM form the forward
+//                      kernel cannot express: both operands are pixel-major, the reduction runs over pixels)
+//   mf_transpose       strided batched fp32 transpose (dgrad weight layout [C][taps flipped][N], P^T / dS^T / q^T / k^T)
+//   mf_colsum          column sums per row segment (bias gradients, d temb, dgamma / dbeta partials)
+//   mf_groupnorm_bwd   GroupNorm(+SiLU) backward over one or two NHWC segments
+//   mf_layernorm_bwd, mf_softmax_bwd, mf_silu_bwd, mf_geglu_bwd, mf_zero_insert2x, mf_sumpool2x2, mf_mse_grad
+//   mf_sumsq / mf_clip_coef / mf_adamw   gradient norm, clip coefficient (device-resident) and fused AdamW over flat
+//                      fp32 arenas (master weights, gradients, exp_avg, exp_avg_sq)
+//
+// dgrad needs no kernel of its own: the data gradient of a stride-1 conv / linear is mf_gemm_conv on the transposed
+// (and tap-flipped) weight; strided and upsampling convs go through mf_zero_insert2x / mf_sumpool2x2.
+// Everything is deterministic (fixed-order reductions, no atomics): two runs give bit-identical gradients.
+#include "mf_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------
+// wgrad
+// ------------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* a0; const float* a1;
+    int C0, Ctot; int64_t lda0, lda1;
+    int Hin, Win, Ho, Wo, HoWo, KW, taps, stride, pad_t, pad_l, ups;
+    const float* dy; int64_t lddy;
+    int M, N;
+    float* out; int64_t ldo;            // dW (splitm == 1) or the slab workspace
+    int64_t slab;                       // floats per slab
+    int splitm, m_per_split, tiles_k_per_tap, tiles_n;
+};
+
+constexpr int WG_BN = 64, WG_BC = 64, WG_BP = 32, WG_PITCH = 68;   // LDS rows of 64 floats + 4 pad (16-byte aligned rows)
+
+template <int DT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) float sY[WG_BP * WG_PITCH];
+    __shared__ __attribute__((aligned(16))) float sA[WG_BP * WG_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    int bid = blockIdx.x;
+    const int tile_n = bid % p.tiles_n;
+    bid /= p.tiles_n;
+    const int tile_k = bid % p.tiles_k_per_tap;
+    const int tap = bid / p.tiles_k_per_tap;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int n0 = tile_n * WG_BN, c0 = tile_k * WG_BC;
+    const int m_begin = blockIdx.y * p.m_per_split;
+    int m_end = m_begin + p.m_per_split;
+    if (m_end > p.M) m_end = p.M;
+
+    f32x16_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // staging coordinates: thread -> (row = tid / 16 (+16), 4 consecutive columns)
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+    const int Hlim = p.Hin << p.ups, Wlim = p.Win << p.ups;
+    for (int m0 = m_begin; m0 < m_end; m0 += WG_BP) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = srow + 16 * i;
+            const int m = m0 + row;
+            float4 vy = make_float4(0, 0, 0, 0), va = make_float4(0, 0, 0, 0);
+            if (m < m_end) {
+                const int n = n0 + scol;
+                if (n + 4 <= p.N) vy = *reinterpret_cast<const float4*>(p.dy + (int64_t)m * p.lddy + n);
+                else {
+                    float t[4] = {0, 0, 0, 0};
+                    for (int j = 0; j < 4 && n + j < p.N; ++j) t[j] = p.dy[(int64_t)m * p.lddy + n + j];
+                    vy = make_float4(t[0], t[1], t[2], t[3]);
+                }
+                const int b = m / p.HoWo, rr = m - b * p.HoWo, oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
+                const int c = c0 + scol;
+                if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim && c < p.Ctot) {
+                    const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+                    const float* src = c < p.C0 ? p.a0 + pix * p.lda0 + c : p.a1 + pix * p.lda1 + (c - p.C0);
+                    va = *reinterpret_cast<const float4*>(src);          // channel counts are multiples of 4: no straddle
+                }
+            }
+            *reinterpret_cast<float4*>(sY + row * WG_PITCH + scol) = vy;
+            *reinterpret_cast<float4*>(sA + row * WG_PITCH + scol) = va;
+        }
+        __syncthreads();
+        const float* py = sY + wn * 32 + r;
+        const float* pa = sA + wk * 32 + r;
+        if constexpr (DT == MF_F32) {
+#pragma unroll
+            for (int s = 0; s < WG_BP / 2; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(py[(2 * s + h) * WG_PITCH], pa[(2 * s + h) * WG_PITCH], acc, 0, 0, 0);
+        } else {
+            // fp32 -> (hi, lo) fp16 halves, three MFMAs per product (the split precision of mf_gemm_conv)
+#pragma unroll
+            for (int s = 0; s < WG_BP / 16; ++s) {
+                unsigned yh[4], yl[4], ah[4], al[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pp = 16 * s + 8 * h + 2 * e;
+                    const float y0 = py[pp * WG_PITCH], y1 = py[(pp + 1) * WG_PITCH];
+                    const float a0 = pa[pp * WG_PITCH], a1 = pa[(pp + 1) * WG_PITCH];
+                    const auto hy = __builtin_amdgcn_cvt_pkrtz(y0, y1);
+                    const auto ly = __builtin_amdgcn_cvt_pkrtz(y0 - (float)hy[0], y1 - (float)hy[1]);
+                    const auto ha = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+                    const auto la = __builtin_amdgcn_cvt_pkrtz(a0 - (float)ha[0], a1 - (float)ha[1]);
+                    yh[e] = __builtin_bit_cast(unsigned, hy); yl[e] = __builtin_bit_cast(unsigned, ly);
+                    ah[e] = __builtin_bit_cast(unsigned, ha); al[e] = __builtin_bit_cast(unsigned, la);
+                }
+                const f16x8_t Yh = __builtin_bit_cast(f16x8_t, uint4{yh[0], yh[1], yh[2], yh[3]});
+                const f16x8_t Yl = __builtin_bit_cast(f16x8_t, uint4{yl[0], yl[1], yl[2], yl[3]});
+                const f16x8_t Ah = __builtin_bit_cast(f16x8_t, uint4{ah[0], ah[1], ah[2], ah[3]});
+                const f16x8_t Al = __builtin_bit_cast(f16x8_t, uint4{al[0], al[1], al[2], al[3]});
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yl, Ah, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh, Al, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh, Ah, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D[row = n (e & 3) + 8 (e >> 2) + 4 h][col = c r]
+    float* out = p.out + (int64_t)blockIdx.y * p.slab;
+    const int c = c0 + wk * 32 + r;
+    if (c < p.Ctot) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (n < p.N) out[(int64_t)n * p.ldo + (int64_t)tap * p.Ctot + c] = acc[e];
+        }
+    }
+}
+
+// out[i] (+)= sum_z slabs[z][i]   (rows of `cols` floats, output row stride ldo)
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* ws, int nslab, int64_t slab, float* out, int64_t ldo,
+                                                        int rows, int cols, int accumulate) {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / cols), col = (int)(i - (int64_t)row * cols);
+        float s = 0.0f;
+        for (int z = 0; z < nslab; ++z) s += ws[(int64_t)z * slab + i];
+        float* o = out + (int64_t)row * ldo + col;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// strided batched transpose: y[z][c][r] = x[z][r][c]
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* x, float* y, int rows, int cols, int64_t ldx, int64_t ldy,
+                                                        int64_t zsx, int64_t zsy) {
+    __shared__ float t[32][33];
+    const float* xs = x + (int64_t)blockIdx.z * zsx;
+    float* ys = y + (int64_t)blockIdx.z * zsy;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + ty + 8 * i, cc = c0 + tx;
+        t[ty + 8 * i][tx] = (rr < rows && cc < cols) ? xs[(int64_t)rr * ldx + cc] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = c0 + ty + 8 * i, rr = r0 + tx;
+        if (cc < cols && rr < rows) ys[(int64_t)cc * ldy + rr] = t[tx][ty + 8 * i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// column sums per row segment: out[s][n] = sum_{m in segment s} x[m][n]; two deterministic stages
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_stage1(const float* x, int64_t ldx, float* part, int n, int64_t rows_per_seg,
+                                                     int chunks, int64_t rows_per_chunk) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int seg = blockIdx.y / chunks, ch = blockIdx.y - seg * chunks;
+    const int64_t r0 = (int64_t)seg * rows_per_seg + (int64_t)ch * rows_per_chunk;
+    int64_t r1 = r0 + rows_per_chunk;
+    if (r1 > (int64_t)(seg + 1) * rows_per_seg) r1 = (int64_t)(seg + 1) * rows_per_seg;
+    float s = 0.0f;
+    if (col < n)
+        for (int64_t rr = r0 + rl; rr < r1; rr += 4) s += x[rr * ldx + col];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < n)
+        part[((int64_t)seg * chunks + ch) * n + col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(const float* part, float* out, int64_t ldo, int n, int segs, int chunks,
+                                                     int accumulate) {
+    const int64_t total = (int64_t)segs * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int seg = (int)(i / n), col = (int)(i - (int64_t)seg * n);
+        float s = 0.0f;
+        for (int c = 0; c < chunks; ++c) s += part[((int64_t)seg * chunks + c) * n + col];
+        float* o = out + (int64_t)seg * ldo + col;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GroupNorm (+SiLU) backward.  One block per (batch, group).  y = act(xhat * gamma + beta), xhat = (x - mean) * rstd.
+// ------------------------------------------------------------------------------------------------------------
+struct GnBwdArgs {
+    const float* x0; const float* x1; int c0, c1;
+    const float* dy;                       // [b][hw][c0 + c1]
+    const float* gamma; const float* beta;
+    float* dx0; float* dx1;                // [b][hw][c0], [b][hw][c1]
+    float* dgamma_part; float* dbeta_part; // [b][c0 + c1] or null
+    int batch, hw, groups, silu; float eps;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* red) {       // 256 threads, fixed order
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const GnBwdArgs p) {
+    __shared__ double red[4];
+    __shared__ float cg[256], cb[256];
+    const int C = p.c0 + p.c1, cpg = C / p.groups;
+    const int b = blockIdx.x / p.groups, g = blockIdx.x - b * p.groups;
+    const int rif = 256 / cpg;                         // pixel rows in flight
+    const int ch = threadIdx.x % cpg, rl = threadIdx.x / cpg;
+    const bool active = rl < rif;
+    const int c = g * cpg + ch;
+    const bool seg1 = c >= p.c0;
+    const float* xb = seg1 ? p.x1 + (int64_t)b * p.hw * p.c1 + (c - p.c0) : p.x0 + (int64_t)b * p.hw * p.c0 + c;
+    const int ldx = seg1 ? p.c1 : p.c0;
+    const float* dyb = p.dy + (int64_t)b * p.hw * C + c;
+    // ---- statistics ----
+    double s = 0.0, ss = 0.0;
+    if (active)
+        for (int px = rl; px < p.hw; px += rif) {
+            const double v = xb[(int64_t)px * ldx];
+            s += v; ss += v * v;
+        }
+    const double n = (double)p.hw * cpg;
+    const double mean = block_sum(s, red) / n;
+    double var = block_sum(ss, red) / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float fmean = (float)mean;
+    const float gam = active ? p.gamma[c] : 0.0f, bet = active ? p.beta[c] : 0.0f;
+    auto dz_of = [&](float xv, float dyv, float& xhat) {
+        xhat = (xv - fmean) * rstd;
+        if (!p.silu) return dyv;
+        const float z = xhat * gam + bet;
+        const float sg = 1.0f / (1.0f + expf(-z));
+        return dyv * (sg * (1.0f + z * (1.0f - sg)));
+    };
+    // ---- sums ----
+    double s1 = 0.0, s2 = 0.0;
+    float dg = 0.0f, db = 0.0f;
+    if (active)
+        for (int px = rl; px < p.hw; px += rif) {
+            float xhat;
+            const float dz = dz_of(xb[(int64_t)px * ldx], dyb[(int64_t)px * C], xhat);
+            s1 += (double)(dz * gam); s2 += (double)(dz * gam * xhat);
+            dg += dz * xhat; db += dz;
+        }
+    const float m1 = (float)(block_sum(s1, red) / n), m2 = (float)(block_sum(s2, red) / n);
+    if (p.dgamma_part) {
+        cg[threadIdx.x] = dg; cb[threadIdx.x] = db;
+        __syncthreads();
+        if (threadIdx.x < cpg) {
+            float a = 0.0f, bb = 0.0f;
+            for (int j = 0; j < rif; ++j) { a += cg[j * cpg + threadIdx.x]; bb += cb[j * cpg + threadIdx.x]; }
+            p.dgamma_part[(int64_t)b * C + c] = a;
+            p.dbeta_part[(int64_t)b * C + c] = bb;
+        }
+    }
+    // ---- dx ----
+    if (active) {
+        float* dxb = seg1 ? p.dx1 + (int64_t)b * p.hw * p.c1 + (c - p.c0) : p.dx0 + (int64_t)b * p.hw * p.c0 + c;
+        for (int px = rl; px < p.hw; px += rif) {
+            float xhat;
+            const float dz = dz_of(xb[(int64_t)px * ldx], dyb[(int64_t)px * C], xhat);
+            dxb[(int64_t)px * ldx] = rstd * (dz * gam - m1 - xhat * m2);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row, 64 rows per block; per-block dgamma / dbeta partials
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXK = 32;      // channels per lane: c <= 2048
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, const float* dy, const float* gamma, float* dx,
+                                                            float* dg_part, float* db_part, int64_t rows, int c, float eps) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nk = (c + 63) / 64;
+    float ag[LN_MAXK], ab[LN_MAXK];
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) { ag[k] = 0.0f; ab[k] = 0.0f; }
+    const int64_t rb = (int64_t)blockIdx.x * 64;
+    for (int i = 0; i < 16; ++i) {
+        const int64_t row = rb + wave * 16 + i;
+        if (row >= rows) break;
+        const float* xr = x + row * c;
+        const float* dr = dy + row * c;
+        float s = 0.0f, ss = 0.0f;
+        for (int k = 0; k < nk; ++k) {
+            const int ch = lane + 64 * k;
+            const float v = ch < c ? xr[ch] : 0.0f;
+            s += v; ss += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+        const float mean = s / c;
+        float var = ss / c - mean * mean;
+        if (var < 0.0f) var = 0.0f;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        float a1 = 0.0f, a2 = 0.0f;
+        for (int k = 0; k < nk; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < c) {
+                const float xh = (xr[ch] - mean) * rstd, d = dr[ch], dgm = d * gamma[ch];
+                a1 += dgm; a2 += dgm * xh;
+                if (k < LN_MAXK) { ag[k] += d * xh; ab[k] += d; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        a1 /= c; a2 /= c;
+        for (int k = 0; k < nk; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < c) {
+                const float xh = (xr[ch] - mean) * rstd;
+                dx[row * c + ch] = rstd * (dr[ch] * gamma[ch] - a1 - xh * a2);
+            }
+        }
+    }
+    if (dg_part) {
+        for (int k = 0; k < nk && k < LN_MAXK; ++k) {
+            const int ch = lane + 64 * k;
+            red[wave][lane] = ag[k];
+            __syncthreads();
+            if (wave == 0 && ch < c) dg_part[(int64_t)blockIdx.x * c + ch] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            __syncthreads();
+            red[wave][lane] = ab[k];
+            __syncthreads();
+            if (wave == 0 && ch < c) db_part[(int64_t)blockIdx.x * c + ch] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+            __syncthreads();
+        }
+    }
+}
+
+// dS = scale * P * (dP - sum_j dP P) per row (block per row)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* pr, const float* dp, float* ds, int cols, int ld, float scale) {
+    __shared__ double red[4];
+    const int64_t row = blockIdx.x;
+    const float* P = pr + row * ld;
+    const float* D = dp + row * ld;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < cols; j += 256) s += (double)(P[j] * D[j]);
+    const float dot = (float)block_sum(s, red);
+    float* o = ds + row * ld;
+    for (int j = threadIdx.x; j < ld; j += 256) o[j] = j < cols ? scale * P[j] * (D[j] - dot) : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const float* x, const float* dy, float* dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float z = x[i], sg = 1.0f / (1.0f + expf(-z));
+        dx[i] = dy[i] * (sg * (1.0f + z * (1.0f - sg)));
+    }
+}
+
+// h = [a | g] (2c per row), out = a * gelu(g): dh = [dout * gelu(g) | dout * a * (Phi(g) + g phi(g))]
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* hin, const float* dout, float* dh, int64_t rows, int c) {
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / c;
+        const int j = (int)(i - row * c);
+        const float a = hin[row * 2 * c + j], g = hin[row * 2 * c + c + j], d = dout[i];
+        const float Phi = 0.5f * (1.0f + erff(g * 0.70710678118654752440f));
+        const float phi = 0.39894228040143267794f * expf(-0.5f * g * g);
+        dh[row * 2 * c + j] = d * (g * Phi);
+        dh[row * 2 * c + c + j] = d * a * (Phi + g * phi);
+    }
+}
+
+// y[b][2h][2w][c]: y[2i][2j] = x[i][j], zeros elsewhere (data gradient of a stride-2 conv as a stride-1 conv)
+__global__ __launch_bounds__(256) void zero_insert2x_kernel(const float* x, float* y, int b, int h, int w, int c4) {
+    const int64_t total = (int64_t)b * 2 * h * 2 * w * c4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cc = (int)(i % c4);
+        int64_t t = i / c4;
+        const int xx = (int)(t % (2 * w)); t /= 2 * w;
+        const int yy = (int)(t % (2 * h));
+        const int bb = (int)(t / (2 * h));
+        float4 v = make_float4(0, 0, 0, 0);
+        if (!(xx & 1) && !(yy & 1)) v = reinterpret_cast<const float4*>(x)[(((int64_t)bb * h + (yy >> 1)) * w + (xx >> 1)) * c4 + cc];
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+
+// y[b][h][w][c] = sum of the 2x2 block of x[b][2h][2w][c] (backward of the nearest-2x upsample)
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* x, float* y, int b, int h, int w, int c4) {
+    const int64_t total = (int64_t)b * h * w * c4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cc = (int)(i % c4);
+        int64_t t = i / c4;
+        const int xx = (int)(t % w); t /= w;
+        const int yy = (int)(t % h);
+        const int bb = (int)(t / h);
+        const float4* src = reinterpret_cast<const float4*>(x);
+        const int64_t base = (((int64_t)bb * 2 * h + 2 * yy) * 2 * w + 2 * xx) * c4 + cc;
+        const float4 a = src[base], b2 = src[base + c4], c2 = src[base + (int64_t)2 * w * c4], d = src[base + (int64_t)2 * w * c4 + c4];
+        reinterpret_cast<float4*>(y)[i] = make_float4((a.x + b2.x) + (c2.x + d.x), (a.y + b2.y) + (c2.y + d.y),
+                                                      (a.z + b2.z) + (c2.z + d.z), (a.w + b2.w) + (c2.w + d.w));
+    }
+}
+
+// d pred of loss = mean_r( w_r * mean_i (pred - target)^2 )
+__global__ __launch_bounds__(256) void mse_grad_kernel(const float* pred, const float* target, const float* w, float* d, int rows,
+                                                       int64_t n) {
+    const int64_t total = (int64_t)rows * n;
+    const float k = 2.0f / ((float)n * (float)rows);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+        d[i] = k * (w ? w[i / n] : 1.0f) * (pred[i] - target[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// gradient norm, clip coefficient, AdamW over flat arenas
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* x, int64_t n, double* part) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)x[i] * (double)x[i];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ __launch_bounds__(256) void sumsq_stage2(const double* part, int nparts, double* out, int accumulate) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + t : t;
+}
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6)); norm_out receives the fp32 norm
+__global__ void clip_coef_kernel(const double* sumsq, float max_norm, float* coef, float* norm_out) {
+    const float norm = (float)sqrt(sumsq[0]);
+    if (norm_out) norm_out[0] = norm;
+    const float c = max_norm / (norm + 1e-6f);
+    coef[0] = c < 1.0f ? c : 1.0f;
+}
+// torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, bias-corrected moments; g is scaled by *gscale
+__global__ __launch_bounds__(256) void adamw_kernel(float* w, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* gscale) {
+    const float gs = gscale ? gscale[0] : 1.0f;
+    const float step = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        float wi = w[i] * (1.0f - lr * wd);
+        const float mi = m[i] * b1 + gi * (1.0f - b1);
+        const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        wi -= step * (mi / denom);
+        w[i] = wi; m[i] = mi; v[i] = vi;
+    }
+}
+
+inline int grid_for(int64_t n, int cap = 8192) {
+    int64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int mf_sizeof_wgrad_desc(void) { return (int)sizeof(mf_wgrad_desc); }
+extern "C" int mf_sizeof_groupnorm_bwd_desc(void) { return (int)sizeof(mf_groupnorm_bwd_desc); }
+
+extern "C" int64_t mf_conv_wgrad_ws_floats(const mf_wgrad_desc* d) {
+    if (!d) return 0;
+    const int64_t M = (int64_t)d->batch * d->h_out * d->w_out;
+    const int64_t K = (int64_t)d->kh * d->kw * (d->c0 + d->c1);
+    int64_t sm = d->splitm;
+    if (sm <= 0) sm = M / 256 > 64 ? 64 : (M / 256 < 1 ? 1 : M / 256);
+    return sm * d->n * K;
+}
+
+extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
+    MF_CHECK_ARG(d != nullptr, "mf_conv_wgrad: null descriptor");
+    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_F16X3, "mf_conv_wgrad: dtype must be MF_F32 or MF_F16X3");
+    MF_CHECK_ARG(d->a0 && d->dy && d->dw, "mf_conv_wgrad: null a0/dy/dw");
+    MF_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && (d->a1 != nullptr) == (d->c1 > 0) && d->c0 % 4 == 0 && d->c1 % 4 == 0 &&
+                     d->lda0 % 4 == 0 && d->lda1 % 4 == 0,
+                 "mf_conv_wgrad: channel counts / pixel strides must be multiples of 4");
+    MF_CHECK_ARG(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->batch >= 1 && d->h_in >= 1 && d->w_in >= 1 && d->h_out >= 1 &&
+                     d->w_out >= 1 && d->n >= 1 && (d->upsample == 0 || d->upsample == 1),
+                 "mf_conv_wgrad: bad geometry");
+    if (!mf_aligned16(d->a0) || (d->a1 && !mf_aligned16(d->a1)) || !mf_aligned16(d->dy) || d->lddy % 4 != 0) {
+        mf_set_error("mf_conv_wgrad: a0/a1/dy must be 16-byte aligned, lddy a multiple of 4");
+        return MF_EALIGN;
+    }
+    WgradArgs a{};
+    a.a0 = d->a0; a.a1 = d->a1; a.C0 = d->c0; a.Ctot = d->c0 + d->c1; a.lda0 = d->lda0; a.lda1 = d->lda1;
+    a.Hin = d->h_in; a.Win = d->w_in; a.Ho = d->h_out; a.Wo = d->w_out; a.HoWo = d->h_out * d->w_out;
+    a.KW = d->kw; a.taps = d->kh * d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.ups = d->upsample;
+    a.dy = d->dy; a.lddy = d->lddy;
+    const int64_t M64 = (int64_t)d->batch * d->h_out * d->w_out;
+    MF_CHECK_ARG(M64 < (1ll << 31), "mf_conv_wgrad: M too large");
+    a.M = (int)M64; a.N = d->n;
+    const int64_t K = (int64_t)a.taps * a.Ctot;
+    MF_CHECK_ARG(d->lddw >= K, "mf_conv_wgrad: lddw < K");
+    a.tiles_n = (a.N + WG_BN - 1) / WG_BN;
+    a.tiles_k_per_tap = (a.Ctot + WG_BC - 1) / WG_BC;
+    const int64_t tiles = (int64_t)a.tiles_n * a.tiles_k_per_tap * a.taps;
+    int sm = d->splitm;
+    if (sm <= 0) {
+        sm = (int)((1024 + tiles - 1) / tiles);
+        const int cap = a.M / 256 < 1 ? 1 : a.M / 256;
+        if (sm > cap) sm = cap;
+        if (sm > 64) sm = 64;
+        if (sm > 1 && (d->ws == nullptr || (int64_t)sm * a.N * K > d->ws_floats)) {
+            sm = d->ws ? (int)(d->ws_floats / ((int64_t)a.N * K)) : 1;
+            if (sm < 1) sm = 1;
+        }
+    }
+    MF_CHECK_ARG(sm == 1 || (d->ws && (int64_t)sm * a.N * K <= d->ws_floats), "mf_conv_wgrad: split-M=%d needs %lld workspace floats", sm,
+                 (long long)sm * a.N * K);
+    a.m_per_split = ((a.M + sm - 1) / sm + WG_BP - 1) / WG_BP * WG_BP;
+    a.splitm = (a.M + a.m_per_split - 1) / a.m_per_split;
+    const bool direct = a.splitm == 1 && !d->accumulate;
+    a.out = direct ? d->dw : d->ws;
+    a.ldo = direct ? d->lddw : K;
+    a.slab = (int64_t)a.N * K;
+    MF_CHECK_ARG(direct || d->ws, "mf_conv_wgrad: accumulate needs a workspace");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)tiles, (unsigned)a.splitm);
+    if (d->dtype == MF_F32) hipLaunchKernelGGL(conv_wgrad_kernel<MF_F32>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<MF_F16X3>, grid, dim3(256), 0, s, a);
+    MF_CHECK_LAUNCH("mf_conv_wgrad");
+    if (!direct) {
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for((int64_t)a.N * K)), dim3(256), 0, s, d->ws, a.splitm, a.slab, d->dw, d->lddw, a.N,
+                           (int)K, d->accumulate);
+        MF_CHECK_LAUNCH("mf_conv_wgrad(sum slabs)");
+    }
+    return MF_OK;
+}
+
+extern "C" int mf_transpose(const float* x, float* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,
+                            int64_t zsy, void* stream) {
+    MF_CHECK_ARG(x && y && nz >= 1 && rows >= 1 && cols >= 1 && nz < 65536, "mf_transpose: bad arguments");
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, nz);
+    MF_CHECK_ARG(grid.y < 65536, "mf_transpose: too many rows");
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ldx, ldy, zsx, zsy);
+    MF_CHECK_LAUNCH("mf_transpose");
+    return MF_OK;
+}
+
+extern "C" int64_t mf_colsum_ws_floats(int32_t segs, int64_t rows_per_seg, int32_t n) {
+    int64_t chunks = (rows_per_seg + 63) / 64;
+    if (chunks > 64) chunks = 64;
+    if (chunks < 1) chunks = 1;
+    return (int64_t)segs * chunks * n;
+}
+
+extern "C" int mf_colsum(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t segs, int64_t rows_per_seg, int32_t n,
+                         int32_t accumulate, float* ws, void* stream) {
+    MF_CHECK_ARG(x && out && ws && segs >= 1 && rows_per_seg >= 1 && n >= 1, "mf_colsum: bad arguments");
+    int64_t chunks = (rows_per_seg + 63) / 64;
+    if (chunks > 64) chunks = 64;
+    const int64_t rpc = (rows_per_seg + chunks - 1) / chunks;
+    MF_CHECK_ARG((int64_t)segs * chunks < 65536, "mf_colsum: too many segments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_stage1, dim3((n + 63) / 64, (unsigned)(segs * chunks)), dim3(256), 0, s, x, ldx, ws, n, rows_per_seg,
+                       (int)chunks, rpc);
+    MF_CHECK_LAUNCH("mf_colsum");
+    hipLaunchKernelGGL(colsum_stage2, dim3(grid_for((int64_t)segs * n, 1024)), dim3(256), 0, s, ws, out, ldo, n, segs, (int)chunks, accumulate);
+    MF_CHECK_LAUNCH("mf_colsum(stage 2)");
+    return MF_OK;
+}
+
+extern "C" int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream) {
+    MF_CHECK_ARG(d && d->x0 && d->dy && d->gamma && d->beta && d->dx0, "mf_groupnorm_bwd: null pointer");
+    const int C = d->c0 + d->c1;
+    MF_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && (d->x1 != nullptr) == (d->c1 > 0) && (d->dx1 != nullptr) == (d->c1 > 0),
+                 "mf_groupnorm_bwd: bad segments");
+    MF_CHECK_ARG(d->groups >= 1 && C % d->groups == 0 && C / d->groups <= 256, "mf_groupnorm_bwd: groups must divide channels, <= 256 channels per group");
+    MF_CHECK_ARG((d->dgamma_part != nullptr) == (d->dbeta_part != nullptr), "mf_groupnorm_bwd: dgamma / dbeta partials go together");
+    GnBwdArgs a{};
+    a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1; a.dy = d->dy; a.gamma = d->gamma; a.beta = d->beta;
+    a.dx0 = d->dx0; a.dx1 = d->dx1; a.dgamma_part = d->dgamma_part; a.dbeta_part = d->dbeta_part;
+    a.batch = d->batch; a.hw = d->hw; a.groups = d->groups; a.silu = d->silu; a.eps = d->eps;
+    hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, (hipStream_t)stream, a);
+    MF_CHECK_LAUNCH("mf_groupnorm_bwd");
+    return MF_OK;
+}
+
+extern "C" int mf_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma_part, float* dbeta_part,
+                                int64_t rows, int32_t c, float eps, void* stream) {
+    MF_CHECK_ARG(x && dy && gamma && dx && rows >= 1 && c >= 1 && c <= 64 * LN_MAXK, "mf_layernorm_bwd: bad arguments (c <= %d)", 64 * LN_MAXK);
+    MF_CHECK_ARG((dgamma_part != nullptr) == (dbeta_part != nullptr), "mf_layernorm_bwd: dgamma / dbeta partials go together");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dx,
+                       dgamma_part, dbeta_part, rows, c, eps);
+    MF_CHECK_LAUNCH("mf_layernorm_bwd");
+    return MF_OK;
+}
+
+extern "C" int mf_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int32_t cols, int32_t ld, float scale, void* stream) {
+    MF_CHECK_ARG(p && dp && ds && rows >= 1 && cols >= 1 && ld >= cols && rows < (1ll << 31), "mf_softmax_bwd: bad arguments");
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, p, dp, ds, cols, ld, scale);
+    MF_CHECK_LAUNCH("mf_softmax_bwd");
+    return MF_OK;
+}
+
+extern "C" int mf_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    MF_CHECK_ARG(x && dy && dx && n >= 0, "mf_silu_bwd: bad arguments");
+    if (n == 0) return MF_OK;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+    MF_CHECK_LAUNCH("mf_silu_bwd");
+    return MF_OK;
+}
+
+extern "C" int mf_geglu_bwd(const float* h, const float* dout, float* dh, int64_t rows, int32_t c, void* stream) {
+    MF_CHECK_ARG(h && dout && dh && rows >= 1 && c >= 1, "mf_geglu_bwd: bad arguments");
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(rows * c)), dim3(256), 0, (hipStream_t)stream, h, dout, dh, rows, c);
+    MF_CHECK_LAUNCH("mf_geglu_bwd");
+    return MF_OK;
+}
+
+extern "C" int mf_zero_insert2x(const float* x, float* y, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+    MF_CHECK_ARG(x && y && batch >= 1 && h >= 1 && w >= 1 && c >= 4 && c % 4 == 0, "mf_zero_insert2x: bad arguments (c %% 4 == 0)");
+    hipLaunchKernelGGL(zero_insert2x_kernel, dim3(grid_for((int64_t)batch * 4 * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+                       batch, h, w, c / 4);
+    MF_CHECK_LAUNCH("mf_zero_insert2x");
+    return MF_OK;
+}
+
+extern "C" int mf_sumpool2x2(const float* x, float* y, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream) {
+    MF_CHECK_ARG(x && y && batch >= 1 && h >= 1 && w >= 1 && c >= 4 && c % 4 == 0, "mf_sumpool2x2: bad arguments (c %% 4 == 0)");
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid_for((int64_t)batch * h * w * (c / 4))), dim3(256), 0, (hipStream_t)stream, x, y, batch, h,
+                       w, c / 4);
+    MF_CHECK_LAUNCH("mf_sumpool2x2");
+    return MF_OK;
+}
+
+extern "C" int mf_mse_grad(const float* pred, const float* target, const float* weights, float* dpred, int32_t rows, int64_t n,
+                           void* stream) {
+    MF_CHECK_ARG(pred && target && dpred && rows >= 1 && n >= 1, "mf_mse_grad: bad arguments");
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(grid_for((int64_t)rows * n)), dim3(256), 0, (hipStream_t)stream, pred, target, weights, dpred,
+                       rows, n);
+    MF_CHECK_LAUNCH("mf_mse_grad");
+    return MF_OK;
+}
+
+extern "C" int64_t mf_sumsq_ws_doubles(void) { return SUMSQ_BLOCKS; }
+
+extern "C" int mf_sumsq(const float* x, int64_t n, double* out, int32_t accumulate, double* ws, void* stream) {
+    MF_CHECK_ARG(x && out && ws && n >= 0, "mf_sumsq: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = grid_for(n, SUMSQ_BLOCKS);
+    hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(256), 0, s, x, n, ws);
+    MF_CHECK_LAUNCH("mf_sumsq");
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, s, ws, blocks, out, accumulate);
+    MF_CHECK_LAUNCH("mf_sumsq(stage 2)");
+    return MF_OK;
+}
+
+extern "C" int mf_clip_coef(const double* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
+    MF_CHECK_ARG(sumsq && coef, "mf_clip_coef: null pointer");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef, norm_out);
+    MF_CHECK_LAUNCH("mf_clip_coef");
+    return MF_OK;
+}
+
+extern "C" int mf_adamw(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int32_t step, const float* grad_scale, void* stream) {
+    MF_CHECK_ARG(w && g && m && v && n >= 0 && step >= 1, "mf_adamw: bad arguments");
+    if (n == 0) return MF_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 16384)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    MF_CHECK_LAUNCH("mf_adamw");
+    return MF_OK;
+}

@@ -1,4 +1,5 @@
-"""Batch-sharded multi-GPU inference: one process per GPU, no data-path collective.
+"""Batch-sharded multi-GPU inference (no data-path collective) and data-parallel training (one gradient all-reduce per
+step, bucketed and overlapped with the backward pass): one process per GPU.
 
 The reference shards its sample list with accelerate's `PartialState().split_between_processes`
 (examples/brushnet/test_brushnet.py:163-168): a static contiguous split where the first `n % world` ranks get
@@ -64,3 +65,97 @@ def sum_over_ranks(value: float, device="cpu") -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+class GradBuckets:
+    """The gradient exchange of data-parallel training (accelerate's DDP wrap, train_brushnet_mirror.py:1267-1269; the
+    all-reduce happens inside `accelerator.backward`, :1459): every rank holds the full model, gradients are AVERAGED.
+
+    Built for the flat gradient arenas and for xGMI: the arena is cut into fixed buckets (default 64 Mi floats = 256 MiB:
+    large enough that RCCL's ring / mesh step time is bandwidth- not latency-bound on 153 GB/s links, small enough that
+    several are in flight under the backward pass).  The tape reports every finished parameter gradient; when all
+    parameters that touch a bucket are final the bucket is all-reduced asynchronously on a side stream (ordered after the
+    compute stream by an event) while backward keeps running.  finish() flushes what is left, waits, and divides by the
+    world size.  With one rank everything is a no-op."""
+
+    def __init__(self, models, bucket_floats: int = 64 * 1024 * 1024):
+        self.models = [m for m in models if m.flat_g is not None]
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.bucket_floats = int(bucket_floats)
+        self._stream = None
+        self._plan = []
+        for m in self.models:
+            n = m.num_arena_floats()
+            nb = max(1, -(-n // self.bucket_floats))
+            pending = [0] * nb
+            where = {}
+            for name, (a, shape, _meta) in m._pmap.items():
+                numel = int(torch.Size(shape).numel())
+                bs = range(a // self.bucket_floats, (a + max(numel, 1) - 1) // self.bucket_floats + 1)
+                where[name] = list(bs)
+                for b in bs:
+                    pending[b] += 1
+            self._plan.append(dict(model=m, n=n, nb=nb, pending0=pending, where=where))
+        self._state = None
+
+    def begin(self, tape) -> None:
+        self._state = [dict(pending=list(p["pending0"]), sent=[False] * p["nb"], handles=[]) for p in self._plan]
+        self._by_grad = {}
+        for pi, p in enumerate(self._plan):
+            self._by_grad[p["model"].flat_g.untyped_storage().data_ptr()] = pi
+        tape.on_param_grad = self._on_param if self.world > 1 else None
+
+    def _on_param(self, param) -> None:
+        pi = self._by_grad.get(param.grad.untyped_storage().data_ptr())
+        if pi is None:
+            return
+        p, st = self._plan[pi], self._state[pi]
+        for b in p["where"].get(param.name, ()):
+            st["pending"][b] -= 1
+            if st["pending"][b] == 0 and not st["sent"][b]:
+                self._send(pi, b)
+
+    def _send(self, pi: int, b: int) -> None:
+        p, st = self._plan[pi], self._state[pi]
+        st["sent"][b] = True
+        lo, hi = b * self.bucket_floats, min((b + 1) * self.bucket_floats, p["n"])
+        buf = p["model"].flat_g[lo:hi]
+        if buf.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=buf.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(buf.device))
+            self._stream.wait_event(ev)
+            with torch.cuda.stream(self._stream):
+                st["handles"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            st["handles"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> None:
+        if self.world == 1:
+            return
+        for pi, p in enumerate(self._plan):
+            for b in range(p["nb"]):
+                if not self._state[pi]["sent"][b]:
+                    self._send(pi, b)
+        for pi, p in enumerate(self._plan):
+            for h in self._state[pi]["handles"]:
+                h.wait()
+            g = p["model"].flat_g[: p["n"]]
+            if g.is_cuda:
+                if self._stream is not None:
+                    torch.cuda.current_stream(g.device).wait_stream(self._stream)
+                from . import hip
+                hip.axpby_n([g], [1.0 / self.world], out=g)
+            else:
+                g.mul_(1.0 / self.world)          # CPU (gloo) test path only
+
+
+def gather_mean(value: torch.Tensor) -> float:
+    """accelerator.gather(loss.repeat(bs)).mean() (train_brushnet_mirror.py:1454-1457): the logging loss over all ranks."""
+    v = value.detach().float().reshape(1).clone()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if v.is_cuda or dist.get_backend() != "nccl":
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            v /= dist.get_world_size()
+    return float(v.item())

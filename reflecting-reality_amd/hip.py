@@ -50,6 +50,35 @@ class GemmDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("a0", C.c_void_p), ("a1", C.c_void_p),
+        ("c0", C.c_int32), ("c1", C.c_int32),
+        ("lda0", C.c_int64), ("lda1", C.c_int64),
+        ("batch", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
+        ("upsample", C.c_int32),
+        ("dy", C.c_void_p), ("lddy", C.c_int64),
+        ("n", C.c_int32),
+        ("dw", C.c_void_p), ("lddw", C.c_int64),
+        ("accumulate", C.c_int32), ("splitm", C.c_int32),
+        ("ws", C.c_void_p), ("ws_floats", C.c_int64),
+    ]
+
+
+class GroupNormBwdDesc(C.Structure):
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p), ("c0", C.c_int32), ("c1", C.c_int32),
+        ("dy", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("dx0", C.c_void_p), ("dx1", C.c_void_p),
+        ("dgamma_part", C.c_void_p), ("dbeta_part", C.c_void_p),
+        ("batch", C.c_int32), ("hw", C.c_int32), ("groups", C.c_int32), ("silu", C.c_int32),
+        ("eps", C.c_float),
+    ]
+
+
 class GroupNormDesc(C.Structure):
     _fields_ = [
         ("x0", C.c_void_p), ("x1", C.c_void_p),
@@ -73,6 +102,10 @@ EXPORTS = [
     "mf_attention_f16x3", "mf_split_halves",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
+    # training (csrc/train.hip)
+    "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
+    "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_layernorm_bwd", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
+    "mf_zero_insert2x", "mf_sumpool2x2", "mf_mse_grad", "mf_sumsq_ws_doubles", "mf_sumsq", "mf_clip_coef", "mf_adamw",
 ]
 
 _lib: Optional[C.CDLL] = None
@@ -95,10 +128,14 @@ def load() -> C.CDLL:
     lib = C.CDLL(path)
     lib.mf_last_error.restype = C.c_char_p
     lib.mf_groupnorm_ws_floats.restype = C.c_int64
+    for fn in ("mf_conv_wgrad_ws_floats", "mf_colsum_ws_floats", "mf_sumsq_ws_doubles"):
+        getattr(lib, fn).restype = C.c_int64
     if lib.mf_abi_version() != ABI_VERSION:
         raise MfhipError(f"libmfhip ABI {lib.mf_abi_version()} != binding ABI {ABI_VERSION}: rebuild the library")
     if lib.mf_sizeof_gemm_desc() != C.sizeof(GemmDesc) or lib.mf_sizeof_groupnorm_desc() != C.sizeof(GroupNormDesc):
         raise MfhipError("descriptor struct layout mismatch between mfhip.h and the ctypes binding")
+    if lib.mf_sizeof_wgrad_desc() != C.sizeof(WgradDesc) or lib.mf_sizeof_groupnorm_bwd_desc() != C.sizeof(GroupNormBwdDesc):
+        raise MfhipError("training descriptor struct layout mismatch between mfhip.h and the ctypes binding")
     _lib = lib
     return lib
 
@@ -562,13 +599,14 @@ def cfg_combine(eps_u: torch.Tensor, eps_c: torch.Tensor, g: float) -> torch.Ten
     return out
 
 
-def axpby_n(xs, coefs) -> torch.Tensor:
-    """y = sum_i coefs[i] * xs[i] over fp32 tensors of equal shape (at most 6)."""
+def axpby_n(xs, coefs, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = sum_i coefs[i] * xs[i] over fp32 tensors of equal shape (at most 6); `out` may be one of the inputs."""
     _req_cuda(*xs)
     n = len(xs)
     arr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
     cf = (C.c_float * n)(*[float(c) for c in coefs])
-    out = torch.empty_like(xs[0])
+    if out is None:
+        out = torch.empty_like(xs[0])
     _check(load().mf_axpby_n(arr, cf, n, C.c_void_p(out.data_ptr()), C.c_int64(out.numel()), _stream()), "mf_axpby_n")
     return out
 
@@ -615,3 +653,169 @@ def nearest_resize(src: torch.Tensor, h_out: int, w_out: int) -> torch.Tensor:
     _check(load().mf_nearest_resize(C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()), b * c, h, w, h_out, w_out,
                                     _stream()), "mf_nearest_resize")
     return out
+
+
+# ---- training (csrc/train.hip): fp32 tensors ---------------------------------------------------------------------
+def _f32(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
+            raise MfhipError("training kernels take fp32 device tensors")
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, code: int, c0: int, batch: int, h_in: int, w_in: int,
+               h_out: int, w_out: int, kh: int = 1, kw: int = 1, stride: int = 1, pad_t: int = 0, pad_l: int = 0,
+               upsample: bool = False, x1: Optional[torch.Tensor] = None, c1: int = 0, n: int, accumulate: bool = True) -> None:
+    """dw[n][kh*kw*(c0+c1)] (+)= sum_m dy[m][n] * im2col(x | x1)[m][:] (mf_conv_wgrad)."""
+    _f32(x, x1, dy, dw)
+    d = WgradDesc()
+    d.dtype = MF_F16X3 if code == MF_F16X3 else MF_F32
+    d.a0, d.a1, d.c0, d.c1, d.lda0, d.lda1 = _ptr(x), _ptr(x1), c0, c1, c0, c1
+    d.batch, d.h_in, d.w_in, d.h_out, d.w_out = batch, h_in, w_in, h_out, w_out
+    d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.upsample = kh, kw, stride, pad_t, pad_l, int(upsample)
+    d.dy, d.lddy, d.n = _ptr(dy), n, n
+    d.dw, d.lddw = _ptr(dw), kh * kw * (c0 + c1)
+    d.accumulate, d.splitm = int(accumulate), 0
+    ws = scratch("wgrad", WGRAD_WS_FLOATS, x.device)
+    d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+    _check(load().mf_conv_wgrad(C.byref(d), _stream()), "mf_conv_wgrad")
+
+
+WGRAD_WS_FLOATS = 64 * 1024 * 1024      # 256 MiB of split-M slabs
+
+
+def transpose(x: torch.Tensor, rows: int, cols: int, *, nz: int = 1, ldx: Optional[int] = None, ldy: Optional[int] = None,
+              zsx: int = 0, zsy: int = 0, out: Optional[torch.Tensor] = None, y_offset: int = 0) -> torch.Tensor:
+    """out[z][c][r] = x[z][r][c] (element strides; see mf_transpose)."""
+    _f32(x, out)
+    ldx = cols if ldx is None else ldx
+    ldy = rows if ldy is None else ldy
+    if out is None:
+        out = torch.empty(nz, cols, ldy, dtype=torch.float32, device=x.device)
+    _check(load().mf_transpose(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr() + 4 * y_offset), nz, rows, cols, C.c_int64(ldx),
+                               C.c_int64(ldy), C.c_int64(zsx), C.c_int64(zsy), _stream()), "mf_transpose")
+    return out
+
+
+def colsum(x: torch.Tensor, n: int, *, segs: int = 1, rows_per_seg: Optional[int] = None, ldx: Optional[int] = None,
+           out: Optional[torch.Tensor] = None, ldo: Optional[int] = None, accumulate: bool = False) -> torch.Tensor:
+    _f32(x, out)
+    ldx = n if ldx is None else ldx
+    rows_per_seg = x.numel() // ldx // segs if rows_per_seg is None else rows_per_seg
+    if out is None:
+        out = torch.empty(segs, n, dtype=torch.float32, device=x.device)
+    lib = load()
+    ws = scratch("colsum", int(lib.mf_colsum_ws_floats(segs, C.c_int64(rows_per_seg), n)), x.device)
+    _check(lib.mf_colsum(C.c_void_p(x.data_ptr()), C.c_int64(ldx), C.c_void_p(out.data_ptr()), C.c_int64(n if ldo is None else ldo), segs,
+                         C.c_int64(rows_per_seg), n, int(accumulate), C.c_void_p(ws.data_ptr()), _stream()), "mf_colsum")
+    return out
+
+
+def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int, eps: float, silu: bool,
+                  x1: Optional[torch.Tensor] = None, want_param_grads: bool = True):
+    """Returns (dx0, dx1 or None, dgamma_part [B, C] or None, dbeta_part)."""
+    _f32(x0, x1, dy, gamma, beta)
+    b, c0 = x0.shape[0], x0.shape[-1]
+    c1 = x1.shape[-1] if x1 is not None else 0
+    hw = x0.numel() // (b * c0)
+    dx0 = torch.empty_like(x0)
+    dx1 = torch.empty_like(x1) if x1 is not None else None
+    dg = torch.empty(b, c0 + c1, dtype=torch.float32, device=x0.device) if want_param_grads else None
+    db = torch.empty_like(dg) if want_param_grads else None
+    d = GroupNormBwdDesc()
+    d.x0, d.x1, d.c0, d.c1, d.dy = _ptr(x0), _ptr(x1), c0, c1, _ptr(dy)
+    d.gamma, d.beta, d.dx0, d.dx1, d.dgamma_part, d.dbeta_part = _ptr(gamma), _ptr(beta), _ptr(dx0), _ptr(dx1), _ptr(dg), _ptr(db)
+    d.batch, d.hw, d.groups, d.silu, d.eps = b, hw, groups, int(silu), eps
+    _check(load().mf_groupnorm_bwd(C.byref(d), _stream()), "mf_groupnorm_bwd")
+    return dx0, dx1, dg, db
+
+
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, want_param_grads: bool = True):
+    _f32(x, dy, gamma)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    dx = torch.empty_like(x)
+    nb = (rows + 63) // 64
+    dg = torch.empty(nb, c, dtype=torch.float32, device=x.device) if want_param_grads else None
+    db = torch.empty_like(dg) if want_param_grads else None
+    _check(load().mf_layernorm_bwd(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(gamma.data_ptr()),
+                                   C.c_void_p(dx.data_ptr()), C.c_void_p(_ptr(dg)), C.c_void_p(_ptr(db)), C.c_int64(rows), c,
+                                   C.c_float(eps), _stream()), "mf_layernorm_bwd")
+    return dx, dg, db
+
+
+def softmax_bwd(p: torch.Tensor, dp: torch.Tensor, cols: int, scale: float) -> torch.Tensor:
+    _f32(p, dp)
+    ld = p.shape[-1]
+    ds = torch.empty_like(p)
+    _check(load().mf_softmax_bwd(C.c_void_p(p.data_ptr()), C.c_void_p(dp.data_ptr()), C.c_void_p(ds.data_ptr()),
+                                 C.c_int64(p.numel() // ld), cols, ld, C.c_float(scale), _stream()), "mf_softmax_bwd")
+    return ds
+
+
+def silu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _f32(x, dy)
+    dx = torch.empty_like(x)
+    _check(load().mf_silu_bwd(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(dx.data_ptr()), C.c_int64(x.numel()),
+                              _stream()), "mf_silu_bwd")
+    return dx
+
+
+def geglu_bwd(h: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    _f32(h, dout)
+    c = h.shape[-1] // 2
+    dh = torch.empty_like(h)
+    _check(load().mf_geglu_bwd(C.c_void_p(h.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(dh.data_ptr()),
+                               C.c_int64(h.numel() // (2 * c)), c, _stream()), "mf_geglu_bwd")
+    return dh
+
+
+def zero_insert2x(x: torch.Tensor) -> torch.Tensor:
+    _f32(x)
+    b, h, w, c = x.shape
+    y = torch.empty(b, 2 * h, 2 * w, c, dtype=torch.float32, device=x.device)
+    _check(load().mf_zero_insert2x(C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), b, h, w, c, _stream()), "mf_zero_insert2x")
+    return y
+
+
+def sumpool2x2(x: torch.Tensor) -> torch.Tensor:
+    _f32(x)
+    b, h2, w2, c = x.shape
+    y = torch.empty(b, h2 // 2, w2 // 2, c, dtype=torch.float32, device=x.device)
+    _check(load().mf_sumpool2x2(C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), b, h2 // 2, w2 // 2, c, _stream()), "mf_sumpool2x2")
+    return y
+
+
+def mse_grad(pred: torch.Tensor, target: torch.Tensor, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _f32(pred, target, weights)
+    rows = pred.shape[0]
+    d = torch.empty_like(pred)
+    _check(load().mf_mse_grad(C.c_void_p(pred.data_ptr()), C.c_void_p(target.data_ptr()), C.c_void_p(_ptr(weights)),
+                              C.c_void_p(d.data_ptr()), rows, C.c_int64(pred.numel() // rows), _stream()), "mf_mse_grad")
+    return d
+
+
+def sumsq(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """out[0] (float64, device) (+)= sum x^2."""
+    _f32(x)
+    lib = load()
+    key = ("sumsq", torch.device(x.device).index, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _scratch.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib.mf_sumsq_ws_doubles()), dtype=torch.float64, device=x.device)
+        _scratch[key] = ws
+    _check(lib.mf_sumsq(C.c_void_p(x.data_ptr()), C.c_int64(x.numel()), C.c_void_p(out.data_ptr()), int(accumulate),
+                        C.c_void_p(ws.data_ptr()), _stream()), "mf_sumsq")
+    return out
+
+
+def clip_coef(sumsq_t: torch.Tensor, max_norm: float, coef: torch.Tensor, norm_out: Optional[torch.Tensor] = None) -> None:
+    _check(load().mf_clip_coef(C.c_void_p(sumsq_t.data_ptr()), C.c_float(max_norm), C.c_void_p(coef.data_ptr()),
+                               C.c_void_p(_ptr(norm_out)), _stream()), "mf_clip_coef")
+
+
+def adamw(w: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+          weight_decay: float = 1e-2, step: int, grad_scale: Optional[torch.Tensor] = None) -> None:
+    _f32(w, g, m, v, grad_scale)
+    _check(load().mf_adamw(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
+                           C.c_int64(w.numel()), C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps),
+                           C.c_float(weight_decay), step, C.c_void_p(_ptr(grad_scale)), _stream()), "mf_adamw")

@@ -22,7 +22,8 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
 
-from . import hip, ops
+from . import autograd, hip, ops
+from .autograd import Param
 from .ops import ConvWeight, Precision
 
 F32 = torch.float32
@@ -96,6 +97,15 @@ class HipModel:
         self._src: Optional[Dict[str, torch.Tensor]] = None   # fp32 master copy (CPU), for save_pretrained
         self._ready = False
         self._weights_gen = 0       # bumped whenever the device weights are rebuilt (captured hipGraphs key on it)
+        # training layout (prepare_training): every parameter is a view of flat fp32 arenas — master weights in the
+        # kernels' layout, gradients, and (owned by training.AdamW) the Adam moments
+        self.training = False
+        self._requires_grad = True
+        self.flat_w: Optional[torch.Tensor] = None
+        self.flat_g: Optional[torch.Tensor] = None
+        self._arena_used = 0
+        self._pmap: "OrderedDict[str, tuple]" = OrderedDict()
+        self.gradient_checkpointing = False
 
     # -- dtype / device surface the callers touch ----------------------------------------------
     @property
@@ -113,7 +123,13 @@ class HipModel:
     def eval(self):
         return self
 
-    def requires_grad_(self, flag: bool = False):
+    def requires_grad_(self, flag: bool = True):
+        """Whether prepare_training() gives this model a gradient arena (train_brushnet_mirror.py:1072-1079: the UNet is
+        frozen unless --train_base_unet, BrushNet trains)."""
+        if self.training and flag != self._requires_grad:
+            self._requires_grad = bool(flag)
+            self.prepare_training()
+        self._requires_grad = bool(flag)
         return self
 
     # -- parameters -----------------------------------------------------------------------------
@@ -121,9 +137,87 @@ class HipModel:
         raise NotImplementedError
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        if self.training:
+            return self._export(self.flat_w)
         if self._src is None:
             raise RuntimeError("no parameters loaded")
         return dict(self._src)
+
+    def grad_state_dict(self) -> Dict[str, torch.Tensor]:
+        """The gradient arena in the reference's parameter layout (what `p.grad` holds there)."""
+        if not (self.training and self.flat_g is not None):
+            raise RuntimeError("no gradients: call prepare_training() with requires_grad")
+        return self._export(self.flat_g)
+
+    # -- training layout ------------------------------------------------------------------------------
+    def prepare_training(self, requires_grad: Optional[bool] = None):
+        """Rebuild the device parameters as views of one flat fp32 arena in the kernels' layout (raw fp32 weights — the
+        optimizer updates them in place every step, so nothing is pre-split or fused) plus, when the model trains, a
+        gradient arena of the same layout.  Precision must be fp32-class ('fp32' or 'f16x3')."""
+        if self.prec.act != F32:
+            raise NotImplementedError("training runs with fp32 master weights and activations: build the model with "
+                                      "precision='fp32' or 'f16x3' (bf16 autocast is not built)")
+        if requires_grad is not None:
+            self._requires_grad = bool(requires_grad)
+        src = self.state_dict() if (self.training or self._src is not None) else None
+        if src is None:
+            raise RuntimeError("no parameters loaded")
+        cap = 0
+        for shp in self.param_shapes().values():
+            cap += (int(torch.Size(shp).numel()) // shp[1] * ((shp[1] + 7) // 8 * 8) if len(shp) == 4 else int(torch.Size(shp).numel())) + 16
+        self.flat_w = torch.zeros(cap, dtype=F32, device=self.device)
+        self.flat_g = torch.zeros(cap, dtype=F32, device=self.device) if self._requires_grad else None
+        self._arena_used = 0
+        self._pmap = OrderedDict()
+        self.training = True
+        self._src = None
+        self._prepare({k: v.to("cpu", F32) for k, v in src.items()})
+        self._weights_gen += 1
+        self._ready = True
+        return self
+
+    def _alloc(self, name: str, t: torch.Tensor, meta: tuple) -> Param:
+        """Bump-allocate t (kernel layout, fp32) in the arena; 16-byte aligned."""
+        n = t.numel()
+        a = self._arena_used
+        if a + n > self.flat_w.numel():
+            raise RuntimeError("training arena overflow")
+        w = self.flat_w[a:a + n].view(t.shape)
+        w.copy_(t.to(self.device, F32))
+        g = self.flat_g[a:a + n].view(t.shape) if self.flat_g is not None else None
+        self._arena_used = a + (n + 3) // 4 * 4
+        p = Param(name, w, g)
+        self._pmap[name] = (a, tuple(t.shape), meta)
+        return p
+
+    def num_arena_floats(self) -> int:
+        return self._arena_used
+
+    def _export(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        out = {}
+        host = flat[: self._arena_used].cpu()
+        for name, (a, shape, meta) in self._pmap.items():
+            t = host[a:a + int(torch.Size(shape).numel())].view(shape)
+            if meta[0] == "conv":                      # [N][kh][kw][cin_pad] -> [N, cin, kh, kw]
+                _, n, cin, kh, kw, cp, is_linear = meta
+                t = t.view(n, kh, kw, cp)[..., :cin].permute(0, 3, 1, 2).contiguous()
+                out[name] = t.view(n, cin) if is_linear else t
+            elif meta[0] == "rows":                    # row blocks of one fused matrix: (names, row counts)
+                off = 0
+                for nm, rows in zip(meta[1], meta[2]):
+                    out[nm] = t[off:off + rows].clone()
+                    off += rows
+            elif meta[0] == "pad_rows":                # leading rows of a row-padded matrix
+                _, nm, rows, inner = meta
+                tt = t[:rows]
+                if inner is not None:
+                    _, n, cin, kh, kw, cp, is_linear = inner
+                    tt = tt.reshape(rows, kh, kw, cp)[..., :cin].permute(0, 3, 1, 2).contiguous()
+                    tt = tt.view(rows, cin) if is_linear else tt
+                out[nm] = tt.clone()
+            else:
+                out[name] = t.clone()
+        return out
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         shapes = self.param_shapes()
@@ -137,6 +231,9 @@ class HipModel:
             if k in sd and tuple(sd[k].shape) != tuple(shp):
                 raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(shp)}")
         self._src = {k: sd[k].detach().to("cpu", F32) for k in shapes if k in sd}
+        if self.training:                  # keep the training layout: rebuild the arenas from the new weights
+            self.training = False
+            return self.prepare_training()
         self._prepare(self._src)
         self._weights_gen += 1
         self._ready = True
@@ -167,13 +264,17 @@ class HipModel:
         return model
 
     def train(self, mode: bool = True):
-        if mode:
-            raise NotImplementedError("training (backward + optimizer) is SURVEY.md §8 f-2: not built; the HIP path is "
-                                      "forward only")
+        """nn.Module.train(): the MirrorFusion nets have no dropout / batch-norm state (dropout 0.0, resnet.py:393), so the
+        only effect is switching the parameters to the training layout the first time."""
+        if mode and not self.training:
+            self.prepare_training()
         return self
 
     def enable_gradient_checkpointing(self):
-        raise NotImplementedError("gradient checkpointing belongs to the training path (SURVEY.md §8 f-2)")
+        """brushnet.py:674-676 / train_brushnet_mirror.py:1153-1155.  Accepted and recorded; the tape keeps every
+        activation (a per-GPU batch of 8 at 512 x 512 holds ~60 GB of fp32 activations in 288 GB of HBM), so nothing is
+        recomputed except the attention probabilities, which are never stored."""
+        self.gradient_checkpointing = True
 
     def save_pretrained(self, path: str, **unused):
         from safetensors.torch import save_file
@@ -187,11 +288,37 @@ class HipModel:
 
     # -- helpers shared by the three models -------------------------------------------------------
     def _conv(self, sd, name, prec=None, cin_pad=None) -> ConvWeight:
+        if self.training:
+            return self._conv_param(name, sd[name + ".weight"], sd.get(name + ".bias"), prec or self.prec, cin_pad)
         # to_v is consumed by ops.linear_t with the weight as the A operand: never pre-split
         return ConvWeight(sd[name + ".weight"], sd.get(name + ".bias"), prec or self.prec, self.device, cin_pad,
                           raw=name.endswith(".to_v"))
 
+    def _conv_param(self, name, weight, bias, prec, cin_pad=None, n_pad: Optional[int] = None) -> ConvWeight:
+        """A conv / linear weight allocated in the training arena ([N][kh][kw][cin_pad] fp32); n_pad zero-pads the rows
+        (the VAE's 8-aligned moments / latents)."""
+        is_linear = weight.dim() == 2
+        w4 = weight[:, :, None, None] if is_linear else weight
+        n, cin, kh, kw = w4.shape
+        cp = cin_pad if cin_pad is not None else (cin + prec.vec - 1) // prec.vec * prec.vec
+        wk = torch.nn.functional.pad(w4.float().permute(0, 2, 3, 1), (0, cp - cin)).reshape(n, kh * kw * cp)
+        meta = ("conv", n, cin, kh, kw, cp, is_linear)
+        rows = n
+        if n_pad is not None and n_pad != n:
+            wk = torch.nn.functional.pad(wk, (0, 0, 0, n_pad - n))
+            meta = ("pad_rows", name + ".weight", n, meta)
+            rows = n_pad
+        p_w = self._alloc(name + ".weight", wk, meta)
+        p_b = None
+        if bias is not None:
+            bk = torch.nn.functional.pad(bias.float(), (0, rows - n))
+            p_b = self._alloc(name + ".bias", bk, ("vec",) if rows == n else ("pad_rows", name + ".bias", n, None))
+        return ConvWeight.from_params(p_w, p_b, prec, rows, cin, cp, kh, kw, self)
+
     def _norm(self, sd, name):
+        if self.training:
+            return (self._alloc(name + ".weight", sd[name + ".weight"].float(), ("vec",)),
+                    self._alloc(name + ".bias", sd[name + ".bias"].float(), ("vec",)))
         return (sd[name + ".weight"].to(self.device, F32).contiguous(), sd[name + ".bias"].to(self.device, F32).contiguous())
 
 
@@ -292,7 +419,16 @@ class _UNetCore(HipModel):
             self.temb_slices[n + "."] = (off, off + w.shape[0])
             off += w.shape[0]
             ws.append(w); bs.append(sd[n + ".time_emb_proj.bias"])
-        self.temb_proj = ConvWeight(torch.cat(ws, 0), torch.cat(bs, 0), f32, self.device)
+        if self.training:          # the fused matrix IS the master copy: its row blocks are the resnets' time_emb_proj
+            rows = [w.shape[0] for w in ws]
+            p_w = self._alloc("time_emb_proj.weight*", torch.cat(ws, 0).float(),
+                              ("rows", [n + ".time_emb_proj.weight" for n in names], rows))
+            p_b = self._alloc("time_emb_proj.bias*", torch.cat(bs, 0).float(),
+                              ("rows", [n + ".time_emb_proj.bias" for n in names], rows))
+            k = ws[0].shape[1]
+            self.temb_proj = ConvWeight.from_params(p_w, p_b, f32, sum(rows), k, k, 1, 1, self)
+        else:
+            self.temb_proj = ConvWeight(torch.cat(ws, 0), torch.cat(bs, 0), f32, self.device)
 
     def _prepare_resnet(self, sd, p):
         self.P[p + "norm1"] = self._norm(sd, p + "norm1")
@@ -314,11 +450,14 @@ class _UNetCore(HipModel):
             for a in ("attn1", "attn2"):
                 for l in ("to_q", "to_k", "to_v", "to_out.0"):
                     self.P[b + a + "." + l] = self._conv(sd, b + a + "." + l)
-            # self-attention: q and k read the same tokens -> one GEMM with N = 2C
-            self.P[b + "attn1.to_qk"] = ConvWeight(torch.cat([sd[b + "attn1.to_q.weight"], sd[b + "attn1.to_k.weight"]], 0),
-                                                   None, self.prec, self.device)
-            self.P[b + "ff.net.0.proj"] = ops.geglu_weight(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"],
-                                                           self.prec, self.device)
+            if self.training:      # no fused / interleaved copies: the arena holds each parameter once
+                self.P[b + "ff.net.0.proj"] = self._conv(sd, b + "ff.net.0.proj")
+            else:
+                # self-attention: q and k read the same tokens -> one GEMM with N = 2C
+                self.P[b + "attn1.to_qk"] = ConvWeight(torch.cat([sd[b + "attn1.to_q.weight"], sd[b + "attn1.to_k.weight"]], 0),
+                                                       None, self.prec, self.device)
+                self.P[b + "ff.net.0.proj"] = ops.geglu_weight(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"],
+                                                               self.prec, self.device)
             self.P[b + "ff.net.2"] = self._conv(sd, b + "ff.net.2")
             i += 1
         self.tdepth[p] = i
@@ -337,6 +476,13 @@ class _UNetCore(HipModel):
             t = t.contiguous()
         c0 = self.config["block_out_channels"][0]
         e = hip.timestep_embedding(t, c0, self.config["flip_sin_to_cos"], float(self.config["freq_shift"]))
+        if ops.TAPE is not None:           # training: every activation is its own differentiated operator
+            if self.add1 is not None:
+                raise NotImplementedError("training the SDXL text_time embedding is not built")
+            ops.TAPE.no_grad(e)
+            e = ops.silu(ops.linear(e, self.te1, out_dtype=F32))
+            e = ops.silu(ops.linear(e, self.te2, out_dtype=F32))
+            return ops.linear(e, self.temb_proj, out_dtype=F32)
         e = ops.linear(e, self.te1, act=hip.ACT_SILU, out_dtype=F32)
         if self.add1 is None:
             if added_cond_kwargs:
@@ -377,9 +523,9 @@ class _UNetCore(HipModel):
             sc, join = self._on_aux(lambda: ops.conv2d(x, P[p + "conv_shortcut"], padding=0, x1=x1))
         else:
             sc = x
-        h = hip.groupnorm(x, *P[p + "norm1"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act, x1=x1)
+        h = ops.groupnorm(x, P[p + "norm1"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act, x1=x1)
         h = ops.conv2d(h, P[p + "conv1"], temb=self._temb(temb_all, p))
-        h = hip.groupnorm(h, *P[p + "norm2"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act)
+        h = ops.groupnorm(h, P[p + "norm2"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act)
         if join is not None:
             join()
         return ops.conv2d(h, P[p + "conv2"], res0=sc, res1=inj)
@@ -414,6 +560,15 @@ class _UNetCore(HipModel):
         P = self.P
         c = x.shape[-1]
         d = c // heads
+        if self.training:
+            # training layout: separate q / k / v projections and the unfused, differentiated attention; the prompt's
+            # K / V are recomputed every step (their weights may be training)
+            src = x if ctx is None else ctx
+            q = ops.linear(x, P[b + "to_q"])
+            k = ops.linear(src, P[b + "to_k"])
+            v = ops.linear(src, P[b + "to_v"])
+            o = ops.attention_train(q, k, v, heads, 1.0 / (d ** 0.5), self.prec)
+            return ops.linear(o, P[b + "to_out.0"], res0=residual)
         if ctx is None:
             skv = x.shape[1]
             # V^T on the auxiliary stream while q | k is projected on this one
@@ -467,16 +622,19 @@ class _UNetCore(HipModel):
         P = self.P
         bsz, hh, ww, c = x.shape
         g = self.config["norm_num_groups"]
-        h = hip.groupnorm(x, *P[p + "norm"], groups=g, eps=1e-6, silu=False, out_dtype=self.prec.act)
+        h = ops.groupnorm(x, P[p + "norm"], groups=g, eps=1e-6, silu=False, out_dtype=self.prec.act)
         h = ops.conv2d(h, P[p + "proj_in"], padding=0).view(bsz, hh * ww, c)
         for i in range(self.tdepth[p]):
             b = f"{p}transformer_blocks.{i}."
-            n = hip.layernorm(h, *P[b + "norm1"], 1e-5, self.prec.act)
+            n = ops.layernorm(h, P[b + "norm1"], 1e-5, self.prec.act)
             h = self._attention(b + "attn1.", n, None, heads, h)
-            n = hip.layernorm(h, *P[b + "norm2"], 1e-5, self.prec.act)
+            n = ops.layernorm(h, P[b + "norm2"], 1e-5, self.prec.act)
             h = self._attention(b + "attn2.", n, ehs, heads, h)
-            n = hip.layernorm(h, *P[b + "norm3"], 1e-5, self.prec.act)
-            gg = ops.linear_geglu(n, P[b + "ff.net.0.proj"])
+            n = ops.layernorm(h, P[b + "norm3"], 1e-5, self.prec.act)
+            if self.training:      # GEGLU as its own (differentiated) launch on the plain, un-interleaved weight
+                gg = ops.geglu(ops.linear(n, P[b + "ff.net.0.proj"]), self.prec.act)
+            else:
+                gg = ops.linear_geglu(n, P[b + "ff.net.0.proj"])
             h = ops.linear(gg, P[b + "ff.net.2"], res0=h)
         return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj)
 
@@ -673,6 +831,8 @@ class BrushNetModel(_UNetCore):
         temb = self._time_embedding(timestep, bsz, added_cond_kwargs)
         x = hip.pack_nhwc(sample.to(self.device).float().contiguous(), brushnet_cond.to(self.device).float().contiguous(),
                           self.cin_pad, self.prec.act)                                            # :810 cat + pad
+        if ops.TAPE is not None:
+            ops.TAPE.no_grad(x)            # the batch's own inputs need no gradient
         x = ops.conv2d(x, self.P["conv_in_condition"])
         n = len(c["block_out_channels"])
         lpb = c["layers_per_block"]
@@ -824,10 +984,12 @@ class UNet2DConditionModel(_UNetCore):
         temb = self._time_embedding(timestep, bsz, added_cond_kwargs)
         ehs = self._bind_prompt(encoder_hidden_states)
         x = from_nchw(sample.to(self.device), self.prec, self.cin_pad)
+        if ops.TAPE is not None:
+            ops.TAPE.no_grad(x, ehs)
         x = ops.conv2d(x, self.P["conv_in"])
         skips = [x]                                                                                 # :1215 pre-add
         if is_brushnet:
-            x = hip.add(x, self._inj(down_block_add_samples.pop(0)), self.prec.act)                 # :1218
+            x = ops.add(x, self._inj(down_block_add_samples.pop(0)), self.prec.act)                 # :1218
 
         def take(lst):
             return self._inj(lst.pop(0)) if (is_brushnet and len(lst) > 0) else None
@@ -863,10 +1025,13 @@ class UNet2DConditionModel(_UNetCore):
             if i != n - 1:
                 inj = take(up_block_add_samples) if is_brushnet else None
                 x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True, res0=inj)
-        x = hip.groupnorm(x, *self.P["conv_norm_out"], groups=c["norm_num_groups"], eps=c["norm_eps"], silu=True,
+        x = ops.groupnorm(x, self.P["conv_norm_out"], groups=c["norm_num_groups"], eps=c["norm_eps"], silu=True,
                           out_dtype=self.prec.act)
         y = ops.conv2d(x, self.P["conv_out"], out_dtype=F32)
         out = hip.unpack_nchw(y, c["out_channels"])
+        if ops.TAPE is not None:           # d eps (NCHW) -> d y (NHWC, the conv's own channel count)
+            autograd.record_pointwise(ops.TAPE, (y,), out,
+                                      lambda g: (hip.pack_nhwc(g.view(out.shape), None, y.shape[-1], F32),))
         if not return_dict:
             return (out,)
         return UNet2DConditionOutput(sample=out)
@@ -911,6 +1076,10 @@ class AutoencoderKL(HipModel):
         cfg.setdefault("norm_num_groups", 32); cfg.setdefault("scaling_factor", 0.18215)
         cfg["block_out_channels"] = tuple(cfg["block_out_channels"])
         super().__init__(cfg, precision, device)
+
+    def prepare_training(self, requires_grad=None):
+        raise NotImplementedError("the VAE is frozen in MirrorFusion training (train_brushnet_mirror.py:1072) and outside the "
+                                  "loss graph: it has no training layout")
 
     def _convert_deprecated_keys(self, sd):
         # modeling_utils.py:929-971: query/key/value/proj_attn -> to_q/to_k/to_v/to_out.0
@@ -1011,9 +1180,9 @@ class AutoencoderKL(HipModel):
     def _resnet(self, p, x):
         g = self.config["norm_num_groups"]
         P = self.P
-        h = hip.groupnorm(x, *P[p + "norm1"], groups=g, eps=1e-6, silu=True, out_dtype=self.prec.act)
+        h = ops.groupnorm(x, P[p + "norm1"], groups=g, eps=1e-6, silu=True, out_dtype=self.prec.act)
         h = ops.conv2d(h, P[p + "conv1"])
-        h = hip.groupnorm(h, *P[p + "norm2"], groups=g, eps=1e-6, silu=True, out_dtype=self.prec.act)
+        h = ops.groupnorm(h, P[p + "norm2"], groups=g, eps=1e-6, silu=True, out_dtype=self.prec.act)
         sc = ops.conv2d(x, P[p + "conv_shortcut"], padding=0) if p + "conv_shortcut" in P else x
         return ops.conv2d(h, P[p + "conv2"], res0=sc)
 
@@ -1023,7 +1192,7 @@ class AutoencoderKL(HipModel):
         x = self._resnet(p + "resnets.0.", x)
         b, hh, ww, c = x.shape
         a = p + "attentions.0."
-        n = hip.groupnorm(x, *P[a + "group_norm"], groups=self.config["norm_num_groups"], eps=1e-6, silu=False,
+        n = ops.groupnorm(x, P[a + "group_norm"], groups=self.config["norm_num_groups"], eps=1e-6, silu=False,
                           out_dtype=self.prec.act).view(b, hh * ww, c)
         q = ops.linear(n, P[a + "to_q"])
         k = ops.linear(n, P[a + "to_k"])
@@ -1044,7 +1213,7 @@ class AutoencoderKL(HipModel):
             if i != n - 1:   # Downsample2D(padding=0): asymmetric (0,1,0,1) pad (downsampling.py:140-142)
                 h = ops.conv2d(h, self.P[f"encoder.down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=(0, 0, 1, 1))
         h = self._mid("encoder.mid_block.", h)
-        h = hip.groupnorm(h, *self.P["encoder.conv_norm_out"], groups=c["norm_num_groups"], eps=1e-6, silu=True,
+        h = ops.groupnorm(h, self.P["encoder.conv_norm_out"], groups=c["norm_num_groups"], eps=1e-6, silu=True,
                           out_dtype=self.prec.act)
         h = ops.conv2d(h, self.P["encoder.conv_out"])
         return ops.conv2d(h, self.P["quant_conv"], padding=0, out_dtype=F32)
@@ -1065,7 +1234,7 @@ class AutoencoderKL(HipModel):
                 h = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}.", h)
             if i != n - 1:
                 h = ops.conv2d(h, self.P[f"decoder.up_blocks.{i}.upsamplers.0.conv"], upsample=True)
-        h = hip.groupnorm(h, *self.P["decoder.conv_norm_out"], groups=c["norm_num_groups"], eps=1e-6, silu=True,
+        h = ops.groupnorm(h, self.P["decoder.conv_norm_out"], groups=c["norm_num_groups"], eps=1e-6, silu=True,
                           out_dtype=self.prec.act)
         y = ops.conv2d(h, self.P["decoder.conv_out"], out_dtype=F32)
         img = hip.unpack_nchw(y, c["out_channels"])

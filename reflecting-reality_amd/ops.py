@@ -15,7 +15,11 @@ from typing import Optional, Tuple, Union
 
 import torch
 
-from . import hip
+from . import autograd, hip
+
+# While a tape is installed (training.train_step does that around the forward pass) every operator below also records its
+# backward closure on it (autograd.py).  None = inference: nothing is recorded, nothing is kept alive.
+TAPE: Optional["autograd.Tape"] = None
 
 
 @dataclass(frozen=True)
@@ -81,6 +85,25 @@ class ConvWeight:
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.n, self.cin, self.cin_pad, self.kh, self.kw = n, cin, cp, kh, kw
         self.prec = prec
+        self.p_w = self.p_bias = None          # autograd.Param views when the weight lives in a training arena
+        self._gen_src = None
+
+    @classmethod
+    def from_params(cls, p_w: "autograd.Param", p_bias: Optional["autograd.Param"], prec: Precision, n: int, cin: int,
+                    cin_pad: int, kh: int, kw: int, gen_src) -> "ConvWeight":
+        """A weight whose storage is a view of a model's flat fp32 arena ([N][kh*kw*cin_pad], never pre-split: the
+        optimizer updates it in place every step)."""
+        self = cls.__new__(cls)
+        self.w, self.bias = p_w.data, (p_bias.data if p_bias is not None else None)
+        self.w_split, self.ldw = 0, kh * kw * cin_pad
+        self.n, self.cin, self.cin_pad, self.kh, self.kw = n, cin, cin_pad, kh, kw
+        self.prec = prec
+        self.p_w, self.p_bias, self._gen_src = p_w, p_bias, gen_src
+        return self
+
+    def generation(self) -> int:
+        """Changes whenever the underlying weights do (layouts derived from them are rebuilt then)."""
+        return self._gen_src._weights_gen if self._gen_src is not None else 0
 
 
 def split_pack(w: torch.Tensor, code: int):
@@ -121,6 +144,9 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
                   pad_t=pt, pad_l=pl, upsample=upsample, n=cw.n, bias=cw.bias,
                   temb=temb, ld_temb=(temb.stride(0) if temb is not None else 0),
                   res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
+    if TAPE is not None:
+        autograd.record_conv(TAPE, x, x1, cw, out, batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, pad_t=pt, pad_l=pl,
+                             upsample=upsample, temb=temb, res0=res0, res1=res1, alpha=alpha, act=act)
     return out
 
 
@@ -137,6 +163,9 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
         out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
     hip.gemm_conv(x, lw.w, out, dtype=lw.prec.code, w_split=lw.w_split, ldw=lw.ldw, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
                   h_out=1, w_out=1, n=lw.n, bias=lw.bias, res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
+    if TAPE is not None:
+        autograd.record_conv(TAPE, x, None, lw, out, batch=m, h_in=1, w_in=1, h_out=1, w_out=1, stride=1, pad_t=0, pad_l=0,
+                             upsample=False, temb=None, res0=res0, res1=res1, alpha=alpha, act=act)
     return out
 
 
@@ -152,6 +181,8 @@ def geglu_weight(weight: torch.Tensor, bias: torch.Tensor, prec: Precision, devi
 
 def linear_geglu(x: torch.Tensor, lw: ConvWeight, tile: int = 0) -> torch.Tensor:
     """hidden * gelu(gate) of FeedForward's GEGLU in the GEMM epilogue: [..., K] -> [..., inner]."""
+    if TAPE is not None:
+        raise hip.MfhipError("training: use ops.linear + ops.geglu (the fused epilogue keeps no pre-activation)")
     k = x.shape[-1]
     m = x.numel() // k
     inner = lw.n // 2
@@ -169,6 +200,8 @@ def linear_t(x: torch.Tensor, lw: ConvWeight, ld_out: int, out: Optional[torch.T
     x: [B, S, K]; returns [B, n, ld_out] with columns [S, ld_out) left untouched (callers zero them once).
     """
     b, s, k = x.shape
+    if TAPE is not None:
+        raise hip.MfhipError("training: use ops.linear + ops.transpose_tokens")
     if lw.w_split:
         raise hip.MfhipError("linear_t: the weight is the A operand here, build it with ConvWeight(..., raw=True)")
     if out is None:
@@ -176,6 +209,85 @@ def linear_t(x: torch.Tensor, lw: ConvWeight, ld_out: int, out: Optional[torch.T
     hip.gemm_conv(lw.w, x, out, dtype=lw.prec.code, c0=k, lda0=k, batch=lw.n, h_in=1, w_in=1, h_out=1, w_out=1,
                   ldw=k, n=s, ldc=ld_out, bias=lw.bias, bias_mode=1, nz=b, zdiv=1,
                   a_zs=(0, 0), w_zs=(s * k, 0), o_zs=(lw.n * ld_out, 0))
+    return out
+
+
+# ---- operators that exist as separate launches only on the training path (inference fuses them away) -----------------
+def groupnorm(x0: torch.Tensor, norm, *, groups: int, eps: float, silu: bool, out_dtype: torch.dtype,
+              x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """hip.groupnorm over `norm` = (gamma, beta) tensors or autograd.Params."""
+    g, b = norm
+    pg = g if isinstance(g, autograd.Param) else None
+    out = hip.groupnorm(x0, g.data if pg else g, b.data if pg else b, groups=groups, eps=eps, silu=silu, out_dtype=out_dtype, x1=x1)
+    if TAPE is not None:
+        if pg is None:
+            raise hip.MfhipError("training: GroupNorm parameters must be autograd.Params (model built with train=True)")
+        autograd.record_groupnorm(TAPE, x0, x1, g, b, out, groups, eps, silu)
+    return out
+
+
+def layernorm(x: torch.Tensor, norm, eps: float, out_dtype: torch.dtype) -> torch.Tensor:
+    g, b = norm
+    pg = g if isinstance(g, autograd.Param) else None
+    out = hip.layernorm(x, g.data if pg else g, b.data if pg else b, eps, out_dtype)
+    if TAPE is not None:
+        if pg is None:
+            raise hip.MfhipError("training: LayerNorm parameters must be autograd.Params (model built with train=True)")
+        autograd.record_layernorm(TAPE, x, g, b, out, eps)
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    out = hip.add(a, b, out_dtype)
+    if TAPE is not None:
+        autograd.record_pointwise(TAPE, (a, b), out, lambda g: (g, g))
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    out = hip.silu_f32(x)
+    if TAPE is not None:
+        autograd.record_pointwise(TAPE, (x,), out, lambda g: (hip.silu_bwd(x, g.view(x.shape)),))
+    return out
+
+
+def geglu(h: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    out = hip.geglu(h, out_dtype)
+    if TAPE is not None:
+        autograd.record_pointwise(TAPE, (h,), out, lambda g: (hip.geglu_bwd(h, g.view(out.shape)),))
+    return out
+
+
+def transpose_tokens(v: torch.Tensor, ld: int) -> torch.Tensor:
+    """[B, S, C] -> V^T [B, C, ld] (columns past S zero): the training path's stand-in for linear_t."""
+    b, s, c = v.shape
+    vt = torch.zeros(b, c, ld, dtype=torch.float32, device=v.device) if ld != s else torch.empty(b, c, ld, dtype=torch.float32, device=v.device)
+    hip.transpose(v, s, c, nz=b, ldx=c, ldy=ld, zsx=s * c, zsy=c * ld, out=vt)
+    return vt
+
+
+def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, prec: Precision) -> torch.Tensor:
+    """Unfused attention on [B, S, C] fp32 q / k / v, differentiated as one operator (autograd.record_attention)."""
+    b, sq, c = q.shape
+    skv = k.shape[1]
+    d = c // heads
+    ld = (skv + 7) // 8 * 8
+    tape = TAPE
+
+    def probs():
+        scores = torch.empty(b * heads, sq, ld, dtype=torch.float32, device=q.device)
+        hip.gemm_conv(q, k, scores, dtype=prec.code, c0=d, lda0=c, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1, ldw=c, n=skv, ldc=ld,
+                      alpha=scale, nz=b * heads, zdiv=heads, a_zs=(sq * c, d), w_zs=(skv * c, d), o_zs=(heads * sq * ld, sq * ld),
+                      splitk=1)
+        return hip.softmax_rows(scores, skv, torch.float32)
+
+    p = probs()
+    vt = transpose_tokens(v, ld)
+    out = torch.empty(b, sq, c, dtype=torch.float32, device=q.device)
+    hip.gemm_conv(p, vt, out, dtype=prec.code, c0=ld, lda0=ld, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1, ldw=ld, n=d, ldc=c,
+                  nz=b * heads, zdiv=heads, a_zs=(heads * sq * ld, sq * ld), w_zs=(c * ld, d * ld), o_zs=(sq * c, d), splitk=1)
+    if tape is not None:
+        autograd.record_attention(tape, q, k, v, out, heads, skv, scale, probs)
     return out
 
 

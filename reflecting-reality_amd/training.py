@@ -1,19 +1,28 @@
-"""Forward half of the reference's training step.
+"""The reference's training step on the HIP path.
 
 Mirrors examples/brushnet/train_brushnet_mirror.py: `MirrorFusionModel` (:836-888, BrushNet residuals injected
-into the UNet, conditioning scale 1), `compute_snr` (src/diffusers/training_utils.py:50-73) and the loss block
-(:1407-1449: add_noise at per-sample timesteps, epsilon / v_prediction target, plain or min-SNR-weighted MSE).
-Everything here runs on the HIP kernels behind libmfhip; there is no autograd graph, so `backward()`, gradient
-clipping and the optimizer step are NOT built (they raise) — this module gives the per-step loss the reference
-logs, e.g. for validation-loss curves over a checkpoint, not training itself.
+into the UNet, conditioning scale 1), `compute_snr` (src/diffusers/training_utils.py:50-73), the loss block
+(:1407-1449: add_noise at per-sample timesteps, epsilon / v_prediction target, plain or min-SNR-weighted MSE), and the
+step itself (:1459-1466): backward, `clip_grad_norm_(max_grad_norm)`, `AdamW.step()`, `zero_grad()`; plus the
+`checkpoint-N/{brushnet,unet}` save / load hooks (:997-1069) and their rotation (:1474-1498).
+
+Forward and backward run on the libmfhip kernels: the backward pass is a tape of hand-written vector-Jacobian products
+(autograd.py) — there is no ATen autograd graph.  Parameters, gradients and the Adam moments live in flat fp32 arenas
+(one launch of mf_adamw per model, one mf_sumsq for the norm; the clip coefficient never leaves the device); with more
+than one rank the gradient arena is all-reduced in buckets over RCCL while the backward pass is still running
+(distributed.GradBuckets).
 """
-from typing import Optional
+import json
+import os
+import shutil
+from typing import List, Optional, Sequence
 
 import torch
 
-from . import hip
+from . import autograd, hip, ops
 
-__all__ = ["MirrorFusionModel", "compute_snr", "training_loss"]
+__all__ = ["MirrorFusionModel", "compute_snr", "training_loss", "AdamW", "clip_grad_norm_", "train_step", "save_state",
+           "load_state"]
 
 
 class MirrorFusionModel:
@@ -32,7 +41,15 @@ class MirrorFusionModel:
         self.weight_dtype = weight_dtype
 
     def get_trainable_modules(self, verbose: bool = True):
-        raise NotImplementedError("no autograd on the HIP path: training (backward / optimizer) is not built")
+        """train_brushnet_mirror.py:845-856: the children that hold trainable parameters."""
+        return [m for m in (self.unet, self.brushnet) if m.training and m._requires_grad]
+
+    def prepare_training(self, train_base_unet: bool = False):
+        """:1072-1079: BrushNet trains; the UNet is frozen unless --train_base_unet (it still needs the training layout:
+        the loss gradient reaches BrushNet's residuals through it)."""
+        self.brushnet.prepare_training(requires_grad=True)
+        self.unet.prepare_training(requires_grad=bool(train_base_unet))
+        return self
 
     def forward(self, noisy_latents, timesteps, encoder_hidden_states=None, conditioning_latents=None, normal=None):
         if normal is not None:
@@ -58,7 +75,7 @@ def compute_snr(noise_scheduler, timesteps: torch.Tensor) -> torch.Tensor:
 
 def training_loss(model: MirrorFusionModel, noise_scheduler, latents: torch.Tensor, noise: torch.Tensor,
                   timesteps: torch.Tensor, encoder_hidden_states: torch.Tensor, conditioning_latents: torch.Tensor,
-                  snr_gamma: Optional[float] = None):
+                  snr_gamma: Optional[float] = None, _return_weights: bool = False):
     """train_brushnet_mirror.py:1407-1449 for already-encoded inputs: returns (loss [1] fp32 on the device,
     model_pred, target).  `latents` are the scaled VAE latents, `noise`/`timesteps` the script's random draws
     (:1408-1412), `conditioning_latents` the 5- (or 9-/8-) channel BrushNet conditioning (:1372-1402)."""
@@ -78,4 +95,145 @@ def training_loss(model: MirrorFusionModel, noise_scheduler, latents: torch.Tens
         weights = weights / snr if ptype == "epsilon" else weights / (snr + 1)
         weights = hip.h2d(weights.float().contiguous(), pred.device)
     loss, _ = hip.mse_loss(pred.float(), target.float(), weights)
+    if _return_weights:
+        return loss, pred, target, weights
     return loss, pred, target
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# optimizer, gradient clipping, the step
+# ---------------------------------------------------------------------------------------------------------------------
+class AdamW:
+    """torch.optim.AdamW over the models' flat arenas (train_brushnet_mirror.py:1188-1200: lr 1e-5, betas 0.9 / 0.999,
+    weight decay 1e-2, eps 1e-8; decay applies to every parameter, like the reference's single param group)."""
+
+    def __init__(self, models: Sequence, lr: float = 1e-5, betas=(0.9, 0.999), weight_decay: float = 1e-2, eps: float = 1e-8):
+        self.models = [m for m in models if m.training and m.flat_g is not None]
+        if not self.models:
+            raise ValueError("AdamW: no model with a gradient arena (call prepare_training(requires_grad=True) first)")
+        self.lr, self.betas, self.weight_decay, self.eps = lr, tuple(betas), weight_decay, eps
+        self.step_count = 0
+        self.exp_avg = [torch.zeros(m.num_arena_floats(), dtype=torch.float32, device=m.device) for m in self.models]
+        self.exp_avg_sq = [torch.zeros_like(t) for t in self.exp_avg]
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for m in self.models:
+            m.flat_g.zero_()
+
+    def step(self, grad_scale: Optional[torch.Tensor] = None) -> None:
+        self.step_count += 1
+        for m, ea, es in zip(self.models, self.exp_avg, self.exp_avg_sq):
+            n = m.num_arena_floats()
+            hip.adamw(m.flat_w[:n], m.flat_g[:n], ea, es, lr=self.lr, betas=self.betas, eps=self.eps,
+                      weight_decay=self.weight_decay, step=self.step_count, grad_scale=grad_scale)
+            m._weights_gen += 1            # derived layouts (dgrad weights, captured graphs) are stale now
+
+    def state_dict(self) -> dict:
+        return dict(step=self.step_count, lr=self.lr, betas=self.betas, weight_decay=self.weight_decay, eps=self.eps,
+                    exp_avg=[t.cpu() for t in self.exp_avg], exp_avg_sq=[t.cpu() for t in self.exp_avg_sq])
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.step_count = int(sd["step"])
+        for dst, src in zip(self.exp_avg + self.exp_avg_sq, list(sd["exp_avg"]) + list(sd["exp_avg_sq"])):
+            if dst.numel() != src.numel():
+                raise ValueError("optimizer state does not match the models' arenas")
+            dst.copy_(src)
+
+
+class _ClipState:
+    def __init__(self, device):
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=device)
+        self.coef = torch.ones(1, dtype=torch.float32, device=device)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=device)
+
+
+_clip_states: dict = {}
+
+
+def clip_grad_norm_(models: Sequence, max_norm: float):
+    """torch.nn.utils.clip_grad_norm_ over every gradient arena (accelerator.clip_grad_norm_, :1463).  Returns
+    (total_norm, coef): one-element DEVICE tensors — the gradients are not rescaled here, mf_adamw reads them times
+    coef, and nothing synchronises with the host."""
+    models = [m for m in models if m.flat_g is not None]
+    dev = models[0].device
+    st = _clip_states.setdefault(str(dev), _ClipState(dev))
+    for i, m in enumerate(models):
+        hip.sumsq(m.flat_g[: m.num_arena_floats()], st.sumsq, accumulate=i > 0)
+    hip.clip_coef(st.sumsq, float(max_norm), st.coef, st.norm)
+    return st.norm, st.coef
+
+
+def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, latents: torch.Tensor, noise: torch.Tensor,
+               timesteps: torch.Tensor, encoder_hidden_states: torch.Tensor, conditioning_latents: torch.Tensor,
+               snr_gamma: Optional[float] = None, max_grad_norm: float = 1.0, grad_sync=None):
+    """One optimisation step (:1407-1466).  Returns (loss, grad_norm) as one-element device tensors.
+    `grad_sync`: a distributed.GradBuckets when several ranks train data-parallel (the DDP wrap of :1267-1269)."""
+    mods = model.get_trainable_modules()
+    if not mods:
+        raise RuntimeError("train_step: call model.prepare_training() first")
+    optimizer.zero_grad()
+    prec = model.brushnet.prec
+    tape = autograd.Tape(prec.code if prec.split else hip.MF_F32)
+    if grad_sync is not None:
+        grad_sync.begin(tape)
+    ops.TAPE = tape
+    try:
+        loss, pred, target, weights = training_loss(model, noise_scheduler, latents, noise, timesteps, encoder_hidden_states,
+                                                    conditioning_latents, snr_gamma, _return_weights=True)
+    finally:
+        ops.TAPE = None
+    tape.add(pred, hip.mse_grad(pred.contiguous(), target.contiguous(), weights))
+    tape.backward()
+    if grad_sync is not None:
+        grad_sync.finish()
+    norm, coef = clip_grad_norm_(mods, max_grad_norm)
+    optimizer.step(grad_scale=coef)
+    return loss, norm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# checkpoints: accelerator.save_state with the script's hooks (:997-1069) and its rotation (:1474-1498)
+# ---------------------------------------------------------------------------------------------------------------------
+def save_state(output_dir: str, global_step: int, model: MirrorFusionModel, optimizer: Optional[AdamW] = None,
+               checkpoints_total_limit: Optional[int] = None, is_main_process: bool = True) -> Optional[str]:
+    """Writes `output_dir/checkpoint-<global_step>/{brushnet,unet}` (config.json + diffusion_pytorch_model.safetensors in
+    the reference's layout; `unet` only when it trains) and `optimizer.bin`; before that, removes the oldest checkpoints so
+    that at most `checkpoints_total_limit` remain — the script's order of operations."""
+    if not is_main_process:
+        return None
+    os.makedirs(output_dir, exist_ok=True)
+    if checkpoints_total_limit is not None:
+        cps = sorted((d for d in os.listdir(output_dir) if d.startswith("checkpoint")), key=lambda x: int(x.split("-")[1]))
+        if len(cps) >= checkpoints_total_limit:
+            for d in cps[: len(cps) - checkpoints_total_limit + 1]:
+                shutil.rmtree(os.path.join(output_dir, d))
+    path = os.path.join(output_dir, f"checkpoint-{global_step}")
+    for m in model.get_trainable_modules():
+        m.save_pretrained(os.path.join(path, "brushnet" if m is model.brushnet else "unet"))
+    if optimizer is not None:
+        torch.save(optimizer.state_dict(), os.path.join(path, "optimizer.bin"))
+    with open(os.path.join(path, "trainer_state.json"), "w") as f:
+        json.dump(dict(global_step=global_step), f)
+    return path
+
+
+def load_state(path: str, model: MirrorFusionModel, optimizer: Optional[AdamW] = None) -> int:
+    """load_model_hook (:1035-1066): each trainable module reloads its weights from its sub-folder; returns the step."""
+    from safetensors.torch import load_file
+    for m in model.get_trainable_modules():
+        sub = "brushnet" if m is model.brushnet else "unet"
+        m.load_state_dict(load_file(os.path.join(path, sub, m.weights_name)))
+    if optimizer is not None and os.path.exists(os.path.join(path, "optimizer.bin")):
+        if [m for m in model.get_trainable_modules()] != optimizer.models:
+            optimizer.models = model.get_trainable_modules()
+        optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.bin")))
+    with open(os.path.join(path, "trainer_state.json")) as f:
+        return int(json.load(f)["global_step"])
+
+
+def latest_checkpoint(output_dir: str) -> Optional[str]:
+    """--resume_from_checkpoint latest (:1285-1290)."""
+    if not os.path.isdir(output_dir):
+        return None
+    cps = sorted((d for d in os.listdir(output_dir) if d.startswith("checkpoint")), key=lambda x: int(x.split("-")[1]))
+    return os.path.join(output_dir, cps[-1]) if cps else None

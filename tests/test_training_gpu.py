@@ -1,5 +1,8 @@
-"""Forward half of the reference's training step on the HIP path: noisy latents, model
-prediction and loss against the imported reference's values (tests/golden/tiny_train.npz) and the oracle."""
+"""The reference's training step on the HIP path: noisy latents, model prediction and loss
+against the imported reference's values (tests/golden/tiny_train.npz), and the backward half — two optimisation steps
+(backward, clip_grad_norm_ 1.0, AdamW) against what the reference's own modules produce under torch autograd +
+torch.optim.AdamW (tests/golden/tiny_train_backward.npz: loss, gradient norm, step-1 gradients of named tensors and
+their movement after two steps), plus the backward kernels one by one against torch autograd on the CPU."""
 import numpy as np
 import pytest
 import torch
@@ -8,7 +11,9 @@ pytestmark = pytest.mark.gpu
 
 from oracle import mirrorfusion_ref as R  # noqa: E402
 from reflecting_reality_amd import DDPMScheduler, hip, models as M, synth  # noqa: E402
-from reflecting_reality_amd.training import MirrorFusionModel, compute_snr, training_loss  # noqa: E402
+from reflecting_reality_amd import ops  # noqa: E402
+from reflecting_reality_amd.training import (AdamW, MirrorFusionModel, clip_grad_norm_, compute_snr, load_state, save_state,  # noqa: E402
+                                             train_step, training_loss)
 from util import golden, keys, report  # noqa: E402
 
 DEV = "cuda"
@@ -80,11 +85,277 @@ def test_compute_snr_and_velocity_match_oracle_tables():
     report("velocity", v, sa * e - sb * x, atol=1e-6, rtol=1e-6)
 
 
-def test_training_backward_is_not_silently_faked():
-    model = _model("fp32")
-    with pytest.raises(NotImplementedError):
-        model.get_trainable_modules()
-    with pytest.raises(NotImplementedError):
-        model.unet.train()
+BATCH2 = None
+
+
+def _batches():
+    g2 = torch.Generator().manual_seed(2025)
+    lat, noi, cond, ehs = _inputs()
+    b2 = (torch.randn(3, 4, 8, 8, generator=g2) * 0.8, torch.randn(3, 4, 8, 8, generator=g2), torch.tensor([702, 3, 250]).long(),
+          torch.randn(3, 77, 32, generator=g2), torch.randn(3, 5, 8, 8, generator=g2))
+    return [(lat, noi, torch.tensor([17, 480, 965]).long(), ehs, cond), b2]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+@pytest.mark.parametrize("tag,train_unet,gamma", [("frozen", False, None), ("unet", True, 5.0)])
+def test_two_training_steps_match_reference(prec, tag, train_unet, gamma):
+    """SURVEY.md §8 a-16's pin: (loss, grad-norm, step-1 gradients, |dw| after two AdamW steps) of the HIP training step
+    against the reference's modules under torch autograd (fixture generated by tools/make_golden.py::tiny_train)."""
+    G = golden("tiny_train_backward.npz")
+    model = _model(prec).prepare_training(train_base_unet=train_unet)
+    assert [m is model.brushnet for m in model.get_trainable_modules()] == ([False, True] if train_unet else [True])
+    w0 = {("unet." if m is model.unet else "") + k: v.clone() for m in model.get_trainable_modules() for k, v in m.state_dict().items()}
+    ns = DDPMScheduler(**SD_SCHED)
+    opt = AdamW(model.get_trainable_modules(), lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    for i, (lat, noi, ts, ehs, cond) in enumerate(_batches()):
+        loss, norm = train_step(model, ns, opt, lat.to(DEV), noi.to(DEV), ts, ehs.to(DEV), cond.to(DEV), snr_gamma=gamma,
+                                max_grad_norm=1.0)
+        ref_l, ref_n = float(G[f"{tag}_loss_{i}"]), float(G[f"{tag}_grad_norm_{i}"])
+        print(f"[{tag} {prec}] step {i}: loss {float(loss):.7f} (ref {ref_l:.7f})  grad norm {float(norm):.6f} (ref {ref_n:.6f})")
+        assert abs(float(loss) - ref_l) < 1e-4 * ref_l
+        assert abs(float(norm) - ref_n) < 2e-4 * ref_n
+        if i == 0:
+            grads = {("unet." if m is model.unet else "") + k: v for m in model.get_trainable_modules()
+                     for k, v in m.grad_state_dict().items()}
+            for key in [k for k in G.files if k.startswith(f"{tag}_grad/")]:
+                name = key.split("/", 1)[1]
+                ref = torch.from_numpy(G[key])
+                err = float((grads[name] - ref).abs().max())
+                scale = float(ref.abs().max())
+                print(f"   grad {name}: max err {err:.3e} (|ref| max {scale:.3e})")
+                assert tuple(grads[name].shape) == tuple(ref.shape)
+                assert err <= 2e-4 * scale + 1e-7, name
+    w2 = {("unet." if m is model.unet else "") + k: v for m in model.get_trainable_modules() for k, v in m.state_dict().items()}
+    for key in [k for k in G.files if k.startswith(f"{tag}_dw/")]:
+        name = key.split("/", 1)[1]
+        dw = float((w2[name] - w0[name]).norm())
+        print(f"   |dw| {name}: {dw:.6e} (ref {float(G[key]):.6e})")
+        assert abs(dw - float(G[key])) < 2e-3 * float(G[key]), name
+    if not train_unet:         # a frozen UNet keeps its weights and has no gradient arena
+        assert model.unet.flat_g is None
+
+
+def test_training_step_is_deterministic_and_checkpoints_resume(tmp_path):
+    """Two identical runs give bit-identical weights (fixed-order reductions, no atomics); save_state writes
+    checkpoint-N/{brushnet} in the reference's layout, rotates old checkpoints, and load_state resumes: step 2 after a
+    reload equals step 2 of the uninterrupted run."""
+    ns = DDPMScheduler(**SD_SCHED)
+    batches = _batches()
+
+    def run(stop_and_resume):
+        model = _model("fp32").prepare_training()
+        opt = AdamW(model.get_trainable_modules())
+        lat, noi, ts, ehs, cond = batches[0]
+        train_step(model, ns, opt, lat.to(DEV), noi.to(DEV), ts, ehs.to(DEV), cond.to(DEV))
+        if stop_and_resume:
+            out = str(tmp_path / "run")
+            for step in (1, 2, 3):
+                path = save_state(out, step, model, opt, checkpoints_total_limit=2)
+            import os
+            assert sorted(os.listdir(out)) == ["checkpoint-2", "checkpoint-3"]
+            assert sorted(os.listdir(path)) == ["brushnet", "optimizer.bin", "trainer_state.json"]
+            assert sorted(os.listdir(os.path.join(path, "brushnet"))) == ["config.json", "diffusion_pytorch_model.safetensors"]
+            model = _model("fp32").prepare_training()
+            opt = AdamW(model.get_trainable_modules())
+            assert load_state(path, model, opt) == 3 and opt.step_count == 1
+        lat, noi, ts, ehs, cond = batches[1]
+        train_step(model, ns, opt, lat.to(DEV), noi.to(DEV), ts, ehs.to(DEV), cond.to(DEV))
+        return model.brushnet.state_dict()
+
+    a, b, c = run(False), run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: two identical runs differ"
+        assert torch.equal(a[k], c[k]), f"{k}: resuming from the checkpoint changes step 2"
+    # the checkpoint's weights load into an inference model of the same class (reference layout on disk)
+    import os
+    bn = M.BrushNetModel.from_pretrained(os.path.join(str(tmp_path / "run"), "checkpoint-3"), subfolder="brushnet",
+                                         precision="fp32", device=DEV)
+    assert set(bn.state_dict()) == set(a)
+
+
+def test_training_needs_fp32_class_precision_and_the_training_layout():
+    model = _model("bf16")
+    with pytest.raises(NotImplementedError, match="fp32 master"):
+        model.brushnet.train()
+    m32 = _model("fp32")
+    lat, noi, cond, ehs = (t.to(DEV) for t in _inputs())
+    with pytest.raises(RuntimeError, match="prepare_training"):
+        train_step(m32, DDPMScheduler(**SD_SCHED), None, lat, noi, torch.tensor([1, 2, 3]), ehs, cond)
     with pytest.raises(NotImplementedError):
         DDPMScheduler(**SD_SCHED).step(None, 0, None)
+    m32.brushnet.enable_gradient_checkpointing()
+    assert m32.brushnet.gradient_checkpointing
+
+
+# ---- backward kernels one by one, against torch autograd on the CPU (float64) ----------------------------------------
+def _rel(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("code_name", ["fp32", "f16x3"])
+@pytest.mark.parametrize("case", ["3x3", "1x1", "s2p1", "s2asym", "up", "cat", "big"])
+def test_conv_wgrad_and_dgrad(code_name, case):
+    """mf_conv_wgrad and the data gradient (mf_gemm_conv on the transposed, tap-flipped weight; mf_zero_insert2x for
+    stride 2, mf_sumpool2x2 behind the fused nearest-2x upsample) against torch autograd."""
+    from reflecting_reality_amd import autograd as AG
+    prec = ops.Precision.get(code_name)
+    g = torch.Generator().manual_seed(51)
+    b, cin, cout, h, w_ = (2, 24, 40, 10, 14) if case != "big" else (2, 320, 320, 32, 32)
+    k = 1 if case == "1x1" else 3
+    c1 = 16 if case == "cat" else 0
+    x = torch.randn(b, cin, h, w_, generator=g, dtype=torch.float64)
+    x1 = torch.randn(b, c1, h, w_, generator=g, dtype=torch.float64) if c1 else None
+    wt = torch.randn(cout, cin + c1, k, k, generator=g, dtype=torch.float64) * 0.05
+    bias = torch.randn(cout, generator=g, dtype=torch.float64)
+    xs = [t.requires_grad_(True) for t in ([x, x1] if c1 else [x])]
+    wt.requires_grad_(True); bias.requires_grad_(True)
+    xin = torch.cat(xs, 1)
+    kw = dict(stride=1, padding=1)
+    if case == "1x1":
+        ref = torch.nn.functional.conv2d(xin, wt, bias); kw = dict(stride=1, padding=0)
+    elif case == "s2p1":
+        ref = torch.nn.functional.conv2d(xin, wt, bias, stride=2, padding=1); kw = dict(stride=2, padding=1)
+    elif case == "s2asym":
+        ref = torch.nn.functional.conv2d(torch.nn.functional.pad(xin, (0, 1, 0, 1)), wt, bias, stride=2); kw = dict(stride=2, padding=(0, 0, 1, 1))
+    elif case == "up":
+        ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(xin, scale_factor=2.0, mode="nearest"), wt, bias, padding=1)
+        kw = dict(stride=1, padding=1, upsample=True)
+    else:
+        ref = torch.nn.functional.conv2d(xin, wt, bias, padding=1)
+    gy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(gy)
+
+    class Holder:            # stands in for a model: owns the arenas' generation counter
+        _weights_gen = 0
+    cp = (cin + c1 + 3) // 4 * 4
+    wk = torch.nn.functional.pad(wt.detach().float().permute(0, 2, 3, 1), (0, cp - cin - c1)).reshape(cout, k * k * cp).to(DEV).contiguous()
+    p_w = AG.Param("w", wk, torch.zeros_like(wk))
+    p_b = AG.Param("b", bias.detach().float().to(DEV), torch.zeros(cout, device=DEV))
+    cw = ops.ConvWeight.from_params(p_w, p_b, prec, cout, cin + c1, cp, k, k, Holder())
+    xa = x.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    x1a = x1.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV) if c1 else None
+    tape = AG.Tape(prec.code if prec.split else 0)
+    ops.TAPE = tape
+    try:
+        y = ops.conv2d(xa, cw, x1=x1a, **kw)
+    finally:
+        ops.TAPE = None
+    assert _rel(y.permute(0, 3, 1, 2), ref.detach()) < 1e-5
+    tape.add(y, gy.float().permute(0, 2, 3, 1).contiguous().to(DEV))
+    got = {}
+    orig_add = tape.add
+    tape.add = lambda t, gg: got.__setitem__(t.data_ptr(), gg) if t is not None else None
+    tape.backward()
+    tol = 1e-5 if code_name == "fp32" else 3e-5
+    dw = p_w.grad.view(cout, k, k, cp)[..., : cin + c1].permute(0, 3, 1, 2)
+    print(f"wgrad[{case},{code_name}] {_rel(dw, wt.grad):.2e}  dbias {_rel(p_b.grad, bias.grad):.2e}  dx {_rel(got[xa.data_ptr()].view(xa.shape).permute(0, 3, 1, 2), xs[0].grad):.2e}")
+    assert _rel(dw, wt.grad) < tol and _rel(p_b.grad, bias.grad) < tol
+    assert _rel(got[xa.data_ptr()].view(xa.shape).permute(0, 3, 1, 2), xs[0].grad) < tol
+    if c1:
+        assert _rel(got[x1a.data_ptr()].view(x1a.shape).permute(0, 3, 1, 2), xs[1].grad) < tol
+
+
+@pytest.mark.parametrize("silu", [True, False])
+@pytest.mark.parametrize("shape", [(2, 64, 0, 6, 10, 32), (2, 1280, 640, 8, 8, 32), (1, 320, 0, 64, 64, 32), (3, 32, 32, 5, 3, 16)])
+def test_groupnorm_backward(shape, silu):
+    b, c0, c1, h, w_, groups = shape
+    g = torch.Generator().manual_seed(52)
+    x = (torch.randn(b, c0 + c1, h, w_, generator=g, dtype=torch.float64) * 1.7 + 0.3).requires_grad_(True)
+    gamma = torch.randn(c0 + c1, generator=g, dtype=torch.float64).requires_grad_(True)
+    beta = torch.randn(c0 + c1, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = torch.nn.functional.group_norm(x, groups, gamma, beta, 1e-5)
+    y = torch.nn.functional.silu(y) if silu else y
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xa = x.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    x0, x1 = (xa[..., :c0].contiguous(), xa[..., c0:].contiguous()) if c1 else (xa, None)
+    dx0, dx1, dg, db = hip.groupnorm_bwd(x0, gy.float().permute(0, 2, 3, 1).contiguous().to(DEV), gamma.detach().float().to(DEV),
+                                         beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu, x1=x1)
+    dx = torch.cat([dx0, dx1], -1) if c1 else dx0
+    e = (_rel(dx.permute(0, 3, 1, 2), x.grad), _rel(hip.colsum(dg, c0 + c1)[0], gamma.grad), _rel(hip.colsum(db, c0 + c1)[0], beta.grad))
+    print(f"groupnorm_bwd{shape} silu={silu}: dx {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
+    assert max(e) < 2e-5
+
+
+def test_layernorm_softmax_geglu_silu_backward():
+    g = torch.Generator().manual_seed(53)
+    for rows, c in ((130, 320), (64, 1280), (5, 32)):
+        x = torch.randn(rows, c, generator=g, dtype=torch.float64).requires_grad_(True)
+        gamma = torch.randn(c, generator=g, dtype=torch.float64).requires_grad_(True)
+        beta = torch.randn(c, generator=g, dtype=torch.float64).requires_grad_(True)
+        y = torch.nn.functional.layer_norm(x, (c,), gamma, beta, 1e-5)
+        gy = torch.randn(rows, c, generator=g, dtype=torch.float64)
+        y.backward(gy)
+        dx, dg, db = hip.layernorm_bwd(x.detach().float().to(DEV), gy.float().to(DEV), gamma.detach().float().to(DEV), 1e-5)
+        e = (_rel(dx, x.grad), _rel(hip.colsum(dg, c)[0], gamma.grad), _rel(hip.colsum(db, c)[0], beta.grad))
+        print(f"layernorm_bwd {rows}x{c}: {e}")
+        assert max(e) < 2e-5
+    s = torch.randn(37, 80, generator=g, dtype=torch.float64).requires_grad_(True)
+    p = torch.softmax(s[:, :77] * 0.3, -1)
+    gp = torch.randn(37, 77, generator=g, dtype=torch.float64)
+    p.backward(gp)
+    pp = torch.zeros(37, 80); pp[:, :77] = p.detach().float()
+    dp = torch.zeros(37, 80); dp[:, :77] = gp.float()
+    ds = hip.softmax_bwd(pp.to(DEV), dp.to(DEV), 77, 0.3)
+    assert _rel(ds[:, :77], s.grad[:, :77]) < 2e-5 and float(ds[:, 77:].abs().max()) == 0.0
+    hh = torch.randn(50, 2 * 96, generator=g, dtype=torch.float64).requires_grad_(True)
+    a, gt = hh.chunk(2, -1)
+    out = a * torch.nn.functional.gelu(gt)
+    go = torch.randn(50, 96, generator=g, dtype=torch.float64)
+    out.backward(go)
+    assert _rel(hip.geglu_bwd(hh.detach().float().to(DEV), go.float().to(DEV)), hh.grad) < 2e-5
+    z = torch.randn(1000, generator=g, dtype=torch.float64).requires_grad_(True)
+    torch.nn.functional.silu(z).backward(torch.ones(1000, dtype=torch.float64))
+    assert _rel(hip.silu_bwd(z.detach().float().to(DEV), torch.ones(1000, device=DEV)), z.grad) < 2e-5
+
+
+@pytest.mark.parametrize("code_name", ["fp32", "f16x3"])
+@pytest.mark.parametrize("heads,d,sq,skv", [(2, 40, 96, 96), (4, 8, 64, 77), (8, 40, 1024, 1024)])
+def test_attention_backward(code_name, heads, d, sq, skv):
+    from reflecting_reality_amd import autograd as AG
+    prec = ops.Precision.get(code_name)
+    g = torch.Generator().manual_seed(54)
+    c = heads * d
+    q, k, v = (torch.randn(2, s_, c, generator=g, dtype=torch.float64).requires_grad_(True) for s_ in (sq, skv, skv))
+    qh, kh, vh = (t.view(2, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    o = (torch.softmax(qh @ kh.transpose(-1, -2) / d ** 0.5, -1) @ vh).transpose(1, 2).reshape(2, sq, c)
+    go = torch.randn(2, sq, c, generator=g, dtype=torch.float64)
+    o.backward(go)
+    qd, kd, vd = (t.detach().float().to(DEV) for t in (q, k, v))
+    tape = AG.Tape(prec.code if prec.split else 0)
+    ops.TAPE = tape
+    try:
+        out = ops.attention_train(qd, kd, vd, heads, 1.0 / d ** 0.5, prec)
+    finally:
+        ops.TAPE = None
+    assert _rel(out, o.detach()) < 2e-5
+    tape.add(out, go.float().to(DEV))
+    got = {}
+    tape.add = lambda t, gg: got.__setitem__(t.data_ptr(), gg)
+    tape.backward()
+    e = [_rel(got[t.data_ptr()].view(t.shape), r.grad) for t, r in ((qd, q), (kd, k), (vd, v))]
+    print(f"attention backward[{code_name}, h{heads} d{d} {sq}x{skv}]: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
+    assert max(e) < 3e-5
+
+
+def test_adamw_and_clip_against_torch():
+    g = torch.Generator().manual_seed(55)
+    n = 100003
+    w = torch.randn(n, generator=g)
+    pt = torch.nn.Parameter(w.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    wd, m, v = w.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=DEV)
+    coef, norm = torch.ones(1, device=DEV), torch.zeros(1, device=DEV)
+    for step in (1, 2, 3):
+        gr = torch.randn(n, generator=g) * (3.0 if step == 2 else 0.001)
+        pt.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+        gd = gr.to(DEV)
+        hip.sumsq(gd, sumsq)
+        hip.clip_coef(sumsq, 1.0, coef, norm)
+        assert abs(float(norm) - float(tn)) < 1e-5 * float(tn)
+        hip.adamw(wd, gd, m, v, lr=1e-3, step=step, grad_scale=coef)
+        assert float((wd.cpu() - pt.detach()).abs().max()) < 2e-6
