@@ -300,9 +300,11 @@ int mf_mse_grad(const float* pred, const float* target, const float* weights, fl
 /* sum of squares of a flat gradient arena into out[0] (double, device), two fixed-order stages */
 int64_t mf_sumsq_ws_doubles(void);
 int mf_sumsq(const float* x, int64_t n, double* out, int32_t accumulate, double* ws, void* stream);
-/* torch.nn.utils.clip_grad_norm_ (train_brushnet_mirror.py:1463): coef[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6)) stays on
- * the device (mf_adamw reads it: no host synchronisation in the step); norm_out[0] (nullable) = sqrt(sumsq) */
-int mf_clip_coef(const double* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (train_brushnet_mirror.py:1463) for an arena that holds gradients x S (S = 1 / unscale, the
+ * loss scale of the split-precision backward; unscale = 1 without one): norm = sqrt(sumsq) * unscale -> norm_out[0]
+ * (nullable); coef[0] = min(1, max_norm / (norm + 1e-6)) * unscale stays on the device (mf_adamw multiplies the stored
+ * gradients with it: no host synchronisation in the step) */
+int mf_clip_coef(const double* sumsq, float max_norm, float unscale, float* coef, float* norm_out, void* stream);
 /* torch.optim.AdamW (train_brushnet_mirror.py:1188-1200; no amsgrad) over flat arenas of n fp32: the gradient is read as
  * g * grad_scale[0] (grad_scale nullable) */
 int mf_adamw(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -443,12 +443,14 @@ __global__ __launch_bounds__(256) void sumsq_stage2(const double* part, int npar
     const double t = block_sum(s, red);
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + t : t;
 }
-// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6)); norm_out receives the fp32 norm
-__global__ void clip_coef_kernel(const double* sumsq, float max_norm, float* coef, float* norm_out) {
-    const float norm = (float)sqrt(sumsq[0]);
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6)); norm_out receives the fp32 norm.  `unscale`
+// undoes a loss scale: the arena holds gradients x S, norm = sqrt(sumsq) / S and the coefficient AdamW multiplies the stored
+// gradients with becomes coef / S.
+__global__ void clip_coef_kernel(const double* sumsq, float max_norm, float unscale, float* coef, float* norm_out) {
+    const float norm = (float)(sqrt(sumsq[0]) * (double)unscale);
     if (norm_out) norm_out[0] = norm;
     const float c = max_norm / (norm + 1e-6f);
-    coef[0] = c < 1.0f ? c : 1.0f;
+    coef[0] = (c < 1.0f ? c : 1.0f) * unscale;
 }
 // torch.optim.AdamW (single tensor, no amsgrad): decoupled decay, bias-corrected moments; g is scaled by *gscale
 __global__ __launch_bounds__(256) void adamw_kernel(float* w, const float* g, float* m, float* v, int64_t n, float lr, float b1,
@@ -666,9 +668,9 @@ extern "C" int mf_sumsq(const float* x, int64_t n, double* out, int32_t accumula
     return MF_OK;
 }
 
-extern "C" int mf_clip_coef(const double* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
-    MF_CHECK_ARG(sumsq && coef, "mf_clip_coef: null pointer");
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef, norm_out);
+extern "C" int mf_clip_coef(const double* sumsq, float max_norm, float unscale, float* coef, float* norm_out, void* stream) {
+    MF_CHECK_ARG(sumsq && coef && unscale > 0.0f, "mf_clip_coef: null pointer or unscale <= 0");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, unscale, coef, norm_out);
     MF_CHECK_LAUNCH("mf_clip_coef");
     return MF_OK;
 }

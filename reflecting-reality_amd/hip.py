@@ -808,8 +808,9 @@ def sumsq(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch
     return out
 
 
-def clip_coef(sumsq_t: torch.Tensor, max_norm: float, coef: torch.Tensor, norm_out: Optional[torch.Tensor] = None) -> None:
-    _check(load().mf_clip_coef(C.c_void_p(sumsq_t.data_ptr()), C.c_float(max_norm), C.c_void_p(coef.data_ptr()),
+def clip_coef(sumsq_t: torch.Tensor, max_norm: float, coef: torch.Tensor, norm_out: Optional[torch.Tensor] = None,
+              unscale: float = 1.0) -> None:
+    _check(load().mf_clip_coef(C.c_void_p(sumsq_t.data_ptr()), C.c_float(max_norm), C.c_float(unscale), C.c_void_p(coef.data_ptr()),
                                C.c_void_p(_ptr(norm_out)), _stream()), "mf_clip_coef")
 
 

@@ -150,16 +150,17 @@ class _ClipState:
 _clip_states: dict = {}
 
 
-def clip_grad_norm_(models: Sequence, max_norm: float):
+def clip_grad_norm_(models: Sequence, max_norm: float, loss_scale: float = 1.0):
     """torch.nn.utils.clip_grad_norm_ over every gradient arena (accelerator.clip_grad_norm_, :1463).  Returns
     (total_norm, coef): one-element DEVICE tensors — the gradients are not rescaled here, mf_adamw reads them times
-    coef, and nothing synchronises with the host."""
+    coef, and nothing synchronises with the host.  `loss_scale`: the arenas hold gradients x loss_scale (the norm and the
+    coefficient account for it)."""
     models = [m for m in models if m.flat_g is not None]
     dev = models[0].device
     st = _clip_states.setdefault(str(dev), _ClipState(dev))
     for i, m in enumerate(models):
         hip.sumsq(m.flat_g[: m.num_arena_floats()], st.sumsq, accumulate=i > 0)
-    hip.clip_coef(st.sumsq, float(max_norm), st.coef, st.norm)
+    hip.clip_coef(st.sumsq, float(max_norm), st.coef, st.norm, unscale=1.0 / float(loss_scale))
     return st.norm, st.coef
 
 
@@ -182,11 +183,21 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
                                                     conditioning_latents, snr_gamma, _return_weights=True)
     finally:
         ops.TAPE = None
-    tape.add(pred, hip.mse_grad(pred.contiguous(), target.contiguous(), weights))
+    d_pred = hip.mse_grad(pred.contiguous(), target.contiguous(), weights)
+    # Split precision (f16x3) multiplies 16-bit halves: a gradient of 1e-5 would keep only the 11 bits of its high half
+    # (its low half falls below the fp16 subnormals).  A power-of-two loss scale that brings d loss / d pred (= 2 (pred -
+    # target) w / (n B)) to O(1) keeps every backward GEMM operand in the range where hi + lo carries 22 bits; it is
+    # exact in fp32 and undone inside the clip coefficient.  fp32 MFMA needs none.
+    scale = 1.0
+    if prec.split:
+        scale = float(2 ** int(pred.numel() - 1).bit_length())
+        d_pred = hip.axpby_n([d_pred], [scale], out=d_pred)
+    model.loss_scale = scale
+    tape.add(pred, d_pred)
     tape.backward()
     if grad_sync is not None:
         grad_sync.finish()
-    norm, coef = clip_grad_norm_(mods, max_grad_norm)
+    norm, coef = clip_grad_norm_(mods, max_grad_norm, loss_scale=scale)
     optimizer.step(grad_scale=coef)
     return loss, norm
 

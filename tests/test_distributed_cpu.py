@@ -78,3 +78,69 @@ def test_bench_world_size_mismatch_is_an_error():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub"], capture_output=True,
                          text=True, timeout=120, env=env)
     assert out.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in (out.stderr + out.stdout)
+
+
+GRAD_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    from collections import OrderedDict
+    from reflecting_reality_amd import distributed as D
+    from reflecting_reality_amd.autograd import Param
+    rank, world, _ = D.init_process_group("gloo")
+
+    class FakeModel:                       # the arena interface GradBuckets reads (models.HipModel.prepare_training)
+        def __init__(self, sizes, seed):
+            self._pmap, off = OrderedDict(), 0
+            for i, n in enumerate(sizes):
+                self._pmap[f"p{i}"] = (off, (n,), ("vec",))
+                off += (n + 3) // 4 * 4
+            self.n = off
+            g = torch.Generator().manual_seed(seed)
+            self.flat_g = torch.randn(off, generator=g)
+        def num_arena_floats(self):
+            return self.n
+        def params(self):
+            return [Param(k, None, self.flat_g[a:a + s[0]]) for k, (a, s, _) in self._pmap.items()]
+
+    class FakeTape:
+        on_param_grad = None
+
+    sizes = [5, 1000, 37, 4096, 3, 250]
+    models = [FakeModel(sizes, 100 + rank), FakeModel(sizes[:3], 200 + rank)]
+    expect = [sum(FakeModel(s, seed + r).flat_g for r in range(world)) / world
+              for s, seed in ((sizes, 100), (sizes[:3], 200))]
+    gb = D.GradBuckets(models, bucket_floats=512)           # several buckets, parameters straddling bucket borders
+    tape = FakeTape()
+    gb.begin(tape)
+    assert tape.on_param_grad is not None
+    for m in models[::-1]:                                   # backward order: last model, last parameter first
+        for p in m.params()[::-1]:
+            if p.name != "p2":                               # a parameter that never reports: finish() flushes its bucket
+                tape.on_param_grad(p)
+    gb.finish()
+    err = max(float((m.flat_g - e).abs().max()) for m, e in zip(models, expect))
+    loss = D.gather_mean(torch.tensor(float(rank + 1)))
+    with open(os.path.join(os.environ["RESULT_DIR"], f"grad{rank}.json"), "w") as f:
+        json.dump(dict(err=err, loss=loss, nb=[p["nb"] for p in gb._plan]), f)
+""") % ROOT
+
+
+def test_bucketed_gradient_allreduce_equals_the_mean_of_the_ranks(tmp_path):
+    """Data-parallel training's one exchange (train_brushnet_mirror.py:1267-1269, :1459): after GradBuckets.finish() every
+    rank's gradient arena holds the mean of the ranks' gradients (= single-process summed gradients / world), whatever the
+    order parameters finish in, with parameters straddling bucket borders and a parameter that never reports."""
+    import json
+    script = tmp_path / "grad_worker.py"
+    script.write_text(GRAD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RESULT_DIR=str(tmp_path))
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = [json.load(open(tmp_path / f"grad{r}.json")) for r in range(2)]
+    for r in res:
+        assert r["err"] < 1e-6 and r["nb"][0] > 5 and abs(r["loss"] - 1.5) < 1e-6

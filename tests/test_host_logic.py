@@ -227,8 +227,20 @@ def test_pipeline_save_and_from_pretrained_roundtrip(tmp_path):
         import shutil
         shutil.rmtree(tmp_path / "brushnet")
         StableDiffusionBrushNetPipeline.from_pretrained(str(tmp_path), device="cpu")
+    # the training layout (flat fp32 arena in the kernels' layout, fused time_emb_proj matrix) exports the reference's
+    # parameter tables unchanged — what the checkpoint hooks write
+    for m, name in ((unet, "unet"), (bn, "brushnet")):
+        before = m.state_dict()
+        m.train()
+        assert m.training and m.flat_g is not None and m.flat_w.numel() >= m.num_arena_floats() > 0
+        after = m.state_dict()
+        assert set(after) == set(shapes[name])
+        for k in before:
+            assert tuple(after[k].shape) == tuple(shapes[name][k]) and torch.equal(after[k], before[k]), k
+        g = m.grad_state_dict()
+        assert set(g) == set(after) and all(float(v.abs().max()) == 0.0 for v in g.values())
     with pytest.raises(NotImplementedError):
-        unet.train()
+        vae.train()
 
 
 def test_split_pack_layout_and_precision():

@@ -113,10 +113,10 @@ def test_two_training_steps_match_reference(prec, tag, train_unet, gamma):
         ref_l, ref_n = float(G[f"{tag}_loss_{i}"]), float(G[f"{tag}_grad_norm_{i}"])
         print(f"[{tag} {prec}] step {i}: loss {float(loss):.7f} (ref {ref_l:.7f})  grad norm {float(norm):.6f} (ref {ref_n:.6f})")
         assert abs(float(loss) - ref_l) < 1e-4 * ref_l
-        assert abs(float(norm) - ref_n) < 2e-4 * ref_n
         if i == 0:
-            grads = {("unet." if m is model.unet else "") + k: v for m in model.get_trainable_modules()
+            grads = {("unet." if m is model.unet else "") + k: v / model.loss_scale for m in model.get_trainable_modules()
                      for k, v in m.grad_state_dict().items()}
+            bad = []
             for key in [k for k in G.files if k.startswith(f"{tag}_grad/")]:
                 name = key.split("/", 1)[1]
                 ref = torch.from_numpy(G[key])
@@ -124,7 +124,9 @@ def test_two_training_steps_match_reference(prec, tag, train_unet, gamma):
                 scale = float(ref.abs().max())
                 print(f"   grad {name}: max err {err:.3e} (|ref| max {scale:.3e})")
                 assert tuple(grads[name].shape) == tuple(ref.shape)
-                assert err <= 2e-4 * scale + 1e-7, name
+                bad.append(name) if err > 2e-4 * scale + 1e-7 else None
+            assert not bad, bad
+        assert abs(float(norm) - ref_n) < 2e-4 * ref_n
     w2 = {("unet." if m is model.unet else "") + k: v for m in model.get_trainable_modules() for k, v in m.state_dict().items()}
     for key in [k for k in G.files if k.startswith(f"{tag}_dw/")]:
         name = key.split("/", 1)[1]
@@ -355,7 +357,8 @@ def test_adamw_and_clip_against_torch():
         opt.step()
         gd = gr.to(DEV)
         hip.sumsq(gd, sumsq)
-        hip.clip_coef(sumsq, 1.0, coef, norm)
+        hip.sumsq(gd * 1024.0, sumsq)                    # an arena holding gradients x 1024 (loss scale)
+        hip.clip_coef(sumsq, 1.0, coef, norm, unscale=1.0 / 1024.0)
         assert abs(float(norm) - float(tn)) < 1e-5 * float(tn)
-        hip.adamw(wd, gd, m, v, lr=1e-3, step=step, grad_scale=coef)
+        hip.adamw(wd, gd * 1024.0, m, v, lr=1e-3, step=step, grad_scale=coef)
         assert float((wd.cpu() - pt.detach()).abs().max()) < 2e-6
