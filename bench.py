@@ -157,12 +157,85 @@ def stub_main(a, D):
     D.barrier()
 
 
+def train_main(a, D):
+    """--mode train: BASELINE.json configs[3] — the MirrorFusion fine-tune step (train_brushnet_mirror.py:1407-1466) on
+    synthetic latents: BrushNet trains, the UNet is frozen (the script's default), per-GPU batch `--batch` (8), 512 x 512
+    (64 x 64 latents), fp32 master weights, split-precision (f16x3) or fp32-MFMA contractions, clip 1.0, AdamW; with
+    --gpus N every rank trains its own batch and the gradient arena is all-reduced in buckets over RCCL under the
+    backward pass.  Secondary workload: reported with its own metric, never as the inference number."""
+    from reflecting_reality_amd import (BrushNetModel, DDPMScheduler, UNet2DConditionModel, hip, synth)
+    from reflecting_reality_amd.configs import SD15_SCHED, SD15_UNET, brushnet_config
+    from reflecting_reality_amd.training import AdamW, MirrorFusionModel, train_step
+    backend = os.environ.get("MF_BENCH_BACKEND") or None
+    rank, world, local = D.init_process_group(backend)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {a.gpus}")
+    if backend == "gloo":
+        local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    hip.load()
+    prec = a.precision if a.precision in ("fp32", "f16x3") else "f16x3"
+    t0 = time.time()
+    unet = UNet2DConditionModel(dict(SD15_UNET), precision=prec, device=device)
+    unet.load_state_dict(synth.state_dict_for(unet.param_shapes(), 0))
+    bn = BrushNetModel(dict(brushnet_config(SD15_UNET, 6)), precision=prec, device=device)
+    bn.load_state_dict(synth.state_dict_for(bn.param_shapes(), 1))
+    model = MirrorFusionModel(unet, bn).prepare_training(train_base_unet=False)
+    opt = AdamW(model.get_trainable_modules(), lr=1e-5)
+    sync = D.GradBuckets(model.get_trainable_modules()) if world > 1 else None
+    ns = DDPMScheduler(**{k: v for k, v in SD15_SCHED.items() if k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule")})
+    log(f"[bench] training models built in {time.time() - t0:.1f}s: BrushNet {bn.num_arena_floats() / 1e6:.1f} M trainable floats")
+    hl = a.size // 8
+    g = torch.Generator().manual_seed(99 + rank)
+    b = a.batch
+    lat, noi = torch.randn(b, 4, hl, hl, generator=g).to(device) * 0.8, torch.randn(b, 4, hl, hl, generator=g).to(device)
+    cond, ehs = torch.randn(b, 6, hl, hl, generator=g).to(device), torch.randn(b, 77, 768, generator=g).to(device)
+
+    def one_step(i):
+        ts = torch.randint(0, 1000, (b,), generator=g)
+        return train_step(model, ns, opt, lat, noi, ts, ehs, cond, max_grad_norm=1.0, grad_sync=sync)
+
+    for i in range(a.warmup):
+        one_step(i)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss, norm = one_step(i)
+    D.barrier()
+    torch.cuda.synchronize()
+    reduce_device = "cpu" if backend == "gloo" else device
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=reduce_device)
+    assert torch.isfinite(loss).all() and torch.isfinite(norm).all()
+    if rank == 0:
+        gflop = 3 * 441.3 + 2 * 803.3            # per sample: BrushNet fwd + dgrad + wgrad, frozen UNet fwd + dgrad (BASELINE.md §2 / 2: no CFG)
+        step_s = elapsed / a.steps
+        print(json.dumps({
+            "metric": "samples/sec, MirrorFusion fine-tune step at 512x512 (BrushNet trains, UNet frozen) — secondary workload",
+            "value": round(b * a.steps * world / elapsed, 4), "unit": "samples/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": f"train_brushnet_mirror.py step, per-GPU batch {b} x {a.size}x{a.size}, BrushNet(6 cond ch) trainable / UNet "
+                                   f"frozen, clip 1.0, AdamW lr 1e-5, random-init weights", "per_gpu_batch": b, "global_batch": b * world,
+                       "parallelism": f"data-parallel x{world}" + (" (bucketed gradient all-reduce over RCCL)" if world > 1 else "")},
+            "achieved_tflops": round(b * gflop * 1e9 / step_s / 1e12, 2),
+            "algorithmic_gflop_per_sample": round(gflop, 1), "last_loss": round(float(loss), 5), "last_grad_norm": round(float(norm), 5)}),
+            flush=True)
+        hip.tune_save()
+        if os.path.isdir("gpurun_out"):
+            hip.tune_save(os.path.join("gpurun_out", "tune_cache_new.json"))
+    D.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer = BASELINE.json's north-star workload; train = configs[3], the fine-tune step (secondary)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 4; 8 for --mode train)")
     ap.add_argument("--size", type=int, default=None, help="image side (default 512; 1024 for --model sdxl)")
     ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl"],
                     help="sd15 = BASELINE.json's north-star workload; sdxl = the §8 f-3 secondary workload")
@@ -182,12 +255,18 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(sys.argv[1:], a.gpus))          # before anything touches the GPU
     xl = a.model == "sdxl"
+    if a.batch is None:
+        a.batch = 8 if a.mode == "train" else 4
     if a.size is None:
         a.size = 1024 if xl else 512
 
     from reflecting_reality_amd import distributed as D
     if a.stub:
         return stub_main(a, D)
+    if a.mode == "train":
+        if a.size is None:
+            a.size = 512
+        return train_main(a, D)
     from reflecting_reality_amd import hip, synth
     # MF_BENCH_BACKEND=gloo: test hook for boxes with fewer GPUs than ranks (ranks then share devices, timings mean
     # nothing); the driver's multi-GPU runs use the default, "nccl" = RCCL, one rank per GPU

@@ -227,6 +227,29 @@ int mf_vae_sample(const void* moments, int32_t m_dtype, int64_t ld, const float*
 int mf_nearest_resize(const float* src, float* dst, int32_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
                       int32_t w_out, void* stream);
 
+/* ---- image front-end on the device (image_processor.py:446-610, pipeline_brushnet.py:1139,1196-1215,
+ * examples/brushnet/dataset/dataset.py:98-145); fp32 NCHW planes, no host synchronisation ------------------- */
+/* out2[0] = min, out2[1] = max of x[0..n) (only where mask[i] > 0 when mask is given); ws: mf_minmax_ws_floats() floats */
+int64_t mf_minmax_ws_floats(void);
+int mf_minmax(const float* x, const float* mask, int64_t n, float* out2, float* ws, void* stream);
+/* VaeImageProcessor.preprocess's normalisation: y = 2x - 1 if minmax[0] >= 0 (device value from mf_minmax) else y = x */
+int mf_image_normalize(const float* x, float* y, int64_t n, const float* minmax, void* stream);
+/* out[b][0][p] = (sum_c mask[b][c][p] < 0) ? 1 : 0: 1 = keep, 0 = hole (pipeline_brushnet.py:1139) */
+int mf_mask_keep(const float* mask, float* out, int32_t batch, int32_t channels, int64_t hw, void* stream);
+/* torch.cat along channels of up to 8 NCHW sources into out [batch][sum channels][hw]; source i has batches[i] images and
+ * is repeated (image b % batches[i]) when that is smaller than batch */
+int mf_concat_channels(const float* const* srcs, const int32_t* channels, const int32_t* batches, int32_t nsrc, float* out,
+                       int32_t batch, int64_t hw, void* stream);
+/* VaeImageProcessor.postprocess: clamp(x / 2 + 0.5, 0, 1) (denormalize) to fp32 NCHW (out_f32) and / or round(. * 255) to
+ * uint8 NHWC (out_u8, what PIL.Image.fromarray takes); either output may be NULL */
+int mf_postprocess(const float* x, float* out_f32, void* out_u8, int32_t batch, int32_t channels, int64_t hw, int32_t denormalize,
+                   void* stream);
+/* apply_transforms_depth(normalization_method="max_scene_depth"): scene = (mask ? max over mask > 0 of depth : max_scene_depth
+ * given) + (mask ? delta : 0); out = clip(depth, 0, scene) / scene, mapped to [-1, 1] when signed_range;
+ * ws: mf_minmax_ws_floats() + 2 floats */
+int mf_depth_normalize(const float* depth, const float* mask, float* out, int64_t n, float max_scene_depth, float delta,
+                       int32_t signed_range, float* ws, void* stream);
+
 /* ============================================================================================
  * Training: the backward pass and the optimizer of examples/brushnet/train_brushnet_mirror.py:1459-1466
  * (accelerator.backward -> ATen autograd in the reference; clip_grad_norm_ :1463; torch.optim.AdamW :1188-1200).

@@ -746,3 +746,26 @@ def training_steps(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, sched_c
                 adamw_update(v, grads[k] * coef, state[k][0], state[k][1], step, lr, betas, eps, weight_decay)
         records.append(dict(loss=float(loss.detach()), grad_norm=float(total), grads=grads))
     return ({k: v.detach() for k, v in bn.items()}, {k: v.detach() for k, v in un.items()}, records)
+
+
+# ---------------------------------------------------------------------------------------------
+# dataset-side depth transform (examples/brushnet/dataset/dataset.py:98-166)
+# PARITY UNPINNED for this one function: the reference module imports h5py / torchvision / cv2, none of which exist in
+# the build container, so it cannot be imported to check this restatement; it follows the numpy statements of
+# :122-145 line by line (the torchvision Resize / CenterCrop of :150-164 are the identity at the native resolution).
+# ---------------------------------------------------------------------------------------------
+def apply_transforms_depth_ref(depth_map, mask=None, max_scene_depth: float = 5.0, norm_range=(-1, 1), delta: float = 0.5):
+    import numpy as np
+    depth_map = np.copy(depth_map)
+    if mask is not None and mask.ndim == 3:
+        mask = mask[:, :, 0]                                                              # :111-112
+    if mask is not None:
+        max_scene_depth = np.max(depth_map[mask > 0]) + delta                             # :129-134
+    clipped = np.clip(depth_map, 0, max_scene_depth)                                      # :137
+    if list(norm_range) == [0, 1]:
+        out = clipped / max_scene_depth                                                   # :141
+    elif list(norm_range) == [-1, 1]:
+        out = 2.0 * (clipped / max_scene_depth) - 1.0                                     # :143
+    else:
+        raise ValueError("Unsupported normalization range. Use [0, 1] or [-1, 1].")
+    return torch.tensor(out, dtype=torch.float32).unsqueeze(0)                            # :150

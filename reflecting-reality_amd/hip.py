@@ -102,6 +102,9 @@ EXPORTS = [
     "mf_attention_f16x3", "mf_split_halves",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
+    # image front-end (csrc/frontend.hip)
+    "mf_minmax_ws_floats", "mf_minmax", "mf_image_normalize", "mf_mask_keep", "mf_concat_channels", "mf_postprocess",
+    "mf_depth_normalize",
     # training (csrc/train.hip)
     "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
     "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_layernorm_bwd", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
@@ -128,7 +131,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(path)
     lib.mf_last_error.restype = C.c_char_p
     lib.mf_groupnorm_ws_floats.restype = C.c_int64
-    for fn in ("mf_conv_wgrad_ws_floats", "mf_colsum_ws_floats", "mf_sumsq_ws_doubles"):
+    for fn in ("mf_conv_wgrad_ws_floats", "mf_colsum_ws_floats", "mf_sumsq_ws_doubles", "mf_minmax_ws_floats"):
         getattr(lib, fn).restype = C.c_int64
     if lib.mf_abi_version() != ABI_VERSION:
         raise MfhipError(f"libmfhip ABI {lib.mf_abi_version()} != binding ABI {ABI_VERSION}: rebuild the library")
@@ -820,3 +823,73 @@ def adamw(w: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *,
     _check(load().mf_adamw(C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(v.data_ptr()),
                            C.c_int64(w.numel()), C.c_float(lr), C.c_float(betas[0]), C.c_float(betas[1]), C.c_float(eps),
                            C.c_float(weight_decay), step, C.c_void_p(_ptr(grad_scale)), _stream()), "mf_adamw")
+
+
+# ---- image front-end (csrc/frontend.hip) ------------------------------------------------------------------------------
+def _mm_ws(device) -> torch.Tensor:
+    return scratch("minmax", int(load().mf_minmax_ws_floats()) + 2, device)
+
+
+def minmax(x: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[min, max] of x (where mask > 0) as a 2-element DEVICE tensor."""
+    _f32(x, mask)
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    _check(load().mf_minmax(C.c_void_p(x.data_ptr()), C.c_void_p(_ptr(mask)), C.c_int64(x.numel()), C.c_void_p(out.data_ptr()),
+                            C.c_void_p(_mm_ws(x.device).data_ptr()), _stream()), "mf_minmax")
+    return out
+
+
+def image_normalize(x: torch.Tensor) -> torch.Tensor:
+    """VaeImageProcessor.preprocess for a device tensor: 2x - 1 unless the tensor already holds negatives."""
+    _f32(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _check(load().mf_image_normalize(C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_int64(x.numel()),
+                                     C.c_void_p(minmax(x).data_ptr()), _stream()), "mf_image_normalize")
+    return y
+
+
+def mask_keep(m: torch.Tensor) -> torch.Tensor:
+    _f32(m)
+    b, c, h, w = m.shape
+    out = torch.empty(b, 1, h, w, dtype=torch.float32, device=m.device)
+    _check(load().mf_mask_keep(C.c_void_p(m.contiguous().data_ptr()), C.c_void_p(out.data_ptr()), b, c, C.c_int64(h * w), _stream()),
+           "mf_mask_keep")
+    return out
+
+
+def concat_channels(srcs, batch: int) -> torch.Tensor:
+    """torch.cat(srcs, 1) for NCHW fp32 tensors whose batch divides `batch` (smaller ones are repeated)."""
+    _f32(*srcs)
+    srcs = [s.contiguous() for s in srcs]
+    h, w = srcs[0].shape[-2:]
+    n = len(srcs)
+    out = torch.empty(batch, sum(s.shape[1] for s in srcs), h, w, dtype=torch.float32, device=srcs[0].device)
+    arr = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    ch = (C.c_int32 * n)(*[s.shape[1] for s in srcs])
+    bs = (C.c_int32 * n)(*[s.shape[0] for s in srcs])
+    _check(load().mf_concat_channels(arr, ch, bs, n, C.c_void_p(out.data_ptr()), batch, C.c_int64(h * w), _stream()), "mf_concat_channels")
+    return out
+
+
+def postprocess(x: torch.Tensor, denormalize: bool = True, uint8: bool = False) -> torch.Tensor:
+    """clamp(x / 2 + 0.5, 0, 1) as fp32 NCHW, or (uint8=True) round(. * 255) as uint8 NHWC."""
+    _f32(x)
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, c) if uint8 else (b, c, h, w), dtype=torch.uint8 if uint8 else torch.float32, device=x.device)
+    _check(load().mf_postprocess(C.c_void_p(x.data_ptr()), C.c_void_p(None if uint8 else out.data_ptr()),
+                                 C.c_void_p(out.data_ptr() if uint8 else None), b, c, C.c_int64(h * w), int(denormalize), _stream()),
+           "mf_postprocess")
+    return out
+
+
+def depth_normalize(depth: torch.Tensor, mask: Optional[torch.Tensor] = None, max_scene_depth: float = 5.0, delta: float = 0.5,
+                    signed_range: bool = True) -> torch.Tensor:
+    _f32(depth, mask)
+    depth = depth.contiguous()
+    out = torch.empty_like(depth)
+    _check(load().mf_depth_normalize(C.c_void_p(depth.data_ptr()), C.c_void_p(_ptr(mask.contiguous()) if mask is not None else None),
+                                     C.c_void_p(out.data_ptr()), C.c_int64(depth.numel()), C.c_float(max_scene_depth), C.c_float(delta),
+                                     int(signed_range), C.c_void_p(_mm_ws(depth.device).data_ptr()), _stream()), "mf_depth_normalize")
+    return out

@@ -638,6 +638,37 @@ class _UNetCore(HipModel):
             h = ops.linear(gg, P[b + "ff.net.2"], res0=h)
         return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj)
 
+    # ---- the reference's operator plug-in point (attention_processor.py:216; brushnet.py:558-590;
+    # unet_2d_condition.py:716-748) ----------------------------------------------------------------------------
+    @property
+    def attn_processors(self) -> Dict[str, Any]:
+        """One entry per attention layer, keyed like the reference ("...attn1.processor"); every layer runs the HIP
+        attention of this library."""
+        from .attn_processor import MfhipAttnProcessor
+        return {k[: -len("to_q")] + "processor": MfhipAttnProcessor() for k in self.P if k.endswith(".to_q")}
+
+    def set_attn_processor(self, processor) -> None:
+        """The reference lets a caller swap the attention arithmetic per layer.  Here attention is fused into the HIP graph
+        (q|k projection in one GEMM, V produced transposed, flash kernel): the only processor these models run is
+        `MfhipAttnProcessor` (the same kernel, exposed on the reference's processor ABI for use inside the reference's own
+        modules).  Passing it — or a dict of it with exactly the reference's keys — is accepted; anything else is refused
+        instead of being silently ignored."""
+        from .attn_processor import MfhipAttnProcessor
+        keys = set(self.attn_processors)
+        if isinstance(processor, dict):
+            if len(processor) != len(keys):
+                raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                                 f" number of attention layers: {len(keys)}. Please make sure to pass {len(keys)} processor classes.")
+            procs = list(processor.values())
+        else:
+            procs = [processor]
+        if not all(isinstance(p, MfhipAttnProcessor) for p in procs):
+            raise NotImplementedError("the HIP models run their own fused attention: only MfhipAttnProcessor is accepted "
+                                      "(use it with the reference's modules to run this kernel there)")
+
+    def set_default_attn_processor(self) -> None:
+        return None
+
     def _ehs(self, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
         return encoder_hidden_states.to(self.device, self.prec.act).contiguous()
 

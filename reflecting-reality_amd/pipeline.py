@@ -74,6 +74,13 @@ class VaeImageProcessor:
             if t.shape[1] == 4:                                             # already latents (:532-533)
                 return t
         t = t.float()
+        if t.is_cuda:
+            # device tensors stay on the device and go through the front-end kernels (csrc/frontend.hip): nearest resize
+            # (F.interpolate's default, :resize()), then 2x - 1 unless the tensor already holds negatives — the min is
+            # reduced on the device and read by the normalising kernel, the host never waits for it
+            if self.do_resize and height is not None and tuple(t.shape[-2:]) != (height, width):
+                t = hip.nearest_resize(t, height, width)
+            return hip.image_normalize(t) if self.do_normalize else t
         if self.do_resize and height is not None and tuple(t.shape[-2:]) != (height, width):
             t = torch.nn.functional.interpolate(t, size=(height, width))    # :resize() for tensors (host, once)
         if self.do_normalize and t.min() >= 0:                              # negatives pass through un-normalised
@@ -87,8 +94,16 @@ class VaeImageProcessor:
             return image
         if do_denormalize is None:
             do_denormalize = [self.do_normalize] * image.shape[0]
-        image = torch.stack([(image[i] / 2 + 0.5).clamp(0, 1) if do_denormalize[i] else image[i]
-                             for i in range(image.shape[0])])
+        if image.is_cuda and image.dtype == torch.float32 and (all(do_denormalize) or not any(do_denormalize)):
+            if output_type == "pil":       # straight to uint8 HWC on the device: the host only copies bytes
+                arr = hip.postprocess(image, denormalize=all(do_denormalize), uint8=True).cpu().numpy()
+                if arr.shape[-1] == 1:
+                    return [PIL.Image.fromarray(a.squeeze(), mode="L") for a in arr]
+                return [PIL.Image.fromarray(a) for a in arr]
+            image = hip.postprocess(image, denormalize=all(do_denormalize))
+        else:
+            image = torch.stack([(image[i] / 2 + 0.5).clamp(0, 1) if do_denormalize[i] else image[i]
+                                 for i in range(image.shape[0])])
         if output_type == "pt":
             return image
         arr = image.cpu().permute(0, 2, 3, 1).float().numpy()
@@ -334,7 +349,7 @@ class StableDiffusionBrushNetPipeline:
         (image, depth, normals) for the 'latents' modes; None draws them in the reference's order from the global RNG."""
         img = self.prepare_image(image, width, height, batch, num_images_per_prompt)
         m3 = self.prepare_image(mask, width, height, batch, num_images_per_prompt)
-        original_mask = (m3.sum(1)[:, None, :, :] < 0).to(torch.float32)                           # :1139 (1 = keep)
+        original_mask = hip.mask_keep(m3) if m3.is_cuda else (m3.sum(1)[:, None, :, :] < 0).to(torch.float32)   # :1139 (1 = keep)
         height, width = img.shape[-2:]
         hl, wl = height // self.vae_scale_factor, width // self.vae_scale_factor
         dup = 2 if do_cfg else 1
@@ -377,7 +392,8 @@ class StableDiffusionBrushNetPipeline:
             else:
                 for ps, h in zip(parts, encode_sample(nrm, noises[2])):                            # :1213-1215
                     ps.append(h)
-        return torch.cat([torch.cat(ps, 1) for ps in parts], 0).contiguous()
+        # torch.cat along channels of each CFG half (:1196-1215) by the front-end kernel; stacking the halves is a copy
+        return torch.cat([hip.concat_channels(ps, batch) for ps in parts], 0).contiguous()
 
     # ---- the call --------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -1,0 +1,70 @@
+"""The image front-end on the device (csrc/frontend.hip) against the host path it replaces (the
+reference's torch / numpy statements) and, for the dataset depth transform, against the oracle's numpy restatement."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mirrorfusion_ref as R  # noqa: E402
+from reflecting_reality_amd import frontend, hip  # noqa: E402
+from reflecting_reality_amd.pipeline import VaeImageProcessor  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_preprocess_on_device_equals_host_path():
+    """VaeImageProcessor.preprocess (image_processor.py:446-555): [0,1] tensors become 2x - 1, tensors that already hold
+    negatives pass through (the decision is a device-side min), nearest resize when the size differs."""
+    g = torch.Generator().manual_seed(1)
+    p = VaeImageProcessor(vae_scale_factor=8, do_convert_rgb=True)
+    for t in (torch.rand(2, 3, 64, 48, generator=g), torch.rand(2, 1, 64, 48, generator=g) * 2 - 1, torch.zeros(1, 3, 8, 8)):
+        host = p.preprocess(t, height=t.shape[-2], width=t.shape[-1])
+        dev = p.preprocess(t.to(DEV), height=t.shape[-2], width=t.shape[-1])
+        assert dev.is_cuda and torch.equal(dev.cpu(), host)
+    t = torch.rand(2, 3, 32, 32, generator=g)
+    assert torch.equal(p.preprocess(t.to(DEV), height=64, width=48).cpu(), p.preprocess(t, height=64, width=48))
+    mm = hip.minmax(t.to(DEV))
+    assert float(mm[0]) == float(t.min()) and float(mm[1]) == float(t.max())
+
+
+def test_mask_keep_concat_and_postprocess():
+    g = torch.Generator().manual_seed(2)
+    m3 = (torch.rand(3, 3, 40, 24, generator=g) > 0.5).float() * 2 - 1
+    m3[0, :, :4] = torch.tensor([1.0, -0.5, -0.5]).view(3, 1, 1)            # sums to exactly 0: not < 0 -> hole
+    assert torch.equal(hip.mask_keep(m3.to(DEV)).cpu(), (m3.sum(1)[:, None] < 0).float())
+    a, b, c = torch.randn(4, 4, 8, 8, generator=g), torch.randn(2, 1, 8, 8, generator=g), torch.randn(4, 3, 8, 8, generator=g)
+    got = hip.concat_channels([a.to(DEV), b.to(DEV), c.to(DEV)], 4)
+    assert torch.equal(got.cpu(), torch.cat([a, b.repeat(2, 1, 1, 1), c], 1))
+    x = torch.randn(2, 3, 16, 20, generator=g) * 1.5
+    ref = (x / 2 + 0.5).clamp(0, 1)
+    assert torch.equal(hip.postprocess(x.to(DEV)).cpu(), ref)
+    u8 = hip.postprocess(x.to(DEV), uint8=True).cpu().numpy()
+    assert u8.dtype == np.uint8 and np.array_equal(u8, (ref.permute(0, 2, 3, 1).numpy() * 255).round().astype("uint8"))
+    p = VaeImageProcessor()
+    pil_dev = p.postprocess(x.to(DEV), output_type="pil", do_denormalize=[True, True])
+    pil_host = p.postprocess(x, output_type="pil", do_denormalize=[True, True])
+    assert all(np.array_equal(np.array(i), np.array(j)) for i, j in zip(pil_dev, pil_host))
+    assert np.array_equal(p.postprocess(x.to(DEV), output_type="np", do_denormalize=[True, True]),
+                          p.postprocess(x, output_type="np", do_denormalize=[True, True]))
+
+
+@pytest.mark.parametrize("use_mask", [True, False])
+@pytest.mark.parametrize("rng", [(-1, 1), (0, 1)])
+def test_apply_transforms_depth_max_scene_depth(use_mask, rng):
+    """examples/brushnet/dataset/dataset.py:98-145 (oracle restatement; the reference module itself cannot be imported:
+    h5py / torchvision / cv2 are absent)."""
+    g = np.random.default_rng(3)
+    depth = (g.random((512, 512), dtype=np.float32) * 7.0).astype(np.float32)
+    mask = np.zeros((512, 512, 3), dtype=np.uint8)
+    mask[100:300, 200:420] = 255
+    ref = R.apply_transforms_depth_ref(depth, mask if use_mask else None, max_scene_depth=5.0, norm_range=rng, delta=0.5)
+    got = frontend.apply_transforms_depth(depth, mask if use_mask else None, max_scene_depth=5.0, norm_range=rng, delta=0.5)
+    assert tuple(got.shape) == (1, 512, 512) and got.is_cuda
+    assert float((got.cpu() - ref).abs().max()) < 2e-7
+    with pytest.raises(NotImplementedError):
+        frontend.apply_transforms_depth(depth, normalization_method="percentile")
+    with pytest.raises(NotImplementedError):
+        frontend.apply_transforms_depth(depth[:256, :256])
+    with pytest.raises(ValueError):
+        frontend.apply_transforms_depth(depth, norm_range=(0, 2))

@@ -2,6 +2,7 @@
 parameter enumeration against the reference's state-dict tables, input validation, image-processor semantics,
 batch sharding."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -310,3 +311,56 @@ def test_tune_cache_versioning_and_atomic_save(tmp_path, monkeypatch):
     assert hip._tune_read(str(path), ver) == {}
     hip._tune_forget("1,1,64,64,64,1,1,0,0,1,0,0,1,1")
     assert "1,1,64,64,64,1,1,0,0,1,0,0,1,1" not in hip._tune_new
+
+
+def test_sharded_inference_harness_with_a_stub_pipeline(tmp_path):
+    """inference.run_sharded (test_brushnet.py:163-168,247-266): contiguous split of the sample list, ONE generator per
+    rank drawn from in sequence, `num_images_per_validation` images per sample; list_checkpoints orders checkpoint-N."""
+    from reflecting_reality_amd import inference as I
+
+    class Out:
+        def __init__(self, x):
+            self.images = [x]
+
+    class StubPipe:
+        device = "cpu"
+        calls = []
+
+        def __call__(self, generator=None, tag=None, **kw):
+            assert kw["num_inference_steps"] == 7 and isinstance(kw["brushnet_conditioning_scale"], float)
+            v = float(torch.randn(1, generator=generator))
+            self.calls.append((tag, v))
+            return Out((tag, v))
+
+    samples = [dict(tag=i) for i in range(7)]
+    got = {}
+    for rank in range(3):
+        pipe = StubPipe()
+        res = I.run_sharded(pipe, samples, seed=11, num_images_per_validation=2, num_inference_steps=7, rank=rank, world=3)
+        got.update(res)
+        g = torch.Generator().manual_seed(11)
+        want = [float(torch.randn(1, generator=g)) for _ in range(2 * len(res))]
+        assert [v for imgs in res.values() for _, v in imgs] == want          # one seeded stream per rank, in order
+    assert sorted(got) == list(range(7)) and all(len(v) == 2 and v[0][0] == i for i, v in got.items())
+    assert [sorted(I.run_sharded(StubPipe(), samples, num_images_per_validation=1, num_inference_steps=7, rank=r, world=3))
+            for r in range(3)] == [[0, 1, 2], [3, 4], [5, 6]]
+    for n in (500, 1000, 90, 1500):
+        (tmp_path / f"checkpoint-{n}").mkdir()
+    (tmp_path / "logs").mkdir()
+    assert [os.path.basename(p) for p in I.list_checkpoints(str(tmp_path))] == ["checkpoint-90", "checkpoint-500", "checkpoint-1000", "checkpoint-1500"]
+    assert [os.path.basename(p) for p in I.list_checkpoints(str(tmp_path), 500)] == ["checkpoint-500", "checkpoint-1000", "checkpoint-1500"]
+
+
+def test_set_attn_processor_surface():
+    from reflecting_reality_amd import MfhipAttnProcessor
+    unet = UNet2DConditionModel(dict(configs.TINY_UNET), precision="fp32", device="cpu")
+    unet.load_state_dict(synth.state_dict_for(keys("tiny")["unet"], 0))
+    procs = unet.attn_processors
+    assert len(procs) == 2 * sum(1 for k in keys("tiny")["unet"] if k.endswith("attn1.to_q.weight"))
+    assert all(k.endswith(".processor") and ".transformer_blocks." in k for k in procs)
+    unet.set_attn_processor(MfhipAttnProcessor())
+    unet.set_attn_processor(procs)
+    with pytest.raises(ValueError, match="number of processors"):
+        unet.set_attn_processor({"a": MfhipAttnProcessor()})
+    with pytest.raises(NotImplementedError):
+        unet.set_attn_processor(object())
