@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl"],
                     help="sd15 = BASELINE.json's north-star workload; sdxl = the §8 f-3 secondary workload")
     ap.add_argument("--denoise-steps", type=int, default=50)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3", "bf16x3", "fp8"])
     ap.add_argument("--no-parity-mode", action="store_true",
                     help="skip the extra passes in the f16x3 parity mode (the mode that meets the 1e-3 latent bound)")
     ap.add_argument("--inputs", default="device", choices=["device", "host"],

@@ -34,6 +34,10 @@ extern "C" {
  * (22 significant bits, |x| < 65504); MF_BF16X3: bf16 halves (16 bits, fp32 range). */
 #define MF_F16X3 2
 #define MF_BF16X3 3
+/* OCP fp8 e4m3 operands (1 byte each, a_dtype == MF_FP8 too) on the block-scaled matrix instruction
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the bf16 MFMA rate); the quantisation scales are
+ * per A row / per W row fp32 vectors applied in the epilogue (mf_gemm_desc.a_scale / w_scale) */
+#define MF_FP8 4
 
 #define MF_OK 0
 #define MF_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -46,7 +50,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 8
+#define MF_ABI_VERSION 9
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -101,6 +105,10 @@ typedef struct mf_gemm_desc {
     int32_t bias_mode;
     const float* temb;    /* [batch][ld_temb] fp32 or NULL; row = m / (h_out*w_out) */
     int64_t ld_temb;
+    /* out = alpha * (a_scale[m] * w_scale[n] * acc + bias + temb) + ... : dequantisation of fp8 operands (either may be
+     * NULL = 1; usable with any dtype).  Batched calls: vector z starts at a_scale + (z / zdiv) * a_scale_zs (w alike) */
+    const float* a_scale; const float* w_scale;
+    int64_t a_scale_zs, w_scale_zs;
     const void* res0; int32_t res0_dtype; int64_t ld_res0;
     const void* res1; int32_t res1_dtype; int64_t ld_res1;
     float alpha;
@@ -173,6 +181,12 @@ int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ldq, const vo
                        int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream);
 /* x (n fp32, n % 4 == 0) -> fp16 planes hi = x rounded toward zero, lo = (x - hi) rounded toward zero */
 int mf_split_halves(const float* x, void* hi, void* lo, int64_t n, void* stream);
+
+/* Per-row dynamic fp8 (e4m3) quantisation of [rows][c] (c % 8 == 0, c <= 2048), optionally fused behind a LayerNorm
+ * (gamma / beta non-NULL: y = LN(x) first, attention.py:203,233,261): out_q[r][j] = fp8(y[r][j] / scale[r]),
+ * scale[r] = max_j |y[r][j]| / 448.  The pair (out_q, scale) is an fp8 GEMM's A operand + a_scale. */
+int mf_quantize_rows_fp8(const void* x, int32_t in_dtype, void* out_q, float* scale, int64_t rows, int32_t c,
+                         const float* gamma, const float* beta, float eps, void* stream);
 
 /* ---- elementwise / layout -------------------------------------------------------------- */
 /* NCHW fp32 -> NHWC (dtype), channels zero-padded to c_pad; two sources concatenated along C

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(_PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmfhip.so")
 INCLUDE = os.path.join(os.path.dirname(_PKG_DIR), "include")
 
-SOURCES = ["gemm_conv.hip", "norm.hip", "attention.hip", "elementwise.hip", "train.hip", "frontend.hip"]
+SOURCES = ["gemm_conv.hip", "norm.hip", "attention.hip", "elementwise.hip", "train.hip", "frontend.hip", "fp8.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                f"-I{INCLUDE}"]
 

@@ -44,6 +44,7 @@ struct GemmArgs {
     int splitk, kt_per_split, nkt, nz;
     float* ws;
     const float* bias; int bias_mode;
+    const float* rs; const float* cs; int64_t rs_zs, cs_zs;   // dequantisation: acc * rs[m] * cs[n]
     const float* temb; int64_t ld_temb;
     const char* res0; int res0_dt; int64_t ld_res0;
     const char* res1; int res1_dt; int64_t ld_res1;
@@ -53,7 +54,9 @@ struct GemmArgs {
 };
 
 // Scalar epilogue for one output element (tails, misaligned outputs, split-K reduce).
-__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int64_t zo, int m, int n, float v) {
+__device__ __forceinline__ void epilogue_store(const GemmArgs& p, int64_t zo, int m, int n, float v, int zq = 0) {
+    if (p.rs) v *= p.rs[zq * p.rs_zs + m];
+    if (p.cs) v *= p.cs[zq * p.cs_zs + n];
     if (p.bias) v += p.bias_mode ? p.bias[m] : p.bias[n];
     if (p.temb) v += p.temb[(int64_t)(m / p.HoWo) * p.ld_temb + n];
     v *= p.alpha;
@@ -87,7 +90,14 @@ __device__ __forceinline__ void unpack8_bf16(const uint4& u, float* o) {
 
 // `pre`: the bf16 residual vectors of this item were fetched ahead of the LDS transposition (q0 / q1).
 __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, int m, int n, float* v, bool pre = false,
-                                                const uint4& q0 = uint4{0, 0, 0, 0}, const uint4& q1 = uint4{0, 0, 0, 0}) {
+                                                const uint4& q0 = uint4{0, 0, 0, 0}, const uint4& q1 = uint4{0, 0, 0, 0}, int zq = 0) {
+    if (p.rs || p.cs) {
+        const float r = p.rs ? p.rs[zq * p.rs_zs + m] : 1.0f;
+        float c8[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        if (p.cs) load8_as_f32((const char*)(p.cs + zq * p.cs_zs), MF_F32, n, c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= r * c8[j];
+    }
     if (p.bias) {
         if (p.bias_mode) {
             const float b = p.bias[m];
@@ -215,7 +225,8 @@ void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;
     constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3);
     static_assert(!WPK || SPLIT, "a pre-split W operand only exists for the split codes");
-    constexpr int ES = (DT == MF_BF16) ? 2 : 4;   // element size of the operands in memory / LDS
+    constexpr bool FP8 = (DT == MF_FP8);
+    constexpr int ES = (DT == MF_BF16) ? 2 : (FP8 ? 1 : 4);   // element size of the operands in memory / LDS
     constexpr int AES = A_F32 ? 4 : ES;          // element size of the A storage dtype
     constexpr int VEC = 16 / ES;                 // elements per 16-byte LDS chunk
     constexpr int BK = 128 / ES;                 // K elements per tile (128 bytes per row)
@@ -480,6 +491,33 @@ void gemm_conv_kernel(const GemmArgs p) {
     // One K tile (32 k = two 16-wide MFMA steps) of a split code.  Ap[i] / Ak[i]: LDS row base and swizzle key of this
     // lane's row of A tile i; Bp: row base of W tile 0 (tile j at + j * 32 rows), key fkey.
     auto compute_split = [&](const char* const (&Ap)[MT], const int (&Ak)[MT], const char* Bp) {
+        if constexpr (FP8) {
+            // fp8 e4m3: a K tile is 128 elements = two 64-wide steps of v_mfma_scale_f32_32x32x64_f8f6f4 (unit block
+            // scales: E8M0 127); a lane's fragment is 32 consecutive bytes (chunks 4 ks + 2 fh, + 1) of its row — A and W
+            // use the same byte -> k map, so the dot product does not depend on the instruction's internal k order
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                i32x8_t fa[MT], fb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const uint4 c0 = *reinterpret_cast<const uint4*>(Ap[i] + (((4 * ks + 2 * fh) ^ Ak[i]) << 4));
+                    const uint4 c1 = *reinterpret_cast<const uint4*>(Ap[i] + (((4 * ks + 2 * fh + 1) ^ Ak[i]) << 4));
+                    fa[i] = i32x8_t{(int)c0.x, (int)c0.y, (int)c0.z, (int)c0.w, (int)c1.x, (int)c1.y, (int)c1.z, (int)c1.w};
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint4 c0 = *reinterpret_cast<const uint4*>(Bp + j * 32 * 128 + (((4 * ks + 2 * fh) ^ fkey) << 4));
+                    const uint4 c1 = *reinterpret_cast<const uint4*>(Bp + j * 32 * 128 + (((4 * ks + 2 * fh + 1) ^ fkey) << 4));
+                    fb[j] = i32x8_t{(int)c0.x, (int)c0.y, (int)c0.z, (int)c0.w, (int)c1.x, (int)c1.y, (int)c1.z, (int)c1.w};
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[i], fb[j], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 ah[MT], al[MT], bh[NT], bl[NT];
@@ -533,7 +571,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE_BYTES + (wm * WM + frow) * 128;
         const char* Bs = smem + stage * STAGE_BYTES + BM * 128 + (wn * WN + frow) * 128;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT || FP8) {
             const char* Ap[MT]; int Ak[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) { Ap[i] = As + i * 32 * 128; Ak[i] = fkey; }
@@ -654,7 +692,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                     aoffs[i] = r * 128;
                     akey[i] = (r >> 1) & 7;
                 }
-                if constexpr (SPLIT) {
+                if constexpr (SPLIT || FP8) {
                     const char* Ap[MT];
 #pragma unroll
                     for (int i = 0; i < MT; ++i) Ap[i] = Ab + aoffs[i];
@@ -799,9 +837,9 @@ void gemm_conv_kernel(const GemmArgs p) {
                         for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
                     }
                 } else if (p.vec_ok && n + 8 <= p.N) {
-                    epilogue_store8(p, zo, m, n, v, res_pre, q0[it0 / 64], q1[it0 / 64]);
+                    epilogue_store8(p, zo, m, n, v, res_pre, q0[it0 / 64], q1[it0 / 64], zq);
                 } else {
-                    for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj]);
+                    for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj], zq);
                 }
             }
         }
@@ -1432,7 +1470,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
             }
             const int zq = z / p.zdiv, zr = z - zq * p.zdiv;
-            epilogue_store8(p, zq * p.o_zs_o + zr * p.o_zs_i, m, n, v);
+            epilogue_store8(p, zq * p.o_zs_o + zr * p.o_zs_i, m, n, v, false, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, zq);
         }
         return;
     }
@@ -1446,7 +1484,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         float v = 0.0f;
         for (int s = 0; s < p.splitk; ++s) v += p.ws[((int64_t)s * p.nz + z) * mn + r];
         const int zq = z / p.zdiv, zr = z - zq * p.zdiv;
-        epilogue_store(p, zq * p.o_zs_o + zr * p.o_zs_i, m, n, v);
+        epilogue_store(p, zq * p.o_zs_o + zr * p.o_zs_i, m, n, v, zq);
     }
 }
 
@@ -1579,6 +1617,21 @@ void launch_pingpong(const GemmArgs& a, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL((conv3x3_pingpong_kernel<BN, 3>), grid, dim3(512), smem, s, a);
 }
 
+// fp8: the tiles instantiated for it
+bool launch_tile_fp8(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    switch (tile) {
+        case 1: launch_one<MF_FP8, 128, 128, 2, 2, false, 2>(a, grid, s); return true;
+        case 2: launch_one<MF_FP8, 128, 64, 2, 2, false, 2>(a, grid, s); return true;
+        case 3: launch_one<MF_FP8, 64, 64, 2, 2, false, 2>(a, grid, s); return true;
+        case 6: launch_one<MF_FP8, 64, 128, 2, 2, false, 2>(a, grid, s); return true;
+        case 7: launch_one<MF_FP8, 128, 128, 2, 2, false, 3>(a, grid, s); return true;
+        case 13: launch_one<MF_FP8, 192, 128, 2, 2, false, 2>(a, grid, s); return true;
+        case 14: launch_one<MF_FP8, 128, 160, 4, 1, false, 2>(a, grid, s); return true;
+        case 15: launch_one<MF_FP8, 128, 192, 2, 2, false, 2>(a, grid, s); return true;
+        default: return false;
+    }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Heuristic tile choice (mf_gemm_desc.tile overrides it; the Python host autotunes per shape).
@@ -1616,9 +1669,10 @@ extern "C" int mf_gemm_tile_shape(int tile, int* bm, int* bn) {
 
 extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(d != nullptr, "mf_gemm_conv: null descriptor");
-    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_BF16 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X3,
+    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_BF16 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X3 || d->dtype == MF_FP8,
                  "mf_gemm_conv: bad dtype %d", d->dtype);
     const bool split = d->dtype == MF_F16X3 || d->dtype == MF_BF16X3;
+    MF_CHECK_ARG((d->dtype == MF_FP8) == (d->a_dtype == MF_FP8), "mf_gemm_conv: fp8 compute takes fp8 activations (and only those)");
     MF_CHECK_ARG(!split || d->a_dtype == MF_F32, "mf_gemm_conv: the split codes take fp32 activations");
     MF_CHECK_ARG(d->w_split == 0 || (d->w_split == 1 && split && d->ldw % 32 == 0),
                  "mf_gemm_conv: w_split needs a split compute code and rows padded to a multiple of 32 k");
@@ -1663,6 +1717,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.a_zs_o = d->a_zs_o; a.a_zs_i = d->a_zs_i; a.w_zs_o = d->w_zs_o; a.w_zs_i = d->w_zs_i;
     a.o_zs_o = d->o_zs_o; a.o_zs_i = d->o_zs_i;
     a.bias = d->bias; a.bias_mode = d->bias_mode; a.temb = d->temb; a.ld_temb = d->ld_temb;
+    a.rs = d->a_scale; a.cs = d->w_scale; a.rs_zs = d->a_scale_zs; a.cs_zs = d->w_scale_zs;
     a.res0 = (const char*)d->res0; a.res0_dt = d->res0_dtype; a.ld_res0 = d->ld_res0;
     a.res1 = (const char*)d->res1; a.res1_dt = d->res1_dtype; a.ld_res1 = d->ld_res1;
     a.alpha = d->alpha; a.act = d->act;
@@ -1676,12 +1731,13 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.vec_ok = (d->n % 8 == 0) && (d->ldc % (d->act == MF_ACT_GEGLU4 ? 4 : 8) == 0) && mf_aligned16(d->out) && (d->o_zs_o % 8 == 0) &&
                (d->o_zs_i % 8 == 0) &&
                (!d->bias || d->bias_mode == 1 || mf_aligned16(d->bias)) &&
+               (!d->w_scale || (mf_aligned16(d->w_scale) && d->w_scale_zs % 4 == 0)) &&
                (!d->temb || (mf_aligned16(d->temb) && d->ld_temb % 4 == 0)) &&
                (!d->res0 || (mf_aligned16(d->res0) && d->ld_res0 % 8 == 0)) &&
                (!d->res1 || (mf_aligned16(d->res1) && d->ld_res1 % 8 == 0));
 
     int tile = d->tile;
-    if (tile <= 0 || tile > kNumTiles) tile = pick_tile(a.M, a.N, a.nz, d->splitk, a_f32 ? 6 : kNumTiles, split);
+    if (tile <= 0 || tile > kNumTiles) tile = pick_tile(a.M, a.N, a.nz, d->splitk, a_f32 ? 6 : kNumTiles, split || d->dtype == MF_FP8);
     if (a_f32) {
         // the converting path only exists for the 2-stage tiles 1..6; 7..12 are the same shapes with a deeper ring.
         // Resolve the EFFECTIVE tile before the grid is derived from it (a 192x128 grid on a 128x128 kernel would leave
@@ -1787,7 +1843,9 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     { static const bool off = getenv("MFHIP_NO_RES_PRE") != nullptr; a.dbg_no_res_pre = off; }     // A/B switch
     dim3 grid((unsigned)nblk, 1, (unsigned)(a.nz * a.splitk));
     hipStream_t s = (hipStream_t)stream;
-    if (split) {
+    if (d->dtype == MF_FP8) {
+        MF_CHECK_ARG(launch_tile_fp8(tile, a, grid, s), "mf_gemm_conv: tile %d is not instantiated for fp8", tile);
+    } else if (split) {
         const bool ok = d->dtype == MF_F16X3
                             ? (d->w_split ? launch_tile_split<MF_F16X3, true>(tile, a, grid, s) : launch_tile_split<MF_F16X3, false>(tile, a, grid, s))
                             : (d->w_split ? launch_tile_split<MF_BF16X3, true>(tile, a, grid, s) : launch_tile_split<MF_BF16X3, false>(tile, a, grid, s));

@@ -7,6 +7,7 @@
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = one MFMA A/B fragment
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t; // 8 fp16 = one MFMA A/B fragment (split precision)
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;       // 32 fp8 = one f8f6f4 MFMA A/B fragment
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
 typedef unsigned short bf16_raw;
@@ -86,5 +87,5 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // bytes per element in memory; the split compute codes keep fp32 operands
-static inline int mf_dtype_size(int dt) { return dt == MF_BF16 ? 2 : 4; }
+static inline int mf_dtype_size(int dt) { return dt == MF_BF16 ? 2 : (dt == MF_FP8 ? 1 : 4); }
 static inline bool mf_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -14,9 +14,10 @@ import torch
 
 from . import _build
 
-MF_F32, MF_BF16, MF_F16X3, MF_BF16X3 = 0, 1, 2, 3
+MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8 = 0, 1, 2, 3, 4
+FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MfhipError(RuntimeError):
@@ -41,6 +42,7 @@ class GemmDesc(C.Structure):
         ("o_zs_o", C.c_int64), ("o_zs_i", C.c_int64),
         ("bias", C.c_void_p), ("bias_mode", C.c_int32),
         ("temb", C.c_void_p), ("ld_temb", C.c_int64),
+        ("a_scale", C.c_void_p), ("w_scale", C.c_void_p), ("a_scale_zs", C.c_int64), ("w_scale_zs", C.c_int64),
         ("res0", C.c_void_p), ("res0_dtype", C.c_int32), ("ld_res0", C.c_int64),
         ("res1", C.c_void_p), ("res1_dtype", C.c_int32), ("ld_res1", C.c_int64),
         ("alpha", C.c_float), ("act", C.c_int32),
@@ -99,7 +101,7 @@ EXPORTS = [
     "mf_abi_version", "mf_last_error", "mf_sizeof_gemm_desc", "mf_sizeof_groupnorm_desc",
     "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape", "mf_gemm_tile_table_version",
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
-    "mf_attention_f16x3", "mf_split_halves",
+    "mf_attention_f16x3", "mf_split_halves", "mf_quantize_rows_fp8",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
     # image front-end (csrc/frontend.hip)
@@ -153,6 +155,8 @@ def dt_code(dtype: torch.dtype) -> int:
         return MF_F32
     if dtype == torch.bfloat16:
         return MF_BF16
+    if dtype == FP8:
+        return MF_FP8
     raise MfhipError(f"unsupported dtype {dtype}")
 
 
@@ -313,7 +317,7 @@ def _tuned_config(d: "GemmDesc", key: tuple):
         return (0, 0)
     lib = load()
     m, n, k = key[2], key[3], key[4]
-    es = 2 if key[0] == MF_BF16 else 4
+    es = 2 if key[0] == MF_BF16 else 1 if key[0] == MF_FP8 else 4
     nkt = (k * es + 127) // 128
     cands = []
     ntiles = lib.mf_gemm_num_tiles()
@@ -359,7 +363,8 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
               res1: Optional[torch.Tensor] = None, ld_res1: Optional[int] = None,
               alpha: float = 1.0, act: int = ACT_NONE,
               nz: int = 1, zdiv: int = 1, a_zs=(0, 0), w_zs=(0, 0), o_zs=(0, 0),
-              splitk: int = 0, tile: int = 0) -> torch.Tensor:
+              a_scale: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None, a_scale_zs: int = 0,
+              w_scale_zs: int = 0, splitk: int = 0, tile: int = 0) -> torch.Tensor:
     """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements.  `dtype`: a torch
     dtype (bf16 / fp32 compute) or an MF_* compute code (the split codes take fp32 a0 and, with w_split=1, a weight
     from ops.split_pack)."""
@@ -373,7 +378,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     d.batch, d.h_in, d.w_in, d.h_out, d.w_out = batch, h_in, w_in, h_out, w_out
     d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.upsample = kh, kw, stride, pad_t, pad_l, int(upsample)
     want_w = ({MF_F16X3: torch.float16, MF_BF16X3: torch.bfloat16}[code] if w_split else
-              torch.bfloat16 if code == MF_BF16 else torch.float32)
+              torch.bfloat16 if code == MF_BF16 else FP8 if code == MF_FP8 else torch.float32)
     if w.dtype != want_w:
         raise MfhipError(f"weight dtype {w.dtype} != {want_w} expected by compute code {code} (w_split={w_split})")
     d.w = _ptr(w)
@@ -389,6 +394,10 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
             raise MfhipError("bias / temb must be fp32")
     d.bias, d.bias_mode = _ptr(bias), bias_mode
     d.temb, d.ld_temb = _ptr(temb), ld_temb
+    for t in (a_scale, w_scale):
+        if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
+            raise MfhipError("a_scale / w_scale must be fp32 device tensors")
+    d.a_scale, d.w_scale, d.a_scale_zs, d.w_scale_zs = _ptr(a_scale), _ptr(w_scale), a_scale_zs, w_scale_zs
     d.res0, d.res0_dtype = _ptr(res0), (dt_code(res0.dtype) if res0 is not None else 0)
     d.ld_res0 = ld_res0 if ld_res0 is not None else n
     d.res1, d.res1_dtype = _ptr(res1), (dt_code(res1.dtype) if res1 is not None else 0)
@@ -480,6 +489,23 @@ def attention_bf16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torc
                                     C.c_int64(ldo), batch, heads, sq, skv, head_dim, C.c_float(scale), _stream()),
            "mf_attention_bf16")
     return out
+
+
+def quantize_rows_fp8(x: torch.Tensor, norm=None, eps: float = 1e-5):
+    """Per-row dynamic fp8 quantisation of [..., C] (optionally LayerNorm(x; gamma, beta) first): returns
+    (q fp8 [..., C], scale fp32 [rows]) with x ~ q * scale[row]."""
+    _req_cuda(x)
+    if not x.is_contiguous():
+        raise MfhipError("quantize_rows_fp8: contiguous input")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    q = torch.empty(x.shape, dtype=FP8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    g, b = norm if norm is not None else (None, None)
+    _check(load().mf_quantize_rows_fp8(C.c_void_p(x.data_ptr()), dt_code(x.dtype), C.c_void_p(q.data_ptr()), C.c_void_p(sc.data_ptr()),
+                                       C.c_int64(rows), c, C.c_void_p(_ptr(g)), C.c_void_p(_ptr(b)), C.c_float(eps), _stream()),
+           "mf_quantize_rows_fp8")
+    return q, sc
 
 
 def split_halves(x: torch.Tensor):

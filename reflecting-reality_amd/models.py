@@ -287,12 +287,12 @@ class HipModel:
         save_file({k: v.contiguous() for k, v in self.state_dict().items()}, os.path.join(path, self.weights_name))
 
     # -- helpers shared by the three models -------------------------------------------------------
-    def _conv(self, sd, name, prec=None, cin_pad=None) -> ConvWeight:
+    def _conv(self, sd, name, prec=None, cin_pad=None, fp8: bool = False) -> ConvWeight:
         if self.training:
             return self._conv_param(name, sd[name + ".weight"], sd.get(name + ".bias"), prec or self.prec, cin_pad)
         # to_v is consumed by ops.linear_t with the weight as the A operand: never pre-split
         return ConvWeight(sd[name + ".weight"], sd.get(name + ".bias"), prec or self.prec, self.device, cin_pad,
-                          raw=name.endswith(".to_v"))
+                          raw=name.endswith(".to_v"), fp8=fp8)
 
     def _conv_param(self, name, weight, bias, prec, cin_pad=None, n_pad: Optional[int] = None) -> ConvWeight:
         """A conv / linear weight allocated in the training arena ([N][kh][kw][cin_pad] fp32); n_pad zero-pads the rows
@@ -439,9 +439,14 @@ class _UNetCore(HipModel):
             self.P[p + "conv_shortcut"] = self._conv(sd, p + "conv_shortcut")
 
     def _prepare_transformer(self, sd, p):
+        # precision "fp8": every Linear of the transformer blocks whose input is a token row of the model width runs on fp8
+        # e4m3 operands (per-row activation scales, per-output-channel weight scales); the prompt's K / V projections (77
+        # tokens, computed once per prompt) and everything outside the transformer blocks stay bf16
+        f8 = self.prec.fp8_linear and not self.training
+        ok8 = lambda name: f8 and sd[name + ".weight"].shape[1] % 16 == 0
         self.P[p + "norm"] = self._norm(sd, p + "norm")
-        self.P[p + "proj_in"] = self._conv(sd, p + "proj_in")
-        self.P[p + "proj_out"] = self._conv(sd, p + "proj_out")
+        self.P[p + "proj_in"] = self._conv(sd, p + "proj_in", fp8=ok8(p + "proj_in") and sd[p + "proj_in.weight"].dim() == 2)
+        self.P[p + "proj_out"] = self._conv(sd, p + "proj_out", fp8=ok8(p + "proj_out") and sd[p + "proj_out.weight"].dim() == 2)
         i = 0
         while f"{p}transformer_blocks.{i}.norm1.weight" in sd:
             b = f"{p}transformer_blocks.{i}."
@@ -449,16 +454,17 @@ class _UNetCore(HipModel):
                 self.P[b + n] = self._norm(sd, b + n)
             for a in ("attn1", "attn2"):
                 for l in ("to_q", "to_k", "to_v", "to_out.0"):
-                    self.P[b + a + "." + l] = self._conv(sd, b + a + "." + l)
+                    nm = b + a + "." + l
+                    self.P[nm] = self._conv(sd, nm, fp8=ok8(nm) and not (a == "attn2" and l in ("to_k", "to_v")))
             if self.training:      # no fused / interleaved copies: the arena holds each parameter once
                 self.P[b + "ff.net.0.proj"] = self._conv(sd, b + "ff.net.0.proj")
             else:
                 # self-attention: q and k read the same tokens -> one GEMM with N = 2C
                 self.P[b + "attn1.to_qk"] = ConvWeight(torch.cat([sd[b + "attn1.to_q.weight"], sd[b + "attn1.to_k.weight"]], 0),
-                                                       None, self.prec, self.device)
+                                                       None, self.prec, self.device, fp8=ok8(b + "attn1.to_q"))
                 self.P[b + "ff.net.0.proj"] = ops.geglu_weight(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"],
-                                                               self.prec, self.device)
-            self.P[b + "ff.net.2"] = self._conv(sd, b + "ff.net.2")
+                                                               self.prec, self.device, fp8=ok8(b + "ff.net.0.proj"))
+            self.P[b + "ff.net.2"] = self._conv(sd, b + "ff.net.2", fp8=ok8(b + "ff.net.2"))
             i += 1
         self.tdepth[p] = i
 
@@ -558,7 +564,8 @@ class _UNetCore(HipModel):
         Self-attention projects q and k with one GEMM; cross-attention K / V^T depend only on the prompt
         embeddings (attention_processor.py:1253-1254) and are cached across denoise steps."""
         P = self.P
-        c = x.shape[-1]
+        xt = x[0] if isinstance(x, tuple) else x          # fp8: x is the (quantised rows, row scales) pair of ops.layernorm
+        c = xt.shape[-1]
         d = c // heads
         if self.training:
             # training layout: separate q / k / v projections and the unfused, differentiated attention; the prompt's
@@ -570,9 +577,9 @@ class _UNetCore(HipModel):
             o = ops.attention_train(q, k, v, heads, 1.0 / (d ** 0.5), self.prec)
             return ops.linear(o, P[b + "to_out.0"], res0=residual)
         if ctx is None:
-            skv = x.shape[1]
+            skv = xt.shape[1]
             # V^T on the auxiliary stream while q | k is projected on this one
-            vt, join = self._on_aux(lambda: ops.linear_t(x, P[b + "to_v"], (skv + 7) // 8 * 8, out=self._vt_buffer(x, c, skv)))
+            vt, join = self._on_aux(lambda: ops.linear_t(x, P[b + "to_v"], (skv + 7) // 8 * 8, out=self._vt_buffer(xt, c, skv)))
             qk = ops.linear(x, P[b + "to_qk"])
             q, k = qk[..., :c], qk[..., c:]
             if join is not None:
@@ -623,19 +630,25 @@ class _UNetCore(HipModel):
         bsz, hh, ww, c = x.shape
         g = self.config["norm_num_groups"]
         h = ops.groupnorm(x, P[p + "norm"], groups=g, eps=1e-6, silu=False, out_dtype=self.prec.act)
-        h = ops.conv2d(h, P[p + "proj_in"], padding=0).view(bsz, hh * ww, c)
+        if P[p + "proj_in"].fp8:           # use_linear_projection (SDXL): a Linear over tokens, on the fp8 path
+            h = ops.linear(h.view(bsz, hh * ww, c), P[p + "proj_in"])
+        else:
+            h = ops.conv2d(h, P[p + "proj_in"], padding=0).view(bsz, hh * ww, c)
         for i in range(self.tdepth[p]):
             b = f"{p}transformer_blocks.{i}."
-            n = ops.layernorm(h, P[b + "norm1"], 1e-5, self.prec.act)
+            n = ops.layernorm(h, P[b + "norm1"], 1e-5, self.prec.act, fp8=P[b + "attn1.to_out.0"].fp8)
             h = self._attention(b + "attn1.", n, None, heads, h)
-            n = ops.layernorm(h, P[b + "norm2"], 1e-5, self.prec.act)
+            n = ops.layernorm(h, P[b + "norm2"], 1e-5, self.prec.act, fp8=P[b + "attn2.to_q"].fp8)
             h = self._attention(b + "attn2.", n, ehs, heads, h)
-            n = ops.layernorm(h, P[b + "norm3"], 1e-5, self.prec.act)
+            n = ops.layernorm(h, P[b + "norm3"], 1e-5, self.prec.act, fp8=P[b + "ff.net.2"].fp8)
             if self.training:      # GEGLU as its own (differentiated) launch on the plain, un-interleaved weight
                 gg = ops.geglu(ops.linear(n, P[b + "ff.net.0.proj"]), self.prec.act)
             else:
                 gg = ops.linear_geglu(n, P[b + "ff.net.0.proj"])
             h = ops.linear(gg, P[b + "ff.net.2"], res0=h)
+        if P[p + "proj_out"].fp8:
+            return ops.linear(h, P[p + "proj_out"], res0=x.view(bsz, hh * ww, c),
+                              res1=inj.view(bsz, hh * ww, c) if inj is not None else None).view(bsz, hh, ww, c)
         return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj)
 
     # ---- the reference's operator plug-in point (attention_processor.py:216; brushnet.py:558-590;

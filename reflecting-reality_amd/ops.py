@@ -24,10 +24,11 @@ TAPE: Optional["autograd.Tape"] = None
 
 @dataclass(frozen=True)
 class Precision:
-    name: str                     # "bf16" | "fp32" | "f16x3" | "bf16x3"
+    name: str                     # "bf16" | "fp32" | "f16x3" | "bf16x3" | "fp8"
     compute: torch.dtype          # dtype of the GEMM operands in memory
     act: torch.dtype              # activation storage dtype
     code: int = -1                # mf_gemm_desc.dtype (MF_BF16 / MF_F32 / MF_F16X3 / MF_BF16X3)
+    fp8_linear: bool = False      # "fp8": the transformer blocks' Linear layers run on fp8 e4m3 operands (the rest bf16)
 
     @staticmethod
     def get(name: Union[str, "Precision", torch.dtype]) -> "Precision":
@@ -41,12 +42,14 @@ class Precision:
             return Precision("f16x3", torch.float32, torch.float32, hip.MF_F16X3)
         if name == "bf16x3":
             return Precision("bf16x3", torch.float32, torch.float32, hip.MF_BF16X3)
+        if name == "fp8":
+            return Precision("fp8", torch.bfloat16, torch.bfloat16, hip.MF_BF16, True)
         if name == torch.float16:
             # the reference's scripts default to fp16 (examples/brushnet/test_brushnet.py:124); the HIP path has no fp16
             # storage mode and will not silently substitute another one
             raise ValueError("torch_dtype=torch.float16 is not built: use torch.bfloat16 (the fast mode), torch.float32 "
                              "or precision='f16x3' (fp32 storage, fp16 matrix pipe)")
-        raise ValueError(f"unsupported precision {name!r} (use 'bf16', 'fp32', 'f16x3' or 'bf16x3')")
+        raise ValueError(f"unsupported precision {name!r} (use 'bf16', 'fp8', 'fp32', 'f16x3' or 'bf16x3')")
 
     @property
     def vec(self) -> int:         # elements per 16-byte vector: channel counts must be multiples of this
@@ -65,7 +68,8 @@ class ConvWeight:
     """Conv2d / Linear parameters re-laid-out once for the implicit-GEMM kernel: [N][kh][kw][Cin_pad]."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], prec: Precision, device,
-                 cin_pad: Optional[int] = None, raw: bool = False):
+                 cin_pad: Optional[int] = None, raw: bool = False, fp8: bool = False):
+        self.fp8, self.w_scale = False, None
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
         n, cin, kh, kw = weight.shape
@@ -75,7 +79,15 @@ class ConvWeight:
             w = torch.nn.functional.pad(w, (0, cp - cin))
         w = w.reshape(n, kh * kw * cp)
         self.w_split, self.ldw = 0, kh * kw * cp
-        if prec.split and not raw:
+        if fp8:
+            # per-output-channel symmetric quantisation to OCP e4m3: w ~ q * w_scale[n], |q| <= 448
+            if (kh * kw * cp) % 16 != 0:
+                raise hip.MfhipError("fp8 weights need K % 16 == 0")
+            amax = w.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+            self.w_scale = (amax / 448.0).reshape(n).contiguous()
+            self.w = (w / (amax / 448.0)).to(hip.FP8).contiguous()
+            self.fp8 = True
+        elif prec.split and not raw:
             # split ahead of time: per block of 32 k, [32 high halves | 32 low halves] (the same 128 bytes as 32
             # floats); rows zero-padded to whole blocks.  `raw` keeps fp32 (the weight is the A operand: linear_t)
             self.w, self.ldw = split_pack(w, prec.code)
@@ -94,6 +106,7 @@ class ConvWeight:
         """A weight whose storage is a view of a model's flat fp32 arena ([N][kh*kw*cin_pad], never pre-split: the
         optimizer updates it in place every step)."""
         self = cls.__new__(cls)
+        self.fp8, self.w_scale = False, None
         self.w, self.bias = p_w.data, (p_bias.data if p_bias is not None else None)
         self.w_split, self.ldw = 0, kh * kw * cin_pad
         self.n, self.cin, self.cin_pad, self.kh, self.kw = n, cin, cin_pad, kh, kw
@@ -154,7 +167,10 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
            res1: Optional[torch.Tensor] = None, alpha: float = 1.0, act: int = hip.ACT_NONE,
            out_dtype: Optional[torch.dtype] = None, splitk: int = 0, tile: int = 0,
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = x @ W^T + b over the last dim of x ([..., K] contiguous)."""
+    """y = x @ W^T + b over the last dim of x ([..., K] contiguous).  An fp8 weight takes x as an (fp8, row scales) pair
+    from hip.quantize_rows_fp8 / ops.layernorm(..., fp8=True), or quantises a bf16 / fp32 x itself."""
+    if lw.fp8:
+        return _linear_fp8(x, lw, res0, res1, alpha, act, out_dtype, out, tile, ldc=None)
     k = x.shape[-1]
     if k != lw.cin_pad:
         raise hip.MfhipError(f"linear: K={k} != weight K={lw.cin_pad}")
@@ -169,20 +185,39 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
     return out
 
 
-def geglu_weight(weight: torch.Tensor, bias: torch.Tensor, prec: Precision, device) -> ConvWeight:
+def _linear_fp8(x, lw: ConvWeight, res0, res1, alpha, act, out_dtype, out, tile, ldc):
+    if TAPE is not None:
+        raise hip.MfhipError("training: fp8 layers are inference only")
+    xq, xs = x if isinstance(x, tuple) else hip.quantize_rows_fp8(x)
+    k = xq.shape[-1]
+    if k != lw.cin_pad:
+        raise hip.MfhipError(f"linear: K={k} != weight K={lw.cin_pad}")
+    m = xq.numel() // k
+    n_out = lw.n // 2 if act == hip.ACT_GEGLU4 else lw.n
+    if out is None:
+        out = torch.empty(*xq.shape[:-1], n_out, dtype=out_dtype or lw.prec.act, device=xq.device)
+    hip.gemm_conv(xq, lw.w, out, dtype=hip.MF_FP8, c0=k, lda0=k, batch=m, h_in=1, w_in=1, h_out=1, w_out=1, n=lw.n, ldc=ldc or n_out,
+                  bias=lw.bias, res0=res0, res1=res1, alpha=alpha, act=act, a_scale=xs, w_scale=lw.w_scale,
+                  splitk=1 if act == hip.ACT_GEGLU4 else 0, tile=tile)
+    return out
+
+
+def geglu_weight(weight: torch.Tensor, bias: torch.Tensor, prec: Precision, device, fp8: bool = False) -> ConvWeight:
     """GEGLU.proj ([2*inner, dim]: value rows then gate rows, activations.py:92,100-103) with rows interleaved
     [4 value | 4 gate] so that mf_gemm_conv's 8-channel epilogue lanes hold matching value/gate pairs."""
     inner = weight.shape[0] // 2
     assert inner % 4 == 0
     idx = torch.arange(inner).view(-1, 4)
     order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
-    return ConvWeight(weight[order], bias[order], prec, device)
+    return ConvWeight(weight[order], bias[order], prec, device, fp8=fp8)
 
 
 def linear_geglu(x: torch.Tensor, lw: ConvWeight, tile: int = 0) -> torch.Tensor:
     """hidden * gelu(gate) of FeedForward's GEGLU in the GEMM epilogue: [..., K] -> [..., inner]."""
     if TAPE is not None:
         raise hip.MfhipError("training: use ops.linear + ops.geglu (the fused epilogue keeps no pre-activation)")
+    if lw.fp8:
+        return _linear_fp8(x, lw, None, None, 1.0, hip.ACT_GEGLU4, None, None, tile, ldc=lw.n // 2)
     k = x.shape[-1]
     m = x.numel() // k
     inner = lw.n // 2
@@ -199,6 +234,15 @@ def linear_t(x: torch.Tensor, lw: ConvWeight, ld_out: int, out: Optional[torch.T
     with keys contiguous and coalesced stores (attention wants V^T; no transpose kernel exists).
     x: [B, S, K]; returns [B, n, ld_out] with columns [S, ld_out) left untouched (callers zero them once).
     """
+    if lw.fp8:           # weight rows (output channels) are the A operand: a_scale = the weight's scales, w_scale = the tokens'
+        xq, xs = x if isinstance(x, tuple) else hip.quantize_rows_fp8(x)
+        b, s, k = xq.shape
+        if out is None:
+            out = torch.zeros(b, lw.n, ld_out, dtype=lw.prec.act, device=xq.device)
+        hip.gemm_conv(lw.w, xq, out, dtype=hip.MF_FP8, c0=k, lda0=k, batch=lw.n, h_in=1, w_in=1, h_out=1, w_out=1, ldw=k, n=s,
+                      ldc=ld_out, bias=lw.bias, bias_mode=1, nz=b, zdiv=1, a_zs=(0, 0), w_zs=(s * k, 0), o_zs=(lw.n * ld_out, 0),
+                      a_scale=lw.w_scale, w_scale=xs, w_scale_zs=s, splitk=1)
+        return out
     b, s, k = x.shape
     if TAPE is not None:
         raise hip.MfhipError("training: use ops.linear + ops.transpose_tokens")
@@ -226,9 +270,12 @@ def groupnorm(x0: torch.Tensor, norm, *, groups: int, eps: float, silu: bool, ou
     return out
 
 
-def layernorm(x: torch.Tensor, norm, eps: float, out_dtype: torch.dtype) -> torch.Tensor:
+def layernorm(x: torch.Tensor, norm, eps: float, out_dtype: torch.dtype, fp8: bool = False):
+    """fp8=True: LayerNorm and per-row fp8 quantisation in one pass; returns the (fp8, row scales) pair an fp8 linear takes."""
     g, b = norm
     pg = g if isinstance(g, autograd.Param) else None
+    if fp8 and TAPE is None and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048:
+        return hip.quantize_rows_fp8(x, (g.data if pg else g, b.data if pg else b), eps)
     out = hip.layernorm(x, g.data if pg else g, b.data if pg else b, eps, out_dtype)
     if TAPE is not None:
         if pg is None:
