@@ -182,7 +182,7 @@ int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ldq, const vo
 /* x (n fp32, n % 4 == 0) -> fp16 planes hi = x rounded toward zero, lo = (x - hi) rounded toward zero */
 int mf_split_halves(const float* x, void* hi, void* lo, int64_t n, void* stream);
 
-/* Per-row dynamic fp8 (e4m3) quantisation of [rows][c] (c % 8 == 0, c <= 2048), optionally fused behind a LayerNorm
+/* Per-row dynamic fp8 (e4m3) quantisation of [rows][c] (c % 8 == 0, c <= 8192), optionally fused behind a LayerNorm
  * (gamma / beta non-NULL: y = LN(x) first, attention.py:203,233,261): out_q[r][j] = fp8(y[r][j] / scale[r]),
  * scale[r] = max_j |y[r][j]| / 448.  The pair (out_q, scale) is an fp8 GEMM's A operand + a_scale. */
 int mf_quantize_rows_fp8(const void* x, int32_t in_dtype, void* out_q, float* scale, int64_t rows, int32_t c,

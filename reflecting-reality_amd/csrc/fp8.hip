@@ -21,19 +21,19 @@ __device__ __forceinline__ void load8f(const char* p, int dt, int64_t idx, float
     }
 }
 
-template <bool LN>
+// LPR lanes per row (32: C <= 2048, two rows per wave; 64: C <= 8192, GEGLU outputs of the 1280-wide SDXL blocks)
+template <bool LN, int LPR, int MAXV>
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const char* x, int in_dt, unsigned char* out, float* scale,
                                                              const float* gamma, const float* beta, int64_t rows, int C, float eps) {
-    const int l32 = threadIdx.x & 31;
-    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int l32 = threadIdx.x & (LPR - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
     const bool live = row < rows;                       // keep every lane alive for the shuffles
-    constexpr int MAXV = 8;
     float v[MAXV][8];
     const int c8n = C >> 3;
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
-        const int c8 = l32 + 32 * j;
+        const int c8 = l32 + LPR * j;
         if (live && c8 < c8n) {
             load8f(x, in_dt, row * C + c8 * 8, v[j]);
 #pragma unroll
@@ -45,21 +45,21 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const char* x, int 
     }
     if constexpr (LN) {
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 32);
+        for (int off = LPR / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off, LPR);
         const float mean = s / (float)C;
         float q = 0.0f;
 #pragma unroll
         for (int j = 0; j < MAXV; ++j)
-            if (l32 + 32 * j < c8n) {
+            if (l32 + LPR * j < c8n) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; q += d * d; }
             }
 #pragma unroll
-        for (int off = 16; off >= 1; off >>= 1) q += __shfl_xor(q, off, 32);
+        for (int off = LPR / 2; off >= 1; off >>= 1) q += __shfl_xor(q, off, LPR);
         const float rstd = 1.0f / sqrtf(q / (float)C + eps);
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) {
-            const int c8 = l32 + 32 * j;
+            const int c8 = l32 + LPR * j;
             if (c8 < c8n) {
                 float g[8], bb[8];
                 load8f(reinterpret_cast<const char*>(gamma), MF_F32, c8 * 8, g);
@@ -75,14 +75,14 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const char* x, int 
 #pragma unroll
         for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[j][e]));
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 32));
+    for (int off = LPR / 2; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, LPR));
     if (!live) return;
     const float sc = amax > 0.0f ? amax * (1.0f / 448.0f) : 1.0f;
     const float inv = 1.0f / sc;
     if (l32 == 0) scale[row] = sc;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
-        const int c8 = l32 + 32 * j;
+        const int c8 = l32 + LPR * j;
         if (c8 < c8n) {
             float y[8];
 #pragma unroll
@@ -101,20 +101,25 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const char* x, int 
 
 extern "C" int mf_quantize_rows_fp8(const void* x, int32_t in_dtype, void* out_q, float* scale, int64_t rows, int32_t c,
                                     const float* gamma, const float* beta, float eps, void* stream) {
-    MF_CHECK_ARG(x && out_q && scale && rows >= 1 && c >= 8 && c % 8 == 0 && c <= 2048, "mf_quantize_rows_fp8: c must be a multiple of 8, <= 2048");
+    MF_CHECK_ARG(x && out_q && scale && rows >= 1 && c >= 8 && c % 8 == 0 && c <= 8192, "mf_quantize_rows_fp8: c must be a multiple of 8, <= 8192");
     MF_CHECK_ARG(in_dtype == MF_F32 || in_dtype == MF_BF16, "mf_quantize_rows_fp8: input must be fp32 or bf16");
     MF_CHECK_ARG((gamma != nullptr) == (beta != nullptr), "mf_quantize_rows_fp8: gamma and beta go together");
     if (!mf_aligned16(x) || (((uintptr_t)out_q) & 7)) {
         mf_set_error("mf_quantize_rows_fp8: x must be 16-byte and out_q 8-byte aligned");
         return MF_EALIGN;
     }
-    const dim3 grid((unsigned)((rows + 7) / 8));
-    if (gamma)
-        hipLaunchKernelGGL(quant_rows_fp8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, in_dtype,
-                           (unsigned char*)out_q, scale, gamma, beta, rows, c, eps);
-    else
-        hipLaunchKernelGGL(quant_rows_fp8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, in_dtype,
-                           (unsigned char*)out_q, scale, gamma, beta, rows, c, eps);
+    hipStream_t s = (hipStream_t)stream;
+    const char* xp = (const char*)x;
+    unsigned char* qp = (unsigned char*)out_q;
+    if (c <= 2048) {
+        const dim3 grid((unsigned)((rows + 7) / 8));
+        if (gamma) hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 32, 8>), grid, dim3(256), 0, s, xp, in_dtype, qp, scale, gamma, beta, rows, c, eps);
+        else hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32, 8>), grid, dim3(256), 0, s, xp, in_dtype, qp, scale, gamma, beta, rows, c, eps);
+    } else {
+        const dim3 grid((unsigned)((rows + 3) / 4));
+        if (gamma) hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 64, 16>), grid, dim3(256), 0, s, xp, in_dtype, qp, scale, gamma, beta, rows, c, eps);
+        else hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 64, 16>), grid, dim3(256), 0, s, xp, in_dtype, qp, scale, gamma, beta, rows, c, eps);
+    }
     MF_CHECK_LAUNCH("mf_quantize_rows_fp8");
     return MF_OK;
 }

@@ -274,7 +274,7 @@ def layernorm(x: torch.Tensor, norm, eps: float, out_dtype: torch.dtype, fp8: bo
     """fp8=True: LayerNorm and per-row fp8 quantisation in one pass; returns the (fp8, row scales) pair an fp8 linear takes."""
     g, b = norm
     pg = g if isinstance(g, autograd.Param) else None
-    if fp8 and TAPE is None and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048:
+    if fp8 and TAPE is None and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192:
         return hip.quantize_rows_fp8(x, (g.data if pg else g, b.data if pg else b), eps)
     out = hip.layernorm(x, g.data if pg else g, b.data if pg else b, eps, out_dtype)
     if TAPE is not None:

@@ -17,7 +17,7 @@ def deq(q, s):
     return q.float().cpu().double() * s.cpu().double().view(*q.shape[:-1], 1)
 
 
-@pytest.mark.parametrize("rows,c", [(300, 320), (64, 1280), (5, 2048), (4096, 640), (9, 8)])
+@pytest.mark.parametrize("rows,c", [(300, 320), (64, 1280), (5, 2048), (4096, 640), (9, 8), (130, 5120), (7, 8192)])
 @pytest.mark.parametrize("ln", [False, True])
 def test_quantize_rows_fp8(rows, c, ln):
     g = torch.Generator().manual_seed(61)
@@ -59,8 +59,9 @@ def test_fp8_linear_matches_its_quantised_operands(m, k, n):
         y = ops.linear((xq, xs), lw, out_dtype=torch.float32, tile=tile)
         e = float((y.double().cpu() - ref).abs().max()) / scale
         assert e < 2e-4, (tile, e)
-    with pytest.raises(hip.MfhipError, match="not instantiated"):
-        ops.linear((xq, xs), lw, out_dtype=torch.float32, tile=20)
+    for bad_tile in (20, 4):          # a dx-reuse tile (3x3 convs only) and a tile fp8 is not instantiated for: refused
+        with pytest.raises(hip.MfhipError, match="does not apply|not instantiated"):
+            ops.linear((xq, xs), lw, out_dtype=torch.float32, tile=bad_tile)
     r0 = torch.randn(m, n, generator=g)
     y = ops.linear(x.to(DEV), lw, res0=r0.to(DEV), alpha=0.5, out_dtype=torch.float32)          # quantises x itself
     assert float((y.double().cpu() - (0.5 * ref + r0.double())).abs().max()) / scale < 2e-4
