@@ -244,6 +244,7 @@ LAST_PROFILE = []
 # for grids that cannot fill 256 CUs) the first time a GEMM shape is seen and remembers the winner.  Winners
 # are persisted in tune_cache.json next to this file so later processes (and graph capture) start tuned.
 AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
+RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
 # The package ships a cache tuned on MI355X (read-only); new winners go to a per-user file (MFHIP_TUNE_CACHE, default
 # ~/.cache/mfhip/tune_cache.json) that is overlaid on it.  Both carry the library's tile-table version: when tiles are
 # renumbered (mf_gemm_tile_table_version changes) stale indices are dropped instead of being trusted.
@@ -311,7 +312,7 @@ def _tuned_config(d: "GemmDesc", key: tuple):
     cache = _tune_load()
     ks = _tune_key(key)
     hit = cache.get(ks)
-    if hit is not None:
+    if hit is not None and not (RETUNE and ks not in _tune_new):
         return hit
     if torch.cuda.is_current_stream_capturing():
         return (0, 0)

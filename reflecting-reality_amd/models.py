@@ -88,6 +88,9 @@ class HipModel:
     config_name = "config.json"
     weights_name = "diffusion_pytorch_model.safetensors"
     _class_name = "HipModel"
+    training = False            # class defaults: objects assembled piecewise (tests) are inference models
+    flat_w = flat_g = None
+    _weights_gen = 0
 
     def __init__(self, config: Dict[str, Any], precision: Union[str, Precision, torch.dtype] = "bf16",
                  device: Union[str, torch.device] = "cuda"):

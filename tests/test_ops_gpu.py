@@ -43,12 +43,12 @@ SPLIT_TILES = (0, 1, 2, 3, 6, 7, 14)          # tiles instantiated for the split
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
-@pytest.mark.parametrize("tile", list(range(16)))
+@pytest.mark.parametrize("tile", list(range(16)) + [25, 26, 29, 30])
 def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     prec = ops.Precision.get(prec_name)
-    if prec.split and tile not in SPLIT_TILES:
+    if (prec.split and tile not in SPLIT_TILES) or (tile >= 25 and prec_name != "bf16"):
         x = torch.zeros(1, 8, 8, 32, device=DEV)
-        with pytest.raises(hip.MfhipError, match="not instantiated"):     # refused, never rerouted
+        with pytest.raises(hip.MfhipError, match="not instantiated|does not apply"):     # refused, never rerouted
             ops.conv2d(x, ops.ConvWeight(torch.zeros(8, 32, 3, 3), None, prec, DEV), tile=tile)
         return
     g = torch.Generator().manual_seed(1)
@@ -63,7 +63,7 @@ def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     check(f"conv3x3[{prec_name},tile{tile}]", nchw(y), ref, atol, rtol)
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28])
 @pytest.mark.parametrize("case", ["plain", "tailN", "cat", "splitk", "epilogue", "big"])
 def test_conv3x3_halo_tiles(tile, case):
     """conv3x3_halo_kernel (input patch resident in LDS, weights streamed per tap) and the 8-wave ping-pong
@@ -93,7 +93,7 @@ def test_conv3x3_halo_tiles(tile, case):
     y = ops.conv2d(nhwc(x, prec.act), cw, x1=nhwc(x1, prec.act) if c1 else None, tile=tile,
                    splitk=3 if case == "splitk" else 1, **kw)
     check(f"conv3x3_halo[tile{tile},{case}]", nchw(y), ref, 2e-2, 1e-2)
-    if tile >= 20 and case in ("plain", "epilogue"):          # dx-tap reuse also runs in the fp32 parity mode, any image size
+    if 20 <= tile <= 24 and case in ("plain", "epilogue"):          # dx-tap reuse also runs in the fp32 parity mode, any image size
         p32 = ops.Precision.get("fp32")
         x32 = torch.randn(3, 64, 7, 16, generator=g)              # M = 336: a ragged last tile, image rows of 16 pixels
         w32 = torch.randn(40, 64, 3, 3, generator=g) * 0.05
