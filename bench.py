@@ -367,12 +367,12 @@ def main():
             a_px = m * stride * stride / (4.0 if ups else 1.0)
             alg_bytes += nz * 2.0 * (a_px * k / (kh * kh) + n * k + m * n)
         traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_family.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_gemm_family.json")
         if os.path.exists(pmc) and a.batch == 4 and a.size == 512 and a.precision == "bf16" and not xl:
             with open(pmc) as f:
                 pj = json.load(f)
             traffic = pj["traffic_bytes_per_launch"]          # separate rocprofv3 --pmc passes (tools/pmc_step.sh)
-            traffic_src = "profiles/r01_pmc_gemm_family.json: " + pj["method"]
+            traffic_src = "profiles/r02_pmc_gemm_family.json: " + pj["method"]
         roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel (all tile instantiations)",
                     "achieved": round(flops / secs / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(flops / secs / 1e12 / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
