@@ -31,6 +31,7 @@ struct AttnArgs {
     char* out; int64_t ldo;
     int heads, sq, skv, batch;
     float c;   // softmax scale * log2(e)
+    int no_xcd_order;   // A/B switch (MFHIP_ATTN_NOXCD=1): keep the hardware's round-robin block order
 };
 
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -68,8 +69,18 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware order: hardware deals consecutive workgroups round-robin over the 8 XCDs; give each XCD a contiguous run of
+    // logical blocks so that the query blocks of one (batch, head) — which stream the same K / V^T — share one XCD's L2
+    // (the plain (x, head, batch) grid spread every head over all 8 L2s: 340 MB fetched for 84 MB of operands, PMC round 2)
+    int bid = blockIdx.x;
+    if (!p.no_xcd_order) {
+        const int nblk = gridDim.x, q = nblk >> 3, rr = nblk & 7, x = bid & 7, j = bid >> 3;
+        bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + j;
+    }
+    const int qblocks = (p.sq + 127) >> 7;
+    const int bx = bid % qblocks, bh = bid / qblocks;
+    const int b = bh / p.heads, head = bh - b * p.heads;
+    const int q0 = bx * 128 + wave * 32;
     const int qi = q0 + r;
 
     // zero the whole staging area once: pad columns / rows must never hold NaN bit patterns
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
 
 template <int HD, bool SP = false>
 void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
-    dim3 grid((a.sq + 127) / 128, a.heads, batch);
+    dim3 grid((unsigned)(((a.sq + 127) / 128) * a.heads * batch));
     hipLaunchKernelGGL((attn_fwd_kernel<HD, true, SP>), grid, dim3(256), 0, s, a);
 }
 
@@ -341,6 +352,7 @@ extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int6
     a.q = (const char*)q; a.ldq = ldq; a.k = (const char*)k; a.ldk = ldk; a.vt = (const char*)vt; a.ldvt = ldvt;
     a.out = (char*)out; a.ldo = ldo; a.heads = heads; a.sq = sq; a.skv = skv; a.batch = batch;
     a.c = scale * 1.44269504088896340736f;
+    { static const bool off = getenv("MFHIP_ATTN_NOXCD") != nullptr; a.no_xcd_order = off; }
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
         case 8: launch_attn<8>(a, batch, s); break;

@@ -1626,6 +1626,14 @@ bool launch_tile_split(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
             case 22: launch_one<DT, 64, 128, 2, 2, false, 2, true, true>(a, grid, s); return true;
             default: break;
         }
+    } else if constexpr (DT == MF_F16X3) {
+        // raw fp32 W (training: the optimizer rewrites the weights every step; dgrad weights): the big-conv tiles too
+        switch (tile) {
+            case 14: launch_one<DT, 128, 160, 4, 1, false, 2, false, false>(a, grid, s); return true;
+            case 20: launch_one<DT, 128, 160, 4, 1, false, 2, true, false>(a, grid, s); return true;
+            case 21: launch_one<DT, 128, 128, 2, 2, false, 2, true, false>(a, grid, s); return true;
+            default: break;
+        }
     }
     return false;
 }

@@ -328,11 +328,15 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
                       splitk=1)
         return hip.softmax_rows(scores, skv, torch.float32)
 
-    p = probs()
     vt = transpose_tokens(v, ld)
-    out = torch.empty(b, sq, c, dtype=torch.float32, device=q.device)
-    hip.gemm_conv(p, vt, out, dtype=prec.code, c0=ld, lda0=ld, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1, ldw=ld, n=d, ldc=c,
-                  nz=b * heads, zdiv=heads, a_zs=(heads * sq * ld, sq * ld), w_zs=(c * ld, d * ld), o_zs=(sq * c, d), splitk=1)
+    if prec.code == hip.MF_F16X3 and d in FLASH_SPLIT_HEAD_DIMS:
+        # forward on the flash kernel (split precision): P is not materialised here at all; backward recomputes it once
+        out = attention(q, k, vt, heads, skv, scale, prec, c=c)
+    else:
+        p = probs()
+        out = torch.empty(b, sq, c, dtype=torch.float32, device=q.device)
+        hip.gemm_conv(p, vt, out, dtype=prec.code, c0=ld, lda0=ld, batch=sq, h_in=1, w_in=1, h_out=1, w_out=1, ldw=ld, n=d, ldc=c,
+                      nz=b * heads, zdiv=heads, a_zs=(heads * sq * ld, sq * ld), w_zs=(c * ld, d * ld), o_zs=(sq * c, d), splitk=1)
     if tape is not None:
         autograd.record_attention(tape, q, k, v, out, heads, skv, scale, probs)
     return out
