@@ -120,7 +120,13 @@ class GradBuckets:
         st["sent"][b] = True
         lo, hi = b * self.bucket_floats, min((b + 1) * self.bucket_floats, p["n"])
         buf = p["model"].flat_g[lo:hi]
-        if buf.is_cuda:
+        if buf.is_cuda and dist.get_backend() == "gloo":
+            # test path (ranks sharing one GPU, no RCCL): stage the bucket through the host
+            torch.cuda.current_stream(buf.device).synchronize()
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+        elif buf.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=buf.device)
             ev = torch.cuda.Event()

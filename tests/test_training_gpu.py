@@ -362,3 +362,87 @@ def test_adamw_and_clip_against_torch():
         assert abs(float(norm) - float(tn)) < 1e-5 * float(tn)
         hip.adamw(wd, gd * 1024.0, m, v, lr=1e-3, step=step, grad_scale=coef)
         assert float((wd.cpu() - pt.detach()).abs().max()) < 2e-6
+
+
+DDP_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import torch
+from oracle import mirrorfusion_ref as R
+from reflecting_reality_amd import DDPMScheduler, models as M, synth, distributed as D
+from reflecting_reality_amd.training import AdamW, MirrorFusionModel, train_step
+from util import keys
+rank, world, _ = D.init_process_group("gloo")
+DEV = "cuda"
+SD = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+def model():
+    unet = M.UNet2DConditionModel(dict(R.TINY_UNET), precision="fp32", device=DEV)
+    unet.load_state_dict(synth.state_dict_for(keys("tiny")["unet"], 0))
+    bn = M.BrushNetModel(dict(R.brushnet_config(R.TINY_UNET, 5)), precision="fp32", device=DEV)
+    bn.load_state_dict(synth.state_dict_for(keys("tiny_train")["brushnet"], 21))
+    return MirrorFusionModel(unet, bn).prepare_training()
+g = torch.Generator().manual_seed(77)
+full = [torch.randn(6, 4, 8, 8, generator=g) * 0.8, torch.randn(6, 4, 8, 8, generator=g), torch.tensor([17, 480, 965, 702, 3, 250]),
+        torch.randn(6, 77, 32, generator=g), torch.randn(6, 5, 8, 8, generator=g)]
+ns = DDPMScheduler(**SD)
+m = model()
+opt = AdamW(m.get_trainable_modules())
+sync = D.GradBuckets(m.get_trainable_modules(), bucket_floats=20000)      # ~25 buckets on the tiny BrushNet
+sl = slice(3 * rank, 3 * rank + 3)
+lat, noi, ts, ehs, cond = (t[sl] for t in full)
+losses = []
+for step in range(2):
+    loss, norm = train_step(m, ns, opt, lat.to(DEV), noi.to(DEV), ts, ehs.to(DEV), cond.to(DEV), grad_sync=sync)
+    losses.append(D.gather_mean(loss))
+sd = m.brushnet.state_dict()
+out = dict(rank=rank, losses=losses, norm=float(norm))
+if rank == 0:
+    # the same two steps in ONE process on the concatenated batch: mean loss over 6 = mean of the ranks' mean losses
+    m1 = model()
+    o1 = AdamW(m1.get_trainable_modules())
+    l1 = []
+    for step in range(2):
+        loss1, norm1 = train_step(m1, ns, o1, *(t.to(DEV) if i != 2 else t for i, t in enumerate(full)))
+        l1.append(float(loss1))
+    sd1 = m1.brushnet.state_dict()
+    out["single_losses"], out["single_norm"] = l1, float(norm1)
+    # Adam's step is ~lr * sign(g): compare the MOVEMENT of every tensor, and the weights themselves where gradients are not ~0
+    w0 = synth.state_dict_for(keys("tiny_train")["brushnet"], 21)
+    out["max_dw_rel"] = max(float(((sd[k] - w0[k]).norm() - (sd1[k] - w0[k]).norm()).abs() / ((sd1[k] - w0[k]).norm() + 1e-12)) for k in sd)
+    out["max_w_diff"] = max(float((sd[k] - sd1[k]).abs().max()) for k in sd)
+torch.save({k: v for k, v in sd.items()}, os.path.join(os.environ["RESULT_DIR"], f"w{rank}.pt"))
+with open(os.path.join(os.environ["RESULT_DIR"], f"ddp{rank}.json"), "w") as f:
+    json.dump(out, f)
+"""
+
+
+def test_data_parallel_training_two_ranks_equal_one_process_on_the_joint_batch(tmp_path):
+    """(e) training: two ranks (sharing this GPU; gloo for the exchange, staged through the host) each train on half of
+    a batch with the bucketed gradient all-reduce hooked into the backward tape; every rank ends with the same weights, and
+    they match ONE process training on the joint batch (mean loss over 6 samples = mean of the two ranks' means)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER % (root, root))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RESULT_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r0, r1 = (json.load(open(tmp_path / f"ddp{r}.json")) for r in range(2))
+    w0, w1 = (torch.load(tmp_path / f"w{r}.pt") for r in range(2))
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), f"{k}: the two ranks diverged"
+    print(r0)
+    assert r0["losses"] == r1["losses"]
+    for a, b in zip(r0["losses"], r0["single_losses"]):
+        assert abs(a - b) < 2e-6 * abs(b)
+    assert abs(r0["norm"] - r0["single_norm"]) < 1e-4 * r0["single_norm"]
+    assert r0["max_dw_rel"] < 2e-3 and r0["max_w_diff"] < 3e-5       # 2 steps x lr 1e-5: a flipped near-zero gradient moves a weight by 2e-5
