@@ -181,9 +181,9 @@ def train_main(a, D):
     unet.load_state_dict(synth.state_dict_for(unet.param_shapes(), 0))
     bn = BrushNetModel(dict(brushnet_config(SD15_UNET, 6)), precision=prec, device=device)
     bn.load_state_dict(synth.state_dict_for(bn.param_shapes(), 1))
-    model = MirrorFusionModel(unet, bn).prepare_training(train_base_unet=False)
+    model = MirrorFusionModel(unet, bn).prepare_training(train_base_unet=a.train_base_unet)
     opt = AdamW(model.get_trainable_modules(), lr=1e-5)
-    sync = D.GradBuckets(model.get_trainable_modules()) if world > 1 else None
+    sync = D.GradBuckets(model.get_trainable_modules()) if (world > 1 or os.environ.get("MF_FORCE_GRAD_SYNC") == "1") else None
     ns = DDPMScheduler(**{k: v for k, v in SD15_SCHED.items() if k in ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule")})
     log(f"[bench] training models built in {time.time() - t0:.1f}s: BrushNet {bn.num_arena_floats() / 1e6:.1f} M trainable floats")
     hl = a.size // 8
@@ -217,7 +217,7 @@ def train_main(a, D):
             "warmup": a.warmup, "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": prec, "data": "synthetic",
             "config": {"workload": f"train_brushnet_mirror.py step, per-GPU batch {b} x {a.size}x{a.size}, BrushNet(6 cond ch) trainable / UNet "
-                                   f"frozen, clip 1.0, AdamW lr 1e-5, random-init weights", "per_gpu_batch": b, "global_batch": b * world,
+                                   f"{'trainable' if a.train_base_unet else 'frozen'}, clip 1.0, AdamW lr 1e-5, random-init weights", "per_gpu_batch": b, "global_batch": b * world,
                        "parallelism": f"data-parallel x{world}" + (" (bucketed gradient all-reduce over RCCL)" if world > 1 else "")},
             "achieved_tflops": round(b * gflop * 1e9 / step_s / 1e12, 2),
             "algorithmic_gflop_per_sample": round(gflop, 1), "last_loss": round(float(loss), 5), "last_grad_norm": round(float(norm), 5)}),
@@ -247,6 +247,7 @@ def main():
                     help="device: inputs resident in HBM when the timed region starts (the contract's `value`); host: the "
                          "caller hands over host tensors, so every pass pays preprocessing on the CPU and the PCIe upload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-base-unet", action="store_true", help="--mode train: the UNet trains too (train_brushnet_mirror.py --train_base_unet)")
     ap.add_argument("--stub", action="store_true",
                     help="test hook: a sleeping stand-in for the pipeline on the CPU (gloo), to exercise the rank logic — "
                          "launch, rendezvous, barrier, max-over-ranks timing, the JSON line — where there is no GPU")

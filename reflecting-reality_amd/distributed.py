@@ -25,7 +25,9 @@ def env_rank_world() -> Tuple[int, int, int]:
 def init_process_group(backend: str = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
     rank, world, local = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    # a torchrun environment initialises the group even for one rank, so a single-GPU box exercises the same RCCL
+    # rendezvous / barrier / all-reduce calls the multi-GPU runs make
+    if (world > 1 or "TORCHELASTIC_RUN_ID" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -81,6 +83,8 @@ class GradBuckets:
     def __init__(self, models, bucket_floats: int = 64 * 1024 * 1024):
         self.models = [m for m in models if m.flat_g is not None]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        # MF_FORCE_GRAD_SYNC=1: run the bucketed exchange even with one rank (exercises the RCCL path on a 1-GPU box)
+        self.force = os.environ.get("MF_FORCE_GRAD_SYNC") == "1" and dist.is_initialized()
         self.bucket_floats = int(bucket_floats)
         self._stream = None
         self._plan = []
@@ -103,7 +107,7 @@ class GradBuckets:
         self._by_grad = {}
         for pi, p in enumerate(self._plan):
             self._by_grad[p["model"].flat_g.untyped_storage().data_ptr()] = pi
-        tape.on_param_grad = self._on_param if self.world > 1 else None
+        tape.on_param_grad = self._on_param if (self.world > 1 or self.force) else None
 
     def _on_param(self, param) -> None:
         pi = self._by_grad.get(param.grad.untyped_storage().data_ptr())
@@ -138,7 +142,7 @@ class GradBuckets:
             st["handles"].append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         for pi, p in enumerate(self._plan):
             for b in range(p["nb"]):

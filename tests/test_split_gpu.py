@@ -38,7 +38,8 @@ def test_split_linear_all_tiles(prec_name, m, k, n):
     b = torch.randn(n, generator=g)
     ref = F.linear(x.double(), w.double(), b.double())
     xd = x.to(DEV)
-    for raw, tiles in ((False, (0, 1, 2, 3, 6, 7, 14)), (True, (0, 1, 2, 3, 6))):
+    raw_tiles = (0, 1, 2, 3, 6, 14) if prec_name == "f16x3" else (0, 1, 2, 3, 6)     # f16x3 keeps the big-conv tile for raw weights (training)
+    for raw, tiles in ((False, (0, 1, 2, 3, 6, 7, 14)), (True, raw_tiles)):
         lw = ops.ConvWeight(w, b, prec, DEV, raw=raw)
         assert lw.w_split == (0 if raw else 1)
         for tile in tiles:
@@ -47,7 +48,7 @@ def test_split_linear_all_tiles(prec_name, m, k, n):
             print(f"split linear[{prec_name}, w_split={lw.w_split}, tile {tile}, {m}x{k}x{n}]: rel err {e:.2e}")
             assert e < REL[prec_name]
     with pytest.raises(hip.MfhipError, match="not instantiated"):
-        ops.linear(xd, ops.ConvWeight(w, b, prec, DEV, raw=True), tile=14)
+        ops.linear(xd, ops.ConvWeight(w, b, prec, DEV, raw=True), tile=7 if prec_name == "f16x3" else 14)
 
 
 def test_split_modes_rank_between_bf16_and_fp32():
