@@ -212,7 +212,7 @@ def train_main(a, D):
         gflop = 3 * 441.3 + 2 * 803.3            # per sample: BrushNet fwd + dgrad + wgrad, frozen UNet fwd + dgrad (no CFG)
         step_s = elapsed / a.steps
         print(json.dumps({
-            "metric": "samples/sec, MirrorFusion fine-tune step at 512x512 (BrushNet trains, UNet frozen) — secondary workload",
+            "metric": f"samples/sec, MirrorFusion fine-tune step at 512x512 (BrushNet trains, UNet {'trains' if a.train_base_unet else 'frozen'}) — secondary workload",
             "value": round(b * a.steps * world / elapsed, 4), "unit": "samples/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(step_s * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": prec, "data": "synthetic",
@@ -470,4 +470,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()
