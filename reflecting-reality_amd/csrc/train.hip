@@ -32,8 +32,11 @@ struct WgradArgs {
     int splitm, m_per_split, tiles_k_per_tap, tiles_n;
 };
 
-constexpr int WG_BN = 64, WG_BC = 64, WG_BP = 32, WG_PITCH = 68;   // LDS rows of 64 floats + 4 pad (16-byte aligned rows)
+constexpr int WG_BN = 128, WG_BC = 128, WG_BP = 32, WG_PITCH = 132;   // LDS rows of 128 floats + 4 pad (16-byte aligned rows)
 
+// Block = 4 waves, output tile 128 (n) x 128 (c of one tap); wave (wn, wk) owns 64 x 64 = 2 x 2 accumulator blocks, so every
+// gathered fragment feeds two MFMAs (the first version's 32 x 32 per wave fed one).  Per iteration 32 pixels are staged
+// (register -> LDS, single buffered: correctness-first; the reduction over pixels is split over blockIdx.y).
 template <int DT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     __shared__ __attribute__((aligned(16))) float sY[WG_BP * WG_PITCH];
@@ -52,20 +55,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     int m_end = m_begin + p.m_per_split;
     if (m_end > p.M) m_end = p.M;
 
-    f32x16_t acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // staging coordinates: thread -> (row = tid / 16 (+16), 4 consecutive columns)
-    const int srow = tid >> 4, scol = (tid & 15) * 4;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    // staging coordinates: thread -> (row = tid / 32 (+8 per pass), 4 consecutive columns of 128)
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
     const int Hlim = p.Hin << p.ups, Wlim = p.Win << p.ups;
     for (int m0 = m_begin; m0 < m_end; m0 += WG_BP) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = srow + 16 * i;
+        for (int i = 0; i < WG_BP / 8; ++i) {
+            const int row = srow + 8 * i;
             const int m = m0 + row;
             float4 vy = make_float4(0, 0, 0, 0), va = make_float4(0, 0, 0, 0);
             if (m < m_end) {
                 const int n = n0 + scol;
                 if (n + 4 <= p.N) vy = *reinterpret_cast<const float4*>(p.dy + (int64_t)m * p.lddy + n);
-                else {
+                else if (n < p.N) {
                     float t[4] = {0, 0, 0, 0};
                     for (int j = 0; j < 4 && n + j < p.N; ++j) t[j] = p.dy[(int64_t)m * p.lddy + n + j];
                     vy = make_float4(t[0], t[1], t[2], t[3]);
@@ -83,50 +92,69 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
             *reinterpret_cast<float4*>(sA + row * WG_PITCH + scol) = va;
         }
         __syncthreads();
-        const float* py = sY + wn * 32 + r;
-        const float* pa = sA + wk * 32 + r;
+        const float* py = sY + wn * 64 + r;
+        const float* pa = sA + wk * 64 + r;
         if constexpr (DT == MF_F32) {
 #pragma unroll
-            for (int s = 0; s < WG_BP / 2; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(py[(2 * s + h) * WG_PITCH], pa[(2 * s + h) * WG_PITCH], acc, 0, 0, 0);
+            for (int s = 0; s < WG_BP / 2; ++s) {
+                const float y0 = py[(2 * s + h) * WG_PITCH], y1 = py[(2 * s + h) * WG_PITCH + 32];
+                const float a0 = pa[(2 * s + h) * WG_PITCH], a1 = pa[(2 * s + h) * WG_PITCH + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, a0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0, a1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1, a0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1, a1, acc[1][1], 0, 0, 0);
+            }
         } else {
             // fp32 -> (hi, lo) fp16 halves, three MFMAs per product (the split precision of mf_gemm_conv)
 #pragma unroll
             for (int s = 0; s < WG_BP / 16; ++s) {
-                unsigned yh[4], yl[4], ah[4], al[4];
+                f16x8_t Yh[2], Yl[2], Ah[2], Al[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int pp = 16 * s + 8 * h + 2 * e;
-                    const float y0 = py[pp * WG_PITCH], y1 = py[(pp + 1) * WG_PITCH];
-                    const float a0 = pa[pp * WG_PITCH], a1 = pa[(pp + 1) * WG_PITCH];
-                    const auto hy = __builtin_amdgcn_cvt_pkrtz(y0, y1);
-                    const auto ly = __builtin_amdgcn_cvt_pkrtz(y0 - (float)hy[0], y1 - (float)hy[1]);
-                    const auto ha = __builtin_amdgcn_cvt_pkrtz(a0, a1);
-                    const auto la = __builtin_amdgcn_cvt_pkrtz(a0 - (float)ha[0], a1 - (float)ha[1]);
-                    yh[e] = __builtin_bit_cast(unsigned, hy); yl[e] = __builtin_bit_cast(unsigned, ly);
-                    ah[e] = __builtin_bit_cast(unsigned, ha); al[e] = __builtin_bit_cast(unsigned, la);
+                for (int t = 0; t < 2; ++t) {
+                    unsigned yh[4], yl[4], ah[4], al[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int pp = 16 * s + 8 * h + 2 * e;
+                        const float y0 = py[pp * WG_PITCH + 32 * t], y1 = py[(pp + 1) * WG_PITCH + 32 * t];
+                        const float a0 = pa[pp * WG_PITCH + 32 * t], a1 = pa[(pp + 1) * WG_PITCH + 32 * t];
+                        const auto hy = __builtin_amdgcn_cvt_pkrtz(y0, y1);
+                        const auto ly = __builtin_amdgcn_cvt_pkrtz(y0 - (float)hy[0], y1 - (float)hy[1]);
+                        const auto ha = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+                        const auto la = __builtin_amdgcn_cvt_pkrtz(a0 - (float)ha[0], a1 - (float)ha[1]);
+                        yh[e] = __builtin_bit_cast(unsigned, hy); yl[e] = __builtin_bit_cast(unsigned, ly);
+                        ah[e] = __builtin_bit_cast(unsigned, ha); al[e] = __builtin_bit_cast(unsigned, la);
+                    }
+                    Yh[t] = __builtin_bit_cast(f16x8_t, uint4{yh[0], yh[1], yh[2], yh[3]});
+                    Yl[t] = __builtin_bit_cast(f16x8_t, uint4{yl[0], yl[1], yl[2], yl[3]});
+                    Ah[t] = __builtin_bit_cast(f16x8_t, uint4{ah[0], ah[1], ah[2], ah[3]});
+                    Al[t] = __builtin_bit_cast(f16x8_t, uint4{al[0], al[1], al[2], al[3]});
                 }
-                const f16x8_t Yh = __builtin_bit_cast(f16x8_t, uint4{yh[0], yh[1], yh[2], yh[3]});
-                const f16x8_t Yl = __builtin_bit_cast(f16x8_t, uint4{yl[0], yl[1], yl[2], yl[3]});
-                const f16x8_t Ah = __builtin_bit_cast(f16x8_t, uint4{ah[0], ah[1], ah[2], ah[3]});
-                const f16x8_t Al = __builtin_bit_cast(f16x8_t, uint4{al[0], al[1], al[2], al[3]});
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yl, Ah, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh, Al, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh, Ah, acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yl[i], Ah[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh[i], Al[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh[i], Ah[j], acc[i][j], 0, 0, 0);
+                    }
             }
         }
         __syncthreads();
     }
     // D[row = n (e & 3) + 8 (e >> 2) + 4 h][col = c r]
     float* out = p.out + (int64_t)blockIdx.y * p.slab;
-    const int c = c0 + wk * 32 + r;
-    if (c < p.Ctot) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (n < p.N) out[(int64_t)n * p.ldo + (int64_t)tap * p.Ctot + c] = acc[e];
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wk * 64 + 32 * j + r;
+            if (c >= p.Ctot) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < p.N) out[(int64_t)n * p.ldo + (int64_t)tap * p.Ctot + c] = acc[i][j][e];
+            }
         }
-    }
 }
 
 // out[i] (+)= sum_z slabs[z][i]   (rows of `cols` floats, output row stride ldo)
