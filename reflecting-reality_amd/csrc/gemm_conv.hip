@@ -244,7 +244,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     constexpr int SR = (WAVES_M * WAVES_N * 32 * EP_RS <= STAGES * STAGE_BYTES) ? 32 : 16;   // rows per epilogue slab
     static_assert(WAVES_M * WAVES_N * SR * EP_RS <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the staging LDS");
-    static_assert(STAGES >= 2 && STAGES <= 4, "2 to 4 LDS stages");
+    static_assert(STAGES >= 2 && STAGES <= 6, "2 to 6 LDS stages");
     static_assert(!A_F32 || STAGES == 2, "the register-staged path is double buffered");
     static_assert(!A_F32 || DT == MF_BF16, "A_F32 only converts fp32 activations for bf16 compute");
 
@@ -808,7 +808,10 @@ void gemm_conv_kernel(const GemmArgs p) {
                 for (int t = 0; t < nt; ++t) {
                     {   // allow the DMAs of the (up to PF-1) newer tiles to stay in flight
                         const int newer = nt - 1 - t < PF - 1 ? nt - 1 - t : PF - 1;
-                        if (PF >= 3 && newer == 2) wait_vmcnt<2 * G>();
+                        static_assert((PF - 1) * G < 64, "vmcnt is a 6-bit counter");
+                        if (PF >= 5 && newer == 4) wait_vmcnt<4 * G>();
+                        else if (PF >= 4 && newer == 3) wait_vmcnt<3 * G>();
+                        else if (PF >= 3 && newer == 2) wait_vmcnt<2 * G>();
                         else if (PF >= 2 && newer == 1) wait_vmcnt<G>();
                         else wait_vmcnt<0>();
                     }
@@ -1590,6 +1593,14 @@ const TileCfg kTiles[] = {
     {128, 128, 256, 2, 0, 1},  // 28
     {64, 128, 256, 2},         // 29
     {128, 64, 256, 2},         // 30
+    // 31-36: deeper LDS rings for the tiles of small-M / short-K calls, where a block walks its K loop at the pace of one
+    // L2 -> LDS round trip (~1 us) per tile in flight: more tiles in flight per block instead of more blocks per CU
+    {128, 128, 256, 4},        // 31
+    {128, 64, 256, 4},         // 32
+    {64, 128, 256, 4},         // 33
+    {64, 64, 256, 4},          // 34
+    {64, 128, 256, 6},         // 35
+    {64, 64, 256, 6},          // 36
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1667,6 +1678,15 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
             case 22: launch_one<DT, 64, 128, 2, 2, false, 2, true>(a, grid, s); break;
             case 23: launch_one<DT, 128, 64, 2, 2, false, 2, true>(a, grid, s); break;
             case 24: launch_one<DT, 192, 128, 2, 2, false, 2, true>(a, grid, s); break;
+            default: break;
+        }
+        switch (tile) {
+            case 31: launch_one<DT, 128, 128, 2, 2, false, 4>(a, grid, s); break;
+            case 32: launch_one<DT, 128, 64, 2, 2, false, 4>(a, grid, s); break;
+            case 33: launch_one<DT, 64, 128, 2, 2, false, 4>(a, grid, s); break;
+            case 34: launch_one<DT, 64, 64, 2, 2, false, 4>(a, grid, s); break;
+            case 35: launch_one<DT, 64, 128, 2, 2, false, 6>(a, grid, s); break;
+            case 36: launch_one<DT, 64, 64, 2, 2, false, 6>(a, grid, s); break;
             default: break;
         }
         if constexpr (DT == MF_BF16) {
@@ -1839,7 +1859,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         if (tile >= 7 && tile <= 12) tile -= 6;
         MF_CHECK_ARG(tile <= 6, "mf_gemm_conv: tile %d does not apply to fp32 activations with bf16 compute (tiles 1-12 do)", tile);
     }
-    MF_CHECK_ARG(tile < 25 || (d->dtype == MF_BF16 && !a_f32), "mf_gemm_conv: tile %d (16x16x32 MFMA form) does not apply: bf16 only", tile);
+    MF_CHECK_ARG(tile < 25 || tile > 30 || (d->dtype == MF_BF16 && !a_f32), "mf_gemm_conv: tile %d (16x16x32 MFMA form) does not apply: bf16 only", tile);
+    MF_CHECK_ARG(tile < 31 || (!a_f32 && !split && d->dtype != MF_FP8), "mf_gemm_conv: tile %d (deep ring) does not apply to this precision", tile);
     const TileCfg& tc = kTiles[tile - 1];
     if (tc.halo) {
         // conv3x3_halo_kernel: bf16, 3x3 / stride 1 / pad 1, whole TH x 16 tiles, 32-channel chunks
