@@ -1,5 +1,5 @@
 // GroupNorm(+SiLU), LayerNorm and row softmax for NHWC / token-major activations on gfx950.
-// All three are HBM-bound: one read + one write of the tensor (GroupNorm reads it twice: stats,
+// All three are HBM-bound: one read + one write of the tensor (GroupNorm above 16x16 reads it twice: stats,
 // then apply), fp32 statistics, vectorised 4-channel accesses, no atomics (bitwise reproducible).
 #include <stdlib.h>
 #include "mf_common.h"
@@ -290,6 +290,113 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
     }
 }
 
+// One-launch GroupNorm for the lowest-resolution levels (HW <= 256: 16x16 / 8x8 latents), where the two-launch form
+// above is a chain of dependent launches and memory round trips, not bytes (tools/bench_gn.py: 12 us at 8x8 for 2 MB).
+// grid (C / SC, batch): a block owns a SLAB of SC = lcm(cpg, 8) channels = whole groups = nv 16-byte vector columns
+// over ALL HW rows of one sample, so the statistics never leave the block and the rows never leave the registers.
+// Thread t = lane * nv + vcol keeps vector column vcol of rows lane, lane + P, ... (at most ROWS): per-channel fp32
+// (sum, sum of squares) -> LDS -> one wave per group combines them in double in a fixed order (bitwise
+// reproducible) -> y = silu(x * a[c] + b[c]) from the registers.
+template <int ROWS>
+__global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, int nv, int P) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2* chan = reinterpret_cast<float2*>(smem_raw);              // [P][SC or SC/8] (sum, sum of squares)
+    __shared__ float gm[8], gr[8];
+    const int slab = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int vcol = t % nv, lane = t / nv;
+    const bool active = lane < P;                      // the block is padded to whole waves for the butterflies
+    const int c = slab * SC + vcol * 8;
+    const int esz = p.in_dt == MF_F32 ? 4 : 2, osz = p.out_dt == MF_F32 ? 4 : 2;
+    const char* base; int64_t ld; int cc;
+    if (c < p.C0) { base = p.x0; ld = p.C0; cc = c; }
+    else { base = p.x1; ld = p.C1; cc = c - p.C0; }
+    const int64_t step = (int64_t)P * ld * esz;
+    const char* ptr = base + (((int64_t)b * p.HW + lane) * ld + cc) * esz;
+    const bool whole = p.cpg % 8 == 0;                 // a thread's 8 channels lie in one group: pre-reduce them
+    const int W = whole ? SC / 8 : SC;                 // LDS items per lane
+    float v[ROWS][8];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            if (lane + i * P < p.HW) load8(ptr + i * step, p.in_dt, 0, v[i]);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = 0.0f;
+            }
+        }
+        float s[8], ss[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[e] = 0.0f; ss[e] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < ROWS; i += 4) {
+                s[e] += (v[i][e] + v[i + 1][e]) + (v[i + 2][e] + v[i + 3][e]);
+                ss[e] += (v[i][e] * v[i][e] + v[i + 1][e] * v[i + 1][e]) + (v[i + 2][e] * v[i + 2][e] + v[i + 3][e] * v[i + 3][e]);
+            }
+        }
+        if (whole) {
+            const float s8 = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+            const float q8 = ((ss[0] + ss[1]) + (ss[2] + ss[3])) + ((ss[4] + ss[5]) + (ss[6] + ss[7]));
+            chan[lane * W + vcol] = make_float2(s8, q8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) chan[lane * W + vcol * 8 + e] = make_float2(s[e], ss[e]);
+        }
+    }
+    __syncthreads();
+    {   // one wave per group of the slab: fixed-order partial sums in double, then a butterfly
+        const int l = t & 63, ipg = whole ? p.cpg / 8 : p.cpg, items = P * ipg, gps = SC / p.cpg;
+        for (int g = t >> 6; g < gps; g += (int)blockDim.x >> 6) {
+            double s = 0.0, ss = 0.0;
+            for (int it = l; it < items; it += 64) {
+                const int tr = it / ipg;
+                const float2 x = chan[tr * W + g * ipg + (it - tr * ipg)];
+                s += (double)x.x;
+                ss += (double)x.y;
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                s += __shfl_xor(s, off, 64);
+                ss += __shfl_xor(ss, off, 64);
+            }
+            if (l == 0) {
+                const double n = (double)p.HW * p.cpg;
+                const double mean = s / n;
+                double m2 = ss - s * mean;
+                if (m2 < 0.0) m2 = 0.0;
+                gm[g] = (float)mean;
+                gr[g] = (float)(1.0 / sqrt(m2 / n + (double)p.eps));
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float sa[8], sb[8];
+    load8(reinterpret_cast<const char*>(p.gamma + c), MF_F32, 0, sa);
+    load8(reinterpret_cast<const char*>(p.beta + c), MF_F32, 0, sb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (vcol * 8 + e) / p.cpg;
+        sa[e] = gr[g] * sa[e];
+        sb[e] = sb[e] - gm[g] * sa[e];
+    }
+    const bool fast_silu = p.out_dt == MF_BF16;
+    const int64_t ostep = (int64_t)P * p.C * osz;
+    char* optr = p.out + (((int64_t)b * p.HW + lane) * p.C + c) * osz;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        if (lane + i * P < p.HW) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = v[i][e] * sa[e] + sb[e];
+                if (p.silu) y = fast_silu ? silu_f(y) : silu_precise(y);
+                v[i][e] = y;
+            }
+            store8(optr + i * ostep, p.out_dt, 0, v[i]);
+        }
+    }
+}
+
 // Half a wave per row (two rows per wave, 8 per block), 8-channel (16-byte) vectors: C % 8 == 0, C <= 2048.
 // For the transformer widths of the path (320 / 640 / 1280) this moves twice the bytes per instruction of the
 // 4-channel kernel below and halves the dependent shuffle chain (5 steps inside 32 lanes).
@@ -448,6 +555,25 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     // measured (tools/bench_gn.py): -1.5...2 us per GroupNorm up to 32x32, +1 us at 64x64 (64 chunks combined by 256 blocks)
     a.fuse_finalize = !gn3 && d->hw <= 1024 && mf_aligned16(d->gamma) && mf_aligned16(d->beta);
     const int vw = (d->c0 % 8 == 0 && d->c1 % 8 == 0) ? 8 : 4;
+    hipStream_t s = (hipStream_t)stream;
+    {   // one-launch slab kernel for the low-resolution levels
+        // measured (tools/bench_gn.py, batch 8, us): 8x8 C 1280: 11.7 -> 5.0, 2560: 13.0 -> 6.0; 16x16 C 1280: 12.8 -> 8.1,
+        // 2560: 17.4 -> 9.8
+        static const bool two_pass = getenv("MFHIP_GN_2PASS") != nullptr;     // A/B switch: always the two-launch form
+        int sc = a.cpg;                                  // lcm(cpg, 8)
+        while (sc % 8) sc += a.cpg;
+        const int nv = sc / 8;
+        const int P = d->hw < 64 ? d->hw : 64, rows = 4;     // 32x32 (P 128, 8 rows, 128 blocks) measured no faster: 17.3 vs 17.6 us
+        const int nthr = (nv * P + 63) / 64 * 64;
+        const size_t smem = (size_t)P * sc * sizeof(float2);
+        if (!two_pass && vw == 8 && d->hw <= P * rows && C % sc == 0 && sc / a.cpg <= 8 && nthr <= 1024 && smem <= 64 * 1024 &&
+            mf_aligned16(d->gamma) && mf_aligned16(d->beta) && mf_aligned16(d->x0) && mf_aligned16(d->out) &&
+            (!d->x1 || mf_aligned16(d->x1))) {
+            hipLaunchKernelGGL(gn_slab_kernel<4>, dim3(C / sc, d->batch), dim3(nthr), smem, s, a, sc, nv, P);
+            MF_CHECK_LAUNCH("mf_groupnorm(slab)");
+            return MF_OK;
+        }
+    }
     a.cvn = C / vw;
     a.tpr = a.cvn < GN_BLK ? a.cvn : GN_BLK;
     a.rif = GN_BLK / a.tpr;
@@ -455,7 +581,6 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     const size_t smem1 = (size_t)a.rif * C * sizeof(float2) > (size_t)2 * d->groups * sizeof(float)
                              ? (size_t)a.rif * C * sizeof(float2) : (size_t)2 * d->groups * sizeof(float);
     MF_CHECK_ARG(smem1 <= 64 * 1024, "mf_groupnorm: C=%d too large", C);
-    hipStream_t s = (hipStream_t)stream;
     // ~4 row blocks per CU, at least 4 rows per thread
     int rows_per_block = (int)(((int64_t)d->hw * d->batch + 1023) / 1024);
     if (rows_per_block < 4 * a.rif) rows_per_block = 4 * a.rif;

@@ -272,7 +272,10 @@ def test_attention_flash_bf16(heads, d, sq, skv):
                                           (torch.float32, torch.bfloat16)])
 @pytest.mark.parametrize("c0,c1,hw,groups,silu", [(320, 0, 64 * 64, 32, True), (1280, 640, 16 * 16, 32, True),
                                                   (640, 320, 32 * 32, 32, False), (32, 0, 9 * 7, 32, True),
-                                                  (64, 32, 5 * 5, 32, False), (512, 0, 1000, 32, True)])
+                                                  (64, 32, 5 * 5, 32, False), (512, 0, 1000, 32, True),
+                                                  (1280, 1280, 8 * 8, 32, True), (1280, 0, 8 * 8, 32, False),
+                                                  (640, 0, 32 * 32, 32, True), (1280, 640, 32 * 32, 32, True),
+                                                  (320, 0, 32 * 32, 32, True), (320, 320, 33 * 31, 32, True)])
 def test_groupnorm(in_dt, out_dt, c0, c1, hw, groups, silu):
     g = torch.Generator().manual_seed(9)
     x0 = torch.randn(2, c0, hw, 1, generator=g) * 2 + 0.7
