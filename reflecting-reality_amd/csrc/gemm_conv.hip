@@ -50,7 +50,7 @@ struct GemmArgs {
     const char* res1; int res1_dt; int64_t ld_res1;
     float alpha; int act;
     char* out; int out_dt; int64_t ldc;
-    int tiles_n, nblk, vec_ok, fast, dbg_no_res_pre;
+    int tiles_n, tiles_m, ord_mfast, ord_pw, nblk, vec_ok, fast, dbg_no_res_pre;
 };
 
 // Scalar epilogue for one output element (tails, misaligned outputs, split-K reduce).
@@ -255,17 +255,31 @@ void gemm_conv_kernel(const GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // XCD-aware order: the 8 XCDs take blocks round-robin, so give each XCD a contiguous run of logical tiles
+    // XCD-aware order: the 8 XCDs take blocks round-robin, so give each XCD a contiguous run of the LOGICAL order
+    // (K split outermost, then the tiles of one split; blockIdx.x counts all of them).  The order inside a split is
+    // chosen on the host (choose_order): n fastest (an XCD owns rows of A, W is shared) or m fastest (an XCD owns
+    // columns of W), optionally in panels of ord_pw tiles of the fast dimension so that the ~64 tiles an XCD runs at
+    // once are a compact rectangle and the panel's operand stays in that XCD's L2 from round to round.
     int bid = blockIdx.x;
     {
         const int q = p.nblk >> 3, r = p.nblk & 7, x = bid & 7, j = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const int tile_m = bid / p.tiles_n;
-    const int tile_n = bid - tile_m * p.tiles_n;
+    const int per_split = p.tiles_m * p.tiles_n;
+    const int ksplit = bid / per_split;
+    int tile_m, tile_n;
+    {
+        const int r = bid - ksplit * per_split;
+        const int Li = p.ord_mfast ? p.tiles_m : p.tiles_n, Lo = p.ord_mfast ? p.tiles_n : p.tiles_m;
+        const int panel = r / (Lo * p.ord_pw), rp = r - panel * Lo * p.ord_pw;
+        int w = Li - panel * p.ord_pw;
+        if (w > p.ord_pw) w = p.ord_pw;
+        const int o = rp / w, i = panel * p.ord_pw + (rp - o * w);
+        tile_m = p.ord_mfast ? i : o;
+        tile_n = p.ord_mfast ? o : i;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int z = blockIdx.z / p.splitk;
-    const int ksplit = blockIdx.z - z * p.splitk;
+    const int z = blockIdx.z;
     const int zq = z / p.zdiv, zr = z - zq * p.zdiv;
 
     const char* a0 = p.a0 + (zq * p.a_zs_o + zr * p.a_zs_i) * AES;
@@ -1953,11 +1967,30 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     }
     MF_CHECK_ARG(d->act != MF_ACT_GEGLU4 || a.vec_ok, "mf_gemm_conv: GEGLU epilogue needs 16-byte aligned bias/out");
     a.tiles_n = cdiv(a.N, tc.bn);
-    const int64_t nblk = (int64_t)cdiv(a.M, tc.bm) * a.tiles_n;
-    MF_CHECK_ARG(nblk < (1ll << 31) && (int64_t)a.nz * a.splitk < 65536, "mf_gemm_conv: grid too large");
+    a.tiles_m = cdiv(a.M, tc.bm);
+    const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * a.splitk;
+    MF_CHECK_ARG(nblk < (1ll << 31) && a.nz < 65536, "mf_gemm_conv: grid too large");
     a.nblk = (int)nblk;
+    a.ord_mfast = 0;
+    a.ord_pw = a.tiles_n;
+    // wide 1x1 GEMMs (FF projections, N = 2560 ... 10240): panels of 8 column tiles, so the ~64 tiles an XCD runs at once
+    // are 8 x 8 and the panel's W stays in its L2 (tools/bench_order.py: 8192 x 5120 x 640 101 -> 93 us, 2048 x 10240 x
+    // 1280 85 -> 82 us, 16384 x 5120 x 640 197 -> 185 us, fetch 426 -> ~115 MB; the 3x3 convs do not care: their W
+    // re-reads are served by the MALL, every order measured within 3 %)
+    if (d->kh == 1 && d->kw == 1 && a.tiles_n > 8) a.ord_pw = 8;
+    {   // A/B switch: MFHIP_ORD="mfast,pw" forces the tile order (pw 0 = no panels)
+        static const char* ord = getenv("MFHIP_ORD");
+        if (ord) {
+            int mf = 0, pw = 0;
+            if (sscanf(ord, "%d,%d", &mf, &pw) == 2) {
+                a.ord_mfast = mf != 0;
+                const int li = a.ord_mfast ? a.tiles_m : a.tiles_n;
+                a.ord_pw = (pw > 0 && pw < li) ? pw : li;
+            }
+        }
+    }
     { static const bool off = getenv("MFHIP_NO_RES_PRE") != nullptr; a.dbg_no_res_pre = off; }     // A/B switch
-    dim3 grid((unsigned)nblk, 1, (unsigned)(a.nz * a.splitk));
+    dim3 grid((unsigned)nblk, 1, (unsigned)a.nz);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MF_FP8) {
         MF_CHECK_ARG(launch_tile_fp8(tile, a, grid, s), "mf_gemm_conv: tile %d is not instantiated for fp8", tile);
