@@ -1620,8 +1620,11 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int smem = DX ? 2 * (BM + WMv * WNv * 8) * 128 + 2 * BN * 128 : ST * (BM + BN) * 128;
-    static_assert(smem <= 160 * 1024, "LDS");
+    constexpr int smem_k = DX ? 2 * (BM + WMv * WNv * 8) * 128 + 2 * BN * 128 : ST * (BM + BN) * 128;
+    static_assert(smem_k <= 160 * 1024, "LDS");
+    // experiment switch: MFHIP_SMEM_MIN=<bytes> raises the LDS request (occupancy control for ring-depth A/B runs)
+    static const int smem_min = getenv("MFHIP_SMEM_MIN") ? atoi(getenv("MFHIP_SMEM_MIN")) : 0;
+    const int smem = smem_k > smem_min ? smem_k : smem_min;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16>),
