@@ -50,7 +50,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 9
+#define MF_ABI_VERSION 10
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -111,6 +111,10 @@ typedef struct mf_gemm_desc {
     int64_t a_scale_zs, w_scale_zs;
     const void* res0; int32_t res0_dtype; int64_t ld_res0;
     const void* res1; int32_t res1_dtype; int64_t ld_res1;
+    /* 0 (or >= M): res1 has one row per output row.  0 < res1_rows < M (must divide M): res1 has res1_rows rows and output
+     * row m adds row m % res1_rows — one residual shared by batch replicas (the BrushNet residual of both halves of a
+     * classifier-free-guidance batch: pipeline_brushnet.py:1256-1296 feeds an attention-free BrushNet the same inputs twice) */
+    int32_t res1_rows;
     float alpha;
     int32_t act;
     void* out; int32_t out_dtype; int64_t ldc;

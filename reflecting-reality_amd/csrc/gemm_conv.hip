@@ -48,10 +48,19 @@ struct GemmArgs {
     const float* temb; int64_t ld_temb;
     const char* res0; int res0_dt; int64_t ld_res0;
     const char* res1; int res1_dt; int64_t ld_res1;
+    int res1_rows;           // > 0: res1 has this many rows, output row m adds row m % res1_rows (shared by batch replicas)
     float alpha; int act;
     char* out; int out_dt; int64_t ldc;
     int tiles_n, tiles_m, ord_mfast, ord_pw, nblk, vec_ok, fast, dbg_no_res_pre;
 };
+
+// res1 shared by batch replicas (the BrushNet residual of both classifier-free-guidance halves): a handful of replicas,
+// so a subtract loop, not a division
+__device__ __forceinline__ int res1_row(const GemmArgs& p, int m) {
+    if (p.res1_rows > 0)
+        while (m >= p.res1_rows) m -= p.res1_rows;
+    return m;
+}
 
 // Scalar epilogue for one output element (tails, misaligned outputs, split-K reduce).
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int64_t zo, int m, int n, float v, int zq = 0) {
@@ -61,7 +70,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int64_t zo, in
     if (p.temb) v += p.temb[(int64_t)(m / p.HoWo) * p.ld_temb + n];
     v *= p.alpha;
     if (p.res0) v += load_as_f32(p.res0, p.res0_dt, (int64_t)m * p.ld_res0 + n);
-    if (p.res1) v += load_as_f32(p.res1, p.res1_dt, (int64_t)m * p.ld_res1 + n);
+    if (p.res1) v += load_as_f32(p.res1, p.res1_dt, (int64_t)res1_row(p, m) * p.ld_res1 + n);
     if (p.act == MF_ACT_SILU) v = silu_precise(v);
     store_from_f32(p.out, p.out_dt, zo + (int64_t)m * p.ldc + n, v);
 }
@@ -128,7 +137,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
     if (p.res1) {
         float r[8];
         if (pre) unpack8_bf16(q1, r);
-        else load8_as_f32(p.res1, p.res1_dt, (int64_t)m * p.ld_res1 + n, r);
+        else load8_as_f32(p.res1, p.res1_dt, (int64_t)res1_row(p, m) * p.ld_res1 + n, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
@@ -884,7 +893,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                 q0[k] = uint4{0, 0, 0, 0}; q1[k] = uint4{0, 0, 0, 0};
                 if ((ITEMS % 64 == 0 || it < ITEMS) && m < p.M && n + 8 <= p.N) {
                     if (p.res0) q0[k] = *reinterpret_cast<const uint4*>(p.res0 + ((int64_t)m * p.ld_res0 + n) * 2);
-                    if (p.res1) q1[k] = *reinterpret_cast<const uint4*>(p.res1 + ((int64_t)m * p.ld_res1 + n) * 2);
+                    if (p.res1) q1[k] = *reinterpret_cast<const uint4*>(p.res1 + ((int64_t)res1_row(p, m) * p.ld_res1 + n) * 2);
                 }
             }
         }
@@ -1851,6 +1860,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.rs = d->a_scale; a.cs = d->w_scale; a.rs_zs = d->a_scale_zs; a.cs_zs = d->w_scale_zs;
     a.res0 = (const char*)d->res0; a.res0_dt = d->res0_dtype; a.ld_res0 = d->ld_res0;
     a.res1 = (const char*)d->res1; a.res1_dt = d->res1_dtype; a.ld_res1 = d->ld_res1;
+    a.res1_rows = (d->res1 && d->res1_rows > 0 && d->res1_rows < a.M) ? d->res1_rows : 0;
+    MF_CHECK_ARG(a.res1_rows == 0 || a.M % a.res1_rows == 0, "mf_gemm_conv: res1_rows=%d must divide M=%d", d->res1_rows, a.M);
     a.alpha = d->alpha; a.act = d->act;
     a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ldc = d->ldc;
     MF_CHECK_ARG(d->act != MF_ACT_GEGLU4 || (d->n % 8 == 0 && d->ldc % 4 == 0 && d->res0 == nullptr && d->res1 == nullptr &&

@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8 = 0, 1, 2, 3, 4
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MfhipError(RuntimeError):
@@ -44,7 +44,7 @@ class GemmDesc(C.Structure):
         ("temb", C.c_void_p), ("ld_temb", C.c_int64),
         ("a_scale", C.c_void_p), ("w_scale", C.c_void_p), ("a_scale_zs", C.c_int64), ("w_scale_zs", C.c_int64),
         ("res0", C.c_void_p), ("res0_dtype", C.c_int32), ("ld_res0", C.c_int64),
-        ("res1", C.c_void_p), ("res1_dtype", C.c_int32), ("ld_res1", C.c_int64),
+        ("res1", C.c_void_p), ("res1_dtype", C.c_int32), ("ld_res1", C.c_int64), ("res1_rows", C.c_int32),
         ("alpha", C.c_float), ("act", C.c_int32),
         ("out", C.c_void_p), ("out_dtype", C.c_int32), ("ldc", C.c_int64),
         ("splitk", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
@@ -361,7 +361,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
               bias: Optional[torch.Tensor] = None, bias_mode: int = 0,
               temb: Optional[torch.Tensor] = None, ld_temb: int = 0,
               res0: Optional[torch.Tensor] = None, ld_res0: Optional[int] = None,
-              res1: Optional[torch.Tensor] = None, ld_res1: Optional[int] = None,
+              res1: Optional[torch.Tensor] = None, ld_res1: Optional[int] = None, res1_rows: int = 0,
               alpha: float = 1.0, act: int = ACT_NONE,
               nz: int = 1, zdiv: int = 1, a_zs=(0, 0), w_zs=(0, 0), o_zs=(0, 0),
               a_scale: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None, a_scale_zs: int = 0,
@@ -403,6 +403,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     d.ld_res0 = ld_res0 if ld_res0 is not None else n
     d.res1, d.res1_dtype = _ptr(res1), (dt_code(res1.dtype) if res1 is not None else 0)
     d.ld_res1 = ld_res1 if ld_res1 is not None else n
+    d.res1_rows = int(res1_rows)
     d.alpha, d.act = alpha, act
     d.out, d.out_dtype = _ptr(out), dt_code(out.dtype)
     d.ldc = ldc if ldc is not None else n
@@ -558,11 +559,14 @@ def unpack_nchw(src: torch.Tensor, c: int) -> torch.Tensor:
     return out
 
 
-def add(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
-    _req_cuda(a, b)
+def add(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req_cuda(a, b, out)
     if a.shape != b.shape:
         raise MfhipError(f"mf_add shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
-    out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    if out is None:
+        out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    elif out.shape != a.shape or out.dtype != out_dtype or not out.is_contiguous():
+        raise MfhipError("mf_add: `out` must be a contiguous tensor of the operands' shape and the output dtype")
     _check(load().mf_add(C.c_void_p(a.data_ptr()), dt_code(a.dtype), C.c_void_p(b.data_ptr()), dt_code(b.dtype),
                          C.c_void_p(out.data_ptr()), dt_code(out_dtype), C.c_int64(a.numel()), _stream()), "mf_add")
     return out

@@ -651,7 +651,7 @@ class _UNetCore(HipModel):
             h = ops.linear(gg, P[b + "ff.net.2"], res0=h)
         if P[p + "proj_out"].fp8:
             return ops.linear(h, P[p + "proj_out"], res0=x.view(bsz, hh * ww, c),
-                              res1=inj.view(bsz, hh * ww, c) if inj is not None else None).view(bsz, hh, ww, c)
+                              res1=inj.view(-1, hh * ww, c) if inj is not None else None).view(bsz, hh, ww, c)
         return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj)
 
     # ---- the reference's operator plug-in point (attention_processor.py:216; brushnet.py:558-590;
@@ -1053,7 +1053,7 @@ class UNet2DConditionModel(_UNetCore):
                 skips.append(x)                                                                     # post-add (:1388-1391)
             if i != n - 1:
                 inj = take(down_block_add_samples) if is_brushnet else None
-                x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1, res0=inj)
+                x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1, res1=inj)
                 skips.append(x)
         x = self._resnet("mid_block.resnets.0.", x, temb)
         x = self._transformer("mid_block.attentions.0.", x, ehs, self._heads(n - 1))
@@ -1071,7 +1071,7 @@ class UNet2DConditionModel(_UNetCore):
                     x = self._resnet(f"up_blocks.{i}.resnets.{j}.", x, temb, x1=sk, inj=inj)
             if i != n - 1:
                 inj = take(up_block_add_samples) if is_brushnet else None
-                x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True, res0=inj)
+                x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True, res1=inj)
         x = ops.groupnorm(x, self.P["conv_norm_out"], groups=c["norm_num_groups"], eps=c["norm_eps"], silu=True,
                           out_dtype=self.prec.act)
         y = ops.conv2d(x, self.P["conv_out"], out_dtype=F32)

@@ -133,6 +133,21 @@ def split_pack(w: torch.Tensor, code: int):
     return packed, kp
 
 
+def _shared_rows(res1: Optional[torch.Tensor], m_out: int, n: int) -> int:
+    """mf_gemm_desc.res1_rows for a residual that has fewer rows than the output: one residual shared by batch
+    replicas (BrushNet's residual for both halves of a classifier-free-guidance batch).  0 = one row per output row."""
+    if res1 is None:
+        return 0
+    rows = res1.numel() // n
+    if rows == m_out:
+        return 0
+    if rows <= 0 or m_out % rows:
+        raise hip.MfhipError(f"residual with {rows} rows cannot be shared by an output of {m_out} rows")
+    if TAPE is not None:
+        raise hip.MfhipError("training: shared (batch-replicated) residuals are inference only")
+    return rows
+
+
 def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
            padding: Union[int, Tuple[int, int, int, int]] = 1, upsample: bool = False,
            x1: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
@@ -156,7 +171,8 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
                   batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, kh=cw.kh, kw=cw.kw, stride=stride,
                   pad_t=pt, pad_l=pl, upsample=upsample, n=cw.n, bias=cw.bias,
                   temb=temb, ld_temb=(temb.stride(0) if temb is not None else 0),
-                  res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
+                  res0=res0, res1=res1, res1_rows=_shared_rows(res1, b * ho * wo, cw.n), alpha=alpha, act=act, splitk=splitk,
+                  tile=tile)
     if TAPE is not None:
         autograd.record_conv(TAPE, x, x1, cw, out, batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, pad_t=pt, pad_l=pl,
                              upsample=upsample, temb=temb, res0=res0, res1=res1, alpha=alpha, act=act)
@@ -178,7 +194,8 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
     if out is None:
         out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
     hip.gemm_conv(x, lw.w, out, dtype=lw.prec.code, w_split=lw.w_split, ldw=lw.ldw, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
-                  h_out=1, w_out=1, n=lw.n, bias=lw.bias, res0=res0, res1=res1, alpha=alpha, act=act, splitk=splitk, tile=tile)
+                  h_out=1, w_out=1, n=lw.n, bias=lw.bias, res0=res0, res1=res1, res1_rows=_shared_rows(res1, m, lw.n), alpha=alpha,
+                  act=act, splitk=splitk, tile=tile)
     if TAPE is not None:
         autograd.record_conv(TAPE, x, None, lw, out, batch=m, h_in=1, w_in=1, h_out=1, w_out=1, stride=1, pad_t=0, pad_l=0,
                              upsample=False, temb=None, res0=res0, res1=res1, alpha=alpha, act=act)
@@ -197,7 +214,8 @@ def _linear_fp8(x, lw: ConvWeight, res0, res1, alpha, act, out_dtype, out, tile,
     if out is None:
         out = torch.empty(*xq.shape[:-1], n_out, dtype=out_dtype or lw.prec.act, device=xq.device)
     hip.gemm_conv(xq, lw.w, out, dtype=hip.MF_FP8, c0=k, lda0=k, batch=m, h_in=1, w_in=1, h_out=1, w_out=1, n=lw.n, ldc=ldc or n_out,
-                  bias=lw.bias, res0=res0, res1=res1, alpha=alpha, act=act, a_scale=xs, w_scale=lw.w_scale,
+                  bias=lw.bias, res0=res0, res1=res1, res1_rows=_shared_rows(res1, m, lw.n), alpha=alpha, act=act, a_scale=xs,
+                  w_scale=lw.w_scale,
                   splitk=1 if act == hip.ACT_GEGLU4 else 0, tile=tile)
     return out
 
@@ -285,6 +303,15 @@ def layernorm(x: torch.Tensor, norm, eps: float, out_dtype: torch.dtype, fp8: bo
 
 
 def add(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """a + b; b may hold 1/r of a's leading (batch) dimension: it is then shared by the r batch replicas of a."""
+    if b.numel() != a.numel():
+        r = a.shape[0] // max(b.shape[0], 1)
+        if TAPE is not None or b.shape[0] * r != a.shape[0] or b.shape[1:] != a.shape[1:]:
+            raise hip.MfhipError(f"add: shapes {tuple(a.shape)} and {tuple(b.shape)} do not match")
+        out = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+        for i in range(r):
+            hip.add(a[i * b.shape[0]:(i + 1) * b.shape[0]], b, out_dtype, out=out[i * b.shape[0]:(i + 1) * b.shape[0]])
+        return out
     out = hip.add(a, b, out_dtype)
     if TAPE is not None:
         autograd.record_pointwise(TAPE, (a, b), out, lambda g: (g, g))

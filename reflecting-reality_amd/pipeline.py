@@ -144,6 +144,12 @@ class StableDiffusionBrushNetPipeline:
         self._num_timesteps = 0
         self.use_hip_graph = True        # capture the denoise step into a hipGraph when the scheduler allows it
         self.overlap_brushnet = True     # BrushNet on a second HIP stream, ordered against the UNet by per-residual events
+        self.share_brushnet_cfg = True   # BrushNet evaluated once when both CFG halves get identical inputs (_brushnet_shareable)
+        # opt-in deviation from pipeline_brushnet.py:1188: draw ONE VAE-posterior sample of the conditioning latents and use
+        # it for both classifier-free-guidance halves (the reference draws one per half); each half's distribution is
+        # unchanged, BrushNet then runs once per image
+        self.cfg_shared_conditioning_sample = False
+        self._brushnet_once = False
         self._side_stream = None
         self.overlap_aux = False         # UNet shortcut convs / V projections on a third stream: measured 0.8 % slower
                                          # (18.15 vs 18.0 ms per step, tools/bench_aux.py), so off by default
@@ -363,7 +369,10 @@ class StableDiffusionBrushNetPipeline:
             once and sampled once per CFG half (the reference encodes the duplicated batch, :1188)."""
             moments = self.vae._moments(x_host)
             if noise is None:
-                noise = torch.randn(dup * batch, lat_c, hl, wl, dtype=torch.float32)   # global RNG, like vae.py:782-791
+                if dup == 2 and self.cfg_shared_conditioning_sample:
+                    noise = torch.randn(batch, lat_c, hl, wl, dtype=torch.float32).repeat(2, 1, 1, 1)
+                else:
+                    noise = torch.randn(dup * batch, lat_c, hl, wl, dtype=torch.float32)   # global RNG, like vae.py:782-791
             noise = noise.to(self.device, torch.float32)
             if noise.shape[0] != dup * batch:
                 raise ValueError(f"conditioning_noise must have batch {dup * batch}")
@@ -445,6 +454,7 @@ class StableDiffusionBrushNetPipeline:
             height, width = height or int(hh), width or int(ww)
         cond = self.build_conditioning(image, mask, depth, height, width, nb, num_images_per_prompt, do_cfg,
                                        conditioning_noise, normals)
+        self._brushnet_once = self._brushnet_shareable(cond, nb, do_cfg)
 
         self.scheduler.set_timesteps(num_inference_steps, device=self.device)                       # :1171
         ts = self.scheduler.timesteps
@@ -473,7 +483,9 @@ class StableDiffusionBrushNetPipeline:
                 x_in = torch.cat([latents] * 2) if do_cfg else latents                               # :1256
                 x_in = self.scheduler.scale_model_input(x_in, t)
                 cond_scale = float(brushnet_conditioning_scale) * keep[i]
-                down, mid, up = self.brushnet(x_in, t, encoder_hidden_states=pe, brushnet_cond=cond,
+                once = self._brushnet_once
+                down, mid, up = self.brushnet(x_in[:nb] if once else x_in, t, encoder_hidden_states=pe[:nb] if once else pe,
+                                              brushnet_cond=cond[:nb] if once else cond,
                                               conditioning_scale=cond_scale, added_cond_kwargs=self._added_cond,
                                               return_dict=False)                                     # :1277
                 eps = self.unet(x_in, t, encoder_hidden_states=pe, down_block_add_samples=down,
@@ -513,6 +525,21 @@ class StableDiffusionBrushNetPipeline:
             return (img, None)
         return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)
 
+    def _brushnet_shareable(self, cond: torch.Tensor, nb: int, do_cfg: bool) -> bool:
+        """Under classifier-free guidance the reference feeds BrushNet the duplicated batch (pipeline_brushnet.py:1256-1277:
+        torch.cat([latents] * 2), [negative | positive] prompt embeddings, the conditioning latents of the duplicated image
+        batch).  The BrushNet built by from_unet is attention-free (brushnet.py:484-486), so it never reads the prompt
+        embeddings: its two halves differ ONLY through the conditioning latents, whose VAE posterior the reference samples
+        independently per half (:1188 on the image doubled at :771-772).  When the two halves of `cond` are bit-identical
+        (conditioning_noise with equal halves, or cfg_shared_conditioning_sample) both halves are the same function of the
+        same inputs: BrushNet is evaluated once per image and the UNet's injection adds read each residual for both
+        halves (mf_gemm_desc.res1_rows).  Never when an added embedding depends on the prompt (SDXL's pooled text
+        embedding enters BrushNet-XL's time embedding)."""
+        if not (do_cfg and self.share_brushnet_cfg and self.brushnet.config.get("addition_embed_type") is None
+                and self.brushnet.config.get("class_embed_type") is None):
+            return False
+        return bool(torch.equal(cond[:nb], cond[nb:]))
+
     def _overlap(self, on: bool):
         """Turn the BrushNet || UNet stream overlap (models._RESIDUAL_EVENTS) on or off for the next forward calls."""
         if on and self.overlap_brushnet and self.device.type == "cuda":
@@ -551,7 +578,7 @@ class StableDiffusionBrushNetPipeline:
         # cross-attention K/V cache), so a graph captured before that points at freed buffers and must not be replayed.
         added = self._added_cond
         key = (tuple(latents.shape), tuple(pe.shape), tuple(cond.shape), float(guidance_scale), cond_scale, ptype, clip,
-               str(dev), id(self.unet), self.unet._weights_gen, id(self.brushnet), self.brushnet._weights_gen,
+               str(dev), id(self.unet), self.unet._weights_gen, id(self.brushnet), self.brushnet._weights_gen, self._brushnet_once,
                tuple((k, tuple(v.shape)) for k, v in sorted(added.items())) if added else None)
         st = self._graph_state if self._graph_state is not None and self._graph_state["key"] == key else None
         if st is None:
@@ -575,7 +602,9 @@ class StableDiffusionBrushNetPipeline:
 
         def one_step():
             x_in = torch.cat([lat] * 2)
-            down, mid, up = self.brushnet(x_in, t_cur, encoder_hidden_states=pe, brushnet_cond=cond,
+            once = self._brushnet_once
+            down, mid, up = self.brushnet(lat if once else x_in, t_cur, encoder_hidden_states=pe[:nb] if once else pe,
+                                          brushnet_cond=cond[:nb] if once else cond,
                                           conditioning_scale=cond_scale, added_cond_kwargs=added, return_dict=False)
             eps = self.unet(x_in, t_cur, encoder_hidden_states=pe, down_block_add_samples=down,
                             mid_block_add_sample=mid, up_block_add_samples=up, added_cond_kwargs=added,

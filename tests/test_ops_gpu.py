@@ -125,6 +125,39 @@ def test_conv_epilogue_temb_res_alpha_silu(prec_name, atol, rtol):
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
+@pytest.mark.parametrize("splitk", [1, 2])
+def test_conv_shared_residual_rows(prec_name, atol, rtol, splitk):
+    """mf_gemm_desc.res1_rows: a residual with 1/r of the output's batch is added to every replica (vector epilogue with
+    prefetched bf16 residuals, fp32 residuals, the split-K reduce, a linear call, and ops.add)."""
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(4, 32, 8, 8, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.05
+    b = torch.randn(64, generator=g)
+    r0 = torch.randn(4, 64, 8, 8, generator=g)
+    r1 = torch.randn(2, 64, 8, 8, generator=g)
+    if prec_name == "bf16":
+        x, w, r0, r1 = rb(x), rb(w), rb(r0), rb(r1)
+    ref = F.conv2d(x, w, b, padding=1) + r0 + torch.cat([r1, r1])
+    cw = ops.ConvWeight(w, b, prec, DEV)
+    for r1_dt in (prec.act, torch.float32):
+        y = ops.conv2d(nhwc(x, prec.act), cw, res0=nhwc(r0, prec.act), res1=nhwc(r1, r1_dt), splitk=splitk)
+        check(f"conv_shared_res1[{prec_name},sk{splitk},{r1_dt}]", nchw(y), ref, atol, rtol)
+    xl = torch.randn(6, 10, 32, generator=g)
+    wl = torch.randn(48, 32, generator=g) * 0.1
+    rl = torch.randn(2, 10, 48, generator=g)
+    if prec_name == "bf16":
+        xl, wl, rl = rb(xl), rb(wl), rb(rl)
+    yl = ops.linear(xl.to(DEV, prec.act), ops.ConvWeight(wl, None, prec, DEV), res1=rl.to(DEV, prec.act), splitk=splitk)
+    check(f"linear_shared_res1[{prec_name}]", yl, xl @ wl.T + torch.cat([rl] * 3), atol, rtol)
+    a = torch.randn(4, 5, 5, 8, generator=g)
+    bb = torch.randn(2, 5, 5, 8, generator=g)
+    check("add_shared", ops.add(a.to(DEV), bb.to(DEV), torch.float32), a + torch.cat([bb, bb]), 1e-6, 1e-6)
+    with pytest.raises(hip.MfhipError):
+        ops.conv2d(nhwc(x, prec.act), cw, res1=nhwc(torch.randn(3, 64, 8, 8), prec.act))
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
 @pytest.mark.parametrize("case", ["s2p1", "s2asym", "up", "cat", "cat_up", "1x1", "splitk"])
 def test_conv_variants(prec_name, atol, rtol, case):
     prec = ops.Precision.get(prec_name)
