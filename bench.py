@@ -175,7 +175,7 @@ def train_main(a, D):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     hip.load()
-    prec = a.precision if a.precision in ("fp32", "f16x3") else "f16x3"
+    prec = a.precision if a.precision in ("fp32", "f16x3", "bf16x1") else "f16x3"
     t0 = time.time()
     unet = UNet2DConditionModel(dict(SD15_UNET), precision=prec, device=device)
     unet.load_state_dict(synth.state_dict_for(unet.param_shapes(), 0))
@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl"],
                     help="sd15 = BASELINE.json's north-star workload; sdxl = the §8 f-3 secondary workload")
     ap.add_argument("--denoise-steps", type=int, default=50)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3", "bf16x3", "fp8"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3", "bf16x3", "bf16x1", "fp8"])
     ap.add_argument("--no-parity-mode", action="store_true",
                     help="skip the extra passes in the f16x3 parity mode (the mode that meets the 1e-3 latent bound)")
     ap.add_argument("--inputs", default="device", choices=["device", "host"],

@@ -38,6 +38,10 @@ extern "C" {
  * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the bf16 MFMA rate); the quantisation scales are
  * per A row / per W row fp32 vectors applied in the epilogue (mf_gemm_desc.a_scale / w_scale) */
 #define MF_FP8 4
+/* fp32 operands in memory (a_dtype == MF_F32, raw fp32 W), each rounded to bf16 (nearest-even) on its way into ONE bf16
+ * MFMA, fp32 accumulate: the arithmetic of the reference's --mixed_precision=bf16 autocast (train_brushnet_mirror.py:567,
+ * 1127-1131) with the activations still stored in fp32.  Training compute code (mf_gemm_conv, mf_conv_wgrad). */
+#define MF_BF16X1 5
 
 #define MF_OK 0
 #define MF_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -50,7 +54,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 10
+#define MF_ABI_VERSION 11
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -77,7 +81,8 @@ int mf_sizeof_groupnorm_desc(void);
  * ------------------------------------------------------------------------------------------ */
 typedef struct mf_gemm_desc {
     /* compute dtype: MF_BF16 (bf16 MFMA 32x32x16, fp32 accumulate), MF_F32 (fp32 MFMA 32x32x2) or a split code
-     * MF_F16X3 / MF_BF16X3 (fp32 operands, three 16-bit MFMAs per product; a_dtype must be MF_F32) */
+     * MF_F16X3 / MF_BF16X3 (fp32 operands, three 16-bit MFMAs per product; a_dtype must be MF_F32), MF_BF16X1 (fp32
+     * operands, one bf16 MFMA per product; raw W only) */
     int32_t dtype;
     /* A operand */
     const void* a0;       /* segment 0, NHWC */

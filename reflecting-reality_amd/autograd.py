@@ -34,7 +34,7 @@ def _key(t: torch.Tensor):
 
 class Tape:
     def __init__(self, code: int):
-        self.code = code                       # MF_F32 or MF_F16X3: the contraction mode of the backward GEMMs
+        self.code = code                       # MF_F32, MF_F16X3 or MF_BF16X1: the contraction mode of the backward GEMMs
         self.ops: List[Callable[[], None]] = []
         self.grads: Dict[int, torch.Tensor] = {}
         self.stop = set()                      # storages that need no gradient (the batch's inputs)

@@ -236,8 +236,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, min_waves(BM + (DXR ? 32 : 0
 void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;
     static_assert(!M16 || (DT == MF_BF16 && !A_F32), "the 16x16x32 form is instantiated for bf16 only");
-    constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3);
-    static_assert(!WPK || SPLIT, "a pre-split W operand only exists for the split codes");
+    constexpr bool X1 = DT == MF_BF16X1;      // fp32 operands rounded to bf16 (RNE) in registers, ONE MFMA per product
+    constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3 || X1);
+    static_assert(!WPK || (SPLIT && !X1), "a pre-split W operand only exists for the three-MFMA split codes");
     constexpr bool FP8 = (DT == MF_FP8);
     constexpr int ES = (DT == MF_BF16) ? 2 : (FP8 ? 1 : 4);   // element size of the operands in memory / LDS
     constexpr int AES = A_F32 ? 4 : ES;          // element size of the A storage dtype
@@ -495,7 +496,10 @@ void gemm_conv_kernel(const GemmArgs p) {
         unsigned h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if constexpr (DT == MF_F16X3) {
+            if constexpr (X1) {
+                h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                                   // nearest-even; no low half
+                l[e] = 0;
+            } else if constexpr (DT == MF_F16X3) {
                 const auto hh = __builtin_amdgcn_cvt_pkrtz(x[2 * e], x[2 * e + 1]);          // v_cvt_pkrtz_f16_f32
                 const auto ll = __builtin_amdgcn_cvt_pkrtz(x[2 * e] - (float)hh[0], x[2 * e + 1] - (float)hh[1]);
                 h[e] = __builtin_bit_cast(unsigned, hh);
@@ -569,8 +573,10 @@ void gemm_conv_kernel(const GemmArgs p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    mma16(al[i], bh[j], acc[i][j]);      // the small terms first
-                    mma16(ah[i], bl[j], acc[i][j]);
+                    if constexpr (!X1) {
+                        mma16(al[i], bh[j], acc[i][j]);      // the small terms first
+                        mma16(ah[i], bl[j], acc[i][j]);
+                    }
                     mma16(ah[i], bh[j], acc[i][j]);
                 }
         }
@@ -1663,7 +1669,7 @@ bool launch_tile_split(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
             case 22: launch_one<DT, 64, 128, 2, 2, false, 2, true, true>(a, grid, s); return true;
             default: break;
         }
-    } else if constexpr (DT == MF_F16X3) {
+    } else if constexpr (DT == MF_F16X3 || DT == MF_BF16X1) {
         // raw fp32 W (training: the optimizer rewrites the weights every step; dgrad weights): the big-conv tiles too
         switch (tile) {
             case 14: launch_one<DT, 128, 160, 4, 1, false, 2, false, false>(a, grid, s); return true;
@@ -1809,9 +1815,11 @@ extern "C" int mf_gemm_tile_shape(int tile, int* bm, int* bn) {
 
 extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(d != nullptr, "mf_gemm_conv: null descriptor");
-    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_BF16 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X3 || d->dtype == MF_FP8,
+    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_BF16 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X3 || d->dtype == MF_FP8 ||
+                     d->dtype == MF_BF16X1,
                  "mf_gemm_conv: bad dtype %d", d->dtype);
-    const bool split = d->dtype == MF_F16X3 || d->dtype == MF_BF16X3;
+    const bool split = d->dtype == MF_F16X3 || d->dtype == MF_BF16X3 || d->dtype == MF_BF16X1;
+    MF_CHECK_ARG(d->dtype != MF_BF16X1 || d->w_split == 0, "mf_gemm_conv: MF_BF16X1 takes the raw fp32 weight");
     MF_CHECK_ARG((d->dtype == MF_FP8) == (d->a_dtype == MF_FP8), "mf_gemm_conv: fp8 compute takes fp8 activations (and only those)");
     MF_CHECK_ARG(!split || d->a_dtype == MF_F32, "mf_gemm_conv: the split codes take fp32 activations");
     MF_CHECK_ARG(d->w_split == 0 || (d->w_split == 1 && split && d->ldw % 32 == 0),
@@ -2009,7 +2017,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     if (d->dtype == MF_FP8) {
         MF_CHECK_ARG(launch_tile_fp8(tile, a, grid, s), "mf_gemm_conv: tile %d is not instantiated for fp8", tile);
     } else if (split) {
-        const bool ok = d->dtype == MF_F16X3
+        const bool ok = d->dtype == MF_BF16X1 ? launch_tile_split<MF_BF16X1, false>(tile, a, grid, s)
+                        : d->dtype == MF_F16X3
                             ? (d->w_split ? launch_tile_split<MF_F16X3, true>(tile, a, grid, s) : launch_tile_split<MF_F16X3, false>(tile, a, grid, s))
                             : (d->w_split ? launch_tile_split<MF_BF16X3, true>(tile, a, grid, s) : launch_tile_split<MF_BF16X3, false>(tile, a, grid, s));
         MF_CHECK_ARG(ok, "mf_gemm_conv: tile %d is not instantiated for the split codes (w_split=%d)", tile, d->w_split);

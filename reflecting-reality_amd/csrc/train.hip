@@ -117,12 +117,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                         const int pp = 16 * s + 8 * h + 2 * e;
                         const float y0 = py[pp * WG_PITCH + 32 * t], y1 = py[(pp + 1) * WG_PITCH + 32 * t];
                         const float a0 = pa[pp * WG_PITCH + 32 * t], a1 = pa[(pp + 1) * WG_PITCH + 32 * t];
-                        const auto hy = __builtin_amdgcn_cvt_pkrtz(y0, y1);
-                        const auto ly = __builtin_amdgcn_cvt_pkrtz(y0 - (float)hy[0], y1 - (float)hy[1]);
-                        const auto ha = __builtin_amdgcn_cvt_pkrtz(a0, a1);
-                        const auto la = __builtin_amdgcn_cvt_pkrtz(a0 - (float)ha[0], a1 - (float)ha[1]);
-                        yh[e] = __builtin_bit_cast(unsigned, hy); yl[e] = __builtin_bit_cast(unsigned, ly);
-                        ah[e] = __builtin_bit_cast(unsigned, ha); al[e] = __builtin_bit_cast(unsigned, la);
+                        if constexpr (DT == MF_BF16X1) {       // one bf16 MFMA per product: operands rounded to nearest-even
+                            yh[e] = pack_bf16x2(y0, y1); ah[e] = pack_bf16x2(a0, a1);
+                            yl[e] = 0; al[e] = 0;
+                        } else {
+                            const auto hy = __builtin_amdgcn_cvt_pkrtz(y0, y1);
+                            const auto ly = __builtin_amdgcn_cvt_pkrtz(y0 - (float)hy[0], y1 - (float)hy[1]);
+                            const auto ha = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+                            const auto la = __builtin_amdgcn_cvt_pkrtz(a0 - (float)ha[0], a1 - (float)ha[1]);
+                            yh[e] = __builtin_bit_cast(unsigned, hy); yl[e] = __builtin_bit_cast(unsigned, ly);
+                            ah[e] = __builtin_bit_cast(unsigned, ha); al[e] = __builtin_bit_cast(unsigned, la);
+                        }
                     }
                     Yh[t] = __builtin_bit_cast(f16x8_t, uint4{yh[0], yh[1], yh[2], yh[3]});
                     Yl[t] = __builtin_bit_cast(f16x8_t, uint4{yl[0], yl[1], yl[2], yl[3]});
@@ -133,9 +138,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yl[i], Ah[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh[i], Al[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh[i], Ah[j], acc[i][j], 0, 0, 0);
+                        if constexpr (DT == MF_BF16X1) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Yh[i]),
+                                                                                __builtin_bit_cast(bf16x8_t, Ah[j]), acc[i][j], 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yl[i], Ah[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh[i], Al[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yh[i], Ah[j], acc[i][j], 0, 0, 0);
+                        }
                     }
             }
         }
@@ -519,7 +529,7 @@ extern "C" int64_t mf_conv_wgrad_ws_floats(const mf_wgrad_desc* d) {
 
 extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     MF_CHECK_ARG(d != nullptr, "mf_conv_wgrad: null descriptor");
-    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_F16X3, "mf_conv_wgrad: dtype must be MF_F32 or MF_F16X3");
+    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X1, "mf_conv_wgrad: dtype must be MF_F32, MF_F16X3 or MF_BF16X1");
     MF_CHECK_ARG(d->a0 && d->dy && d->dw, "mf_conv_wgrad: null a0/dy/dw");
     MF_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && (d->a1 != nullptr) == (d->c1 > 0) && d->c0 % 4 == 0 && d->c1 % 4 == 0 &&
                      d->lda0 % 4 == 0 && d->lda1 % 4 == 0,
@@ -567,6 +577,7 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)a.splitm);
     if (d->dtype == MF_F32) hipLaunchKernelGGL(conv_wgrad_kernel<MF_F32>, grid, dim3(256), 0, s, a);
+    else if (d->dtype == MF_BF16X1) hipLaunchKernelGGL(conv_wgrad_kernel<MF_BF16X1>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(conv_wgrad_kernel<MF_F16X3>, grid, dim3(256), 0, s, a);
     MF_CHECK_LAUNCH("mf_conv_wgrad");
     if (!direct) {

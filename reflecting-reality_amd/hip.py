@@ -14,10 +14,10 @@ import torch
 
 from . import _build
 
-MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8 = 0, 1, 2, 3, 4
+MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1 = 0, 1, 2, 3, 4, 5
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class MfhipError(RuntimeError):
@@ -413,7 +413,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     tkey = None
     if tile == 0 and splitk in (0, 1) and AUTOTUNE:
         tkey = (code, d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), int(c1 > 0),
-                nz, int(splitk == 1), act, h_out, w_out) + ((w_split,) if code >= MF_F16X3 else ())
+                nz, int(splitk == 1), act, h_out, w_out) + ((w_split,) if code in (MF_F16X3, MF_BF16X3) else ())
         d.tile, d.splitk = _tuned_config(d, tkey)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -702,7 +702,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, code: int
     """dw[n][kh*kw*(c0+c1)] (+)= sum_m dy[m][n] * im2col(x | x1)[m][:] (mf_conv_wgrad)."""
     _f32(x, x1, dy, dw)
     d = WgradDesc()
-    d.dtype = MF_F16X3 if code == MF_F16X3 else MF_F32
+    d.dtype = code if code in (MF_F16X3, MF_BF16X1) else MF_F32
     d.a0, d.a1, d.c0, d.c1, d.lda0, d.lda1 = _ptr(x), _ptr(x1), c0, c1, c0, c1
     d.batch, d.h_in, d.w_in, d.h_out, d.w_out = batch, h_in, w_in, h_out, w_out
     d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.upsample = kh, kw, stride, pad_t, pad_l, int(upsample)

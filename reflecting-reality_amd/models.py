@@ -156,10 +156,11 @@ class HipModel:
     def prepare_training(self, requires_grad: Optional[bool] = None):
         """Rebuild the device parameters as views of one flat fp32 arena in the kernels' layout (raw fp32 weights — the
         optimizer updates them in place every step, so nothing is pre-split or fused) plus, when the model trains, a
-        gradient arena of the same layout.  Precision must be fp32-class ('fp32' or 'f16x3')."""
+        gradient arena of the same layout.  Precision must keep fp32 storage ('fp32', 'f16x3', or 'bf16x1': the arithmetic
+        of the reference's --mixed_precision=bf16)."""
         if self.prec.act != F32:
             raise NotImplementedError("training runs with fp32 master weights and activations: build the model with "
-                                      "precision='fp32' or 'f16x3' (bf16 autocast is not built)")
+                                      "precision='fp32', 'f16x3' or 'bf16x1' (bf16 products, fp32 storage)")
         if requires_grad is not None:
             self._requires_grad = bool(requires_grad)
         src = self.state_dict() if (self.training or self._src is not None) else None

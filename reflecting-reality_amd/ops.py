@@ -7,6 +7,8 @@ compute mode of a whole model:
   "f16x3"  fp32 storage, every GEMM operand split into two fp16 halves and multiplied with three fp16 MFMAs
            (22 significant bits): the parity mode that runs on the fast matrix pipe.  "split" / "parity" are
            aliases.  "bf16x3" is the same scheme on bf16 halves (16 bits, fp32 exponent range).
+  "bf16x1" fp32 storage, every GEMM operand rounded to bf16 (nearest-even) for ONE bf16 MFMA per product: the
+           arithmetic of the reference's --mixed_precision=bf16 training (no loss scaling needed); training only.
 """
 from __future__ import annotations
 
@@ -24,10 +26,10 @@ TAPE: Optional["autograd.Tape"] = None
 
 @dataclass(frozen=True)
 class Precision:
-    name: str                     # "bf16" | "fp32" | "f16x3" | "bf16x3" | "fp8"
+    name: str                     # "bf16" | "fp32" | "f16x3" | "bf16x3" | "bf16x1" | "fp8"
     compute: torch.dtype          # dtype of the GEMM operands in memory
     act: torch.dtype              # activation storage dtype
-    code: int = -1                # mf_gemm_desc.dtype (MF_BF16 / MF_F32 / MF_F16X3 / MF_BF16X3)
+    code: int = -1                # mf_gemm_desc.dtype (MF_BF16 / MF_F32 / MF_F16X3 / MF_BF16X3 / MF_BF16X1)
     fp8_linear: bool = False      # "fp8": the transformer blocks' Linear layers run on fp8 e4m3 operands (the rest bf16)
 
     @staticmethod
@@ -42,6 +44,8 @@ class Precision:
             return Precision("f16x3", torch.float32, torch.float32, hip.MF_F16X3)
         if name == "bf16x3":
             return Precision("bf16x3", torch.float32, torch.float32, hip.MF_BF16X3)
+        if name in ("bf16x1", "mixed-bf16"):
+            return Precision("bf16x1", torch.float32, torch.float32, hip.MF_BF16X1)
         if name == "fp8":
             return Precision("fp8", torch.bfloat16, torch.bfloat16, hip.MF_BF16, True)
         if name == torch.float16:
@@ -49,15 +53,19 @@ class Precision:
             # storage mode and will not silently substitute another one
             raise ValueError("torch_dtype=torch.float16 is not built: use torch.bfloat16 (the fast mode), torch.float32 "
                              "or precision='f16x3' (fp32 storage, fp16 matrix pipe)")
-        raise ValueError(f"unsupported precision {name!r} (use 'bf16', 'fp8', 'fp32', 'f16x3' or 'bf16x3')")
+        raise ValueError(f"unsupported precision {name!r} (use 'bf16', 'fp8', 'fp32', 'f16x3', 'bf16x3' or 'bf16x1')")
 
     @property
     def vec(self) -> int:         # elements per 16-byte vector: channel counts must be multiples of this
         return 8 if self.compute == torch.bfloat16 else 4
 
     @property
-    def split(self) -> bool:
+    def split(self) -> bool:      # three MFMAs per product on (hi, lo) halves: weights are pre-split, gradients loss-scaled
         return self.code in (hip.MF_F16X3, hip.MF_BF16X3)
+
+    @property
+    def tape_code(self) -> int:   # contraction mode of the backward GEMMs (fp32 storage modes only)
+        return self.code if self.code in (hip.MF_F16X3, hip.MF_BF16X3, hip.MF_BF16X1) else hip.MF_F32
 
 
 def _round_up(x: int, m: int) -> int:

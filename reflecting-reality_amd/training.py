@@ -174,7 +174,7 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
         raise RuntimeError("train_step: call model.prepare_training() first")
     optimizer.zero_grad()
     prec = model.brushnet.prec
-    tape = autograd.Tape(prec.code if prec.split else hip.MF_F32)
+    tape = autograd.Tape(prec.tape_code)
     if grad_sync is not None:
         grad_sync.begin(tape)
     ops.TAPE = tape
