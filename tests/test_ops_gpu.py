@@ -233,6 +233,24 @@ def test_linear(prec_name, atol, rtol, m, k, n):
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
+@pytest.mark.parametrize("tile,splitk", [(1, 1), (2, 1), (6, 3), (14, 1), (3, 2)])
+def test_linear_column_panels_and_flattened_splits(prec_name, atol, rtol, tile, splitk):
+    """Wide 1x1 GEMMs run their column tiles in panels of 8 (the last panel narrower) and K splits are part of the 1-D
+    block order: every (tile_m, tile_n, split) must be visited exactly once — N = 1448 gives 12 / 23 / 10 column tiles, M
+    and N both ragged."""
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(55)
+    m, k, n = 700, 192, 1448
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / math.sqrt(k)
+    b = torch.randn(n, generator=g)
+    if prec_name == "bf16":
+        x, w = rb(x), rb(w)
+    y = ops.linear(x.to(DEV, prec.act), ops.ConvWeight(w, b, prec, DEV), tile=tile, splitk=splitk)
+    check(f"linear_panels[{prec_name},tile{tile},sk{splitk}]", y, F.linear(x, w, b), atol, rtol)
+
+
+@pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
 def test_linear_t(prec_name, atol, rtol):
     prec = ops.Precision.get(prec_name)
     g = torch.Generator().manual_seed(6)
