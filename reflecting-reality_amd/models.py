@@ -627,6 +627,25 @@ class _UNetCore(HipModel):
             self._ehs_gen = getattr(self, "_ehs_gen", 0) + 1
         return self._ehs_val
 
+    def bind_prompt(self, encoder_hidden_states: torch.Tensor) -> bool:
+        """(Re)compute everything that depends only on the prompt embeddings — their device copy and the K / V^T of every
+        cross-attention layer — into the persistent buffers the forward pass (and a captured denoise graph) reads,
+        without running a forward pass.  Returns False when the buffers do not exist yet or no longer fit (first call,
+        new prompt shape): the caller then runs one eager forward, which creates them."""
+        if not self._cross_kv:
+            return False
+        ctx = self._bind_prompt(encoder_hidden_states)
+        for b, kv in list(self._cross_kv.items()):
+            if kv[2] == self._ehs_gen:
+                continue
+            if kv[0].shape[:2] != ctx.shape[:2]:
+                return False
+            skv = ctx.shape[1]
+            ops.linear(ctx, self.P[b + "to_k"], out=kv[0])
+            ops.linear_t(ctx, self.P[b + "to_v"], (skv + 7) // 8 * 8, out=kv[1])
+            self._cross_kv[b] = (kv[0], kv[1], self._ehs_gen)
+        return True
+
     def _transformer(self, p: str, x: torch.Tensor, ehs: torch.Tensor, heads: int,
                      inj: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Transformer2DModel + BasicTransformerBlock(s) (transformer_2d.py:334-430, attention.py:291-412)."""

@@ -14,6 +14,7 @@ the pipeline a transformers `text_encoder` + `tokenizer` pair.
 """
 from __future__ import annotations
 
+import os
 import time
 
 from dataclasses import dataclass
@@ -614,12 +615,16 @@ class StableDiffusionBrushNetPipeline:
             else:
                 st["eps"].copy_(hip.cfg_combine(eps[:nb], eps[nb:], float(guidance_scale)))         # :1310-1312
 
+        # A graph captured by an earlier call with this key serves every step, the first included: what depends on the
+        # prompt alone (its device copy, the cross-attention K / V^T) is recomputed into the buffers the graph reads.
+        replay_all = (st["graph"] is not None and os.environ.get("MFHIP_EAGER_FIRST") != "1"      # A/B switch
+                      and self.unet.bind_prompt(pe))
         for i in range(len(ts)):
             t_cur.copy_(tvals[i:i + 1])
             if fused_ddim:
                 coef_cur.copy_(coefs[i])
-            if i == 0:
-                one_step()                                   # eager: tunes GEMMs, (re)binds the prompt K/V, sizes scratch
+            if i == 0 and not replay_all:
+                one_step()                                   # eager: tunes GEMMs, binds the prompt K/V, sizes scratch
             else:
                 if st["graph"] is None:
                     torch.cuda.synchronize()
