@@ -208,6 +208,10 @@ def train_main(a, D):
     reduce_device = "cpu" if backend == "gloo" else device
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=reduce_device)
     assert torch.isfinite(loss).all() and torch.isfinite(norm).all()
+    # configs[3] asks for the all-reduce time beside samples/s: one un-overlapped pass over every gradient bucket, after
+    # the timed steps (inside a step the buckets are reduced on a side stream under the backward pass)
+    ar_ms = sync.time_all_reduce() if sync is not None else None
+    ar_bytes = sum(m.num_arena_floats() for m in model.get_trainable_modules()) * 4
     if rank == 0:
         gflop = 3 * 441.3 + 2 * 803.3            # per sample: BrushNet fwd + dgrad + wgrad, frozen UNet fwd + dgrad (no CFG)
         step_s = elapsed / a.steps
@@ -219,6 +223,9 @@ def train_main(a, D):
             "config": {"workload": f"train_brushnet_mirror.py step, per-GPU batch {b} x {a.size}x{a.size}, BrushNet(6 cond ch) trainable / UNet "
                                    f"{'trainable' if a.train_base_unet else 'frozen'}, clip 1.0, AdamW lr 1e-5, random-init weights", "per_gpu_batch": b, "global_batch": b * world,
                        "parallelism": f"data-parallel x{world}" + (" (bucketed gradient all-reduce over RCCL)" if world > 1 else "")},
+            "all_reduce": ({"ms": round(ar_ms, 2), "bytes": ar_bytes, "GB/s_per_rank": round(2 * (world - 1) / max(world, 1) * ar_bytes / (ar_ms * 1e-3) / 1e9, 1),
+                            "note": "one un-overlapped bucketed all-reduce of the gradient arenas (64 Mi-float buckets), measured after the timed steps; "
+                                    "in the step it runs on a side stream under the backward pass"} if ar_ms else None),
             "achieved_tflops": round(b * gflop * 1e9 / step_s / 1e12, 2),
             "algorithmic_gflop_per_sample": round(gflop, 1), "last_loss": round(float(loss), 5), "last_grad_norm": round(float(norm), 5)}),
             flush=True)

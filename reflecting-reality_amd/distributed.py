@@ -10,7 +10,7 @@ contract asks for (RCCL when the tensors are on the GPU, gloo on the CPU for tes
 from __future__ import annotations
 
 import os
-from typing import List, Sequence, Tuple, TypeVar
+from typing import List, Optional, Sequence, Tuple, TypeVar
 
 import torch
 import torch.distributed as dist
@@ -159,6 +159,31 @@ class GradBuckets:
                 hip.axpby_n([g], [1.0 / self.world], out=g)
             else:
                 g.mul_(1.0 / self.world)          # CPU (gloo) test path only
+
+
+    def time_all_reduce(self, reps: int = 3) -> Optional[float]:
+        """Milliseconds one un-overlapped all-reduce of every gradient bucket takes (outside any training step: the arenas are
+        summed `reps` times and left scaled — call it after the last optimizer step; BASELINE.json configs[3] asks for this
+        number beside samples/s).  None with one rank."""
+        if self.world == 1 and not self.force:
+            return None
+        import time
+        bufs = []
+        for p in self._plan:
+            for b in range(p["nb"]):
+                bufs.append(p["model"].flat_g[b * self.bucket_floats: min((b + 1) * self.bucket_floats, p["n"])])
+        if not bufs[0].is_cuda or dist.get_backend() == "gloo":
+            return None
+        torch.cuda.synchronize()
+        for buf in bufs:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)           # warm the communicator for these sizes
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for buf in bufs:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
 
 
 def gather_mean(value: torch.Tensor) -> float:
