@@ -204,7 +204,7 @@ def upsample(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
 # BrushNet (models/brushnet.py:678-925)
 # ---------------------------------------------------------------------------------------------
 def brushnet_forward(sd: SD, cfg: dict, sample: torch.Tensor, timestep, brushnet_cond: torch.Tensor,
-                     conditioning_scale: float = 1.0, added: Optional[dict] = None
+                     conditioning_scale: float = 1.0, added: Optional[dict] = None, guess_mode: bool = False
                      ) -> Tuple[List[torch.Tensor], torch.Tensor, List[torch.Tensor]]:
     g, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     nlev = len(cfg["block_out_channels"])
@@ -237,6 +237,11 @@ def brushnet_forward(sd: SD, cfg: dict, sample: torch.Tensor, timestep, brushnet
             up_res.append(x)
     bn_up = [F.conv2d(r, sd[f"brushnet_up_blocks.{k}.weight"], sd[f"brushnet_up_blocks.{k}.bias"])
              for k, r in enumerate(up_res)]                                            # :890-893
+    if guess_mode:                                                                     # :896-902: 0.1 ... 1.0, log-spaced
+        scales = torch.logspace(-1, 0, len(bn_down) + 1 + len(bn_up)) * conditioning_scale
+        nd = len(bn_down)
+        return ([d * sc for d, sc in zip(bn_down, scales[:nd])], bn_mid * scales[nd],
+                [u * sc for u, sc in zip(bn_up, scales[nd + 1:])])
     s = conditioning_scale                                                             # :904-906
     return [d * s for d in bn_down], bn_mid * s, [u * s for u in bn_up]
 
@@ -655,14 +660,23 @@ def build_conditioning(vae_sd: SD, vae_cfg: dict, image: torch.Tensor, mask: tor
 
 def denoise(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, scheduler, latents: torch.Tensor,
             cond_latents: torch.Tensor, prompt_embeds_2b: torch.Tensor, num_steps: int, guidance_scale: float = 7.5,
-            conditioning_scale: float = 1.0, trace: Optional[list] = None, added: Optional[dict] = None) -> torch.Tensor:
+            conditioning_scale: float = 1.0, trace: Optional[list] = None, added: Optional[dict] = None,
+            guess_mode: bool = False) -> torch.Tensor:
     """The hot loop (pipeline_brushnet.py:1250-1332, pipeline_brushnet_sd_xl.py:1398-1500) with CFG;
-    prompt_embeds_2b = cat([negative, positive]); `added` = SDXL's added_cond_kwargs for the duplicated batch."""
+    prompt_embeds_2b = cat([negative, positive]); `added` = SDXL's added_cond_kwargs for the duplicated batch.
+    guess_mode (:1260-1264, 1287-1293): BrushNet sees only the conditional batch (cond_latents of the UN-duplicated
+    images), its residuals are log-scaled and the unconditional half of the UNet gets zeros."""
     scheduler.set_timesteps(num_steps)
     latents = latents * scheduler.init_noise_sigma
     for t in scheduler.timesteps:
         x2 = torch.cat([latents] * 2)
-        down, mid, up = brushnet_forward(bn_sd, bn_cfg, x2, t, cond_latents, conditioning_scale, added)
+        if guess_mode:
+            down, mid, up = brushnet_forward(bn_sd, bn_cfg, latents, t, cond_latents, conditioning_scale, added, guess_mode=True)
+            down = [torch.cat([torch.zeros_like(d), d]) for d in down]
+            mid = torch.cat([torch.zeros_like(mid), mid])
+            up = [torch.cat([torch.zeros_like(u), u]) for u in up]
+        else:
+            down, mid, up = brushnet_forward(bn_sd, bn_cfg, x2, t, cond_latents, conditioning_scale, added)
         eps = unet_forward(unet_sd, unet_cfg, x2, t, prompt_embeds_2b, down, mid, up, added)
         eu, ec = eps.chunk(2)
         eps = eu + guidance_scale * (ec - eu)                                            # :1310-1312

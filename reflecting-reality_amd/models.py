@@ -863,13 +863,13 @@ class BrushNetModel(_UNetCore):
             raise ValueError(f"unknown `brushnet_conditioning_channel_order`: {order}")        # brushnet.py:741
         if not self._ready:
             raise RuntimeError("BrushNetModel has no parameters loaded")
-        if guess_mode:
-            raise NotImplementedError("guess_mode logspace scaling (brushnet.py:896-902) is off in every MirrorFusion config")
+        if guess_mode and ops.TAPE is not None:
+            raise NotImplementedError("guess_mode is an inference feature")
         if class_labels is not None or timestep_cond is not None or attention_mask is not None:
             raise NotImplementedError("class/timestep_cond/attention_mask inputs are outside the SD1.5 / SDXL hot path")
         side = self.side_stream
         if side is None:
-            d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, None, added_cond_kwargs)
+            d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, None, added_cond_kwargs, guess_mode)
         else:
             main = torch.cuda.current_stream(self.device)
             _RESIDUAL_EVENTS.clear()
@@ -882,30 +882,41 @@ class BrushNetModel(_UNetCore):
                 _RESIDUAL_EVENTS[t.data_ptr()] = ev
 
             with torch.cuda.stream(side):
-                d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs)
+                d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs,
+                                             guess_mode)
         if not return_dict:
             return d, m, u
         return BrushNetOutput(down_block_res_samples=d, mid_block_res_sample=m, up_block_res_samples=u)
 
     side_stream: Optional["torch.cuda.Stream"] = None
 
-    def _forward_impl(self, sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs=None):
+    def _forward_impl(self, sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs=None,
+                      guess_mode: bool = False):
         """Each zero-conv (brushnet.py:889-894) runs right after the feature it reads is produced — the same
-        arithmetic as the reference's end-of-forward loops, but residual k is final as early as possible."""
+        arithmetic as the reference's end-of-forward loops, but residual k is final as early as possible.
+        guess_mode (brushnet.py:896-902): residual k of the [down | mid | up] list is scaled by logspace(-1, 0)[k] *
+        conditioning_scale (fp32, like the reference's tensor arithmetic) instead of conditioning_scale."""
         c = self.config
         bsz = sample.shape[0]
-        s = float(conditioning_scale)
+        n = len(c["block_out_channels"])
+        lpb = c["layers_per_block"]
+        n_down, n_up = 1 + n * lpb + (n - 1), n * (lpb + 1) + (n - 1)
+        if guess_mode:
+            sc = (torch.logspace(-1, 0, n_down + 1 + n_up) * conditioning_scale).tolist()
+        else:
+            sc = [float(conditioning_scale)] * (n_down + 1 + n_up)
+        scale_of = {f"brushnet_down_blocks.{k}": sc[k] for k in range(n_down)}
+        scale_of["brushnet_mid_block"] = sc[n_down]
+        scale_of.update({f"brushnet_up_blocks.{k}": sc[n_down + 1 + k] for k in range(n_up)})
         temb = self._time_embedding(timestep, bsz, added_cond_kwargs)
         x = hip.pack_nhwc(sample.to(self.device).float().contiguous(), brushnet_cond.to(self.device).float().contiguous(),
                           self.cin_pad, self.prec.act)                                            # :810 cat + pad
         if ops.TAPE is not None:
             ops.TAPE.no_grad(x)            # the batch's own inputs need no gradient
         x = ops.conv2d(x, self.P["conv_in_condition"])
-        n = len(c["block_out_channels"])
-        lpb = c["layers_per_block"]
 
         def zero_conv(name: str, r: torch.Tensor) -> torch.Tensor:
-            y = ops.conv2d(r, self.P[name], padding=0, alpha=s)
+            y = ops.conv2d(r, self.P[name], padding=0, alpha=scale_of[name])
             if publish is not None:
                 publish(y)
             return to_nchw_view(y)

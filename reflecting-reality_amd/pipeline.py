@@ -424,8 +424,10 @@ class StableDiffusionBrushNetPipeline:
         callback_steps = kwargs.pop("callback_steps", None)
         if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
             raise NotImplementedError("IP-Adapter inputs are outside the BASELINE configs (SURVEY.md §2 #14)")
-        if guess_mode or cross_attention_kwargs or clip_skip is not None or timesteps is not None:
-            raise NotImplementedError("guess_mode / cross_attention_kwargs / clip_skip / custom timesteps are not built")
+        if cross_attention_kwargs or clip_skip is not None or timesteps is not None:
+            raise NotImplementedError("cross_attention_kwargs / clip_skip / custom timesteps are not built")
+        if guess_mode and type(self) is not StableDiffusionBrushNetPipeline:
+            raise NotImplementedError("guess_mode is built for the SD1.5 pipeline")
         if isinstance(control_guidance_start, list) or isinstance(control_guidance_end, list):
             control_guidance_start = control_guidance_start[0] if isinstance(control_guidance_start, list) else control_guidance_start
             control_guidance_end = control_guidance_end[0] if isinstance(control_guidance_end, list) else control_guidance_end
@@ -453,9 +455,10 @@ class StableDiffusionBrushNetPipeline:
             else:
                 ww, hh = first.size
             height, width = height or int(hh), width or int(ww)
-        cond = self.build_conditioning(image, mask, depth, height, width, nb, num_images_per_prompt, do_cfg,
+        # guess_mode (:771-772, 1260-1264): the conditioning is NOT doubled, BrushNet sees the conditional batch only
+        cond = self.build_conditioning(image, mask, depth, height, width, nb, num_images_per_prompt, do_cfg and not guess_mode,
                                        conditioning_noise, normals)
-        self._brushnet_once = self._brushnet_shareable(cond, nb, do_cfg)
+        self._brushnet_once = (not guess_mode) and self._brushnet_shareable(cond, nb, do_cfg)
 
         self.scheduler.set_timesteps(num_inference_steps, device=self.device)                       # :1171
         ts = self.scheduler.timesteps
@@ -472,7 +475,7 @@ class StableDiffusionBrushNetPipeline:
             _timing["denoise_end"] = torch.cuda.Event(enable_timing=True)
             _timing["denoise_start"].record()
         use_graph = (self.use_hip_graph and do_cfg and callback is None and (fused_ddim or eta == 0.0)
-                     and all(k == 1.0 for k in keep) and len(ts) > 2)
+                     and all(k == 1.0 for k in keep) and len(ts) > 2 and not guess_mode)
         with self.progress_bar(total=num_inference_steps) as bar:
             if use_graph:
                 latents = self._denoise_graph(latents, ts, pe, cond, nb, guidance_scale, float(brushnet_conditioning_scale),
@@ -480,15 +483,22 @@ class StableDiffusionBrushNetPipeline:
                                               negative_prompt_embeds, bar, fused_ddim, eta, generator)
                 ts = []
             for i, t in enumerate(ts):                                                               # :1250 HOT LOOP
-                self._overlap(i > 0)                         # step 0 autotunes GEMM tiles: keep its timings undisturbed
+                # step 0 autotunes GEMM tiles: keep its timings undisturbed; guess_mode re-packs the residuals on this
+                # stream (the per-residual events are keyed by the tensors BrushNet returned)
+                self._overlap(i > 0 and not guess_mode)
                 x_in = torch.cat([latents] * 2) if do_cfg else latents                               # :1256
                 x_in = self.scheduler.scale_model_input(x_in, t)
                 cond_scale = float(brushnet_conditioning_scale) * keep[i]
-                once = self._brushnet_once
-                down, mid, up = self.brushnet(x_in[:nb] if once else x_in, t, encoder_hidden_states=pe[:nb] if once else pe,
+                once = self._brushnet_once or (guess_mode and do_cfg)      # BrushNet on the conditional batch only
+                down, mid, up = self.brushnet(x_in[nb:] if (guess_mode and do_cfg) else x_in[:nb] if once else x_in, t,
+                                              encoder_hidden_states=pe[nb:] if (guess_mode and do_cfg) else pe[:nb] if once else pe,
                                               brushnet_cond=cond[:nb] if once else cond,
                                               conditioning_scale=cond_scale, added_cond_kwargs=self._added_cond,
-                                              return_dict=False)                                     # :1277
+                                              guess_mode=guess_mode, return_dict=False)              # :1277
+                if guess_mode and do_cfg:           # zeros keep the unconditional half unchanged (:1287-1293); copies only
+                    down = [torch.cat([torch.zeros_like(d), d]) for d in down]
+                    mid = torch.cat([torch.zeros_like(mid), mid])
+                    up = [torch.cat([torch.zeros_like(u), u]) for u in up]
                 eps = self.unet(x_in, t, encoder_hidden_states=pe, down_block_add_samples=down,
                                 mid_block_add_sample=mid, up_block_add_samples=up, added_cond_kwargs=self._added_cond,
                                 return_dict=False)[0]                                                # :1296

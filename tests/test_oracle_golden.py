@@ -42,6 +42,30 @@ def test_tiny_models_match_reference():
     report("vae_decode", R.vae_decode(vsd, R.TINY_VAE, z), G["vae_decode"], **TOL)
 
 
+def test_guess_mode_matches_reference():
+    """guess_mode (brushnet.py:896-902; pipeline_brushnet.py:1260-1264,1287-1293): log-spaced residual scales, BrushNet on
+    the conditional batch only, zeros for the unconditional half — residuals and the 4-step DDIM latents of the imported
+    reference (tools/make_golden.py::tiny_guess_mode)."""
+    usd, bsd, vsd = sds("tiny")
+    G = golden("tiny_guess_mode.npz")
+    x, cond, ehs, g = tiny_inputs()
+    bcfg = R.brushnet_config(R.TINY_UNET, 6)
+    down, mid, up = R.brushnet_forward(bsd, bcfg, x, 501, cond, 0.8, guess_mode=True)
+    for i, d in enumerate(down):
+        report(f"guess bn_down_{i}", d, G[f"bn_down_{i}"], **TOL)
+    report("guess bn_mid", mid, G["bn_mid"], **TOL)
+    for i, u in enumerate(up):
+        report(f"guess bn_up_{i}", u, G[f"bn_up_{i}"], **TOL)
+    inp = synth.pipeline_inputs(2, 16, 32, seed=4321, cross_dim=32, vae_scale=2)
+    ocond = R.build_conditioning(vsd, R.TINY_VAE, inp["image"], inp["mask"], inp["depth"], torch.from_numpy(G["vae_noise"]),
+                                 cfg_dup=False)
+    trace = []
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    R.denoise(usd, R.TINY_UNET, bsd, bcfg, R.DDIMRef(**R.SD15_SCHED), inp["latents"], ocond, pe, 4, 7.5, 0.9, trace, guess_mode=True)
+    for i, l in enumerate(trace):
+        report(f"guess latents {i}", l, G[f"latents_{i}"], **TOL)
+
+
 @pytest.mark.parametrize("name", ["ddim", "pndm", "unipc"])
 def test_tiny_pipeline_matches_reference(name):
     usd, bsd, vsd = sds("tiny")

@@ -246,6 +246,30 @@ def test_brushnet_evaluated_once_when_cfg_halves_are_identical():
     pipe.cfg_shared_conditioning_sample = False
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-3), ("f16x3", 1e-3)])
+def test_guess_mode_pipeline_against_reference(prec, tol):
+    """guess_mode=True (pipeline_brushnet.py:771-772,1260-1264,1287-1293): conditioning not doubled, BrushNet on the
+    conditional batch with log-spaced residual scales, zeros for the unconditional half — per-step latents of the
+    imported reference (tests/golden/tiny_guess_mode.npz)."""
+    G = golden("tiny_guess_mode.npz")
+    pipe = _tiny_pipe(prec)
+    inp = synth.pipeline_inputs(2, 16, 32, seed=4321, cross_dim=32, vae_scale=2)
+    trace = []
+
+    def cb(p_, i, t, kw_):
+        trace.append(kw_["latents"].float().cpu().clone())
+        return {}
+
+    got = _run(pipe, inp, 4, 16, 32, torch.from_numpy(G["vae_noise"]), brushnet_conditioning_scale=0.9, guess_mode=True,
+               callback_on_step_end=cb)
+    assert len(trace) == 4
+    for i, l in enumerate(trace):
+        report(f"guess-mode latents step {i}[{prec}]", l, G[f"latents_{i}"], atol=tol)
+    report(f"guess-mode final[{prec}]", got, G["latents_3"], atol=tol)
+    with pytest.raises(ValueError):          # the conditioning is not CFG-doubled in guess mode: noise for 2B images is a mismatch
+        _run(pipe, inp, 2, 16, 32, torch.randn(4, 4, 8, 16), guess_mode=True)
+
+
 @pytest.mark.parametrize("name", ["pndm", "unipc"])
 def test_multistep_schedulers_graph_matches_eager(name):
     """PNDM / UniPC: the captured model evaluation + eager scheduler step gives the eager loop's latents bit for bit."""

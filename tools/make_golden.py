@@ -380,6 +380,57 @@ def tiny_train():
     print("tiny training backward fixture written")
 
 
+def tiny_guess_mode():
+    """guess_mode (brushnet.py:896-902, pipeline_brushnet.py:1260-1264,1287-1293): log-spaced residual scales, BrushNet on
+    the conditional batch only, zeros for the unconditional half.  Model-level residuals + a 4-step DDIM pipeline run."""
+    ucfg, vcfg = R.TINY_UNET, R.TINY_VAE
+    (unet, unet_sd, _), (brushnet, bn_sd, _), (vae, vae_sd, _) = models(ucfg, vcfg, 0)
+    bcfg = R.brushnet_config(ucfg, 6)
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    cond = torch.randn(2, 6, 8, 8, generator=g)
+    ehs = torch.randn(2, 77, ucfg["cross_attention_dim"], generator=g)
+    out = {}
+    down, mid, up = brushnet(x, 501, encoder_hidden_states=ehs, brushnet_cond=cond, conditioning_scale=0.8, guess_mode=True,
+                             return_dict=False)
+    od, om, ou = R.brushnet_forward(bn_sd, bcfg, x, 501, cond, 0.8, guess_mode=True)
+    print("[guess] brushnet oracle-vs-ref:", max(maxdiff(a, b) for a, b in zip(list(down) + [mid] + list(up), od + [om] + ou)))
+    for i, d in enumerate(down):
+        out[f"bn_down_{i}"] = d.numpy()
+    out["bn_mid"] = mid.numpy()
+    for i, u in enumerate(up):
+        out[f"bn_up_{i}"] = u.numpy()
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=R.SD15_SCHED["beta_start"], beta_end=R.SD15_SCHED["beta_end"],
+                          beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=brushnet,
+                                           scheduler=sched, safety_checker=None, feature_extractor=None,
+                                           requires_safety_checker=False, depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(2, 16, 32, seed=4321, cross_dim=ucfg["cross_attention_dim"], vae_scale=2)
+    trace = []
+
+    def cb(p_, i, t, kw_):
+        trace.append(kw_["latents"].clone())
+        return {}
+
+    torch.manual_seed(778)           # the reference draws the VAE posterior noise from the global RNG (:1188); not CFG-doubled here
+    res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
+               mask=inp["mask"], depth=inp["depth"], num_inference_steps=4, guidance_scale=7.5, latents=inp["latents"].clone(),
+               output_type="latent", brushnet_conditioning_scale=0.9, guess_mode=True, callback_on_step_end=cb, height=16, width=32)
+    torch.manual_seed(778)
+    vae_noise = torch.randn(2, 4, 8, 16)
+    ocond = R.build_conditioning(vae_sd, vcfg, inp["image"], inp["mask"], inp["depth"], vae_noise, cfg_dup=False)
+    otrace = []
+    pe = torch.cat([inp["negative_prompt_embeds"], inp["prompt_embeds"]])
+    R.denoise(unet_sd, ucfg, bn_sd, bcfg, R.DDIMRef(**R.SD15_SCHED), inp["latents"], ocond, pe, 4, 7.5, 0.9, otrace, guess_mode=True)
+    print("[guess] per-step latents oracle-vs-ref:", [round(maxdiff(a, b), 8) for a, b in zip(trace, otrace)])
+    out["vae_noise"] = vae_noise.numpy()
+    for i, l in enumerate(trace):
+        out[f"latents_{i}"] = l.numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_guess_mode.npz"), **out)
+    print("guess-mode fixture written")
+
+
 def layers_full():
     """F6: single layers at the production sizes of the SD1.5 path, from the reference's own modules
     (ResnetBlock2D 320->320 @64x64, ResnetBlock2D 2560->1280 @16x16 with the 1x1 shortcut, Transformer2DModel 320 ch /
@@ -641,6 +692,7 @@ if __name__ == "__main__":
     ap.add_argument("--only-xl", action="store_true")
     ap.add_argument("--only-train", action="store_true")
     ap.add_argument("--only-layers", action="store_true")
+    ap.add_argument("--only-guess", action="store_true")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     if a.only_config1:
@@ -655,8 +707,12 @@ if __name__ == "__main__":
     if a.only_layers:
         layers_full()
         sys.exit(0)
+    if a.only_guess:
+        tiny_guess_mode()
+        sys.exit(0)
     if not a.only_full:
         tiny()
+        tiny_guess_mode()
         tiny_train()
         layers_full()
         tiny_xl()
