@@ -108,6 +108,17 @@ def _pipe():
         requires_safety_checker=False, depth_conditioning_mode="concat")
 
 
+def test_memory_switches_of_the_reference_pipeline_are_accepted():
+    """DiffusionPipeline's memory-saving switches (pipeline_utils.py:940-1683) never change a result: a script that calls
+    them keeps working, the modules stay resident."""
+    pipe = _pipe()
+    for name in ("enable_model_cpu_offload", "enable_sequential_cpu_offload", "enable_attention_slicing", "disable_attention_slicing",
+                 "enable_vae_slicing", "disable_vae_slicing", "enable_vae_tiling", "disable_vae_tiling",
+                 "enable_xformers_memory_efficient_attention", "disable_xformers_memory_efficient_attention"):
+        assert getattr(pipe, name)() is None
+    pipe.set_progress_bar_config(disable=True)
+
+
 def test_check_inputs_error_conventions():
     """pipeline_brushnet.py:573-693."""
     pipe = _pipe()
