@@ -484,7 +484,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": ("images/sec at 512x512, 50-step DDIM, SD1.5+BrushNet" if not xl else
+            "metric": (f"images/sec at {a.size}x{a.size}, {a.denoise_steps}-step DDIM, SD1.5+BrushNet" if not xl else
                        f"images/sec at {a.size}x{a.size}, {a.denoise_steps}-step DDIM, SDXL+BrushNet-XL (secondary workload)"),
             "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
