@@ -245,6 +245,7 @@ LAST_PROFILE = []
 # are persisted in tune_cache.json next to this file so later processes (and graph capture) start tuned.
 AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
+TUNE_GRAPH = os.environ.get("MFHIP_TUNE_GRAPH", "0") == "1"   # developer switch: time candidates from a hipGraph (see _tuned_config)
 # The package ships a cache tuned on MI355X (read-only); new winners go to a per-user file (MFHIP_TUNE_CACHE, default
 # ~/.cache/mfhip/tune_cache.json) that is overlaid on it.  Both carry the library's tile-table version: when tiles are
 # renumbered (mf_gemm_tile_table_version changes) stale indices are dropped instead of being trusted.
@@ -339,13 +340,30 @@ def _tuned_config(d: "GemmDesc", key: tuple):
         if lib.mf_gemm_conv(C.byref(d), st) != 0:
             continue
         dt = float("inf")
-        for _trial in range(2):          # best of two bursts: one burst alone mis-ranks candidates that are within a few %
-            e0.record()
-            for _ in range(4):
-                lib.mf_gemm_conv(C.byref(d), st)
-            e1.record()
-            e1.synchronize()
-            dt = min(dt, e0.elapsed_time(e1))
+        if TUNE_GRAPH:
+            # developer re-tune: 8 launches replayed from a hipGraph, so that launches shorter than a ctypes call
+            # (~16 us) are ranked by their kernel time, not by the host's launch rate (slow: a capture per candidate)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                cs = _stream()
+                for _ in range(8):
+                    lib.mf_gemm_conv(C.byref(d), cs)
+            g.replay()
+            for _trial in range(2):
+                e0.record()
+                g.replay()
+                e1.record()
+                e1.synchronize()
+                dt = min(dt, e0.elapsed_time(e1))
+            del g
+        else:
+            for _trial in range(2):      # best of two bursts: one burst alone mis-ranks candidates that are within a few %
+                e0.record()
+                for _ in range(4):
+                    lib.mf_gemm_conv(C.byref(d), st)
+                e1.record()
+                e1.synchronize()
+                dt = min(dt, e0.elapsed_time(e1))
         if dt < best_t:
             best, best_t = (t, s), dt
     cache[ks] = best
