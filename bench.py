@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="image side (default 512; 1024 for --model sdxl)")
     ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl"],
                     help="sd15 = BASELINE.json's north-star workload; sdxl = the §8 f-3 secondary workload")
-    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--denoise-steps", type=int, default=None, help="default 50; 30 for --model sdxl (BASELINE.json configs[4])")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f16x3", "bf16x3", "bf16x1", "fp8"])
     ap.add_argument("--no-parity-mode", action="store_true",
                     help="skip the extra passes in the f16x3 parity mode (the mode that meets the 1e-3 latent bound)")
@@ -263,8 +263,10 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(sys.argv[1:], a.gpus))          # before anything touches the GPU
     xl = a.model == "sdxl"
-    if a.batch is None:
-        a.batch = 8 if a.mode == "train" else 4
+    if a.batch is None:          # BASELINE.json: configs[1] batch 4, configs[3] per-GPU batch 8, configs[4] (SDXL) batch 2
+        a.batch = 8 if a.mode == "train" else 2 if xl else 4
+    if a.denoise_steps is None:  # configs[1] 50-step DDIM, configs[4] 30-step
+        a.denoise_steps = 30 if xl else 50
     if a.size is None:
         a.size = 1024 if xl else 512
 
