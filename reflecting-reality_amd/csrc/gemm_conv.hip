@@ -231,10 +231,18 @@ constexpr int min_waves(int bm, int bn, int stages, int nthr) {
 // M16 (bf16 only): the same 32x32 accumulator blocks computed as four 16x16 tiles with v_mfma_f32_16x16x32_bf16 — the same
 // LDS reads and matrix-pipe cycles as 32x32x16, but the chip sustains a higher clock on this shape under load
 // (MI355X_MICROARCH.md, DVFS give-back (7): 1.12-1.14x in LDS-fed loops).
-template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES, bool DXR = false, bool WPK = false, bool M16 = false>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, min_waves(BM + (DXR ? 32 : 0), BN, STAGES, WAVES_M* WAVES_N * 64))
+// WS (dx-reuse convs only): warp specialisation.  The block has four more waves: waves [0, W) compute (MFMA + epilogue),
+// the last four (one per SIMD) only stage operands (LDS-DMA issue + counted waits), two taps ahead through a 3-deep W ring.  A wave's K
+// tile costs ~640 MFMA cycles AND ~1000 cycles of DMA issue when one wave does both; split over two waves of
+// the same SIMD the two streams issue from different ports and overlap.
+template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES, bool DXR = false, bool WPK = false, bool M16 = false,
+          bool WS = false>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64 + (WS ? 256 : 0),
+                             WS ? (WAVES_M * WAVES_N + 4) / 4 : min_waves(BM + (DXR ? 32 : 0), BN, STAGES, WAVES_M* WAVES_N * 64))
 void gemm_conv_kernel(const GemmArgs p) {
-    constexpr int NTHR = WAVES_M * WAVES_N * 64;
+    constexpr int NTHR = WAVES_M * WAVES_N * 64;      // compute threads (also the staging threads unless WS)
+    constexpr int NSTG = WS ? 256 : NTHR;             // staging threads: WS adds four producer waves, one per SIMD
+    static_assert(!WS || (DXR && DT == MF_BF16 && !A_F32), "warp specialisation is built for the bf16 dx-reuse loop");
     static_assert(!M16 || (DT == MF_BF16 && !A_F32), "the 16x16x32 form is instantiated for bf16 only");
     constexpr bool X1 = DT == MF_BF16X1;      // fp32 operands rounded to bf16 (RNE) in registers, ONE MFMA per product
     constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3 || X1);
@@ -246,7 +254,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     constexpr int BK = 128 / ES;                 // K elements per tile (128 bytes per row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int RPP = NTHR / 8;                // rows staged per pass (8 lanes per 128-B row)
+    constexpr int RPP = NSTG / 8;                // rows staged per pass (8 lanes per 128-B row)
     constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int EP_RS = (WN + 4) * 4;          // epilogue slab row stride (bytes)
@@ -260,7 +268,8 @@ void gemm_conv_kernel(const GemmArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x;
+    const bool producer = WS && (int)threadIdx.x >= NTHR;                 // wave-uniform
+    const int tid = producer ? (int)threadIdx.x - NTHR : (int)threadIdx.x;   // index within the role
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -689,6 +698,7 @@ void gemm_conv_kernel(const GemmArgs p) {
             // A-side DMAs drop to ~40 % of the per-tap scheme; the vector-memory path, not the bytes in L2, is what
             // bounds these kernels.  LDS: [A window x 2][W tile x 2].
             static_assert(!A_F32 && STAGES == 2, "dx reuse: DMA staging, double buffered");
+            constexpr int WST = WS ? 3 : 2;                        // W ring depth
             constexpr int AROWS = BM + RPP, A3_IT = AROWS / RPP;
             constexpr int AB = AROWS * 128, WB = BN * 128;
             const int nck = p.Ctot / BK;                           // K chunks per tap
@@ -814,6 +824,39 @@ void gemm_conv_kernel(const GemmArgs p) {
                 mma(fa0, fb0);
                 mma(fa1, fb1);
             };
+            if constexpr (WS) {
+                // Producers run two taps ahead: tap t + 2 goes to W stage (t + 2) % 3 (last read in tap t - 1, which every
+                // consumer finished before barrier #t) and, when it opens a group, to the A buffer that group g - 2 used.
+                // Loads return in order: leaving exactly the newest batch in flight means tap t + 1 has landed.
+                // Barrier #k (k = 0 .. nt - 1) separates "tap k landed / tap k - 1 consumed" for both roles.
+                (void)WST;
+                if (producer) {
+                    int kx2 = 0, st2 = 0;                          // kx and W stage of the next tap to issue
+                    auto issue_next = [&]() { issue3(st2); st2 = st2 == 2 ? 0 : st2 + 1; kx2 = kx2 == 2 ? 0 : kx2 + 1; };
+                    issue_next();                                  // tap 0: A window + W
+                    if (nt > 1) { issue_next(); wait_vmcnt<B_IT>(); } else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();                  // #0
+                    for (int t = 0; t + 1 < nt; ++t) {
+                        if (t + 2 < nt) {
+                            const bool with_a = kx2 == 0;          // tap t + 2 opens a group: its batch carries the A window too
+                            issue_next();
+                            if (with_a) wait_vmcnt<B_IT + A3_IT>(); else wait_vmcnt<B_IT>();
+                        } else {
+                            wait_vmcnt<0>();
+                        }
+                        __builtin_amdgcn_s_barrier();              // #(t + 1)
+                    }
+                } else {
+                    int c_kx = 0, c_grp = 0, c_st = 0;
+                    __builtin_amdgcn_s_barrier();                  // #0
+                    for (int t = 0; t < nt; ++t) {
+                        compute3(c_grp & 1, c_st, c_kx);
+                        c_st = c_st == 2 ? 0 : c_st + 1;
+                        if (++c_kx == 3) { c_kx = 0; ++c_grp; }
+                        if (t + 1 < nt) __builtin_amdgcn_s_barrier();   // #(t + 1)
+                    }
+                }
+            } else {
             issue3(0);
             int c_kx = 0, c_grp = 0;
             for (int t = 0; t < nt; ++t) {
@@ -822,6 +865,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                 if (t + 1 < nt) issue3((t + 1) & 1);
                 compute3(c_grp & 1, t & 1, c_kx);
                 if (++c_kx == 3) { c_kx = 0; ++c_grp; }
+            }
             }
         } else if constexpr (!A_F32) {
             // LDS ring, STAGES-1 tiles in flight while tile t is multiplied.  Only a COUNTED vmcnt (all but the newer
@@ -873,6 +917,7 @@ void gemm_conv_kernel(const GemmArgs p) {
         }
     }
     __syncthreads();   // every wave is done reading the staging LDS: reuse it for the epilogue slabs
+    if (producer) return;
 
     // ---- epilogue ---------------------------------------------------------------------------
     char* slab = smem + wave * (SR * EP_RS);        // private to this wave: [SR rows][WN + 4] fp32
@@ -1630,23 +1675,29 @@ const TileCfg kTiles[] = {
     {64, 64, 256, 4},          // 34
     {64, 128, 256, 6},         // 35
     {64, 64, 256, 6},          // 36
+    // 37-38: warp-specialised dx-reuse conv (bf16): 4 compute waves + 4 staging waves per block, 3-deep W ring, one block
+    // per CU.  `threads` = the staging threads (the A window is BM + threads / 8 rows)
+    {256, 160, 256, 2, 0, 1},  // 37  8x1 compute waves of 32x160 (+ 4 staging): three waves per SIMD
+    {128, 160, 256, 2, 0, 1},  // 38  4x1 compute waves of 32x160 (+ 4 staging): for grids of <= 256 tiles of 128 rows
+    {256, 160, 256, 2, 0, 1},  // 39  = 37 on 16x16x32 MFMAs
+    {128, 160, 256, 2, 0, 1},  // 40  = 38 on 16x16x32 MFMAs
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false>
+template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int smem_k = DX ? 2 * (BM + WMv * WNv * 8) * 128 + 2 * BN * 128 : ST * (BM + BN) * 128;
+    constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? 3 : 2) * BN * 128 : ST * (BM + BN) * 128;
     static_assert(smem_k <= 160 * 1024, "LDS");
     // experiment switch: MFHIP_SMEM_MIN=<bytes> raises the LDS request (occupancy control for ring-depth A/B runs)
     static const int smem_min = getenv("MFHIP_SMEM_MIN") ? atoi(getenv("MFHIP_SMEM_MIN")) : 0;
     const int smem = smem_k > smem_min ? smem_k : smem_min;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16>), grid, dim3(WMv * WNv * 64), smem, s, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS>), grid, dim3(WMv * WNv * 64 + (WS ? 256 : 0)), smem, s, a);
 }
 
 // Split codes: the tiles whose register budget holds the split fragments (see kTiles).  Returns false for a tile that
@@ -1729,6 +1780,10 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
                 case 28: launch_one<DT, 128, 128, 2, 2, false, 2, true, false, true>(a, grid, s); break;
                 case 29: launch_one<DT, 64, 128, 2, 2, false, 2, false, false, true>(a, grid, s); break;
                 case 30: launch_one<DT, 128, 64, 2, 2, false, 2, false, false, true>(a, grid, s); break;
+                case 37: launch_one<DT, 256, 160, 8, 1, false, 2, true, false, false, true>(a, grid, s); break;
+                case 38: launch_one<DT, 128, 160, 4, 1, false, 2, true, false, false, true>(a, grid, s); break;
+                case 39: launch_one<DT, 256, 160, 8, 1, false, 2, true, false, true, true>(a, grid, s); break;
+                case 40: launch_one<DT, 128, 160, 4, 1, false, 2, true, false, true, true>(a, grid, s); break;
                 default: break;
             }
         }
@@ -1897,6 +1952,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     }
     MF_CHECK_ARG(tile < 25 || tile > 30 || (d->dtype == MF_BF16 && !a_f32), "mf_gemm_conv: tile %d (16x16x32 MFMA form) does not apply: bf16 only", tile);
     MF_CHECK_ARG(tile < 31 || (!a_f32 && !split && d->dtype != MF_FP8), "mf_gemm_conv: tile %d (deep ring) does not apply to this precision", tile);
+    MF_CHECK_ARG(tile < 37 || d->dtype == MF_BF16, "mf_gemm_conv: tile %d (warp-specialised) does not apply: bf16 only", tile);
     const TileCfg& tc = kTiles[tile - 1];
     if (tc.halo) {
         // conv3x3_halo_kernel: bf16, 3x3 / stride 1 / pad 1, whole TH x 16 tiles, 32-channel chunks
