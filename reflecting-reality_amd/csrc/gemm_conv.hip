@@ -697,8 +697,8 @@ void gemm_conv_kernel(const GemmArgs p) {
             // hardware zeros of the DMA range check — the horizontal padding needs no per-fragment masking.
             // A-side DMAs drop to ~40 % of the per-tap scheme; the vector-memory path, not the bytes in L2, is what
             // bounds these kernels.  LDS: [A window x 2][W tile x 2].
-            static_assert(!A_F32 && STAGES == 2, "dx reuse: DMA staging, double buffered");
-            constexpr int WST = WS ? 3 : 2;                        // W ring depth
+            static_assert(!A_F32 && (WS ? STAGES == 3 : STAGES == 2), "dx reuse: DMA staging; W ring 2 deep, 3 when WS (a 4-deep ring measured no faster)");
+            constexpr int WST = WS ? STAGES : 2;                   // W ring depth
             constexpr int AROWS = BM + RPP, A3_IT = AROWS / RPP;
             constexpr int AB = AROWS * 128, WB = BN * 128;
             const int nck = p.Ctot / BK;                           // K chunks per tap
@@ -825,25 +825,37 @@ void gemm_conv_kernel(const GemmArgs p) {
                 mma(fa1, fb1);
             };
             if constexpr (WS) {
-                // Producers run two taps ahead: tap t + 2 goes to W stage (t + 2) % 3 (last read in tap t - 1, which every
-                // consumer finished before barrier #t) and, when it opens a group, to the A buffer that group g - 2 used.
+                // Producers run PFD = WST - 1 taps ahead: tap t + PFD goes to W stage (t + PFD) % WST (last read in tap t - 1,
+                // which every consumer finished before barrier #t) and, when it opens a group, to the A buffer that group
+                // g - 2 used (its last tap is at most t - 1 for PFD <= 3).
                 // Loads return in order: leaving exactly the newest batch in flight means tap t + 1 has landed.
                 // Barrier #k (k = 0 .. nt - 1) separates "tap k landed / tap k - 1 consumed" for both roles.
-                (void)WST;
+                constexpr int PFD = WST - 1;                       // taps in flight ahead of the one being multiplied
                 if (producer) {
-                    int kx2 = 0, st2 = 0;                          // kx and W stage of the next tap to issue
-                    auto issue_next = [&]() { issue3(st2); st2 = st2 == 2 ? 0 : st2 + 1; kx2 = kx2 == 2 ? 0 : kx2 + 1; };
-                    issue_next();                                  // tap 0: A window + W
-                    if (nt > 1) { issue_next(); wait_vmcnt<B_IT>(); } else wait_vmcnt<0>();
+                    int kx2 = 0, st2 = 0, issued = 0;              // kx, W stage and index of the next tap to issue
+                    auto issue_next = [&]() {
+                        issue3(st2);
+                        st2 = st2 == WST - 1 ? 0 : st2 + 1;
+                        kx2 = kx2 == 2 ? 0 : kx2 + 1;
+                        ++issued;
+                    };
+                    // wait until tap `need` has landed: everything issued after it may stay in flight.  Those are at most
+                    // PFD - 1 <= 2 taps, at most one of which opens a group (and carries the A window's DMAs too).
+                    auto wait_for = [&](int need) {
+                        const int newer = issued - 1 - need;       // taps issued after `need`
+                        bool with_a = false;
+                        for (int q = need + 1; q < issued; ++q) with_a |= (q % 3 == 0);
+                        if (newer <= 0) wait_vmcnt<0>();
+                        else if (newer == 1) { if (with_a) wait_vmcnt<B_IT + A3_IT>(); else wait_vmcnt<B_IT>(); }
+                        else { if (with_a) wait_vmcnt<2 * B_IT + A3_IT>(); else wait_vmcnt<2 * B_IT>(); }
+                    };
+                    static_assert(2 * B_IT + A3_IT < 64, "vmcnt is a 6-bit counter");
+                    for (int k = 0; k < PFD && k < nt; ++k) issue_next();
+                    wait_for(0);
                     __builtin_amdgcn_s_barrier();                  // #0
                     for (int t = 0; t + 1 < nt; ++t) {
-                        if (t + 2 < nt) {
-                            const bool with_a = kx2 == 0;          // tap t + 2 opens a group: its batch carries the A window too
-                            issue_next();
-                            if (with_a) wait_vmcnt<B_IT + A3_IT>(); else wait_vmcnt<B_IT>();
-                        } else {
-                            wait_vmcnt<0>();
-                        }
+                        if (t + PFD < nt) issue_next();            // tap t + PFD
+                        wait_for(t + 1);
                         __builtin_amdgcn_s_barrier();              // #(t + 1)
                     }
                 } else {
@@ -851,7 +863,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                     __builtin_amdgcn_s_barrier();                  // #0
                     for (int t = 0; t < nt; ++t) {
                         compute3(c_grp & 1, c_st, c_kx);
-                        c_st = c_st == 2 ? 0 : c_st + 1;
+                        c_st = c_st == WST - 1 ? 0 : c_st + 1;
                         if (++c_kx == 3) { c_kx = 0; ++c_grp; }
                         if (t + 1 < nt) __builtin_amdgcn_s_barrier();   // #(t + 1)
                     }
@@ -1686,7 +1698,7 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? 3 : 2) * BN * 128 : ST * (BM + BN) * 128;
+    constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? ST : 2) * BN * 128 : ST * (BM + BN) * 128;
     static_assert(smem_k <= 160 * 1024, "LDS");
     // experiment switch: MFHIP_SMEM_MIN=<bytes> raises the LDS request (occupancy control for ring-depth A/B runs)
     static const int smem_min = getenv("MFHIP_SMEM_MIN") ? atoi(getenv("MFHIP_SMEM_MIN")) : 0;
@@ -1780,10 +1792,10 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
                 case 28: launch_one<DT, 128, 128, 2, 2, false, 2, true, false, true>(a, grid, s); break;
                 case 29: launch_one<DT, 64, 128, 2, 2, false, 2, false, false, true>(a, grid, s); break;
                 case 30: launch_one<DT, 128, 64, 2, 2, false, 2, false, false, true>(a, grid, s); break;
-                case 37: launch_one<DT, 256, 160, 8, 1, false, 2, true, false, false, true>(a, grid, s); break;
-                case 38: launch_one<DT, 128, 160, 4, 1, false, 2, true, false, false, true>(a, grid, s); break;
-                case 39: launch_one<DT, 256, 160, 8, 1, false, 2, true, false, true, true>(a, grid, s); break;
-                case 40: launch_one<DT, 128, 160, 4, 1, false, 2, true, false, true, true>(a, grid, s); break;
+                case 37: launch_one<DT, 256, 160, 8, 1, false, 3, true, false, false, true>(a, grid, s); break;
+                case 38: launch_one<DT, 128, 160, 4, 1, false, 3, true, false, false, true>(a, grid, s); break;
+                case 39: launch_one<DT, 256, 160, 8, 1, false, 3, true, false, true, true>(a, grid, s); break;
+                case 40: launch_one<DT, 128, 160, 4, 1, false, 3, true, false, true, true>(a, grid, s); break;
                 default: break;
             }
         }
