@@ -701,6 +701,7 @@ void gemm_conv_kernel(const GemmArgs p) {
             constexpr int WST = WS ? STAGES : 2;                   // W ring depth
             constexpr int AROWS = BM + RPP, A3_IT = AROWS / RPP;
             constexpr int AB = AROWS * 128, WB = BN * 128;
+            static_assert(WAVES_M * WAVES_N * SR * EP_RS <= 2 * AB + WST * WB, "epilogue slabs must fit in this loop's LDS");
             const int nck = p.Ctot / BK;                           // K chunks per tap
             const int weff = p.Wo < BM ? p.Wo : BM;                // pixels of one image row inside the tile
             const int wfr = weff + 2;                              // ... plus the frame
