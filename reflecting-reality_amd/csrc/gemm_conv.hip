@@ -242,7 +242,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 + (WS ? 256 : 0),
 void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;      // compute threads (also the staging threads unless WS)
     constexpr int NSTG = WS ? 256 : NTHR;             // staging threads: WS adds four producer waves, one per SIMD
-    static_assert(!WS || (DXR && DT == MF_BF16 && !A_F32), "warp specialisation is built for the bf16 dx-reuse loop");
+    static_assert(!WS || (DT == MF_BF16 && !A_F32 && STAGES == 3), "warp specialisation: bf16, LDS-DMA staging, 3-deep ring");
     static_assert(!M16 || (DT == MF_BF16 && !A_F32), "the 16x16x32 form is instantiated for bf16 only");
     constexpr bool X1 = DT == MF_BF16X1;      // fp32 operands rounded to bf16 (RNE) in registers, ONE MFMA per product
     constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3 || X1);
@@ -268,7 +268,8 @@ void gemm_conv_kernel(const GemmArgs p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const bool producer = WS && (int)threadIdx.x >= NTHR;                 // wave-uniform
+    // wave-uniform, and provably so (a scalar compare): the staging code keeps descriptors and loop state in SGPRs
+    const bool producer = WS && __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NTHR;
     const int tid = producer ? (int)threadIdx.x - NTHR : (int)threadIdx.x;   // index within the role
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -908,7 +909,45 @@ void gemm_conv_kernel(const GemmArgs p) {
                     st_i = st_i == STAGES - 1 ? 0 : st_i + 1;
                 }
             };
-            if (p.fast) {
+            // Warp-specialised form of the same ring (see the dx-reuse loop): the producer waves keep PF tiles in flight
+            // and meet the compute waves at one barrier per K tile; barrier #k separates "tile k landed / tile k - 1 consumed".
+            auto ring_ws = [&](auto issue) {
+                if (producer) {
+                    int st_i = 0, issued = 0;
+                    auto issue_next = [&]() { issue(st_i); st_i = st_i == STAGES - 1 ? 0 : st_i + 1; ++issued; };
+                    auto wait_for = [&](int need) {                // tile `need` landed; the (<= PF - 1) newer ones may fly
+                        const int newer = issued - 1 - need;
+                        static_assert((PF - 1) * G < 64, "vmcnt is a 6-bit counter");
+                        if (PF >= 3 && newer >= 2) wait_vmcnt<2 * G>();
+                        else if (PF >= 2 && newer == 1) wait_vmcnt<G>();
+                        else wait_vmcnt<0>();
+                    };
+                    for (int k = 0; k < PF && k < nt; ++k) issue_next();
+                    wait_for(0);
+                    __builtin_amdgcn_s_barrier();                  // #0
+                    for (int t = 0; t + 1 < nt; ++t) {
+                        if (t + PF < nt) issue_next();
+                        wait_for(t + 1);
+                        __builtin_amdgcn_s_barrier();              // #(t + 1)
+                    }
+                } else {
+                    int st_c = 0;
+                    __builtin_amdgcn_s_barrier();                  // #0
+                    for (int t = 0; t < nt; ++t) {
+                        compute(st_c);
+                        st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
+                        if (t + 1 < nt) __builtin_amdgcn_s_barrier();   // #(t + 1)
+                    }
+                }
+            };
+            if constexpr (WS) {
+                if (p.fast) {
+                    if (producer) fast_init();
+                    ring_ws(issue_tile_fast);
+                } else {
+                    ring_ws(issue_tile);
+                }
+            } else if (p.fast) {
                 fast_init();
                 ring(issue_tile_fast);
             } else {
@@ -1694,6 +1733,13 @@ const TileCfg kTiles[] = {
     {128, 160, 256, 2, 0, 1},  // 38  4x1 compute waves of 32x160 (+ 4 staging): for grids of <= 256 tiles of 128 rows
     {256, 160, 256, 2, 0, 1},  // 39  = 37 on 16x16x32 MFMAs
     {128, 160, 256, 2, 0, 1},  // 40  = 38 on 16x16x32 MFMAs
+    // 41-46: the warp-specialised form of the plain ring (any call of the implicit-GEMM kernel: 1x1, strided, upsampled)
+    {128, 160, 256, 3},        // 41  4 + 4 waves
+    {256, 160, 256, 3},        // 42  8 + 4 waves, 16x16x32 MFMAs
+    {128, 160, 256, 3},        // 43  = 41 on 16x16x32 MFMAs
+    {128, 128, 256, 3},        // 44  4 (2x2) + 4 waves
+    {256, 128, 256, 3},        // 45  8 (4x2) + 4 waves
+    {256, 128, 256, 3},        // 46  = 45 on 16x16x32 MFMAs
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1797,6 +1843,12 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
                 case 38: launch_one<DT, 128, 160, 4, 1, false, 3, true, false, false, true>(a, grid, s); break;
                 case 39: launch_one<DT, 256, 160, 8, 1, false, 3, true, false, true, true>(a, grid, s); break;
                 case 40: launch_one<DT, 128, 160, 4, 1, false, 3, true, false, true, true>(a, grid, s); break;
+                case 41: launch_one<DT, 128, 160, 4, 1, false, 3, false, false, false, true>(a, grid, s); break;
+                case 42: launch_one<DT, 256, 160, 8, 1, false, 3, false, false, true, true>(a, grid, s); break;
+                case 43: launch_one<DT, 128, 160, 4, 1, false, 3, false, false, true, true>(a, grid, s); break;
+                case 44: launch_one<DT, 128, 128, 2, 2, false, 3, false, false, false, true>(a, grid, s); break;
+                case 45: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, false, true>(a, grid, s); break;
+                case 46: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, true, true>(a, grid, s); break;
                 default: break;
             }
         }

@@ -43,10 +43,10 @@ SPLIT_TILES = (0, 1, 2, 3, 6, 7, 14)          # tiles instantiated for the split
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
-@pytest.mark.parametrize("tile", list(range(16)) + [25, 26, 29, 30, 31, 32, 33, 34, 35, 36])
+@pytest.mark.parametrize("tile", list(range(16)) + [25, 26, 29, 30, 31, 32, 33, 34, 35, 36, 41, 42, 43, 44, 45, 46])
 def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     prec = ops.Precision.get(prec_name)
-    if (prec.split and tile not in SPLIT_TILES) or (25 <= tile <= 30 and prec_name != "bf16"):
+    if (prec.split and tile not in SPLIT_TILES) or ((25 <= tile <= 30 or tile >= 37) and prec_name != "bf16"):
         x = torch.zeros(1, 8, 8, 32, device=DEV)
         with pytest.raises(hip.MfhipError, match="not instantiated|does not apply"):     # refused, never rerouted
             ops.conv2d(x, ops.ConvWeight(torch.zeros(8, 32, 3, 3), None, prec, DEV), tile=tile)
@@ -205,6 +205,39 @@ def test_conv_variants(prec_name, atol, rtol, case):
     check(f"conv_{case}[{prec_name}]", nchw(y), ref, atol, rtol)
 
 
+@pytest.mark.parametrize("tile", [41, 42, 43, 44, 45, 46])
+@pytest.mark.parametrize("case", ["up", "s2", "cat", "1x1res"])
+def test_conv_warp_specialised_ring(tile, case):
+    """The warp-specialised form of the plain ring (four staging waves + the compute waves, 3-deep LDS ring) on the fast
+    staging path (channel counts that are multiples of 64): upsampled, strided, concatenated and 1x1 calls with a fused
+    epilogue, ragged M and N."""
+    prec = ops.Precision.get("bf16")
+    g = torch.Generator().manual_seed(77 + tile)
+    b, h, w_, c0, c1, n = {"up": (2, 9, 12, 64, 0, 200), "s2": (2, 18, 14, 128, 0, 72), "cat": (1, 13, 16, 64, 128, 330),
+                           "1x1res": (3, 10, 10, 192, 0, 170)}[case]
+    x = rb(torch.randn(b, c0, h, w_, generator=g))
+    x1 = rb(torch.randn(b, c1, h, w_, generator=g)) if c1 else None
+    k = 1 if case == "1x1res" else 3
+    w = rb(torch.randn(n, c0 + c1, k, k, generator=g) * 0.04)
+    bias = torch.randn(n, generator=g)
+    cw = ops.ConvWeight(w, bias, prec, DEV)
+    xin = torch.cat([x, x1], 1) if c1 else x
+    if case == "up":
+        ref = F.conv2d(F.interpolate(xin, scale_factor=2.0, mode="nearest"), w, bias, padding=1)
+        y = ops.conv2d(nhwc(x, prec.act), cw, upsample=True, tile=tile, splitk=1)
+    elif case == "s2":
+        ref = F.conv2d(xin, w, bias, stride=2, padding=1)
+        y = ops.conv2d(nhwc(x, prec.act), cw, stride=2, padding=1, tile=tile, splitk=2)
+    elif case == "cat":
+        ref = F.conv2d(xin, w, bias, padding=1)
+        y = ops.conv2d(nhwc(x, prec.act), cw, x1=nhwc(x1, prec.act), tile=tile, splitk=1)
+    else:
+        r0 = rb(torch.randn(b, n, h, w_, generator=g))
+        ref = F.silu(F.conv2d(xin, w, bias) + r0)
+        y = ops.conv2d(nhwc(x, prec.act), cw, padding=0, res0=nhwc(r0, prec.act), act=hip.ACT_SILU, tile=tile, splitk=1)
+    check(f"conv_ws_ring[tile{tile},{case}]", nchw(y), ref, 2e-2, 1e-2)
+
+
 def test_conv_f32_activations_bf16_compute():
     prec = ops.Precision.get("bf16")
     g = torch.Generator().manual_seed(4)
@@ -233,12 +266,14 @@ def test_linear(prec_name, atol, rtol, m, k, n):
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
-@pytest.mark.parametrize("tile,splitk", [(1, 1), (2, 1), (6, 3), (14, 1), (3, 2)])
+@pytest.mark.parametrize("tile,splitk", [(1, 1), (2, 1), (6, 3), (14, 1), (3, 2), (41, 1), (42, 2), (45, 1)])
 def test_linear_column_panels_and_flattened_splits(prec_name, atol, rtol, tile, splitk):
     """Wide 1x1 GEMMs run their column tiles in panels of 8 (the last panel narrower) and K splits are part of the 1-D
     block order: every (tile_m, tile_n, split) must be visited exactly once — N = 1448 gives 12 / 23 / 10 column tiles, M
     and N both ragged."""
     prec = ops.Precision.get(prec_name)
+    if tile >= 37 and prec_name != "bf16":
+        pytest.skip("the warp-specialised tiles are bf16 only")
     g = torch.Generator().manual_seed(55)
     m, k, n = 700, 192, 1448
     x = torch.randn(m, k, generator=g)
