@@ -236,7 +236,7 @@ constexpr int min_waves(int bm, int bn, int stages, int nthr) {
 // tile costs ~640 MFMA cycles AND ~1000 cycles of DMA issue when one wave does both; split over two waves of
 // the same SIMD the two streams issue from different ports and overlap.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES, bool DXR = false, bool WPK = false, bool M16 = false,
-          bool WS = false>
+          bool WS = false, bool P16 = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 + (WS ? 256 : 0),
                              WS ? (WAVES_M * WAVES_N + 4) / 4 : min_waves(BM + (DXR ? 32 : 0), BN, STAGES, WAVES_M* WAVES_N * 64))
 void gemm_conv_kernel(const GemmArgs p) {
@@ -253,12 +253,17 @@ void gemm_conv_kernel(const GemmArgs p) {
     constexpr int VEC = 16 / ES;                 // elements per 16-byte LDS chunk
     constexpr int BK = 128 / ES;                 // K elements per tile (128 bytes per row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    constexpr int MT = WM / 32, NT = WN / 32;
+    // P16 (warp-specialised dx-reuse convs, bf16): the wave tile is made of 16x16 MFMA tiles only (v_mfma_f32_16x16x32_bf16), so
+    // WN needs to be a multiple of 16, not 32: 4x2 compute waves of 32x80 put TWO compute waves on every SIMD for a
+    // 128x160 block (a CU's whole share of the 32x32-level convs)
+    static_assert(!P16 || (WS && DXR && DT == MF_BF16 && !M16 && WM == 32 && WN % 16 == 0), "P16: WS dx-reuse form, 32-row wave tiles");
+    constexpr int MT = WM / 32, NT = P16 ? 1 : WN / 32;
+    constexpr int MT16 = WM / 16, NT16 = WN / 16;
     constexpr int RPP = NSTG / 8;                // rows staged per pass (8 lanes per 128-B row)
     constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
     constexpr int EP_RS = (WN + 4) * 4;          // epilogue slab row stride (bytes)
-    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+    static_assert(WM % 32 == 0 && (P16 || WN % 32 == 0), "wave tile must be a multiple of 32x32");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     constexpr int SR = (WAVES_M * WAVES_N * 32 * EP_RS <= STAGES * STAGE_BYTES) ? 32 : 16;   // rows per epilogue slab
     static_assert(WAVES_M * WAVES_N * SR * EP_RS <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the staging LDS");
@@ -492,6 +497,11 @@ void gemm_conv_kernel(const GemmArgs p) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    f32x4_t acc16[P16 ? MT16 : 1][P16 ? NT16 : 1];          // P16: the accumulators (acc above stays unused)
+#pragma unroll
+    for (int a = 0; a < (P16 ? MT16 : 1); ++a)
+#pragma unroll
+        for (int b = 0; b < (P16 ? NT16 : 1); ++b) acc16[a][b] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int frow = lane & 31;              // fragment row (A: m, W: n) within a 32-row tile
     const int fh = lane >> 5;                // which half of the k-step this lane holds
@@ -777,6 +787,36 @@ void gemm_conv_kernel(const GemmArgs p) {
             }
             auto compute3 = [&](int abuf, int wstage, int kx) {
                 const char* Ab = smem + abuf * AB;
+                if constexpr (P16) {
+                    // 16-row A fragments of this wave's 32 rows, 16-column W fragments of its WN columns; W tile bases are
+                    // multiples of 16 rows, so every fragment's swizzle key is ((r16 >> 1) & 7)
+                    const char* Bp = smem + 2 * AB + wstage * WB + (wn * WN + r16) * 128;
+                    const int key16 = (r16 >> 1) & 7;
+                    const char* Ap[MT16]; int Ak[MT16];
+#pragma unroll
+                    for (int t = 0; t < MT16; ++t) {
+                        const int r = arow16[t] + kx;
+                        Ap[t] = Ab + r * 128;
+                        Ak[t] = (r >> 1) & 7;
+                    }
+                    uint4 fa[2][MT16], fb[2][NT16];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                        for (int t = 0; t < MT16; ++t) fa[ks][t] = *reinterpret_cast<const uint4*>(Ap[t] + (((4 * ks + kg) ^ Ak[t]) << 4));
+#pragma unroll
+                        for (int b = 0; b < NT16; ++b) fb[ks][b] = *reinterpret_cast<const uint4*>(Bp + b * 16 * 128 + (((4 * ks + kg) ^ key16) << 4));
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int a = 0; a < MT16; ++a)
+#pragma unroll
+                            for (int b = 0; b < NT16; ++b)
+                                acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][a]),
+                                                                                      __builtin_bit_cast(bf16x8_t, fb[ks][b]), acc16[a][b], 0, 0, 0);
+                    return;
+                }
                 const char* Bs = smem + 2 * AB + wstage * WB + (wn * WN + frow) * 128;
                 if constexpr (M16) {
                     const char* Ap[2 * MT]; int Ak[2 * MT];
@@ -1000,6 +1040,18 @@ void gemm_conv_kernel(const GemmArgs p) {
                 }
             }
         }
+        if constexpr (P16) {      // acc16[a][b] element r: row 16a + 4 kg + r, column 16b + r16 of the wave tile
+#pragma unroll
+            for (int a = 0; a < MT16; ++a)
+#pragma unroll
+                for (int b = 0; b < NT16; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * a + 4 * kg + r - half * SR;
+                        if (SR == 32 || a == half)
+                            *reinterpret_cast<float*>(slab + row * EP_RS + (16 * b + r16) * 4) = acc16[a][b][r];
+                    }
+        } else
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -1740,10 +1792,12 @@ const TileCfg kTiles[] = {
     {128, 128, 256, 3},        // 44  4 (2x2) + 4 waves
     {256, 128, 256, 3},        // 45  8 (4x2) + 4 waves
     {256, 128, 256, 3},        // 46  = 45 on 16x16x32 MFMAs
+    {128, 160, 256, 2, 0, 1},  // 47  = 38 / 40 with EIGHT compute waves (4x2 of 32x80, 16x16x32 MFMAs only) + 4 staging
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false>
+template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false,
+          bool P16 = false>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? ST : 2) * BN * 128 : ST * (BM + BN) * 128;
     static_assert(smem_k <= 160 * 1024, "LDS");
@@ -1752,11 +1806,11 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     const int smem = smem_k > smem_min ? smem_k : smem_min;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS>), grid, dim3(WMv * WNv * 64 + (WS ? 256 : 0)), smem, s, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16>), grid, dim3(WMv * WNv * 64 + (WS ? 256 : 0)), smem, s, a);
 }
 
 // Split codes: the tiles whose register budget holds the split fragments (see kTiles).  Returns false for a tile that
@@ -1849,6 +1903,7 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
                 case 44: launch_one<DT, 128, 128, 2, 2, false, 3, false, false, false, true>(a, grid, s); break;
                 case 45: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, false, true>(a, grid, s); break;
                 case 46: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, true, true>(a, grid, s); break;
+                case 47: launch_one<DT, 128, 160, 4, 2, false, 3, true, false, false, true, true>(a, grid, s); break;
                 default: break;
             }
         }

@@ -63,7 +63,7 @@ def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     check(f"conv3x3[{prec_name},tile{tile}]", nchw(y), ref, atol, rtol)
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28, 37, 38, 39, 40])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28, 37, 38, 39, 40, 47])
 @pytest.mark.parametrize("case", ["plain", "tailN", "cat", "splitk", "epilogue", "big"])
 def test_conv3x3_halo_tiles(tile, case):
     """conv3x3_halo_kernel (input patch resident in LDS, weights streamed per tap) and the 8-wave ping-pong

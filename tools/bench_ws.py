@@ -6,9 +6,9 @@ from reflecting_reality_amd import hip, ops
 from bench_k import timed
 hip.AUTOTUNE = False
 prec = ops.Precision.get("bf16")
-for (b, h, w, ci, co, tiles) in [(8, 64, 64, 320, 320, (20, 27, 37, 38, 39, 40)), (8, 64, 64, 640, 320, (20, 27, 37, 38, 39, 40)), (8, 64, 64, 960, 320, (20, 27, 37, 38, 39, 40)),
-                                  (8, 32, 32, 640, 640, (20, 27, 1, 37, 38, 39, 40)), (8, 32, 32, 1280, 640, (20, 27, 37, 38, 39, 40)),
-                                  (8, 16, 16, 1280, 1280, (20, 27, 37, 38, 39, 40))]:
+for (b, h, w, ci, co, tiles) in [(8, 64, 64, 320, 320, (27, 37, 38, 39, 40, 47)), (8, 64, 64, 640, 320, (27, 37, 38, 39, 40, 47)), (8, 64, 64, 960, 320, (27, 37, 38, 39, 40, 47)),
+                                  (8, 32, 32, 640, 640, (27, 1, 37, 38, 39, 40, 47)), (8, 32, 32, 1280, 640, (27, 37, 38, 39, 40, 47)),
+                                  (8, 16, 16, 1280, 1280, (27, 37, 38, 39, 40, 47))]:
     x = torch.randn(b, h, w, ci, device="cuda").bfloat16()
     cw = ops.ConvWeight(torch.randn(co, ci, 3, 3) * 0.02, torch.randn(co), prec, "cuda")
     res = torch.randn(b, h, w, co, device="cuda").bfloat16()
