@@ -1009,7 +1009,6 @@ void gemm_conv_kernel(const GemmArgs p) {
         }
     }
     __syncthreads();   // every wave is done reading the staging LDS: reuse it for the epilogue slabs
-    if (producer) return;
 
     // ---- epilogue ---------------------------------------------------------------------------
     char* slab = smem + wave * (SR * EP_RS);        // private to this wave: [SR rows][WN + 4] fp32
@@ -1022,6 +1021,99 @@ void gemm_conv_kernel(const GemmArgs p) {
     const bool res_pre = !ws && p.vec_ok && (p.res0 || p.res1) && (!p.res0 || p.res0_dt == MF_BF16) &&
                          (!p.res1 || p.res1_dt == MF_BF16) && !p.dbg_no_res_pre;
     constexpr int NIT = (ITEMS + 63) / 64;
+    if constexpr (WS) {
+        // Warp-specialised blocks: the four staging waves have nothing left to stage, so they take their share of the
+        // epilogue's memory phase.  The compute waves transpose their accumulators into their slabs; after a block
+        // barrier the 64-item chunks of ALL slabs are dealt round-robin to all waves (compute and staging alike), each
+        // of which fetches its chunks' residuals ahead of the barrier and then reads, finishes and stores them.
+        constexpr int NCW = WAVES_M * WAVES_N, TW = NCW + 4, NCHUNK = NCW * NIT, MAXC = (NCHUNK + TW - 1) / TW;
+        const int g = producer ? NCW + wave : wave;
+#pragma unroll
+        for (int ih = 0; ih < MT * (32 / SR); ++ih) {
+            const int i = ih / (32 / SR), half = ih % (32 / SR);
+            uint4 q0[MAXC], q1[MAXC];
+            auto coords = [&](int u, int& sw, int& row, int& ec, int& m, int& n) -> bool {
+                const int c = g + u * TW;
+                sw = c / NIT;
+                const int it = (c - sw * NIT) * 64 + lane;
+                row = it / CPR; ec = (it - row * CPR) * 8;
+                const int swm = sw / WAVES_N, swn = sw - swm * WAVES_N;
+                m = m0 + swm * WM + i * 32 + half * SR + row;
+                n = n0 + swn * WN + ec;
+                return c < NCHUNK && (ITEMS % 64 == 0 || it < ITEMS);
+            };
+            if (res_pre) {
+#pragma unroll
+                for (int u = 0; u < MAXC; ++u) {
+                    int sw, row, ec, m, n;
+                    const bool on = coords(u, sw, row, ec, m, n);
+                    q0[u] = uint4{0, 0, 0, 0}; q1[u] = uint4{0, 0, 0, 0};
+                    if (on && m < p.M && n + 8 <= p.N) {
+                        if (p.res0) q0[u] = *reinterpret_cast<const uint4*>(p.res0 + ((int64_t)m * p.ld_res0 + n) * 2);
+                        if (p.res1) q1[u] = *reinterpret_cast<const uint4*>(p.res1 + ((int64_t)res1_row(p, m) * p.ld_res1 + n) * 2);
+                    }
+                }
+            }
+            if (!producer) {
+                if constexpr (P16) {
+#pragma unroll
+                    for (int a = 0; a < MT16; ++a)
+#pragma unroll
+                        for (int b = 0; b < NT16; ++b)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = 16 * a + 4 * kg + r - half * SR;
+                                if (SR == 32 || a == half)
+                                    *reinterpret_cast<float*>(slab + row * EP_RS + (16 * b + r16) * 4) = acc16[a][b][r];
+                            }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int e = half * (SR / 2); e < half * (SR / 2) + SR / 2; ++e) {
+                            if constexpr (M16) {
+                                const int row = 16 * (e >> 3) + 4 * kg + (e & 3) - half * SR;
+                                *reinterpret_cast<float*>(slab + row * EP_RS + (j * 32 + 16 * ((e >> 2) & 1) + r16) * 4) = acc[i][j][e];
+                            } else {
+                                const int row = (e & 3) + 8 * (e >> 2) + 4 * fh - half * SR;
+                                *reinterpret_cast<float*>(slab + row * EP_RS + (j * 32 + frow) * 4) = acc[i][j][e];
+                            }
+                        }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's slab writes are done ...
+            __builtin_amdgcn_s_barrier();                // ... and everybody else's
+#pragma unroll
+            for (int u = 0; u < MAXC; ++u) {
+                int sw, row, ec, m, n;
+                if (!coords(u, sw, row, ec, m, n)) continue;
+                const char* sl = smem + sw * (SR * EP_RS);
+                float v[8];
+                const float4 lo = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4);
+                const float4 hi = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4 + 16);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                if (m < p.M && n < p.N) {
+                    if (ws) {
+                        if (n + 8 <= p.N && (p.N & 3) == 0) {
+                            *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n) = lo;
+                            *reinterpret_cast<float4*>(ws + (int64_t)m * p.N + n + 4) = hi;
+                        } else {
+                            for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
+                        }
+                    } else if (p.vec_ok && n + 8 <= p.N) {
+                        epilogue_store8(p, zo, m, n, v, res_pre, q0[u], q1[u], zq);
+                    } else {
+                        for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj], zq);
+                    }
+                }
+            }
+            if (ih + 1 < MT * (32 / SR)) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // slab reads done before the next round overwrites the slabs
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ih = 0; ih < MT * (32 / SR); ++ih) {
         const int i = ih / (32 / SR), half = ih % (32 / SR);     // accumulator rows [half*SR, half*SR + SR) of tile i
