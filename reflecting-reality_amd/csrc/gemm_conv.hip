@@ -256,7 +256,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     // P16 (warp-specialised dx-reuse convs, bf16): the wave tile is made of 16x16 MFMA tiles only (v_mfma_f32_16x16x32_bf16), so
     // WN needs to be a multiple of 16, not 32: 4x2 compute waves of 32x80 put TWO compute waves on every SIMD for a
     // 128x160 block (a CU's whole share of the 32x32-level convs)
-    static_assert(!P16 || (WS && DXR && DT == MF_BF16 && !M16 && WM == 32 && WN % 16 == 0), "P16: WS dx-reuse form, 32-row wave tiles");
+    static_assert(!P16 || (WS && DT == MF_BF16 && !M16 && WM == 32 && WN % 16 == 0), "P16: warp-specialised forms, 32-row wave tiles");
     constexpr int MT = WM / 32, NT = P16 ? 1 : WN / 32;
     constexpr int MT16 = WM / 16, NT16 = WN / 16;
     constexpr int RPP = NSTG / 8;                // rows staged per pass (8 lanes per 128-B row)
@@ -654,6 +654,28 @@ void gemm_conv_kernel(const GemmArgs p) {
     // Fragment reads are software-pipelined: the ds_read_b128s of k-step ks+1 are in flight while the MFMAs of
     // k-step ks run, so one wave alone keeps its matrix pipe fed across the LDS latency.
     auto compute = [&](int stage) {
+        if constexpr (P16) {      // 16x16x32 MFMA tiles only (see compute3): tile bases are multiples of 16 rows
+            const char* A16 = smem + stage * STAGE_BYTES + (wm * WM + r16) * 128;
+            const char* B16 = smem + stage * STAGE_BYTES + BM * 128 + (wn * WN + r16) * 128;
+            const int key16 = (r16 >> 1) & 7;
+            uint4 fa[2][MT16], fb[2][NT16];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int t = 0; t < MT16; ++t) fa[ks][t] = *reinterpret_cast<const uint4*>(A16 + t * 16 * 128 + (((4 * ks + kg) ^ key16) << 4));
+#pragma unroll
+                for (int b = 0; b < NT16; ++b) fb[ks][b] = *reinterpret_cast<const uint4*>(B16 + b * 16 * 128 + (((4 * ks + kg) ^ key16) << 4));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int a = 0; a < MT16; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT16; ++b)
+                        acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][a]),
+                                                                              __builtin_bit_cast(bf16x8_t, fb[ks][b]), acc16[a][b], 0, 0, 0);
+            return;
+        }
         const char* As = smem + stage * STAGE_BYTES + (wm * WM + frow) * 128;
         const char* Bs = smem + stage * STAGE_BYTES + BM * 128 + (wn * WN + frow) * 128;
         if constexpr (SPLIT || FP8) {
@@ -1885,6 +1907,7 @@ const TileCfg kTiles[] = {
     {256, 128, 256, 3},        // 45  8 (4x2) + 4 waves
     {256, 128, 256, 3},        // 46  = 45 on 16x16x32 MFMAs
     {128, 160, 256, 2, 0, 1},  // 47  = 38 / 40 with EIGHT compute waves (4x2 of 32x80, 16x16x32 MFMAs only) + 4 staging
+    {128, 160, 256, 3},        // 48  = 41 / 43 with eight compute waves of 32x80 + 4 staging
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -1996,6 +2019,7 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
                 case 45: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, false, true>(a, grid, s); break;
                 case 46: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, true, true>(a, grid, s); break;
                 case 47: launch_one<DT, 128, 160, 4, 2, false, 3, true, false, false, true, true>(a, grid, s); break;
+                case 48: launch_one<DT, 128, 160, 4, 2, false, 3, false, false, false, true, true>(a, grid, s); break;
                 default: break;
             }
         }

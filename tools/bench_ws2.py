@@ -6,7 +6,7 @@ from reflecting_reality_amd import hip, ops
 from bench_k import timed
 hip.AUTOTUNE = False
 prec = ops.Precision.get("bf16")
-TILES = (14, 26, 1, 25, 41, 42, 43, 44, 45, 46)
+TILES = (14, 1, 29, 6, 41, 43, 44, 48)
 for (b, h, w, ci, co, k, up) in [(8, 64, 64, 1280, 320, 1, 0), (8, 64, 64, 320, 320, 1, 0), (8, 32, 32, 2560, 640, 1, 0), (8, 32, 32, 640, 640, 1, 0),
                                   (8, 16, 16, 5120, 1280, 1, 0), (8, 16, 16, 1280, 1280, 1, 0), (8, 64, 64, 320, 1280, 1, 0),
                                   (8, 32, 32, 640, 640, 3, 1), (8, 16, 16, 1280, 1280, 3, 1), (8, 64, 64, 320, 640, 1, 0)]:
