@@ -131,8 +131,8 @@ typedef struct mf_gemm_desc {
     /* tile selection: 0 = library heuristic, else an index into the instantiated tile table (mf_gemm_num_tiles).
      * 1-15: implicit-GEMM tiles (any call); 16-19: 3x3 / stride-1 kernels with the input patch resident in LDS (bf16,
      * image sizes that tile by 8x16 / 16x16); 20-24: implicit GEMM with dx-tap reuse of the A window (3x3 / stride 1,
-     * W divides or is divided by BM); 25-30: 16x16x32-MFMA forms (bf16); 31-36: deeper LDS rings; 37-40: warp-specialised
-     * dx-reuse convs (bf16: extra waves that only stage operands); 41-46: the warp-specialised form of the plain ring
+     * W divides or is divided by BM); 25-30: 16x16x32-MFMA forms (bf16); 31-36: deeper LDS rings; 37-40, 47: warp-specialised
+     * dx-reuse convs (bf16: extra waves that only stage operands); 41-46, 48: the warp-specialised form of the plain ring
      * (bf16, any call).  A tile that does not apply to the call returns MF_EINVAL (the host autotuner skips it); nothing
      * is silently rerouted. */
     int32_t tile;
