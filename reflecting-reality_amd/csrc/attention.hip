@@ -65,6 +65,15 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
     constexpr int LDS_BYTES = (NBUF * BUF_BYTES) > O_BYTES ? (NBUF * BUF_BYTES) : O_BYTES;
     static_assert(DB, "K / V^T tiles are double buffered");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    // MJ ("max injected"): head dims whose QK^T reduction has >= 3 spare (zero) k slots (40 -> 48, 8 -> 16) run the softmax
+    // exponent ON THE MATRIX PIPE: Q is pre-multiplied by scale*log2(e) once, and the spare slots of the Q~ fragment carry
+    // -m (the running exponent offset as three bf16 pieces, exact to 24 bits) against ones in K~, so the MFMA result already
+    // is  log2(e)*scale*q.k - m  and the 32 v_fma per lane and tile disappear (the loop is VALU-issue bound: PMC round 2).  m only
+    // moves when some score exceeds the offset by more than MJ_T (defer-max: P <= 2^MJ_T, exact in the fp32 sums), so the
+    // rescale of O^T and the update of the Q~ slots are rare wave-uniform branches.
+    constexpr bool MJ = !SP && (DK - HD >= 3);
+    constexpr float MJ_T = 5.0f;
+    static_assert(!MJ || HD % 16 == 8, "MJ: the pad k slots must be the whole last fragment of the h = 1 half-wave");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,6 +115,12 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
             const int kk = 16 * ks + 8 * h;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (kk < HD && qi < p.sq) v = ldg16(qrow + kk * 2);
+            if constexpr (MJ) {          // Q~ = bf16(q * scale * log2 e): scores leave the MFMA in exp2 units
+                unsigned* w = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    w[e] = pack_bf16x2(__uint_as_float(w[e] << 16) * p.c, __uint_as_float(w[e] & 0xffff0000u) * p.c);
+            }
             qf[pl][ks] = v;
         }
     }
@@ -169,7 +184,10 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[d][e] = 0.0f;
-    float m = -INFINITY, l = 0.0f;
+    float m = MJ ? 0.0f : -INFINITY, l = 0.0f;
+    // MJ: bf16 ones in k slots HD, HD+1, HD+2 of the last K fragment, for the half-wave that reads the pad chunk
+    const unsigned ones_x = (MJ && h) ? 0x3F803F80u : 0u, ones_y = (MJ && h) ? 0x00003F80u : 0u;
+    (void)ones_x; (void)ones_y;
 
     const int ntiles = (p.skv + 63) / 64;
     __syncthreads();   // zero-fill (and the ones rows) done
@@ -196,6 +214,10 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
                     st[tt] = mfma16(a2, qf[0][ks], ks == 0 ? zero16 : st[tt], true);      // the small terms first
                     st[tt] = mfma16(a, qf[1][ks], st[tt], true);
                     st[tt] = mfma16(a, qf[0][ks], st[tt], true);
+                } else if constexpr (MJ) {
+                    uint4 am = a;
+                    if (ks == KS - 1) { am.x |= ones_x; am.y |= ones_y; }     // K~[key][HD .. HD+2] = 1 (the DMA left zeros there)
+                    st[tt] = mfma16(am, qf[0][ks], ks == 0 ? zero16 : st[tt], false);
                 } else {
                     st[tt] = mfma16(a, qf[0][ks], ks == 0 ? zero16 : st[tt], false);
                 }
@@ -215,25 +237,66 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(fmaxf(mx, st[0][e]), st[1][e]);     // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx * p.c);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        m = m_new;
         float rs = 0.0f;
+        if constexpr (MJ) {
+            // st already is score - m.  Move the offset only when some lane's scores run more than MJ_T above it (and on
+            // the first tile, where the offset is still 0): wave-uniform, rare after the first few tiles
+            if (t == 0 || __builtin_amdgcn_ballot_w64(mx > MJ_T) != 0) {
+                const float want = m + (t == 0 ? mx : fmaxf(mx, 0.0f));
+                // the offset the matrix pipe can subtract exactly: three bf16 pieces
+                const unsigned b0 = pack_bf16x2(want, 0.0f) & 0xffffu;
+                const float r1 = want - __uint_as_float(b0 << 16);
+                const unsigned b1 = pack_bf16x2(r1, 0.0f) & 0xffffu;
+                const float r2 = r1 - __uint_as_float(b1 << 16);
+                const unsigned b2 = pack_bf16x2(r2, 0.0f) & 0xffffu;
+                const float m_rep = __uint_as_float(b0 << 16) + __uint_as_float(b1 << 16) + __uint_as_float(b2 << 16);
+                const float dlt = m_rep - m;
+                m = m_rep;
+                if (h) {               // Q~[q][HD .. HD+2] = -(b0, b1, b2): the half-wave whose last fragment is the pad slots
+                    qf[0][KS - 1].x = (b0 | (b1 << 16)) ^ 0x80008000u;
+                    qf[0][KS - 1].y = b2 ^ 0x8000u;
+                }
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(st[tt][e], p.c, -m_new));
-                st[tt][e] = pv;
-                if (!ONES) rs += pv;
+                    for (int e = 0; e < 16; ++e) st[tt][e] -= dlt;
+                if (t != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-dlt);
+                    l *= alpha;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+                }
             }
-        // the running max settles after the first few tiles: skip the O^T rescale when no lane's max moved
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-            l *= alpha;
 #pragma unroll
-            for (int d = 0; d < DT; ++d)
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(st[tt][e]);
+                    st[tt][e] = pv;
+                    if (!ONES) rs += pv;
+                }
+        } else {
+            const float m_new = fmaxf(m, mx * p.c);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[tt][e], p.c, -m_new));
+                    st[tt][e] = pv;
+                    if (!ONES) rs += pv;
+                }
+            // the running max settles after the first few tiles: skip the O^T rescale when no lane's max moved
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+                l *= alpha;
+#pragma unroll
+                for (int d = 0; d < DT; ++d)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+            }
         }
         if (!ONES) l += rs;
         // ---- P^T fragments: accumulator registers 8s..8s+7 of tile tt are k-step 2*tt+s ----

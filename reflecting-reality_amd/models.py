@@ -514,6 +514,29 @@ class _UNetCore(HipModel):
         e = ops.linear(a, self.add2, res0=e, act=hip.ACT_SILU, out_dtype=F32)
         return ops.linear(e, self.temb_proj, out_dtype=F32)
 
+    def time_embedding_table(self, timesteps: torch.Tensor, batch: int, added_cond_kwargs=None) -> torch.Tensor:
+        """Every resnet's time_emb_proj(SiLU(time_embedding(t))) for ALL timesteps of a schedule in one batched pass
+        (the timesteps are known after set_timesteps; resnet.py:369-376) -> [steps, rows, sum(Cout)] fp32.
+        rows = 1 when the embedding depends on the timestep alone (SD1.5: every image of the batch reads the same row,
+        `forward(..., _temb=table[i])`), rows = batch with SDXL's per-image text_time embedding."""
+        t = timesteps.to(self.device, F32).reshape(-1)
+        steps = t.numel()
+        if self.add1 is None:
+            return self._time_embedding(t, steps, None).view(steps, 1, -1)
+        added = {k: v.to(self.device, F32).repeat(steps, *([1] * (v.dim() - 1))) for k, v in added_cond_kwargs.items()}
+        return self._time_embedding(t.repeat_interleave(batch), steps * batch, added).view(steps, batch, -1)
+
+    def _temb_rows(self, temb: Optional[torch.Tensor], timestep, bsz: int, added_cond_kwargs) -> torch.Tensor:
+        """The [bsz, sum(Cout)] time-embedding rows of one forward pass: computed here, or a precomputed row block of
+        time_embedding_table (one shared row is broadcast with a zero row stride: mf_gemm_desc.ld_temb = 0)."""
+        if temb is None:
+            return self._time_embedding(timestep, bsz, added_cond_kwargs)
+        if ops.TAPE is not None:
+            raise hip.MfhipError("training differentiates its own time embedding: _temb is an inference input")
+        if temb.shape[0] not in (1, bsz):
+            raise hip.MfhipError(f"_temb has {temb.shape[0]} rows for a batch of {bsz}")
+        return temb.expand(bsz, -1) if temb.shape[0] == 1 else temb
+
     def _temb(self, temb_all: Optional[torch.Tensor], p: str) -> Optional[torch.Tensor]:
         if temb_all is None:
             return None
@@ -853,8 +876,9 @@ class BrushNetModel(_UNetCore):
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: Optional[torch.Tensor] = None,
                 brushnet_cond: torch.Tensor = None, conditioning_scale: float = 1.0, class_labels=None,
                 timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
-                guess_mode: bool = False, return_dict: bool = True):
-        """brushnet.py:678-925.  Returns NCHW-shaped channels-last views (see module docstring)."""
+                guess_mode: bool = False, return_dict: bool = True, *, _temb: Optional[torch.Tensor] = None):
+        """brushnet.py:678-925.  Returns NCHW-shaped channels-last views (see module docstring).
+        `_temb` (not in the reference): a row block of time_embedding_table for this timestep."""
         c = self.config
         order = c["brushnet_conditioning_channel_order"]
         if order == "bgr":
@@ -869,7 +893,8 @@ class BrushNetModel(_UNetCore):
             raise NotImplementedError("class/timestep_cond/attention_mask inputs are outside the SD1.5 / SDXL hot path")
         side = self.side_stream
         if side is None:
-            d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, None, added_cond_kwargs, guess_mode)
+            d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, None, added_cond_kwargs, guess_mode,
+                                         _temb)
         else:
             main = torch.cuda.current_stream(self.device)
             _RESIDUAL_EVENTS.clear()
@@ -883,7 +908,7 @@ class BrushNetModel(_UNetCore):
 
             with torch.cuda.stream(side):
                 d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs,
-                                             guess_mode)
+                                             guess_mode, _temb)
         if not return_dict:
             return d, m, u
         return BrushNetOutput(down_block_res_samples=d, mid_block_res_sample=m, up_block_res_samples=u)
@@ -891,7 +916,7 @@ class BrushNetModel(_UNetCore):
     side_stream: Optional["torch.cuda.Stream"] = None
 
     def _forward_impl(self, sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs=None,
-                      guess_mode: bool = False):
+                      guess_mode: bool = False, temb_rows: Optional[torch.Tensor] = None):
         """Each zero-conv (brushnet.py:889-894) runs right after the feature it reads is produced — the same
         arithmetic as the reference's end-of-forward loops, but residual k is final as early as possible.
         guess_mode (brushnet.py:896-902): residual k of the [down | mid | up] list is scaled by logspace(-1, 0)[k] *
@@ -908,7 +933,7 @@ class BrushNetModel(_UNetCore):
         scale_of = {f"brushnet_down_blocks.{k}": sc[k] for k in range(n_down)}
         scale_of["brushnet_mid_block"] = sc[n_down]
         scale_of.update({f"brushnet_up_blocks.{k}": sc[n_down + 1 + k] for k in range(n_up)})
-        temb = self._time_embedding(timestep, bsz, added_cond_kwargs)
+        temb = self._temb_rows(temb_rows, timestep, bsz, added_cond_kwargs)
         x = hip.pack_nhwc(sample.to(self.device).float().contiguous(), brushnet_cond.to(self.device).float().contiguous(),
                           self.cin_pad, self.prec.act)                                            # :810 cat + pad
         if ops.TAPE is not None:
@@ -1043,7 +1068,7 @@ class UNet2DConditionModel(_UNetCore):
                 down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict: bool = True,
                 down_block_add_samples: Optional[List[torch.Tensor]] = None,
                 mid_block_add_sample: Optional[torch.Tensor] = None,
-                up_block_add_samples: Optional[List[torch.Tensor]] = None):
+                up_block_add_samples: Optional[List[torch.Tensor]] = None, *, _temb: Optional[torch.Tensor] = None):
         """unet_2d_condition.py:1039-1348.  `down_block_add_samples` / `up_block_add_samples` are consumed with
         pop(0) exactly like the reference does (the caller's lists are emptied)."""
         if not self._ready:
@@ -1059,7 +1084,7 @@ class UNet2DConditionModel(_UNetCore):
         is_brushnet = down_block_add_samples is not None and mid_block_add_sample is not None \
             and up_block_add_samples is not None                                                    # :1202
         bsz = sample.shape[0]
-        temb = self._time_embedding(timestep, bsz, added_cond_kwargs)
+        temb = self._temb_rows(_temb, timestep, bsz, added_cond_kwargs)
         ehs = self._bind_prompt(encoder_hidden_states)
         x = from_nchw(sample.to(self.device), self.prec, self.cin_pad)
         if ops.TAPE is not None:

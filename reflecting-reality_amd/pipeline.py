@@ -154,6 +154,9 @@ class StableDiffusionBrushNetPipeline:
         self._side_stream = None
         self.overlap_aux = False         # UNet shortcut convs / V projections on a third stream: measured 0.8 % slower
                                          # (18.15 vs 18.0 ms per step, tools/bench_aux.py), so off by default
+        # both nets' time embeddings + fused time_emb_proj for the whole schedule in one batched pass before the loop
+        # (graph path): 8 dependent launches fewer at the head of every step; A/B switch for tools/
+        self.precompute_time_embedding = os.environ.get("MFHIP_NO_TEMB_TABLE") != "1"
         self._added_cond = None          # SDXL: added_cond_kwargs of the (CFG-duplicated) batch, set by the XL subclass
         self._graph_state = None
 
@@ -643,16 +646,30 @@ class StableDiffusionBrushNetPipeline:
         st["pe"].copy_(pe)
         st["cond"].copy_(cond)
         pe, cond = st["pe"], st["cond"]
+        # every timestep is known here: both nets' time embeddings and the fused time_emb_proj GEMM run ONCE for
+        # the whole schedule (4 batched launches per net) instead of 8 dependent launches at the head of every step; the
+        # graph reads one row block per step from a static buffer.  Kept across calls with the same schedule.
+        tkey = (tuple(float(t) for t in ts.tolist()), self.unet._weights_gen, self.brushnet._weights_gen)
+        if self.precompute_time_embedding and (st.get("temb_key") != tkey or added):
+            nrows_b = nb if self._brushnet_once else pe.shape[0]
+            st["temb_tab"] = (self.unet.time_embedding_table(tvals, pe.shape[0], added),
+                              self.brushnet.time_embedding_table(tvals, nrows_b, added))
+            st["temb_key"] = tkey
+            if "temb_cur" not in st or any(c.shape != t.shape[1:] for c, t in zip(st["temb_cur"], st["temb_tab"])):
+                if st["graph"] is not None:
+                    raise RuntimeError("time-embedding table changed shape under a captured graph")
+                st["temb_cur"] = tuple(torch.empty_like(t[0]) for t in st["temb_tab"])
+        temb_u, temb_b = st["temb_cur"] if self.precompute_time_embedding else (None, None)
 
         def one_step():
             x_in = torch.cat([lat] * 2)
             once = self._brushnet_once
             down, mid, up = self.brushnet(lat if once else x_in, t_cur, encoder_hidden_states=pe[:nb] if once else pe,
                                           brushnet_cond=cond[:nb] if once else cond,
-                                          conditioning_scale=cond_scale, added_cond_kwargs=added, return_dict=False)
+                                          conditioning_scale=cond_scale, added_cond_kwargs=added, return_dict=False, _temb=temb_b)
             eps = self.unet(x_in, t_cur, encoder_hidden_states=pe, down_block_add_samples=down,
                             mid_block_add_sample=mid, up_block_add_samples=up, added_cond_kwargs=added,
-                            return_dict=False)[0]
+                            return_dict=False, _temb=temb_u)[0]
             if fused_ddim:
                 hip.cfg_ddim_step_dev(eps[:nb], eps[nb:], float(guidance_scale), lat, coef_cur, ptype, clip, out=lat)
             else:
@@ -666,6 +683,9 @@ class StableDiffusionBrushNetPipeline:
             t_cur.copy_(tvals[i:i + 1])
             if fused_ddim:
                 coef_cur.copy_(coefs[i])
+            if temb_u is not None:
+                temb_u.copy_(st["temb_tab"][0][i])
+                temb_b.copy_(st["temb_tab"][1][i])
             if i == 0 and not replay_all:
                 one_step()                                   # eager: tunes GEMMs, binds the prompt K/V, sizes scratch
             else:

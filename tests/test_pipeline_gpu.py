@@ -486,3 +486,42 @@ def test_baseline_config1_batch4_512_against_reference(prec, tol):
     st = G["image_stats"]
     check(f"config1 image 0, decoded [{prec}]", strided_sample(res.images[:1], st[2], 4096), G["image_sample"], prec,
           dict(atol=2e-3), "sd15_config1_slice/image")
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-3), ("bf16", None)])
+def test_baseline_config1_all_50_steps_against_reference(prec, tol):
+    """The benchmark's REAL workload: BASELINE.json configs[1] — batch 4 x 512 x 512, all 50 DDIM steps, CFG 7.5 — against
+    what the REFERENCE pipeline (pipeline_brushnet.py:1250-1332, scheduling_ddim.py:344-470) produced for image 0 of the
+    same inputs over the same 50 steps (tests/golden/sd15_config1_50steps.npz, tools/make_golden.py --only-config1-50:
+    latents after steps 1, 5, 10, 20, 30, 40, 50 and the decoded image).  f16x3 (the parity mode bench.py times as
+    `parity_mode`): 1e-3 latent L-inf at EVERY recorded step, the north-star bar; bf16 (the mode `value` is measured in):
+    inside the reference's own bf16 envelope over the same 50 steps, at the tightened multipliers of tests/util.py."""
+    unet, bn, vae = build("sd15", prec)
+    G = golden("sd15_config1_50steps.npz")
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn,
+                                           scheduler=DDIMScheduler(clip_sample=False, **SD_SCHED), safety_checker=None,
+                                           feature_extractor=None, requires_safety_checker=False,
+                                           depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+    want = [int(n) for n in G["steps"]]
+    trace = {}
+
+    def cb(p, i, t, kw):
+        if i + 1 in want:
+            trace[i + 1] = kw["latents"][:1].clone()
+        return {}
+
+    res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
+               mask=inp["mask"], depth=inp["depth"], num_inference_steps=50, guidance_scale=7.5, latents=inp["latents"].clone(),
+               output_type="pt", height=512, width=512, conditioning_noise=inp["vae_noise"], callback_on_step_end=cb)
+    assert pipe.scheduler.timesteps.tolist() == G["timesteps"].tolist() and len(G["timesteps"]) == 50
+    assert pipe._graph_state is not None and pipe._graph_state["graph"] is not None, "the 50 steps must run the captured graph"
+    assert tuple(res.images.shape) == (4, 3, 512, 512) and torch.isfinite(res.images).all()
+    assert sorted(trace) == want
+    for n in want:
+        check(f"config1 x 50 steps, image 0, latents after step {n} [{prec}]", trace[n], G[f"latents_{n}"], prec, dict(atol=tol),
+              f"sd15_config1_50steps/latents_{n}")
+    st = G["image_stats"]
+    check(f"config1 x 50 steps, image 0, decoded [{prec}]", strided_sample(res.images[:1], st[2], 4096), G["image_sample"], prec,
+          dict(atol=2e-3), "sd15_config1_50steps/image")

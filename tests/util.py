@@ -38,7 +38,9 @@ _ENV = None
 # The HIP bf16 path must stay inside this multiple of the REFERENCE's own bf16 deviation from its fp32 results
 # (tests/golden/bf16_envelope.json, tools/make_bf16_envelope.py).  Two independent bf16 evaluations of the same net draw
 # their rounding errors independently: the means agree closely, the maxima (an extreme-value statistic) less so.
-ENV_K_LINF, ENV_K_MEAN = 2.0, 1.5
+# Round 3: cut from 2.0 / 1.5 to 1.25 / 1.1 — every ratio observed on MI355X is <= 0.85 (printed by report_env as
+# "ratio linf / mean"), so a regression that doubles the bf16 error now fails.
+ENV_K_LINF, ENV_K_MEAN = 1.25, 1.1
 
 
 def envelope(key):
@@ -57,7 +59,8 @@ def report_env(name, got, ref, key, k_linf=ENV_K_LINF, k_mean=ENV_K_MEAN):
     env = envelope(key)
     linf, mean = err.max().item(), err.mean().item()
     print(f"{name}: max_abs_err={linf:.3e} (reference bf16: {env['linf']:.3e}) mean_abs_err={mean:.3e} "
-          f"(reference bf16: {env['mean']:.3e}) ref_absmax={ref.abs().max().item():.3e}")
+          f"(reference bf16: {env['mean']:.3e}) ref_absmax={ref.abs().max().item():.3e} "
+          f"ENVRATIO linf {linf / max(env['linf'], 1e-30):.3f} mean {mean / max(env['mean'], 1e-30):.3f}")
     assert linf == linf, f"{name}: NaN"
     assert linf <= k_linf * env["linf"], f"{name}: L-inf {linf:.3e} > {k_linf} x the reference's bf16 envelope {env['linf']:.3e}"
     assert mean <= k_mean * env["mean"], f"{name}: mean error {mean:.3e} > {k_mean} x the reference's bf16 envelope {env['mean']:.3e}"

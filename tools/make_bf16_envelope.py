@@ -270,9 +270,46 @@ def config1_slice(out):
     out["sd15_config1_slice/image"] = stats(sample_like(res.images, C["image_stats"][2], 4096), C["image_sample"])
 
 
+def config1_50steps(out):
+    """The reference in bf16 over the benchmark's real 50 DDIM steps (the case of make_golden.config1_50steps)."""
+    import time
+    ucfg, vcfg = R.SD15_UNET, R.SD15_VAE
+    (unet, _, _), (brushnet, _, _), (vae, _, _) = MG.models(ucfg, vcfg, 0)
+    for m in (unet, brushnet, vae):
+        m.to(BF)
+    C = np.load(os.path.join(GOLD, "sd15_config1_50steps.npz"))
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=brushnet,
+                                           scheduler=sched, safety_checker=None, feature_extractor=None,
+                                           requires_safety_checker=False, depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+    sl = slice(0, 1)
+    nz = inp["vae_noise"]
+    noise = torch.cat([nz[:4][sl], nz[4:][sl]])
+    trace = []
+    t0 = time.time()
+
+    def cb(p, i, t, k):
+        trace.append(k["latents"].clone())
+        print(f"[bf16 config1 50] step {i + 1} at {time.time() - t0:.0f} s", flush=True)
+        return {}
+
+    with fixed_noise([noise]):
+        res = pipe(prompt_embeds=inp["prompt_embeds"][sl].to(BF), negative_prompt_embeds=inp["negative_prompt_embeds"][sl].to(BF),
+                   image=inp["image"][sl], mask=inp["mask"][sl], depth=inp["depth"][sl], num_inference_steps=50,
+                   guidance_scale=7.5, latents=inp["latents"][sl].clone().to(BF), output_type="pt",
+                   brushnet_conditioning_scale=1.0, callback_on_step_end=cb, height=512, width=512)
+    for n in MG.C1_50_STEPS:
+        out[f"sd15_config1_50steps/latents_{n}"] = stats(trace[n - 1], C[f"latents_{n}"])
+    out["sd15_config1_50steps/image"] = stats(sample_like(res.images, C["image_stats"][2], 4096), C["image_sample"])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-config1", action="store_true")
+    ap.add_argument("--only-config1-50", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     a = ap.parse_args()
@@ -283,12 +320,14 @@ if __name__ == "__main__":
             out = json.load(f)
     out["_about"] = ("|reference(bf16) - reference(fp32)| of the imported reference on the golden cases "
                      "(tools/make_bf16_envelope.py): linf / mean abs error, and the fp32 result's abs max / mean")
-    if a.only_config1:
+    if a.only_config1_50:
+        config1_50steps(out)
+    elif a.only_config1:
         config1_slice(out)
     elif not a.only_full:
         tiny(out)
         tiny_xl(out)
-    if (a.full or a.only_full) and not a.only_config1:
+    if (a.full or a.only_full) and not (a.only_config1 or a.only_config1_50):
         full(out)
         config1_slice(out)
     with open(path, "w") as f:

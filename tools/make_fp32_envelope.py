@@ -1,0 +1,83 @@
+"""fp32 noise floor of the REFERENCE ITSELF on the benchmark's 50-step workload: the oracle restatement (bit-exact with the
+imported reference in fp32: tools/make_golden.py) evaluated in FLOAT64 on the inputs of tests/golden/sd15_config1_50steps.npz,
+against the reference's fp32 latents stored there.  With seeded random weights the latents grow to |x| ~ 70 over 50 steps
+and the denoise loop amplifies rounding differences, so "1e-3 absolute" has to be read against how far the reference's own
+fp32 arithmetic is from the exact result of the same function.  Output: tests/golden/fp32_envelope.json (numbers only).
+
+Runs in the build container only (the oracle itself needs no reference import, but the golden it compares with came from it).
+
+    python tools/make_fp32_envelope.py            # ~15 min of CPU (float64 convolutions)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import mirrorfusion_ref as R  # noqa: E402
+from reflecting_reality_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+D = torch.float64
+
+
+def _temb64(timesteps, dim, flip_sin_to_cos, freq_shift):
+    import math
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=D) / (half - freq_shift)
+    emb = timesteps[:, None].to(D) * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def stats(got, ref):
+    e = (got.double() - torch.as_tensor(ref).double()).abs()
+    r = torch.as_tensor(ref).double().abs()
+    return dict(linf=float(e.max()), mean=float(e.mean()), ref_absmax=float(r.max()), ref_absmean=float(r.mean()))
+
+
+def main():
+    R.timestep_embedding = _temb64
+    with open(os.path.join(GOLD, "keys_sd15.json")) as f:
+        shapes = {m: {k: tuple(v) for k, v in d.items()} for m, d in json.load(f).items()}
+    usd = {k: v.to(D) for k, v in synth.state_dict_for(shapes["unet"], 0).items()}
+    bsd = {k: v.to(D) for k, v in synth.state_dict_for(shapes["brushnet"], 1).items()}
+    vsd = {k: v.to(D) for k, v in synth.state_dict_for(shapes["vae"], 2).items()}
+    G = np.load(os.path.join(GOLD, "sd15_config1_50steps.npz"))
+    inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+    sl = slice(0, 1)
+    nz = inp["vae_noise"]
+    noise = torch.cat([nz[:4][sl], nz[4:][sl]]).to(D)
+    cond = R.build_conditioning(vsd, R.SD15_VAE, inp["image"][sl].to(D), inp["mask"][sl].to(D), inp["depth"][sl].to(D), noise)
+    pe = torch.cat([inp["negative_prompt_embeds"][sl], inp["prompt_embeds"][sl]]).to(D)
+    sched = R.DDIMRef(**R.SD15_SCHED)
+    sched.alphas_cumprod = sched.alphas_cumprod.to(D)          # the reference's fp32 constants, exactly
+    sched.final_alpha_cumprod = sched.final_alpha_cumprod.to(D)
+    trace = []
+    t0 = time.time()
+
+    class T(list):
+        def append(self, x):
+            super().append(x)
+            print(f"[fp64 oracle] step {len(self)} at {time.time() - t0:.0f} s", flush=True)
+
+    trace = T()
+    R.denoise(usd, R.SD15_UNET, bsd, R.brushnet_config(R.SD15_UNET, 6), sched, inp["latents"][sl].to(D), cond.to(D), pe, 50, 7.5, 1.0, trace)
+    out = {"_about": "|reference(fp32) - oracle(float64)| on tests/golden/sd15_config1_50steps.npz (tools/make_fp32_envelope.py): "
+                     "how far the reference's own fp32 arithmetic is from the exact value of the same function"}
+    for n in [int(s) for s in G["steps"]]:
+        out[f"sd15_config1_50steps/latents_{n}"] = stats(trace[n - 1], G[f"latents_{n}"])
+        print(n, out[f"sd15_config1_50steps/latents_{n}"], flush=True)
+    with open(os.path.join(GOLD, "fp32_envelope.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
