@@ -52,6 +52,11 @@ struct GemmArgs {
     float alpha; int act;
     char* out; int out_dt; int64_t ldc;
     int tiles_n, tiles_m, ord_mfast, ord_pw, nblk, vec_ok, fast, dbg_no_res_pre;
+    // LayerNorm folded into this GEMM (warp-specialised ring tiles): ln_cs[n] = sum_k W'[n][k] of the gamma-scaled weight;
+    // the staging waves accumulate every A row's (sum, sum of squares) while they wait, the epilogue applies
+    // rstd[m] * (acc - mean[m] * ln_cs[n]).  vt_out: columns n >= vt_n0 are written TRANSPOSED ([image][n - vt_n0][token]).
+    const float* ln_cs; float ln_eps;
+    char* vt_out; int vt_n0, vt_tokens; int64_t vt_ld;
 };
 
 // res1 shared by batch replicas (the BrushNet residual of both classifier-free-guidance halves): a handful of replicas,
@@ -984,13 +989,60 @@ void gemm_conv_kernel(const GemmArgs p) {
                         else if (PF >= 2 && newer == 1) wait_vmcnt<G>();
                         else wait_vmcnt<0>();
                     };
+                    // LayerNorm fold: this thread reads back the 16-byte chunks of the A tile its own DMAs wrote (tile t has
+                    // landed for this wave since wait_for(t); its stage is next written by this wave's own issue of tile
+                    // t + STAGES) and accumulates them into the row's sum / sum of squares: 8 v_dot2c_f32_bf16 per chunk on
+                    // waves that otherwise only wait.  A row's 8 lanes are combined once after the loop.
+                    const bool lnf = p.ln_cs != nullptr;
+                    float ln_s[A_IT], ln_q[A_IT];
+#pragma unroll
+                    for (int i = 0; i < A_IT; ++i) { ln_s[i] = 0.0f; ln_q[i] = 0.0f; }
+                    int st_s = 0;
+                    auto ln_tile = [&]() {
+                        if constexpr (DT == MF_BF16) {
+                            typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+                            const bf2_t ones = __builtin_bit_cast(bf2_t, 0x3F803F80u);
+                            const char* As = smem + st_s * STAGE_BYTES + tid * 16;
+#pragma unroll
+                            for (int i = 0; i < A_IT; ++i) {
+                                const uint4 u = *reinterpret_cast<const uint4*>(As + i * RPP * 128);
+                                const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const bf2_t v = __builtin_bit_cast(bf2_t, w4[e]);
+                                    ln_s[i] = __builtin_amdgcn_fdot2_f32_bf16(v, ones, ln_s[i], false);
+                                    ln_q[i] = __builtin_amdgcn_fdot2_f32_bf16(v, v, ln_q[i], false);
+                                }
+                            }
+                        }
+                        st_s = st_s == STAGES - 1 ? 0 : st_s + 1;
+                    };
                     for (int k = 0; k < PF && k < nt; ++k) issue_next();
                     wait_for(0);
                     __builtin_amdgcn_s_barrier();                  // #0
                     for (int t = 0; t + 1 < nt; ++t) {
+                        if (lnf) ln_tile();                        // tile t
                         if (t + PF < nt) issue_next();
                         wait_for(t + 1);
                         __builtin_amdgcn_s_barrier();              // #(t + 1)
+                    }
+                    if (lnf) {
+                        ln_tile();                                 // tile nt - 1
+                        float2* lnst = reinterpret_cast<float2*>(smem + STAGES * STAGE_BYTES);   // [BM] (mean, rstd): past the ring
+                        const float invk = 1.0f / (float)p.K;
+#pragma unroll
+                        for (int i = 0; i < A_IT; ++i) {
+                            float s1 = ln_s[i], q1 = ln_q[i];
+#pragma unroll
+                            for (int off = 1; off < 8; off <<= 1) {
+                                s1 += __shfl_xor(s1, off, 64);
+                                q1 += __shfl_xor(q1, off, 64);
+                            }
+                            const float mean = s1 * invk;
+                            float var = q1 * invk - mean * mean;
+                            if (var < 0.0f) var = 0.0f;
+                            if ((tid & 7) == 0) lnst[lrow + i * RPP] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
+                        }
                     }
                 } else {
                     int st_c = 0;
@@ -1110,9 +1162,51 @@ void gemm_conv_kernel(const GemmArgs p) {
                 int sw, row, ec, m, n;
                 if (!coords(u, sw, row, ec, m, n)) continue;
                 const char* sl = smem + sw * (SR * EP_RS);
+                const float2* lnst = reinterpret_cast<const float2*>(smem + STAGES * STAGE_BYTES);
+                if (p.vt_out && n0 + (sw % WAVES_N) * WN >= p.vt_n0) {
+                    // transposed columns (the V third of a fused q | k | v projection): this slab is dealt as (column, group of 8
+                    // rows) items; a lane gathers 8 consecutive tokens of ONE channel from the slab's column and stores them as
+                    // 16 bytes of V^T[image][channel][token] (attention reads V^T with keys contiguous)
+                    static_assert(SR % 8 == 0 && (SR / 8) * WN == ITEMS, "transposed items cover the slab");
+                    const int c = g + u * TW, it = (c - sw * NIT) * 64 + lane;
+                    const int col = it % WN, rg = it / WN;
+                    const int swm = sw / WAVES_N, swn = sw - swm * WAVES_N;
+                    const int mt = m0 + swm * WM + i * 32 + half * SR + rg * 8, nt_ = n0 + swn * WN + col;
+                    if (mt < p.M && nt_ < p.N) {
+                        float tv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) tv[j] = *reinterpret_cast<const float*>(sl + (rg * 8 + j) * EP_RS + col * 4);
+                        if (p.ln_cs) {
+                            const float cs = p.ln_cs[nt_];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float2 st = lnst[mt - m0 + j];
+                                tv[j] = st.y * (tv[j] - st.x * cs);
+                            }
+                        }
+                        const float b = p.bias ? p.bias[nt_] : 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) tv[j] = (tv[j] + b) * p.alpha;
+                        const int img = mt / p.vt_tokens, tok = mt - img * p.vt_tokens;
+                        uint4 o;
+                        o.x = pack_bf16x2(tv[0], tv[1]); o.y = pack_bf16x2(tv[2], tv[3]);
+                        o.z = pack_bf16x2(tv[4], tv[5]); o.w = pack_bf16x2(tv[6], tv[7]);
+                        *reinterpret_cast<uint4*>(p.vt_out + (((int64_t)img * (p.N - p.vt_n0) + (nt_ - p.vt_n0)) * p.vt_ld + tok) * 2) = o;
+                    }
+                    continue;
+                }
                 float v[8];
-                const float4 lo = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4);
-                const float4 hi = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4 + 16);
+                float4 lo = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4);
+                float4 hi = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4 + 16);
+                if (p.ln_cs && m < p.M && n + 8 <= p.N) {            // LayerNorm fold: rstd * (acc - mean * colsum)
+                    const float2 st = lnst[m - m0];
+                    const float4 c0 = *reinterpret_cast<const float4*>(p.ln_cs + n);
+                    const float4 c1 = *reinterpret_cast<const float4*>(p.ln_cs + n + 4);
+                    lo.x = st.y * (lo.x - st.x * c0.x); lo.y = st.y * (lo.y - st.x * c0.y);
+                    lo.z = st.y * (lo.z - st.x * c0.z); lo.w = st.y * (lo.w - st.x * c0.w);
+                    hi.x = st.y * (hi.x - st.x * c1.x); hi.y = st.y * (hi.y - st.x * c1.y);
+                    hi.z = st.y * (hi.z - st.x * c1.z); hi.w = st.y * (hi.w - st.x * c1.w);
+                }
                 v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
                 if (m < p.M && n < p.N) {
                     if (ws) {
@@ -1914,7 +2008,8 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false,
           bool P16 = false>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? ST : 2) * BN * 128 : ST * (BM + BN) * 128;
+    // warp-specialised ring tiles keep BM (mean, rstd) pairs of a folded LayerNorm past the ring
+    constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? ST : 2) * BN * 128 : ST * (BM + BN) * 128 + (WS ? BM * 8 : 0);
     static_assert(smem_k <= 160 * 1024, "LDS");
     // experiment switch: MFHIP_SMEM_MIN=<bytes> raises the LDS request (occupancy control for ring-depth A/B runs)
     static const int smem_min = getenv("MFHIP_SMEM_MIN") ? atoi(getenv("MFHIP_SMEM_MIN")) : 0;
@@ -2163,6 +2258,23 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(a.res1_rows == 0 || a.M % a.res1_rows == 0, "mf_gemm_conv: res1_rows=%d must divide M=%d", d->res1_rows, a.M);
     a.alpha = d->alpha; a.act = d->act;
     a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ldc = d->ldc;
+    a.ln_cs = d->ln_colsum; a.ln_eps = d->ln_eps;
+    a.vt_out = (char*)d->vt_out; a.vt_n0 = d->vt_n0; a.vt_tokens = d->vt_tokens; a.vt_ld = d->vt_ld;
+    if (d->ln_colsum || d->vt_out) {
+        // served by the warp-specialised ring tiles only (41-46, 48): the staging waves gather the row statistics
+        MF_CHECK_ARG(d->dtype == MF_BF16 && d->a_dtype == MF_BF16 && d->kh == 1 && d->kw == 1 && d->c1 == 0 && d->nz == 1 &&
+                         (d->splitk == 0 || d->splitk == 1) && d->a_scale == nullptr && d->w_scale == nullptr,
+                     "mf_gemm_conv: ln_colsum / vt_out need a plain bf16 1x1 GEMM (one A segment, no batching, no split-K, no scales)");
+        MF_CHECK_ARG(d->tile == 0 || (d->tile >= 41 && d->tile <= 48 && d->tile != 47), "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (tiles 41-46, 48 do)", d->tile);
+        MF_CHECK_ARG(!d->ln_colsum || (mf_aligned16(d->ln_colsum) && d->n % 8 == 0 && d->ln_eps > 0.0f), "mf_gemm_conv: ln_colsum must be 16-byte aligned, n %% 8 == 0, ln_eps > 0");
+        if (d->vt_out) {
+            MF_CHECK_ARG(d->out_dtype == MF_BF16 && mf_aligned16(d->vt_out) && d->vt_tokens > 0 && d->vt_tokens % 8 == 0 && a.M % d->vt_tokens == 0 &&
+                             d->vt_ld % 8 == 0 && d->vt_ld >= d->vt_tokens && d->vt_n0 > 0 && d->vt_n0 < d->n && d->vt_n0 % 160 == 0 &&
+                             d->vt_n0 % 128 == 0 && d->res0 == nullptr && d->res1 == nullptr && d->temb == nullptr && d->act == MF_ACT_NONE &&
+                             d->bias_mode == 0,
+                         "mf_gemm_conv: vt_out needs bf16 output, tokens %% 8 == 0 dividing M, vt_n0 a multiple of 640 inside (0, n), no residual / temb / activation");
+        }
+    }
     MF_CHECK_ARG(d->act != MF_ACT_GEGLU4 || (d->n % 8 == 0 && d->ldc % 4 == 0 && d->res0 == nullptr && d->res1 == nullptr &&
                                              (d->splitk == 0 || d->splitk == 1)),
                  "mf_gemm_conv: the GEGLU epilogue needs n %% 8 == 0, ldc %% 4 == 0, no residuals and no forced split-K");
@@ -2178,7 +2290,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
                (!d->res1 || (mf_aligned16(d->res1) && d->ld_res1 % 8 == 0));
 
     int tile = d->tile;
-    if (tile <= 0 || tile > kNumTiles) tile = pick_tile(a.M, a.N, a.nz, d->splitk, a_f32 ? 6 : 24, split || d->dtype == MF_FP8);
+    if (tile <= 0 || tile > kNumTiles) tile = (d->ln_colsum || d->vt_out) ? 48 : pick_tile(a.M, a.N, a.nz, d->splitk, a_f32 ? 6 : 24, split || d->dtype == MF_FP8);
     if (a_f32) {
         // the converting path only exists for the 2-stage tiles 1..6; 7..12 are the same shapes with a deeper ring.
         // Resolve the EFFECTIVE tile before the grid is derived from it (a 192x128 grid on a 128x128 kernel would leave
@@ -2256,7 +2368,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     if (splitk == 0) {
         // heuristic: fill the 256 CUs when the output grid alone cannot, keeping >= 4 K-tiles per split
         splitk = 1;
-        if (tiles_mn <= 192 && a.nkt >= 8 && d->ws != nullptr && d->act != MF_ACT_GEGLU4) {
+        if (tiles_mn <= 192 && a.nkt >= 8 && d->ws != nullptr && d->act != MF_ACT_GEGLU4 && !d->ln_colsum && !d->vt_out) {
             splitk = (int)((384 + tiles_mn - 1) / tiles_mn);
             if (splitk > a.nkt / 4) splitk = a.nkt / 4;
             const int64_t per_split = (int64_t)a.nz * a.M * a.N;

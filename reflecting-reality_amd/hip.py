@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1 = 0, 1, 2, 3, 4, 5
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class MfhipError(RuntimeError):
@@ -49,6 +49,8 @@ class GemmDesc(C.Structure):
         ("out", C.c_void_p), ("out_dtype", C.c_int32), ("ldc", C.c_int64),
         ("splitk", C.c_int32), ("ws", C.c_void_p), ("ws_floats", C.c_int64),
         ("tile", C.c_int32),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("vt_out", C.c_void_p), ("vt_n0", C.c_int32), ("vt_tokens", C.c_int32), ("vt_ld", C.c_int64),
     ]
 
 
@@ -306,7 +308,7 @@ def _tune_forget(ks: str) -> None:
 
 
 def _tune_key(key: tuple) -> str:
-    return ",".join(str(int(x)) for x in key)
+    return ",".join(x if isinstance(x, str) else str(int(x)) for x in key)
 
 
 def _tuned_config(d: "GemmDesc", key: tuple):
@@ -383,7 +385,8 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
               alpha: float = 1.0, act: int = ACT_NONE,
               nz: int = 1, zdiv: int = 1, a_zs=(0, 0), w_zs=(0, 0), o_zs=(0, 0),
               a_scale: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None, a_scale_zs: int = 0,
-              w_scale_zs: int = 0, splitk: int = 0, tile: int = 0) -> torch.Tensor:
+              w_scale_zs: int = 0, splitk: int = 0, tile: int = 0, ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+              vt_out: Optional[torch.Tensor] = None, vt_n0: int = 0, vt_tokens: int = 0) -> torch.Tensor:
     """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements.  `dtype`: a torch
     dtype (bf16 / fp32 compute) or an MF_* compute code (the split codes take fp32 a0 and, with w_split=1, a weight
     from ops.split_pack)."""
@@ -428,10 +431,24 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     ws = scratch("splitk", SPLITK_WS_FLOATS, out.device)
     d.splitk, d.ws, d.ws_floats = splitk, ws.data_ptr(), ws.numel()
     d.tile = tile
+    fused = 0
+    if ln_colsum is not None:
+        _req_cuda(ln_colsum)
+        if ln_colsum.dtype != torch.float32 or ln_colsum.numel() != n:
+            raise MfhipError("ln_colsum must be n fp32 values")
+        d.ln_colsum, d.ln_eps = _ptr(ln_colsum), ln_eps
+        fused |= 1
+    if vt_out is not None:
+        _req_cuda(vt_out)
+        if vt_out.dtype != torch.bfloat16 or vt_out.dim() != 3 or not vt_out.is_contiguous():
+            raise MfhipError("vt_out must be a contiguous bf16 [images][n - vt_n0][ld] tensor")
+        d.vt_out, d.vt_n0, d.vt_tokens, d.vt_ld = _ptr(vt_out), vt_n0, vt_tokens, vt_out.shape[-1]
+        fused |= 2
     tkey = None
     if tile == 0 and splitk in (0, 1) and AUTOTUNE:
         tkey = (code, d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), int(c1 > 0),
-                nz, int(splitk == 1), act, h_out, w_out) + ((w_split,) if code in (MF_F16X3, MF_BF16X3) else ())
+                nz, int(splitk == 1) if not fused else 1, act, h_out, w_out) + ((w_split,) if code in (MF_F16X3, MF_BF16X3) else ()) \
+            + ((("ln", "vt", "lnvt")[fused - 1],) if fused else ())
         d.tile, d.splitk = _tuned_config(d, tkey)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

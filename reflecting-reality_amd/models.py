@@ -469,6 +469,19 @@ class _UNetCore(HipModel):
                 self.P[b + "ff.net.0.proj"] = ops.geglu_weight(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"],
                                                                self.prec, self.device, fp8=ok8(b + "ff.net.0.proj"))
             self.P[b + "ff.net.2"] = self._conv(sd, b + "ff.net.2", fp8=ok8(b + "ff.net.2"))
+            c = sd[b + "norm1.weight"].shape[0]
+            if self.prec.name == "bf16" and not self.training and c % 320 == 0:
+                # bf16 inference: the three LayerNorms of the block are FOLDED into the Linears that consume them (W diag(gamma),
+                # bias + W beta; the GEMM gathers the row statistics itself and normalises in its epilogue), and q | k | v of the
+                # self-attention are one GEMM whose V third is stored transposed: 3 LayerNorm launches and the V^T launch less
+                # per block, the normalised tensors are never written (attention.py:203,233,261,291-412)
+                ln = lambda n: (sd[b + n + ".weight"], sd[b + n + ".bias"], 1e-5)
+                self.P[b + "attn1.to_qkv_ln"] = ConvWeight(torch.cat([sd[b + "attn1.to_q.weight"], sd[b + "attn1.to_k.weight"],
+                                                                      sd[b + "attn1.to_v.weight"]], 0), None, self.prec, self.device,
+                                                           ln=ln("norm1"))
+                self.P[b + "attn2.to_q_ln"] = ConvWeight(sd[b + "attn2.to_q.weight"], None, self.prec, self.device, ln=ln("norm2"))
+                self.P[b + "ff.net.0.proj_ln"] = ops.geglu_weight(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"],
+                                                                  self.prec, self.device, ln=ln("norm3"))
             i += 1
         self.tdepth[p] = i
 
@@ -585,8 +598,10 @@ class _UNetCore(HipModel):
             cur.wait_event(done)
         return out, join
 
-    def _attention(self, b: str, x: torch.Tensor, ctx: Optional[torch.Tensor], heads: int, residual: torch.Tensor
-                   ) -> torch.Tensor:
+    ln_fold = os.environ.get("MFHIP_NO_LNFOLD") != "1"      # A/B switch for the folded LayerNorms / fused q | k | v (bf16 inference)
+
+    def _attention(self, b: str, x: torch.Tensor, ctx: Optional[torch.Tensor], heads: int, residual: torch.Tensor,
+                   fold: bool = False) -> torch.Tensor:
         """Attention + AttnProcessor2_0 (attention_processor.py:1213-1286) + the block's residual add.
         Self-attention projects q and k with one GEMM; cross-attention K / V^T depend only on the prompt
         embeddings (attention_processor.py:1253-1254) and are cached across denoise steps."""
@@ -603,7 +618,12 @@ class _UNetCore(HipModel):
             v = ops.linear(src, P[b + "to_v"])
             o = ops.attention_train(q, k, v, heads, 1.0 / (d ** 0.5), self.prec)
             return ops.linear(o, P[b + "to_out.0"], res0=residual)
-        if ctx is None:
+        if fold and ctx is None:
+            # x is the UN-normalised residual stream: norm1 lives inside the fused q | k | v GEMM
+            skv = xt.shape[1]
+            qk, vt = ops.linear_qkv(x, P[b + "to_qkv_ln"])
+            q, k = qk[..., :c], qk[..., c:]
+        elif ctx is None:
             skv = xt.shape[1]
             # V^T on the auxiliary stream while q | k is projected on this one
             vt, join = self._on_aux(lambda: ops.linear_t(x, P[b + "to_v"], (skv + 7) // 8 * 8, out=self._vt_buffer(xt, c, skv)))
@@ -613,7 +633,7 @@ class _UNetCore(HipModel):
                 join()
         else:
             skv = ctx.shape[1]
-            q = ops.linear(x, P[b + "to_q"])
+            q = ops.linear(x, P[b + ("to_q_ln" if fold else "to_q")])
             kv = self._cross_kv.get(b)
             if kv is None or kv[2] != self._ehs_gen:
                 # (re)compute into persistent buffers: a captured hipGraph keeps reading the same addresses
@@ -682,6 +702,11 @@ class _UNetCore(HipModel):
             h = ops.conv2d(h, P[p + "proj_in"], padding=0).view(bsz, hh * ww, c)
         for i in range(self.tdepth[p]):
             b = f"{p}transformer_blocks.{i}."
+            if self.ln_fold and (b + "attn1.to_qkv_ln") in P and (hh * ww) % 8 == 0 and ops.TAPE is None:
+                h = self._attention(b + "attn1.", h, None, heads, h, fold=True)
+                h = self._attention(b + "attn2.", h, ehs, heads, h, fold=True)
+                h = ops.linear(ops.linear_geglu(h, P[b + "ff.net.0.proj_ln"]), P[b + "ff.net.2"], res0=h)
+                continue
             n = ops.layernorm(h, P[b + "norm1"], 1e-5, self.prec.act, fp8=P[b + "attn1.to_out.0"].fp8)
             h = self._attention(b + "attn1.", n, None, heads, h)
             n = ops.layernorm(h, P[b + "norm2"], 1e-5, self.prec.act, fp8=P[b + "attn2.to_q"].fp8)

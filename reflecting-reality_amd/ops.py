@@ -76,10 +76,22 @@ class ConvWeight:
     """Conv2d / Linear parameters re-laid-out once for the implicit-GEMM kernel: [N][kh][kw][Cin_pad]."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], prec: Precision, device,
-                 cin_pad: Optional[int] = None, raw: bool = False, fp8: bool = False):
+                 cin_pad: Optional[int] = None, raw: bool = False, fp8: bool = False, ln=None):
+        """`ln` = (gamma, beta, eps) of a LayerNorm whose output this Linear consumes (attention.py:203,233,261): the norm is
+        FOLDED into the GEMM — W' = W diag(gamma), bias' = bias + W beta, ln_colsum[n] = sum_k W'[n][k] (of the rounded W', so the
+        epilogue's mean correction cancels what the matrix pipe accumulated) — and mf_gemm_conv normalises in its epilogue."""
         self.fp8, self.w_scale = False, None
+        self.ln_colsum, self.ln_eps = None, 0.0
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
+        if ln is not None:
+            if fp8 or raw or prec.name != "bf16" or weight.shape[2:] != (1, 1):
+                raise hip.MfhipError("a folded LayerNorm needs a plain bf16 Linear")
+            g, b, eps = ln
+            w2 = weight.detach().float().reshape(weight.shape[0], -1)
+            bias = (bias.detach().float() if bias is not None else 0.0) + w2 @ b.detach().float().to(w2.device)
+            weight = (w2 * g.detach().float().to(w2.device)[None, :])[:, :, None, None]
+            self.ln_eps = float(eps)
         n, cin, kh, kw = weight.shape
         cp = cin_pad if cin_pad is not None else _round_up(cin, prec.vec)
         w = weight.detach().to(device=device, dtype=torch.float32).permute(0, 2, 3, 1)   # [N, kh, kw, Cin]
@@ -102,6 +114,8 @@ class ConvWeight:
             self.w_split = 1
         else:
             self.w = w.to(prec.compute).contiguous()
+        if ln is not None:
+            self.ln_colsum = self.w.float().sum(1).contiguous()
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.n, self.cin, self.cin_pad, self.kh, self.kw = n, cin, cp, kh, kw
         self.prec = prec
@@ -115,6 +129,7 @@ class ConvWeight:
         optimizer updates it in place every step)."""
         self = cls.__new__(cls)
         self.fp8, self.w_scale = False, None
+        self.ln_colsum, self.ln_eps = None, 0.0
         self.w, self.bias = p_w.data, (p_bias.data if p_bias is not None else None)
         self.w_split, self.ldw = 0, kh * kw * cin_pad
         self.n, self.cin, self.cin_pad, self.kh, self.kw = n, cin, cin_pad, kh, kw
@@ -203,8 +218,10 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
         out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
     hip.gemm_conv(x, lw.w, out, dtype=lw.prec.code, w_split=lw.w_split, ldw=lw.ldw, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
                   h_out=1, w_out=1, n=lw.n, bias=lw.bias, res0=res0, res1=res1, res1_rows=_shared_rows(res1, m, lw.n), alpha=alpha,
-                  act=act, splitk=splitk, tile=tile)
+                  act=act, splitk=splitk, tile=tile, ln_colsum=lw.ln_colsum, ln_eps=lw.ln_eps)
     if TAPE is not None:
+        if lw.ln_colsum is not None:
+            raise hip.MfhipError("training: folded LayerNorms are inference only")
         autograd.record_conv(TAPE, x, None, lw, out, batch=m, h_in=1, w_in=1, h_out=1, w_out=1, stride=1, pad_t=0, pad_l=0,
                              upsample=False, temb=None, res0=res0, res1=res1, alpha=alpha, act=act)
     return out
@@ -228,14 +245,30 @@ def _linear_fp8(x, lw: ConvWeight, res0, res1, alpha, act, out_dtype, out, tile,
     return out
 
 
-def geglu_weight(weight: torch.Tensor, bias: torch.Tensor, prec: Precision, device, fp8: bool = False) -> ConvWeight:
+def linear_qkv(x: torch.Tensor, lw: ConvWeight, tile: int = 0):
+    """Self-attention's three projections as ONE GEMM over x [B, S, C] with lw = cat([to_q, to_k, to_v]) ([3C, C], usually with
+    the block's norm1 folded in): returns (qk [B, S, 2C] — q and k as column slices — and V^T [B, C, S]); the V third leaves
+    the epilogue transposed (mf_gemm_desc.vt_out), so attention reads keys contiguously and no second launch re-reads x."""
+    b, s, k = x.shape
+    c = lw.n // 3
+    if TAPE is not None or k != lw.cin_pad or lw.n != 3 * c or s % 8 or (2 * c) % 640:
+        raise hip.MfhipError("linear_qkv: inference only, [3C, C] weight, tokens % 8 == 0, C % 320 == 0")
+    qk = torch.empty(b, s, 2 * c, dtype=lw.prec.act, device=x.device)
+    vt = torch.empty(b, c, s, dtype=lw.prec.act, device=x.device)
+    hip.gemm_conv(x, lw.w, qk, dtype=lw.prec.code, ldw=lw.ldw, c0=k, lda0=k, batch=b * s, h_in=1, w_in=1, h_out=1, w_out=1,
+                  n=lw.n, ldc=2 * c, bias=lw.bias, tile=tile, ln_colsum=lw.ln_colsum, ln_eps=lw.ln_eps, vt_out=vt, vt_n0=2 * c,
+                  vt_tokens=s)
+    return qk, vt
+
+
+def geglu_weight(weight: torch.Tensor, bias: torch.Tensor, prec: Precision, device, fp8: bool = False, ln=None) -> ConvWeight:
     """GEGLU.proj ([2*inner, dim]: value rows then gate rows, activations.py:92,100-103) with rows interleaved
     [4 value | 4 gate] so that mf_gemm_conv's 8-channel epilogue lanes hold matching value/gate pairs."""
     inner = weight.shape[0] // 2
     assert inner % 4 == 0
     idx = torch.arange(inner).view(-1, 4)
     order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
-    return ConvWeight(weight[order], bias[order], prec, device, fp8=fp8)
+    return ConvWeight(weight[order], bias[order], prec, device, fp8=fp8, ln=ln)
 
 
 def linear_geglu(x: torch.Tensor, lw: ConvWeight, tile: int = 0) -> torch.Tensor:
@@ -249,7 +282,8 @@ def linear_geglu(x: torch.Tensor, lw: ConvWeight, tile: int = 0) -> torch.Tensor
     inner = lw.n // 2
     out = torch.empty(*x.shape[:-1], inner, dtype=lw.prec.act, device=x.device)
     hip.gemm_conv(x, lw.w, out, dtype=lw.prec.code, w_split=lw.w_split, ldw=lw.ldw, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
-                  h_out=1, w_out=1, n=lw.n, ldc=inner, bias=lw.bias, act=hip.ACT_GEGLU4, splitk=1, tile=tile)
+                  h_out=1, w_out=1, n=lw.n, ldc=inner, bias=lw.bias, act=hip.ACT_GEGLU4, splitk=1, tile=tile,
+                  ln_colsum=lw.ln_colsum, ln_eps=lw.ln_eps)
     return out
 
 

@@ -610,3 +610,63 @@ def test_add_vector_and_scalar_paths():
     b = torch.randn(1003, generator=g)
     assert torch.equal(hip.add(a.to(DEV), b.to(DEV), torch.float32).cpu(), a.float() + b)      # mixed dtypes: generic kernel
     assert torch.equal(hip.add(a.to(DEV), a.to(DEV), torch.bfloat16).cpu(), (a.float() * 2).bfloat16())   # n % 8 != 0
+
+
+WS_RING_TILES = (0, 41, 42, 43, 44, 45, 46, 48)     # the tiles that serve ln_colsum / vt_out (0 = autotuned among them)
+
+
+@pytest.mark.parametrize("tile", WS_RING_TILES)
+@pytest.mark.parametrize("rows,c,n,mode", [(2 * 1024, 640, 640, "linear"), (2 * 4096, 320, 320, "res"), (300, 320, 1280, "linear"),
+                                           (2 * 256, 1280, 1280, "linear"), (2 * 1024, 640, 2 * 2560, "geglu"), (77, 64, 72, "linear")])
+def test_linear_with_folded_layernorm(tile, rows, c, n, mode):
+    """LayerNorm folded into the Linear that consumes it (attention.py:203,233,261 + the to_q / GEGLU projections): the GEMM
+    reads the UN-normalised rows, its staging waves gather (mean, rstd) of every row, the epilogue applies
+    rstd * (acc - mean * colsum(W gamma)) + (bias + W beta).  Reference: fp32 LayerNorm -> Linear on the bf16-rounded rows."""
+    prec = ops.Precision.get("bf16")
+    g = torch.Generator().manual_seed(31)
+    x = rb(torch.randn(rows, c, generator=g) * 1.7 + 0.9)                  # mean != 0: the rank-1 correction is live
+    gamma, beta = torch.randn(c, generator=g) * 0.5 + 1.0, torch.randn(c, generator=g) * 0.3
+    w = torch.randn(n, c, generator=g) / math.sqrt(c)
+    b = torch.randn(n, generator=g)
+    res = rb(torch.randn(rows, n, generator=g)) if mode == "res" else None
+    xn = F.layer_norm(x, (c,), gamma, beta, 1e-5)
+    if mode == "geglu":
+        hh, gate = F.linear(xn, w, b).chunk(2, dim=-1)
+        ref = hh * F.gelu(gate)
+        y = ops.linear_geglu(x.to(DEV, prec.act), ops.geglu_weight(w, b, prec, DEV, ln=(gamma, beta, 1e-5)), tile=tile)
+    else:
+        ref = F.linear(xn, w, b) + (res if res is not None else 0.0)
+        lw = ops.ConvWeight(w, b, prec, DEV, ln=(gamma, beta, 1e-5))
+        y = ops.linear(x.to(DEV, prec.act), lw, res0=res.to(DEV, prec.act) if res is not None else None, tile=tile)
+    # W gamma is rounded to bf16 once more than in the unfused path: the usual bf16 GEMM tolerance
+    check(f"linear_ln[{mode},{rows}x{c}->{n},tile{tile}]", y, ref, 3e-2, 2e-2)
+
+
+def test_folded_layernorm_is_refused_where_it_cannot_run():
+    prec = ops.Precision.get("bf16")
+    lw = ops.ConvWeight(torch.randn(64, 64), None, prec, DEV, ln=(torch.ones(64), torch.zeros(64), 1e-5))
+    x = torch.randn(128, 64, device=DEV).bfloat16()
+    with pytest.raises(hip.MfhipError, match="does not serve"):
+        ops.linear(x, lw, tile=14)                       # a tile without staging waves
+    with pytest.raises(hip.MfhipError, match="plain bf16 Linear"):
+        ops.ConvWeight(torch.randn(64, 64), None, ops.Precision.get("f16x3"), DEV, ln=(torch.ones(64), torch.zeros(64), 1e-5))
+
+
+@pytest.mark.parametrize("tile", WS_RING_TILES)
+@pytest.mark.parametrize("batch,tokens,c,with_ln", [(2, 4096, 320, True), (2, 1024, 640, True), (3, 256, 1280, True), (2, 64, 1280, True),
+                                                    (2, 1024, 320, False)])
+def test_fused_qkv_projection_with_transposed_v(tile, batch, tokens, c, with_ln):
+    """Self-attention's to_q | to_k | to_v as ONE GEMM (attention_processor.py:1246-1254): q | k leave as [B, S, 2C], the V third
+    leaves the epilogue transposed as V^T [B, C, S] (what mf_attention_bf16 reads), norm1 folded in."""
+    prec = ops.Precision.get("bf16")
+    g = torch.Generator().manual_seed(32)
+    x = rb(torch.randn(batch, tokens, c, generator=g) * 1.3 - 0.4)
+    gamma, beta = torch.randn(c, generator=g) * 0.5 + 1.0, torch.randn(c, generator=g) * 0.3
+    w = torch.randn(3 * c, c, generator=g) / math.sqrt(c)
+    xn = F.layer_norm(x, (c,), gamma, beta, 1e-5) if with_ln else x
+    ref = F.linear(xn, w if with_ln else rb(w))
+    lw = ops.ConvWeight(w, None, prec, DEV, ln=(gamma, beta, 1e-5) if with_ln else None)
+    qk, vt = ops.linear_qkv(x.to(DEV, prec.act), lw, tile=tile)
+    assert qk.shape == (batch, tokens, 2 * c) and vt.shape == (batch, c, tokens)
+    check(f"qkv.qk[{batch}x{tokens}x{c},tile{tile}]", qk, ref[..., :2 * c], 3e-2, 2e-2)
+    check(f"qkv.vt[{batch}x{tokens}x{c},tile{tile}]", vt.transpose(1, 2), ref[..., 2 * c:], 3e-2, 2e-2)

@@ -49,13 +49,13 @@ def main():
         shapes = {m: {k: tuple(v) for k, v in d.items()} for m, d in json.load(f).items()}
     usd = {k: v.to(D) for k, v in synth.state_dict_for(shapes["unet"], 0).items()}
     bsd = {k: v.to(D) for k, v in synth.state_dict_for(shapes["brushnet"], 1).items()}
-    vsd = {k: v.to(D) for k, v in synth.state_dict_for(shapes["vae"], 2).items()}
+    vsd = synth.state_dict_for(shapes["vae"], 2)          # the conditioning is an INPUT of the loop: built in fp32, as the reference did
     G = np.load(os.path.join(GOLD, "sd15_config1_50steps.npz"))
     inp = synth.pipeline_inputs(4, 512, 512, seed=77)
     sl = slice(0, 1)
     nz = inp["vae_noise"]
-    noise = torch.cat([nz[:4][sl], nz[4:][sl]]).to(D)
-    cond = R.build_conditioning(vsd, R.SD15_VAE, inp["image"][sl].to(D), inp["mask"][sl].to(D), inp["depth"][sl].to(D), noise)
+    noise = torch.cat([nz[:4][sl], nz[4:][sl]])
+    cond = R.build_conditioning(vsd, R.SD15_VAE, inp["image"][sl], inp["mask"][sl], inp["depth"][sl], noise)
     pe = torch.cat([inp["negative_prompt_embeds"][sl], inp["prompt_embeds"][sl]]).to(D)
     sched = R.DDIMRef(**R.SD15_SCHED)
     sched.alphas_cumprod = sched.alphas_cumprod.to(D)          # the reference's fp32 constants, exactly
