@@ -717,10 +717,35 @@ class _UNetCore(HipModel):
             else:
                 gg = ops.linear_geglu(n, P[b + "ff.net.0.proj"])
             h = ops.linear(gg, P[b + "ff.net.2"], res0=h)
+        if isinstance(inj, LazyResidual):
+            fused = self._fused_proj_out(p, inj)
+            if fused is not None and inj.feature.shape == x.shape:
+                inj.wait()
+                return ops.conv2d(h.view(bsz, hh, ww, c), fused, padding=0, x1=inj.feature, res0=x)
+            inj = inj.materialize()
         if P[p + "proj_out"].fp8:
             return ops.linear(h, P[p + "proj_out"], res0=x.view(bsz, hh * ww, c),
                               res1=inj.view(-1, hh * ww, c) if inj is not None else None).view(bsz, hh, ww, c)
         return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj)
+
+    def _fused_proj_out(self, p: str, lz: "LazyResidual") -> Optional[ConvWeight]:
+        """[W_proj_out | scale * W_zero_conv] over K = 2C with bias b_po + scale * b_zc, built once per (layer, BrushNet weights,
+        scale) from the two models' fp32 master copies; None where the projection is not a plain 1x1 conv of this precision."""
+        bn = lz.owner
+        key = (p, lz.name, lz.scale, id(bn), bn._weights_gen, self._weights_gen)
+        cache = self.__dict__.setdefault("_fused_po", {})
+        if key in cache:
+            return cache[key]
+        cw = None
+        if (self._src is not None and bn._src is not None and not self.P[p + "proj_out"].fp8 and not self.training
+                and self._src[p + "proj_out.weight"].dim() == 4 and bn.prec.name == self.prec.name):
+            w = torch.cat([self._src[p + "proj_out.weight"].float(), lz.scale * bn._src[lz.name + ".weight"].float()], 1)
+            b = self._src[p + "proj_out.bias"].float() + lz.scale * bn._src[lz.name + ".bias"].float()
+            cw = ConvWeight(w, b, self.prec, self.device)
+        for k in [k for k in cache if k[0] == p and k != key]:     # weights or scale changed: drop the stale entry
+            del cache[k]
+        cache[key] = cw
+        return cw
 
     # ---- the reference's operator plug-in point (attention_processor.py:216; brushnet.py:558-590;
     # unet_2d_condition.py:716-748) ----------------------------------------------------------------------------
@@ -756,13 +781,34 @@ class _UNetCore(HipModel):
     def _ehs(self, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
         return encoder_hidden_states.to(self.device, self.prec.act).contiguous()
 
-    def _inj(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    def _inj(self, t, keep_lazy: bool = False):
         if t is None:
             return None
+        if isinstance(t, LazyResidual):
+            return t if keep_lazy else t.materialize()
         ev = _RESIDUAL_EVENTS.pop(t.data_ptr(), None)          # produced on BrushNet's side stream: order after it
         if ev is not None:
             torch.cuda.current_stream(t.device).wait_event(ev)
         return from_nchw(t, self.prec)
+
+
+class LazyResidual:
+    """A BrushNet residual that has NOT been computed: the feature its zero-conv reads (NHWC), the zero-conv's name and scale.
+    The UNet consumes it where the injection lands on a 1x1 proj_out (unet_2d_blocks.py:1389,1484,2627,2752 after a
+    Transformer2DModel): proj_out(h) + x + zero_conv(f) = [W_po | s W_zc] . [h | f] + (b_po + s b_zc) + x — ONE GEMM over two K
+    segments, so the zero-conv launch, its output and the residual read disappear.  Anywhere else it is materialised."""
+
+    def __init__(self, feature: torch.Tensor, name: str, scale: float, owner: "BrushNetModel"):
+        self.feature, self.name, self.scale, self.owner = feature, name, float(scale), owner
+
+    def wait(self):
+        ev = _RESIDUAL_EVENTS.pop(self.feature.data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream(self.feature.device).wait_event(ev)
+
+    def materialize(self) -> torch.Tensor:
+        self.wait()
+        return ops.conv2d(self.feature, self.owner.P[self.name], padding=0, alpha=self.scale)
 
 
 # BrushNet || UNet overlap.  BrushNet has no data dependence on the UNet, and the UNet needs BrushNet's residual k
@@ -901,9 +947,12 @@ class BrushNetModel(_UNetCore):
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: Optional[torch.Tensor] = None,
                 brushnet_cond: torch.Tensor = None, conditioning_scale: float = 1.0, class_labels=None,
                 timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
-                guess_mode: bool = False, return_dict: bool = True, *, _temb: Optional[torch.Tensor] = None):
+                guess_mode: bool = False, return_dict: bool = True, *, _temb: Optional[torch.Tensor] = None,
+                _lazy: Optional[set] = None):
         """brushnet.py:678-925.  Returns NCHW-shaped channels-last views (see module docstring).
-        `_temb` (not in the reference): a row block of time_embedding_table for this timestep."""
+        `_temb` (not in the reference): a row block of time_embedding_table for this timestep.  `_lazy` (not in the reference):
+        names of zero-convs to hand over as LazyResidual objects instead of tensors (the pipeline passes
+        UNet2DConditionModel.lazy_injection_names(): the residuals that land on a proj_out)."""
         c = self.config
         order = c["brushnet_conditioning_channel_order"]
         if order == "bgr":
@@ -919,7 +968,7 @@ class BrushNetModel(_UNetCore):
         side = self.side_stream
         if side is None:
             d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, None, added_cond_kwargs, guess_mode,
-                                         _temb)
+                                         _temb, _lazy)
         else:
             main = torch.cuda.current_stream(self.device)
             _RESIDUAL_EVENTS.clear()
@@ -933,7 +982,7 @@ class BrushNetModel(_UNetCore):
 
             with torch.cuda.stream(side):
                 d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs,
-                                             guess_mode, _temb)
+                                             guess_mode, _temb, _lazy)
         if not return_dict:
             return d, m, u
         return BrushNetOutput(down_block_res_samples=d, mid_block_res_sample=m, up_block_res_samples=u)
@@ -941,7 +990,7 @@ class BrushNetModel(_UNetCore):
     side_stream: Optional["torch.cuda.Stream"] = None
 
     def _forward_impl(self, sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs=None,
-                      guess_mode: bool = False, temb_rows: Optional[torch.Tensor] = None):
+                      guess_mode: bool = False, temb_rows: Optional[torch.Tensor] = None, lazy: Optional[set] = None):
         """Each zero-conv (brushnet.py:889-894) runs right after the feature it reads is produced — the same
         arithmetic as the reference's end-of-forward loops, but residual k is final as early as possible.
         guess_mode (brushnet.py:896-902): residual k of the [down | mid | up] list is scaled by logspace(-1, 0)[k] *
@@ -965,7 +1014,11 @@ class BrushNetModel(_UNetCore):
             ops.TAPE.no_grad(x)            # the batch's own inputs need no gradient
         x = ops.conv2d(x, self.P["conv_in_condition"])
 
-        def zero_conv(name: str, r: torch.Tensor) -> torch.Tensor:
+        def zero_conv(name: str, r: torch.Tensor):
+            if lazy and name in lazy and ops.TAPE is None and not guess_mode:
+                if publish is not None:
+                    publish(r)                 # the UNet reads the FEATURE: ready one launch earlier than the residual was
+                return LazyResidual(r, name, scale_of[name], self)
             y = ops.conv2d(r, self.P[name], padding=0, alpha=scale_of[name])
             if publish is not None:
                 publish(y)
@@ -1069,6 +1122,31 @@ class UNet2DConditionModel(_UNetCore):
         out["conv_out.weight"] = (c["out_channels"], boc[0], 3, 3); out["conv_out.bias"] = (c["out_channels"],)
         return out
 
+    def lazy_injection_names(self) -> set:
+        """The BrushNet zero-convs whose residual this UNet adds in a Transformer2DModel's proj_out epilogue (the blocks with
+        attention): the pipeline asks BrushNet to hand those over as LazyResidual objects (see there)."""
+        c = self.config
+        if c["use_linear_projection"]:
+            return set()
+        n, lpb = len(c["block_out_channels"]), c["layers_per_block"]
+        names, k = set(), 1                                            # down residual 0 is added to conv_in's output
+        for i, bt in enumerate(c["down_block_types"]):
+            for j in range(lpb):
+                if bt == "CrossAttnDownBlock2D":
+                    names.add(f"brushnet_down_blocks.{k}")
+                k += 1
+            if i != n - 1:
+                k += 1
+        k = 0
+        for i, bt in enumerate(c["up_block_types"]):
+            for j in range(lpb + 1):
+                if bt == "CrossAttnUpBlock2D":
+                    names.add(f"brushnet_up_blocks.{k}")
+                k += 1
+            if i != n - 1:
+                k += 1
+        return names
+
     def _prepare(self, sd):
         c = self.config
         self.P = {}
@@ -1119,13 +1197,13 @@ class UNet2DConditionModel(_UNetCore):
         if is_brushnet:
             x = ops.add(x, self._inj(down_block_add_samples.pop(0)), self.prec.act)                 # :1218
 
-        def take(lst):
-            return self._inj(lst.pop(0)) if (is_brushnet and len(lst) > 0) else None
+        def take(lst, keep_lazy=False):
+            return self._inj(lst.pop(0), keep_lazy) if (is_brushnet and len(lst) > 0) else None
 
         for i, bt in enumerate(c["down_block_types"]):
             has_attn = bt == "CrossAttnDownBlock2D"
             for j in range(lpb):
-                inj = take(down_block_add_samples) if is_brushnet else None
+                inj = take(down_block_add_samples, has_attn) if is_brushnet else None
                 if has_attn:
                     x = self._resnet(f"down_blocks.{i}.resnets.{j}.", x, temb)
                     x = self._transformer(f"down_blocks.{i}.attentions.{j}.", x, ehs, self._heads(i), inj)
@@ -1143,7 +1221,7 @@ class UNet2DConditionModel(_UNetCore):
         for i, bt in enumerate(c["up_block_types"]):
             has_attn = bt == "CrossAttnUpBlock2D"
             for j in range(lpb + 1):
-                inj = take(up_block_add_samples) if is_brushnet else None
+                inj = take(up_block_add_samples, has_attn) if is_brushnet else None
                 sk = skips.pop()
                 if has_attn:
                     x = self._resnet(f"up_blocks.{i}.resnets.{j}.", x, temb, x1=sk)

@@ -157,6 +157,8 @@ class StableDiffusionBrushNetPipeline:
         # both nets' time embeddings + fused time_emb_proj for the whole schedule in one batched pass before the loop
         # (graph path): 8 dependent launches fewer at the head of every step; A/B switch for tools/
         self.precompute_time_embedding = os.environ.get("MFHIP_NO_TEMB_TABLE") != "1"
+        # the 15 BrushNet zero-convs whose residual lands on a Transformer2DModel.proj_out run INSIDE that GEMM (models.LazyResidual)
+        self.fold_zero_convs = os.environ.get("MFHIP_NO_ZC_FOLD") != "1"
         self._added_cond = None          # SDXL: added_cond_kwargs of the (CFG-duplicated) batch, set by the XL subclass
         self._graph_state = None
 
@@ -661,12 +663,16 @@ class StableDiffusionBrushNetPipeline:
                 st["temb_cur"] = tuple(torch.empty_like(t[0]) for t in st["temb_tab"])
         temb_u, temb_b = st["temb_cur"] if self.precompute_time_embedding else (None, None)
 
+        # residuals that land on a proj_out are never computed: their zero-conv becomes a second K segment of that GEMM
+        lazy = self.unet.lazy_injection_names() if (self.fold_zero_convs and not self._brushnet_once) else None
+
         def one_step():
             x_in = torch.cat([lat] * 2)
             once = self._brushnet_once
             down, mid, up = self.brushnet(lat if once else x_in, t_cur, encoder_hidden_states=pe[:nb] if once else pe,
                                           brushnet_cond=cond[:nb] if once else cond,
-                                          conditioning_scale=cond_scale, added_cond_kwargs=added, return_dict=False, _temb=temb_b)
+                                          conditioning_scale=cond_scale, added_cond_kwargs=added, return_dict=False, _temb=temb_b,
+                                          _lazy=lazy)
             eps = self.unet(x_in, t_cur, encoder_hidden_states=pe, down_block_add_samples=down,
                             mid_block_add_sample=mid, up_block_add_samples=up, added_cond_kwargs=added,
                             return_dict=False, _temb=temb_u)[0]
