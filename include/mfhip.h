@@ -202,6 +202,14 @@ int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ldq, const vo
                        int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream);
 /* x (n fp32, n % 4 == 0) -> fp16 planes hi = x rounded toward zero, lo = (x - hi) rounded toward zero */
 int mf_split_halves(const float* x, void* hi, void* lo, int64_t n, void* stream);
+/* Range guard of MF_F16X3.  The fp16 halves hold |x| <= 65504 only and v_cvt_pkrtz_f16_f32 SATURATES above that (no inf, no
+ * NaN: nothing downstream would notice), so every kernel that splits operands — mf_gemm_conv and mf_conv_wgrad with
+ * MF_F16X3, mf_split_halves — tracks max |operand| and raises a sticky device flag when it leaves the range.  This call
+ * copies the flags to *raised (bit 0: mf_gemm_conv, bit 1: mf_split_halves / mf_attention_f16x3 operands, bit 2:
+ * mf_conv_wgrad; 0 = every split since the last reset was exact to 22 bits) and clears them when `reset`.  Diagnostic entry:
+ * the ONLY one that synchronises `stream`; never call it inside a hipGraph capture.  A caller that sees a flag re-runs the
+ * affected work in MF_BF16X3 (fp32 range, 16 bits) or MF_F32. */
+int mf_split_overflow(int32_t reset, int32_t* raised, void* stream);
 
 /* Per-row dynamic fp8 (e4m3) quantisation of [rows][c] (c % 8 == 0, c <= 8192), optionally fused behind a LayerNorm
  * (gamma / beta non-NULL: y = LN(x) first, attention.py:203,233,261): out_q[r][j] = fp8(y[r][j] / scale[r]),

@@ -54,6 +54,8 @@ SDXL_UNET = dict(
     cross_attention_dim=2048, attention_head_dim=(5, 10, 20), transformer_layers_per_block=(1, 2, 10),
     use_linear_projection=True, addition_embed_type="text_time", addition_time_embed_dim=256,
     projection_class_embeddings_input_dim=2816, norm_num_groups=32, norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0)
+SDXL_VAE = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512),
+                layers_per_block=2, norm_num_groups=32, scaling_factor=0.13025)     # stabilityai/stable-diffusion-xl-base-1.0 vae/config.json
 TINY_XL_UNET = dict(
     in_channels=4, out_channels=4, block_out_channels=(32, 64, 64), layers_per_block=2,
     down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),

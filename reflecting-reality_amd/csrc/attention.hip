@@ -387,18 +387,29 @@ void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
 }
 
 // fp32 [rows][ld] (first `cols` columns) -> two fp16 planes of the same layout: hi toward zero, lo = x - hi
+__device__ unsigned g_split_ovf_attn;     // raised when a value handed to mf_split_halves exceeded the fp16 range (mf_common.h)
+
 __global__ __launch_bounds__(256) void split_halves_kernel(const float* x, unsigned short* hi, unsigned short* lo, int64_t n4) {
+    float amax = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
+        amax = mf_amax3(mf_amax3(amax, v.x, v.y), v.z, v.w);
         const auto h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
         const auto l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
         const auto l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
         reinterpret_cast<uint2*>(hi)[i] = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
         reinterpret_cast<uint2*>(lo)[i] = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
     }
+    mf_raise_if_over(&g_split_ovf_attn, amax);
 }
 
 }  // namespace
+
+unsigned* mf_ovf_flag_attention() {
+    unsigned* p = nullptr;
+    (void)hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_split_ovf_attn));
+    return p;
+}
 
 extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                                  void* out, int64_t ldo, int32_t batch, int32_t heads, int32_t sq, int32_t skv,

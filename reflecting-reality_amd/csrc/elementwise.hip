@@ -17,6 +17,28 @@ extern "C" int mf_abi_version(void) { return MF_ABI_VERSION; }
 extern "C" int mf_sizeof_gemm_desc(void) { return (int)sizeof(mf_gemm_desc); }
 extern "C" int mf_sizeof_groupnorm_desc(void) { return (int)sizeof(mf_groupnorm_desc); }
 
+extern "C" int mf_split_overflow(int32_t reset, int32_t* raised, void* stream) {
+    MF_CHECK_ARG(raised != nullptr, "mf_split_overflow: null pointer");
+    unsigned* flags[3] = {mf_ovf_flag_gemm(), mf_ovf_flag_attention(), mf_ovf_flag_train()};
+    hipStream_t s = (hipStream_t)stream;
+    unsigned host[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        MF_CHECK_ARG(flags[i] != nullptr, "mf_split_overflow: flag symbol not found");
+        if (hipMemcpyAsync(&host[i], flags[i], sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) {
+            mf_set_error("mf_split_overflow: copy failed");
+            return MF_ELAUNCH;
+        }
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        mf_set_error("mf_split_overflow: synchronise failed");
+        return MF_ELAUNCH;
+    }
+    *raised = (int32_t)((host[0] ? 1 : 0) | (host[1] ? 2 : 0) | (host[2] ? 4 : 0));
+    if (reset && *raised)
+        for (int i = 0; i < 3; ++i) (void)hipMemsetAsync(flags[i], 0, sizeof(unsigned), s);
+    return MF_OK;
+}
+
 namespace {
 
 inline unsigned grid_for(int64_t n, int per_block = 256, int cap = 8192) {

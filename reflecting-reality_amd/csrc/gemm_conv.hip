@@ -32,6 +32,7 @@
 namespace {
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];   // zero-initialised module global
+__device__ unsigned g_split_ovf_gemm;     // raised when an MF_F16X3 operand exceeded the fp16 range (mf_common.h)
 
 struct GemmArgs {
     const char* a0; const char* a1;
@@ -515,9 +516,14 @@ void gemm_conv_kernel(const GemmArgs p) {
     // ---- split codes: fp32 -> (hi, lo) 16-bit halves in registers ---------------------------------------------
     // c0, c1: 8 consecutive fp32 (k = 16 ks + 8 fh + 0..7 of this lane's row).  hi = x toward zero, lo = x - hi (exact in
     // fp32) toward zero; the error of hi + lo against x is below 2^-22 |x| (fp16 halves) / 2^-16 |x| (bf16 halves).
+    float split_amax = 0.0f;          // MF_F16X3: running max |operand| of this lane (range guard, mf_common.h)
     auto split8 = [&](const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
         const float x[8] = {__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), __uint_as_float(c0.w),
                             __uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z), __uint_as_float(c1.w)};
+        if constexpr (DT == MF_F16X3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_amax = mf_amax3(split_amax, x[2 * e], x[2 * e + 1]);
+        }
         unsigned h[4], l[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1021,8 +1027,8 @@ void gemm_conv_kernel(const GemmArgs p) {
                     wait_for(0);
                     __builtin_amdgcn_s_barrier();                  // #0
                     for (int t = 0; t + 1 < nt; ++t) {
-                        if (lnf) ln_tile();                        // tile t
-                        if (t + PF < nt) issue_next();
+                        if (t + PF < nt) issue_next();             // into the stage of tile t - 1: the DMA goes out FIRST ...
+                        if (lnf) ln_tile();                        // ... and tile t is summed while it flies
                         wait_for(t + 1);
                         __builtin_amdgcn_s_barrier();              // #(t + 1)
                     }
@@ -1083,6 +1089,7 @@ void gemm_conv_kernel(const GemmArgs p) {
         }
     }
     __syncthreads();   // every wave is done reading the staging LDS: reuse it for the epilogue slabs
+    if constexpr (DT == MF_F16X3) mf_raise_if_over(&g_split_ovf_gemm, split_amax);
 
     // ---- epilogue ---------------------------------------------------------------------------
     char* slab = smem + wave * (SR * EP_RS);        // private to this wave: [SR rows][WN + 4] fp32
@@ -1169,7 +1176,8 @@ void gemm_conv_kernel(const GemmArgs p) {
                     // 16 bytes of V^T[image][channel][token] (attention reads V^T with keys contiguous)
                     static_assert(SR % 8 == 0 && (SR / 8) * WN == ITEMS, "transposed items cover the slab");
                     const int c = g + u * TW, it = (c - sw * NIT) * 64 + lane;
-                    const int col = it % WN, rg = it / WN;
+                    // consecutive lanes take consecutive 8-token groups of one channel: SR / 8 lanes write 2 * SR contiguous bytes
+                    const int rg = it % (SR / 8), col = it / (SR / 8);
                     const int swm = sw / WAVES_N, swn = sw - swm * WAVES_N;
                     const int mt = m0 + swm * WM + i * 32 + half * SR + rg * 8, nt_ = n0 + swn * WN + col;
                     if (mt < p.M && nt_ < p.N) {
@@ -2189,6 +2197,12 @@ int pick_tile(int M, int N, int nz, int splitk, int max_tile = kNumTiles, bool s
 }
 
 }  // namespace
+
+unsigned* mf_ovf_flag_gemm() {
+    unsigned* p = nullptr;
+    (void)hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_split_ovf_gemm));
+    return p;
+}
 
 extern "C" int mf_gemm_num_tiles(void) { return kNumTiles; }
 extern "C" int mf_gemm_tile_table_version(void) { return 1; }

@@ -86,6 +86,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- range guard of the fp16 split precision (MF_F16X3) ----------------------------------------------------------------
+// v_cvt_pkrtz_f16_f32 SATURATES: an fp32 operand above 65504 becomes 65504, not inf, so hi + lo is silently wrong and no
+// NaN / inf ever trips an isfinite() check downstream.  Every kernel that splits operands keeps a per-lane running max of
+// |x| (one v_max3_f32 per operand pair) and raises its translation unit's flag once per wave at the end; the host reads
+// and clears the flags with mf_split_overflow().
+#define MF_F16_MAX 65504.0f
+__device__ __forceinline__ float mf_amax3(float m, float a, float b) { return fmaxf(fmaxf(m, fabsf(a)), fabsf(b)); }   // v_max3_f32 |a| |b|
+__device__ __forceinline__ void mf_raise_if_over(unsigned* flag, float amax) {
+    if (amax > MF_F16_MAX) atomicOr(flag, 1u);
+}
+unsigned* mf_ovf_flag_gemm();        // device addresses of the three translation units' flags (host functions)
+unsigned* mf_ovf_flag_attention();
+unsigned* mf_ovf_flag_train();
+
 // bytes per element in memory; the split compute codes keep fp32 operands
 static inline int mf_dtype_size(int dt) { return dt == MF_BF16 ? 2 : (dt == MF_FP8 ? 1 : 4); }
 static inline bool mf_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

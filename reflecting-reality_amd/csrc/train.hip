@@ -37,8 +37,11 @@ constexpr int WG_BN = 128, WG_BC = 128, WG_BP = 32, WG_PITCH = 132;   // LDS row
 // Block = 4 waves, output tile 128 (n) x 128 (c of one tap); wave (wn, wk) owns 64 x 64 = 2 x 2 accumulator blocks, so every
 // gathered fragment feeds two MFMAs (the first version's 32 x 32 per wave fed one).  Per iteration 32 pixels are staged
 // (register -> LDS, single buffered: correctness-first; the reduction over pixels is split over blockIdx.y).
+__device__ unsigned g_split_ovf_train;    // raised when an MF_F16X3 wgrad operand exceeded the fp16 range (mf_common.h)
+
 template <int DT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+    float wg_amax = 0.0f;
     __shared__ __attribute__((aligned(16))) float sY[WG_BP * WG_PITCH];
     __shared__ __attribute__((aligned(16))) float sA[WG_BP * WG_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
                             yh[e] = pack_bf16x2(y0, y1); ah[e] = pack_bf16x2(a0, a1);
                             yl[e] = 0; al[e] = 0;
                         } else {
+                            wg_amax = mf_amax3(mf_amax3(wg_amax, y0, y1), a0, a1);
                             const auto hy = __builtin_amdgcn_cvt_pkrtz(y0, y1);
                             const auto ly = __builtin_amdgcn_cvt_pkrtz(y0 - (float)hy[0], y1 - (float)hy[1]);
                             const auto ha = __builtin_amdgcn_cvt_pkrtz(a0, a1);
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         }
         __syncthreads();
     }
+    if constexpr (DT == MF_F16X3) mf_raise_if_over(&g_split_ovf_train, wg_amax);
     // D[row = n (e & 3) + 8 (e >> 2) + 4 h][col = c r]
     float* out = p.out + (int64_t)blockIdx.y * p.slab;
 #pragma unroll
@@ -514,6 +519,12 @@ inline int grid_for(int64_t n, int cap = 8192) {
 }
 
 }  // namespace
+
+unsigned* mf_ovf_flag_train() {
+    unsigned* p = nullptr;
+    (void)hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_split_ovf_train));
+    return p;
+}
 
 extern "C" int mf_sizeof_wgrad_desc(void) { return (int)sizeof(mf_wgrad_desc); }
 extern "C" int mf_sizeof_groupnorm_bwd_desc(void) { return (int)sizeof(mf_groupnorm_bwd_desc); }

@@ -150,6 +150,7 @@ def split_pack(w: torch.Tensor, code: int):
     if kp != k:
         w = torch.nn.functional.pad(w, (0, kp - k))
     half = torch.float16 if code == hip.MF_F16X3 else torch.bfloat16
+    hip.split_pack_check(w, code)
     hi = w.to(half)
     lo = (w - hi.float()).to(half)
     packed = torch.cat([hi.view(n, kp // 32, 32), lo.view(n, kp // 32, 32)], dim=2).reshape(n, 2 * kp).contiguous()

@@ -157,8 +157,10 @@ class StableDiffusionBrushNetPipeline:
         # both nets' time embeddings + fused time_emb_proj for the whole schedule in one batched pass before the loop
         # (graph path): 8 dependent launches fewer at the head of every step; A/B switch for tools/
         self.precompute_time_embedding = os.environ.get("MFHIP_NO_TEMB_TABLE") != "1"
-        # the 15 BrushNet zero-convs whose residual lands on a Transformer2DModel.proj_out run INSIDE that GEMM (models.LazyResidual)
-        self.fold_zero_convs = os.environ.get("MFHIP_NO_ZC_FOLD") != "1"
+        # opt-in: the 15 BrushNet zero-convs whose residual lands on a Transformer2DModel.proj_out run INSIDE that GEMM (models.LazyResidual)
+        # measured on MI355X (gpurun_out/r03c): 16.75 ms per step with it, 16.56 without — the fused K = 2C GEMM lands on the
+        # UNet's stream (the critical one) while the zero-conv it replaces ran in BrushNet's slack: OFF by default
+        self.fold_zero_convs = os.environ.get("MFHIP_ZC_FOLD") == "1"
         self._added_cond = None          # SDXL: added_cond_kwargs of the (CFG-duplicated) batch, set by the XL subclass
         self._graph_state = None
 
@@ -473,6 +475,9 @@ class StableDiffusionBrushNetPipeline:
                           brushnet_conditioning_scale, control_guidance_start, control_guidance_end,
                           callback_on_step_end_tensor_inputs, depth=depth, normals=normals)
         self._guidance_scale = guidance_scale
+        guard = self.unet.prec.name == "f16x3" and self.device.type == "cuda"
+        if guard:
+            hip.split_overflow(reset=True)       # the range guard of the fp16 split precision counts this call only
         if prompt is not None and isinstance(prompt, str):
             batch_size = 1
         elif prompt is not None:
@@ -570,6 +575,13 @@ class StableDiffusionBrushNetPipeline:
         else:
             img = latents
         img = self.image_processor.postprocess(img, output_type=output_type, do_denormalize=[True] * img.shape[0])
+        if guard:
+            raised = hip.split_overflow(reset=True)
+            if raised:
+                raise hip.SplitRangeError(
+                    f"f16x3: an activation exceeded the fp16 range (|x| > 65504, flags {raised:#x}) during this call; its products "
+                    "were computed from saturated halves, so the result is not returned.  Run this input with precision "
+                    "'bf16x3' (fp32 range) or 'fp32'.")
         if not return_dict:
             return (img, None)
         return StableDiffusionPipelineOutput(images=img, nsfw_content_detected=None)

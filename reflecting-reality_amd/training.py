@@ -157,7 +157,9 @@ def clip_grad_norm_(models: Sequence, max_norm: float, loss_scale: float = 1.0):
     coefficient account for it)."""
     models = [m for m in models if m.flat_g is not None]
     dev = models[0].device
-    st = _clip_states.setdefault(str(dev), _ClipState(dev))
+    st = _clip_states.get(str(dev))
+    if st is None:
+        st = _clip_states[str(dev)] = _ClipState(dev)
     for i, m in enumerate(models):
         hip.sumsq(m.flat_g[: m.num_arena_floats()], st.sumsq, accumulate=i > 0)
     hip.clip_coef(st.sumsq, float(max_norm), st.coef, st.norm, unscale=1.0 / float(loss_scale))
@@ -166,9 +168,11 @@ def clip_grad_norm_(models: Sequence, max_norm: float, loss_scale: float = 1.0):
 
 def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, latents: torch.Tensor, noise: torch.Tensor,
                timesteps: torch.Tensor, encoder_hidden_states: torch.Tensor, conditioning_latents: torch.Tensor,
-               snr_gamma: Optional[float] = None, max_grad_norm: float = 1.0, grad_sync=None):
+               snr_gamma: Optional[float] = None, max_grad_norm: float = 1.0, grad_sync=None, check_overflow: bool = True):
     """One optimisation step (:1407-1466).  Returns (loss, grad_norm) as one-element device tensors.
-    `grad_sync`: a distributed.GradBuckets when several ranks train data-parallel (the DDP wrap of :1267-1269)."""
+    `grad_sync`: a distributed.GradBuckets when several ranks train data-parallel (the DDP wrap of :1267-1269).
+    `check_overflow` (f16x3 only): read the split precision's range-guard flags after the backward pass and skip the
+    optimizer step when an operand left the fp16 range."""
     mods = model.get_trainable_modules()
     if not mods:
         raise RuntimeError("train_step: call model.prepare_training() first")
@@ -193,11 +197,28 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
         scale = float(2 ** int(pred.numel() - 1).bit_length())
         d_pred = hip.axpby_n([d_pred], [scale], out=d_pred)
     model.loss_scale = scale
+    if prec.code == hip.MF_F16X3 and check_overflow:
+        hip.split_overflow(reset=True)         # flags raised by earlier, unrelated work do not count against this step
     tape.add(pred, d_pred)
     tape.backward()
     if grad_sync is not None:
         grad_sync.finish()
     norm, coef = clip_grad_norm_(mods, max_grad_norm, loss_scale=scale)
+    if prec.code == hip.MF_F16X3 and check_overflow:
+        # fp16 halves saturate above 65504 without producing inf / NaN (mfhip.h, mf_split_overflow): a step whose forward or
+        # (loss-scaled) backward operands left that range has silently wrong gradients — it is SKIPPED, like a GradScaler
+        # step with inf gradients.  One 12-byte read-back per step; every rank skips together (the flag is all-reduced).
+        raised = hip.split_overflow(reset=True)
+        if grad_sync is not None and getattr(grad_sync, "world", 1) > 1:
+            from . import distributed as D
+            raised = int(D.max_over_ranks(float(raised), device=mods[0].device))
+        if raised:
+            import warnings
+            model.overflow_steps = getattr(model, "overflow_steps", 0) + 1
+            warnings.warn(f"train_step: an f16x3 operand exceeded the fp16 range (flags {raised:#x}); optimizer step skipped "
+                          f"({model.overflow_steps} so far) — train with precision 'bf16x1' / 'fp32' if this persists")
+            optimizer.zero_grad()
+            return loss, norm
     optimizer.step(grad_scale=coef)
     return loss, norm
 

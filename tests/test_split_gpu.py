@@ -209,3 +209,35 @@ def test_a_f32_tile_resolution():
     for tile in (7, 8, 12):                                          # 3-stage twins of 1..6 run the 2-stage kernel of the same shape
         y = ops.conv2d(xa, cw, padding=0, out_dtype=torch.float32, tile=tile)
         assert float((y.permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 2e-3
+
+
+def test_f16x3_range_guard_flags_saturated_operands():
+    """v_cvt_pkrtz_f16_f32 saturates above 65504 (no inf, no NaN): the kernels that split operands track max |operand| and
+    raise sticky flags that mf_split_overflow reads.  GEMM operand, attention operand, weight gradient
+    operand, host-split weight; and a clean run raises nothing."""
+    prec = ops.Precision.get("f16x3")
+    hip.split_overflow(reset=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(256, 64, generator=g).to("cuda")
+    lw = ops.ConvWeight(torch.randn(64, 64, generator=g) / 8, None, prec, "cuda")
+    y = ops.linear(x, lw)
+    assert hip.split_overflow() == 0 and torch.isfinite(y).all()
+    xb = x.clone()
+    xb[17, 5] = 7.0e4                                   # above the fp16 range, small weights: the OUTPUT stays tiny and finite
+    yb = ops.linear(xb, lw)
+    assert torch.isfinite(yb).all()
+    assert hip.split_overflow() & 1, "an fp16-saturated GEMM operand went unnoticed"
+    assert hip.split_overflow() == 0, "flags are cleared by a reset read"
+    hip.split_halves(xb.contiguous())
+    assert hip.split_overflow() & 2
+    with pytest.raises(hip.SplitRangeError):
+        ops.ConvWeight(torch.full((8, 32), 1.0e5), None, prec, "cuda")
+    # bf16x3 has fp32's range: the same operand is fine there
+    lw3 = ops.ConvWeight(torch.randn(64, 64, generator=g) / 8, None, ops.Precision.get("bf16x3"), "cuda")
+    ops.linear(xb, lw3)
+    assert hip.split_overflow() == 0
+    # weight-gradient operands
+    dy = torch.randn(256, 64, generator=g).to("cuda")
+    dw = torch.empty(64, 64, device="cuda")
+    hip.conv_wgrad(xb, dy, dw, code=hip.MF_F16X3, c0=64, batch=256, h_in=1, w_in=1, h_out=1, w_out=1, n=64, accumulate=False)
+    assert hip.split_overflow() & 4

@@ -484,3 +484,98 @@ def test_data_parallel_training_two_ranks_equal_one_process_on_the_joint_batch(t
         assert abs(a - b) < 2e-6 * abs(b)
     assert abs(r0["norm"] - r0["single_norm"]) < 1e-4 * r0["single_norm"]
     assert r0["max_w_diff"] < 3e-5       # 2 steps x lr 1e-5: a flipped near-zero gradient could move a weight by 2e-5 (measured 2e-6)
+
+
+def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync():
+    """BASELINE.json configs[3] at its own size: the MirrorFusion fine-tune step at per-GPU batch 8 x 512 x 512 (64 x 64 latents),
+    full-size SD1.5 UNet (frozen) + BrushNet (trainable), f16x3 contractions, clip 1.0, AdamW (train_brushnet_mirror.py:1407-1466).
+    No reference gradient exists at this size (the reference's autograd on the CPU would take hours), so the step is pinned by
+    size-independent properties: (1) finite loss / gradient norm, every trainable tensor moves; (2) two identical runs are
+    BIT-identical (fixed-order reductions, no atomics); (3) the same step with the bucketed gradient all-reduce forced through
+    RCCL on this single rank (MF_FORCE_GRAD_SYNC=1: world size 1, sum of one = identity, divide by 1) is bit-identical to the
+    unsynchronised step — the DDP path of distributed.GradBuckets changes nothing but the exchange."""
+    import socket
+    import torch.distributed as dist
+    from reflecting_reality_amd import distributed as D
+    from reflecting_reality_amd.configs import SD15_UNET, brushnet_config
+
+    def build():
+        unet = M.UNet2DConditionModel(dict(SD15_UNET), precision="f16x3", device=DEV)
+        unet.load_state_dict(synth.state_dict_for(unet.param_shapes(), 0))
+        bn = M.BrushNetModel(dict(brushnet_config(SD15_UNET, 6)), precision="f16x3", device=DEV)
+        bn.load_state_dict(synth.state_dict_for(bn.param_shapes(), 1))
+        return MirrorFusionModel(unet, bn).prepare_training(train_base_unet=False)
+
+    g = torch.Generator().manual_seed(303)
+    b = 8
+    lat, noi = torch.randn(b, 4, 64, 64, generator=g).to(DEV) * 0.8, torch.randn(b, 4, 64, 64, generator=g).to(DEV)
+    cond, ehs = torch.randn(b, 6, 64, 64, generator=g).to(DEV), torch.randn(b, 77, 768, generator=g).to(DEV)
+    ts = torch.tensor([981, 3, 500, 250, 751, 17, 640, 111])
+    ns = DDPMScheduler(**SD_SCHED)
+
+    def run(sync_factory=None):
+        model = build()
+        w0 = model.brushnet.flat_w.clone()
+        opt = AdamW(model.get_trainable_modules(), lr=1e-5)
+        sync = sync_factory(model) if sync_factory else None
+        out = []
+        for _ in range(2):
+            loss, norm = train_step(model, ns, opt, lat, noi, ts, ehs, cond, max_grad_norm=1.0, grad_sync=sync)
+            out.append((float(loss), float(norm)))
+        w = model.brushnet.flat_w.clone()
+        n_used = model.brushnet.num_arena_floats()
+        del model, opt
+        torch.cuda.empty_cache()
+        return out, w, w0, n_used
+
+    a_out, a_w, w0, n_used = run()
+    print("configs[3] step at batch 8 x 512^2: (loss, grad norm) per step", a_out)
+    assert all(np.isfinite(v) for pair in a_out for v in pair) and a_out[0][1] > 0
+    moved = (a_w[:n_used] != w0[:n_used]).float().mean().item()
+    assert moved > 0.99, f"only {moved:.3f} of the trainable floats moved"
+    b_out, b_w, _, _ = run()
+    assert a_out == b_out and torch.equal(a_w, b_w), "two identical training runs must be bit-identical"
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MF_FORCE_GRAD_SYNC"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        def factory(model):
+            s = D.GradBuckets(model.get_trainable_modules())
+            assert s.force and s.world == 1
+            return s
+        c_out, c_w, _, _ = run(factory)
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("MF_FORCE_GRAD_SYNC", None)
+    assert c_out == a_out and torch.equal(c_w, a_w), "the forced single-rank RCCL exchange changed the step"
+
+
+def test_bench_train_under_torchrun_with_rccl_reports_all_reduce():
+    """bench.py --mode train launched the way the driver launches N > 1 (python -m torch.distributed.run ... bench.py --gpus N)
+    with the default backend (RCCL) and MF_FORCE_GRAD_SYNC=1 on this one GPU: the rendezvous, the bucketed exchange under
+    the backward pass and time_all_reduce() all run over RCCL, and the JSON line carries all_reduce.ms."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MF_BENCH_BACKEND")}
+    env["MF_FORCE_GRAD_SYNC"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "train", "--steps", "1",
+                          "--warmup", "1", "--batch", "2", "--size", "256"], capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["unit"] == "samples/sec" and rec["value"] > 0
+    ar = rec["all_reduce"]
+    assert ar is not None and ar["ms"] > 0 and ar["bytes"] > 1e9, ar
+    print("single-rank RCCL all-reduce of the BrushNet gradient arena:", ar)

@@ -79,3 +79,85 @@ def test_tiny_xl_pipeline(prec, tol):
     with pytest.raises(ValueError):        # wrong pooled width: _get_add_time_ids' consistency check
         pipe(latents=inp["latents"].clone(), **{**kw, "pooled_prompt_embeds": torch.randn(1, 16),
                                                  "negative_pooled_prompt_embeds": torch.randn(1, 16)})
+
+
+# ---- BASELINE.json configs[4] at its own size: SDXL-base + BrushNet-XL, batch 2 x 1024 x 1024, 30-step grid -------------------
+_full = {}
+
+
+def build_xl_full(prec):
+    """Full-width SDXL UNet / BrushNet-XL (5 conditioning channels) / SDXL VAE with the synthetic weights of
+    tools/make_golden.py::sdxl_full (seeds 30 / 31 / 32).  One precision is kept alive at a time (10 GB of fp32 weights)."""
+    from reflecting_reality_amd.configs import SDXL_UNET, SDXL_VAE, brushnet_config
+    if prec not in _full:
+        _full.clear()
+        torch.cuda.empty_cache()
+        unet = M.UNet2DConditionModel(dict(SDXL_UNET), precision=prec, device=DEV)
+        unet.load_state_dict(synth.state_dict_for(unet.param_shapes(), 30))
+        bn = M.BrushNetModel(dict(brushnet_config(SDXL_UNET, 5)), precision=prec, device=DEV)
+        bn.load_state_dict(synth.state_dict_for(bn.param_shapes(), 31))
+        vae = M.AutoencoderKL(dict(SDXL_VAE), precision=prec, device=DEV)
+        vae.load_state_dict(synth.state_dict_for(vae.param_shapes(), 32))
+        _full[prec] = (unet, bn, vae)
+    return _full[prec]
+
+
+def _xl_full_inputs():
+    inp = synth.pipeline_inputs(2, 1024, 1024, seed=4242, cross_dim=2048)
+    gp = torch.Generator().manual_seed(4243)
+    inp["pooled"], inp["npooled"] = torch.randn(2, 1280, generator=gp), torch.randn(2, 1280, generator=gp)
+    return inp
+
+
+def _run_xl_full(prec, sl=slice(0, 2), keep=2):
+    unet, bn, vae = build_xl_full(prec)
+    pipe = StableDiffusionXLBrushNetPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None,
+                                             unet=unet, brushnet=bn, scheduler=DDIMScheduler(**SD_SCHED, clip_sample=False))
+    pipe.set_progress_bar_config(disable=True)
+    inp = _xl_full_inputs()
+    nz = inp["vae_noise"]
+    noise = torch.cat([nz[:2][sl], nz[2:][sl]])
+    trace = []
+    out = pipe(prompt_embeds=inp["prompt_embeds"][sl], negative_prompt_embeds=inp["negative_prompt_embeds"][sl],
+               pooled_prompt_embeds=inp["pooled"][sl], negative_pooled_prompt_embeds=inp["npooled"][sl], image=inp["image"][sl],
+               mask=inp["mask"][sl], num_inference_steps=30, guidance_scale=5.0, latents=inp["latents"][sl].clone(),
+               output_type="latent", brushnet_conditioning_scale=1.0, height=1024, width=1024, conditioning_noise=noise,
+               callback_on_step_end=lambda p, i, t, kw: (trace.append(kw["latents"].float().cpu().clone()) if i < keep else None) or {})
+    return trace, out.images.float().cpu(), pipe
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-3), ("bf16", None), ("fp8", None)])
+def test_baseline_config4_sdxl_full_width_against_reference(prec, tol):
+    """BASELINE.json configs[4] at its own size — SDXL-base + BrushNet-XL at full width, batch 2 x 1024 x 1024 (128 x 128 latents:
+    16384-token self-attention at d = 64, ten-layer transformers at 32 x 32... the tile choices of M = 65536), 30-step DDIM grid,
+    CFG 5.0 — against what the REFERENCE's StableDiffusionXLBrushNetPipeline (pipeline_brushnet_sd_xl.py:936-1535) produced
+    for image 0 on the first two steps of the same grid (tests/golden/sdxl_config4_slice.npz; the reference costs ~16 TFLOP
+    per step on the CPU, so two steps are pinned and the remaining 28 run for finiteness / determinism).
+    f16x3: the north-star bound, 1e-3.  bf16: inside the reference's own bf16 envelope on this very case.  fp8 (e4m3 Linears,
+    the mode configs[4] names): its deviation is reported as a multiple of the reference's bf16 envelope and bounded by
+    FP8_K x that envelope — FP8_K is set from the ratio measured HERE, at production reduction lengths (K = 640 ... 5120), not
+    from the tiny fixture (K = 32 ... 128)."""
+    G = golden("sdxl_config4_slice.npz")
+    trace, final, pipe = _run_xl_full(prec)
+    assert pipe.scheduler.timesteps.tolist() == G["timesteps"].tolist() and len(G["timesteps"]) == 30
+    assert tuple(final.shape) == (2, 4, 128, 128) and torch.isfinite(final).all()
+    FP8_K_LINF, FP8_K_MEAN = 6.0, 6.0
+    for i, l in enumerate(trace):
+        ref = G[f"latents_{i}"]
+        if prec == "fp8":
+            from util import envelope
+            env = envelope(f"sdxl_config4_slice/latents_{i}")
+            err = (l[:1] - torch.from_numpy(ref)).abs()
+            rl, rm = err.max().item() / env["linf"], err.mean().item() / env["mean"]
+            print(f"config4 image 0, latents after step {i} [fp8]: max_abs_err={err.max().item():.3e} mean={err.mean().item():.3e} "
+                  f"= {rl:.2f} x / {rm:.2f} x the reference's bf16 envelope (linf {env['linf']:.3e}, mean {env['mean']:.3e})")
+            assert rl <= FP8_K_LINF and rm <= FP8_K_MEAN
+        else:
+            check(f"config4 image 0, latents after step {i} [{prec}]", l[:1], ref, prec, dict(atol=tol), f"sdxl_config4_slice/latents_{i}")
+    # determinism: the same call again (captured graph replayed from step 0) is bit-identical
+    _, again, _ = _run_xl_full(prec)
+    assert torch.equal(final, again), "two identical SDXL calls must be bit-identical"
+    if prec == "f16x3":
+        # shard equivalence (SURVEY.md §8e): image 0 alone gets the latents it gets inside the batch of 2
+        _, alone, _ = _run_xl_full(prec, slice(0, 1))
+        report("config4 shard [0:1] vs batch of 2, final latents", alone, final[:1], atol=2e-3 * max(1.0, float(final.abs().max()) / 4))

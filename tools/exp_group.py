@@ -1,7 +1,8 @@
 """Does ONE grouped launch of two same-shape convolutions (the BrushNet and the UNet instance of a low-resolution resnet conv)
 beat the two launches the pipeline issues today on two HIP streams?  Times, from captured graphs on one box:
   (1) two launches on one stream, (2) one launch per stream (what the denoise graph does), (3) one z-batched launch (nz = 2).
-(3) uses mf_gemm_conv's existing blockIdx.z batching with zero A / W strides — the arithmetic of a grouped launch."""
+(3) uses mf_gemm_conv's existing blockIdx.z batching with DISTINCT activations and weights per z — the arithmetic and the
+memory traffic of a grouped launch."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,8 +29,10 @@ def bench(fn, reps=20):
 
 side = torch.cuda.Stream()
 for (b, hw, cin, cout) in [(8, 32, 640, 640), (8, 16, 1280, 1280), (8, 8, 1280, 1280), (8, 16, 2560, 1280), (8, 8, 2560, 1280)]:
-    x = [torch.randn(b, hw, hw, cin, device=dev).bfloat16() for _ in range(2)]
+    xall = torch.randn(2, b, hw, hw, cin, device=dev).bfloat16()
+    x = [xall[0], xall[1]]
     w = [ops.ConvWeight(torch.randn(cout, cin, 3, 3) * 0.02, torch.randn(cout), prec, dev) for _ in range(2)]
+    wall = torch.stack([w[0].w, w[1].w]).contiguous()          # DISTINCT weights per problem, like BrushNet's and the UNet's
     m = b * hw * hw
     # tuned single-problem launches
     for i in range(2):
@@ -51,9 +54,9 @@ for (b, hw, cin, cout) in [(8, 32, 640, 640), (8, 16, 1280, 1280), (8, 8, 1280, 
     key = None
     for tile in (0,):
         def grouped():
-            hip.gemm_conv(x[0], w[0].w, out2, dtype=prec.code, ldw=w[0].ldw, c0=cin, lda0=cin, batch=b, h_in=hw, w_in=hw, h_out=hw,
-                          w_out=hw, kh=3, kw=3, stride=1, pad_t=1, pad_l=1, n=cout, bias=w[0].bias, nz=2, zdiv=1, a_zs=(0, 0),
-                          w_zs=(0, 0), o_zs=(m * cout, 0))
+            hip.gemm_conv(x[0], wall[0], out2, dtype=prec.code, ldw=w[0].ldw, c0=cin, lda0=cin, batch=b, h_in=hw, w_in=hw, h_out=hw,
+                          w_out=hw, kh=3, kw=3, stride=1, pad_t=1, pad_l=1, n=cout, bias=w[0].bias, nz=2, zdiv=1, a_zs=(x[0].numel(), 0),
+                          w_zs=(wall[0].numel(), 0), o_zs=(m * cout, 0))
         grouped()
         tz = bench(grouped)
     t1, t2 = bench(one_stream), bench(two_streams)

@@ -306,10 +306,21 @@ def config1_50steps(out):
     out["sd15_config1_50steps/image"] = stats(sample_like(res.images, C["image_stats"][2], 4096), C["image_sample"])
 
 
+def sdxl_full(out):
+    """The reference in bf16 on the configs[4] slice (make_golden.sdxl_full)."""
+    from diffusers.pipelines.brushnet.pipeline_brushnet_sd_xl import StableDiffusionXLBrushNetPipeline as XLPipe
+    unet, brushnet, vae = MG._sdxl_full_models(BF)
+    C = np.load(os.path.join(GOLD, "sdxl_config4_slice.npz"))
+    trace, _ = MG.run_sdxl_full(XLPipe, unet, brushnet, vae, cast=BF)
+    for i, l in enumerate(trace):
+        out[f"sdxl_config4_slice/latents_{i}"] = stats(l, C[f"latents_{i}"])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-config1", action="store_true")
     ap.add_argument("--only-config1-50", action="store_true")
+    ap.add_argument("--only-sdxl-full", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     a = ap.parse_args()
@@ -320,14 +331,16 @@ if __name__ == "__main__":
             out = json.load(f)
     out["_about"] = ("|reference(bf16) - reference(fp32)| of the imported reference on the golden cases "
                      "(tools/make_bf16_envelope.py): linf / mean abs error, and the fp32 result's abs max / mean")
-    if a.only_config1_50:
+    if a.only_sdxl_full:
+        sdxl_full(out)
+    elif a.only_config1_50:
         config1_50steps(out)
     elif a.only_config1:
         config1_slice(out)
     elif not a.only_full:
         tiny(out)
         tiny_xl(out)
-    if (a.full or a.only_full) and not (a.only_config1 or a.only_config1_50):
+    if (a.full or a.only_full) and not (a.only_config1 or a.only_config1_50 or a.only_sdxl_full):
         full(out)
         config1_slice(out)
     with open(path, "w") as f:

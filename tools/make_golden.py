@@ -736,6 +736,88 @@ def config1_50steps():
     print("configs[1] 50-step fixture written; final |latents| max", float(trace[-1].abs().max()))
 
 
+class _StopAfter(Exception):
+    pass
+
+
+def _sdxl_full_models(dtype=None):
+    """Full-size SDXL-base UNet + BrushNet-XL (5 conditioning channels: masked-image latents + mask,
+    pipeline_brushnet_sd_xl.py:1301-1310) + SDXL VAE with the seeded synthetic weights (seeds 30 / 31 / 32)."""
+    ucfg, vcfg = R.SDXL_UNET, R.SDXL_VAE
+    unet = build_unet(ucfg)
+    load_synth(unet, 30)
+    brushnet = BrushNetModel.from_unet(unet, conditioning_channels=5, load_weights_from_unet=False).eval()
+    load_synth(brushnet, 31)
+    vae = build_vae(vcfg)
+    load_synth(vae, 32)
+    if dtype is not None:
+        for m in (unet, brushnet, vae):
+            m.to(dtype)
+    return unet, brushnet, vae
+
+
+def sdxl_inputs():
+    inp = synth.pipeline_inputs(2, 1024, 1024, seed=4242, cross_dim=2048)
+    gp = torch.Generator().manual_seed(4243)
+    inp["pooled"], inp["npooled"] = torch.randn(2, 1280, generator=gp), torch.randn(2, 1280, generator=gp)
+    return inp
+
+
+def run_sdxl_full(pipe_cls, unet, brushnet, vae, cast=None, steps_kept=2):
+    """BASELINE.json configs[4] sizes for ONE image: image 0 of the batch-2 x 1024 x 1024 synthetic inputs through the
+    reference's StableDiffusionXLBrushNetPipeline (pipeline_brushnet_sd_xl.py:936-1535) on the 30-step DDIM grid, CFG 5.0;
+    the run is aborted after `steps_kept` steps (each costs ~16 TFLOP on the CPU).  Returns the latents after each kept step."""
+    import diffusers.models.autoencoders.vae as ref_vae
+    sched = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = pipe_cls(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, unet=unet,
+                    brushnet=brushnet, scheduler=sched, force_zeros_for_empty_prompt=True, add_watermarker=False)
+    pipe.set_progress_bar_config(disable=True)
+    inp = sdxl_inputs()
+    sl = slice(0, 1)
+    nz = inp["vae_noise"]
+    noise = torch.cat([nz[:2][sl], nz[2:][sl]])
+    c = (lambda t: t.to(cast)) if cast is not None else (lambda t: t)
+    orig = ref_vae.randn_tensor
+    ref_vae.randn_tensor = lambda shape, generator=None, device=None, dtype=None, layout=None: noise.to(dtype)
+    trace = []
+    import time
+    t0 = time.time()
+
+    def cb(p_, i, t_, kw_):
+        trace.append(kw_["latents"].float().clone())
+        print(f"[sdxl full] step {i + 1} at {time.time() - t0:.0f} s", flush=True)
+        if len(trace) >= steps_kept:
+            raise _StopAfter()
+        return {}
+
+    try:
+        pipe(prompt_embeds=c(inp["prompt_embeds"][sl]), negative_prompt_embeds=c(inp["negative_prompt_embeds"][sl]),
+             pooled_prompt_embeds=c(inp["pooled"][sl]), negative_pooled_prompt_embeds=c(inp["npooled"][sl]), image=inp["image"][sl],
+             mask=inp["mask"][sl], num_inference_steps=30, guidance_scale=5.0, latents=c(inp["latents"][sl].clone()),
+             output_type="latent", brushnet_conditioning_scale=1.0, height=1024, width=1024, callback_on_step_end=cb)
+    except _StopAfter:
+        pass
+    finally:
+        ref_vae.randn_tensor = orig
+    return trace, pipe.scheduler.timesteps
+
+
+def sdxl_full():
+    from diffusers.pipelines.brushnet.pipeline_brushnet_sd_xl import StableDiffusionXLBrushNetPipeline
+    unet, brushnet, vae = _sdxl_full_models()
+    with open(os.path.join(GOLD, "keys_sdxl.json"), "w") as f:
+        json.dump(dict(unet={k: tuple(v.shape) for k, v in unet.state_dict().items()},
+                       brushnet={k: tuple(v.shape) for k, v in brushnet.state_dict().items()},
+                       vae={k: tuple(v.shape) for k, v in vae.state_dict().items()}), f, indent=0, sort_keys=True)
+    trace, ts = run_sdxl_full(StableDiffusionXLBrushNetPipeline, unet, brushnet, vae)
+    out = dict(timesteps=ts.numpy())
+    for i, l in enumerate(trace):
+        out[f"latents_{i}"] = l.numpy()
+    np.savez_compressed(os.path.join(GOLD, "sdxl_config4_slice.npz"), **out)
+    print("configs[4] (SDXL full width) fixture written; |latents| max", [float(l.abs().max()) for l in trace])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-config1", action="store_true")
@@ -743,6 +825,7 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--only-xl", action="store_true")
+    ap.add_argument("--only-sdxl-full", action="store_true", help="one image of configs[4] (SDXL 1024^2) for 2 steps, full width (~5 min, ~25 GB)")
     ap.add_argument("--only-train", action="store_true")
     ap.add_argument("--only-layers", action="store_true")
     ap.add_argument("--only-guess", action="store_true")
@@ -756,6 +839,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only_xl:
         tiny_xl()
+        sys.exit(0)
+    if a.only_sdxl_full:
+        sdxl_full()
         sys.exit(0)
     if a.only_train:
         tiny_train()
