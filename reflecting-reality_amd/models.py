@@ -480,8 +480,6 @@ class _UNetCore(HipModel):
                                                                       sd[b + "attn1.to_v.weight"]], 0), None, self.prec, self.device,
                                                            ln=ln("norm1"))
                 self.P[b + "attn2.to_q_ln"] = ConvWeight(sd[b + "attn2.to_q.weight"], None, self.prec, self.device, ln=ln("norm2"))
-                self.P[b + "ff.net.0.proj_ln"] = ops.geglu_weight(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"],
-                                                                  self.prec, self.device, ln=ln("norm3"))
             i += 1
         self.tdepth[p] = i
 
@@ -703,9 +701,25 @@ class _UNetCore(HipModel):
         for i in range(self.tdepth[p]):
             b = f"{p}transformer_blocks.{i}."
             if self.ln_fold and (b + "attn1.to_qkv_ln") in P and (hh * ww) % 8 == 0 and ops.TAPE is None:
-                h = self._attention(b + "attn1.", h, None, heads, h, fold=True)
-                h = self._attention(b + "attn2.", h, ehs, heads, h, fold=True)
-                h = ops.linear(ops.linear_geglu(h, P[b + "ff.net.0.proj_ln"]), P[b + "ff.net.2"], res0=h)
+                # which LayerNorms fold into their consumer is decided per level from measurements on MI355X (tools/bench_fold.py,
+                # gpurun_out/r03d: batch 8): the in-kernel row statistics cost ~5 us per GEMM and run on the warp-specialised
+                # ring tiles only, so the fold pays where the LayerNorm launch it removes costs more than that
+                #   norm2 -> to_q (N = C):           64x64 35.4 -> 27.6 us, 32x32 22.7 -> 18.3, 16x16 23.2 -> 21.2, 8x8 14.8 -> 20.2 (no)
+                #   norm1 -> q | k | v^T (N = 3C):   64x64 68.9 -> 72.2 (no), 32x32 51.0 -> 49.6, 16x16 45.9 -> 38.0, 8x8 26.7 -> 21.4
+                #   norm3 -> GEGLU (N = 8C):         slower at every level (16 column tiles repeat the statistics, and the
+                #                                    GEGLU epilogue prefers the small tiles): stays a LayerNorm launch
+                tokens = hh * ww
+                f_qkv, f_q = tokens <= 1024, tokens >= 256
+                if f_qkv:
+                    h = self._attention(b + "attn1.", h, None, heads, h, fold=True)
+                else:
+                    h = self._attention(b + "attn1.", ops.layernorm(h, P[b + "norm1"], 1e-5, self.prec.act), None, heads, h)
+                if f_q:
+                    h = self._attention(b + "attn2.", h, ehs, heads, h, fold=True)
+                else:
+                    h = self._attention(b + "attn2.", ops.layernorm(h, P[b + "norm2"], 1e-5, self.prec.act), ehs, heads, h)
+                n = ops.layernorm(h, P[b + "norm3"], 1e-5, self.prec.act)
+                h = ops.linear(ops.linear_geglu(n, P[b + "ff.net.0.proj"]), P[b + "ff.net.2"], res0=h)
                 continue
             n = ops.layernorm(h, P[b + "norm1"], 1e-5, self.prec.act, fp8=P[b + "attn1.to_out.0"].fp8)
             h = self._attention(b + "attn1.", n, None, heads, h)

@@ -49,6 +49,28 @@ def test_mask_keep_concat_and_postprocess():
                           p.postprocess(x, output_type="np", do_denormalize=[True, True]))
 
 
+def test_device_front_end_matches_the_reference_vae_image_processor():
+    """The device kernels (mf_minmax / mf_image_normalize / mf_nearest_resize / mf_postprocess through VaeImageProcessor on
+    cuda tensors) against the outputs of the REFERENCE's VaeImageProcessor (image_processor.py:446-610) on the same seeded
+    inputs (tests/golden/frontend.npz, tools/make_golden.py::frontend) — not against the package's own host path."""
+    import os
+    from test_host_logic import _frontend_inputs
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend.npz"))
+    I = _frontend_inputs()
+    ip = VaeImageProcessor(vae_scale_factor=8, do_convert_rgb=True)
+    for name in ("t01", "tneg", "mask"):
+        x = I[name].to(DEV)
+        for tag, kw in (("same", dict(height=40, width=56)), ("resized", dict(height=32, width=48))):
+            got = ip.preprocess(x, **kw)
+            assert got.is_cuda and np.array_equal(got.cpu().numpy(), G[f"{name}_{tag}"]), (name, tag)
+    post = I["post"].to(DEV)
+    assert np.array_equal(ip.postprocess(post, output_type="pt", do_denormalize=[True, True]).cpu().numpy(), G["post_pt"])
+    assert np.array_equal(ip.postprocess(post, output_type="np", do_denormalize=[True, True]), G["post_np"])
+    assert np.array_equal(np.stack([np.array(im) for im in ip.postprocess(post, output_type="pil", do_denormalize=[True, True])]),
+                          G["post_pil"])
+    assert np.array_equal(ip.postprocess(post, output_type="pt", do_denormalize=[True, False]).cpu().numpy(), G["post_pt_mixed"])
+
+
 @pytest.mark.parametrize("use_mask", [True, False])
 @pytest.mark.parametrize("rng", [(-1, 1), (0, 1)])
 def test_apply_transforms_depth_max_scene_depth(use_mask, rng):

@@ -375,3 +375,41 @@ def test_set_attn_processor_surface():
         unet.set_attn_processor({"a": MfhipAttnProcessor()})
     with pytest.raises(NotImplementedError):
         unet.set_attn_processor(object())
+
+
+def _frontend_inputs():
+    """The seeded inputs of tools/make_golden.py::frontend_inputs (kept in step with it; the PIL pixels come from the fixture)."""
+    g = torch.Generator().manual_seed(515)
+    t01 = torch.rand(2, 3, 40, 56, generator=g)
+    tneg = torch.rand(2, 3, 40, 56, generator=g) * 2.0 - 1.0
+    mask = (torch.rand(2, 3, 40, 56, generator=g) > 0.6).float()
+    arr = torch.rand(40, 56, 3, generator=g).numpy()
+    _u8 = (torch.rand(40, 56, 3, generator=g) * 255).to(torch.uint8).numpy()
+    post = torch.rand(2, 3, 24, 32, generator=g) * 2.4 - 1.2
+    return dict(t01=t01, tneg=tneg, mask=mask, arr=arr, post=post)
+
+
+def test_image_processor_host_path_matches_the_reference_vae_image_processor():
+    """The package's VaeImageProcessor on host inputs (torch / numpy / PIL, with and without resize, default sizes) and its
+    postprocess against the outputs of the REFERENCE's VaeImageProcessor (image_processor.py:446-610) recorded in
+    tests/golden/frontend.npz by tools/make_golden.py::frontend."""
+    import warnings
+    import PIL.Image
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend.npz"))
+    I = _frontend_inputs()
+    ip = VaeImageProcessor(vae_scale_factor=8, do_convert_rgb=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name in ("t01", "tneg", "mask"):
+            assert np.array_equal(ip.preprocess(I[name], height=40, width=56).numpy(), G[f"{name}_same"]), name
+            assert np.array_equal(ip.preprocess(I[name], height=32, width=48).numpy(), G[f"{name}_resized"]), name
+        assert np.array_equal(ip.preprocess(I["arr"], height=32, width=48).numpy(), G["np_resized"])
+        assert np.array_equal(ip.preprocess([I["arr"], I["arr"][::-1].copy()], height=40, width=56).numpy(), G["np_list"])
+        pil = PIL.Image.fromarray(G["pil_u8"])
+        assert np.array_equal(ip.preprocess(pil, height=40, width=56).numpy(), G["pil_same"])
+        assert np.array_equal(ip.preprocess(pil, height=32, width=48).numpy(), G["pil_resized"])
+    assert np.array_equal(ip.postprocess(I["post"], output_type="pt", do_denormalize=[True, True]).numpy(), G["post_pt"])
+    assert np.array_equal(ip.postprocess(I["post"], output_type="np", do_denormalize=[True, True]), G["post_np"])
+    assert np.array_equal(np.stack([np.array(im) for im in ip.postprocess(I["post"], output_type="pil", do_denormalize=[True, True])]),
+                          G["post_pil"])
+    assert np.array_equal(ip.postprocess(I["post"], output_type="pt", do_denormalize=[True, False]).numpy(), G["post_pt_mixed"])

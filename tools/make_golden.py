@@ -818,6 +818,44 @@ def sdxl_full():
     print("configs[4] (SDXL full width) fixture written; |latents| max", [float(l.abs().max()) for l in trace])
 
 
+def frontend_inputs():
+    """Seeded inputs of the image front-end fixture (regenerated by the tests; only the PIL source is stored, as uint8)."""
+    g = torch.Generator().manual_seed(515)
+    t01 = torch.rand(2, 3, 40, 56, generator=g)                        # tensor in [0, 1]
+    tneg = torch.rand(2, 3, 40, 56, generator=g) * 2.0 - 1.0            # tensor that already holds negatives
+    mask = (torch.rand(2, 3, 40, 56, generator=g) > 0.6).float()        # a mask-like tensor
+    arr = torch.rand(40, 56, 3, generator=g).numpy()                    # one HWC float image
+    u8 = (torch.rand(40, 56, 3, generator=g) * 255).to(torch.uint8).numpy()     # the PIL image's pixels
+    post = torch.rand(2, 3, 24, 32, generator=g) * 2.4 - 1.2            # decoder output incl. values outside [-1, 1]
+    return dict(t01=t01, tneg=tneg, mask=mask, arr=arr, u8=u8, post=post)
+
+
+def frontend():
+    """The reference's REAL VaeImageProcessor (image_processor.py:446-610: preprocess with its resize / normalise rules for
+    torch / numpy / PIL inputs, postprocess to pt / np / pil) on seeded inputs -> tests/golden/frontend.npz.  The device
+    front-end kernels (csrc/frontend.hip) and the host class of the package are checked against THESE outputs."""
+    import PIL.Image
+    from diffusers.image_processor import VaeImageProcessor
+    vp = VaeImageProcessor(vae_scale_factor=8, do_convert_rgb=True)
+    I = frontend_inputs()
+    out = dict(pil_u8=I["u8"])
+    for name in ("t01", "tneg", "mask"):
+        out[f"{name}_same"] = vp.preprocess(I[name], height=40, width=56).numpy()          # no resize
+        out[f"{name}_resized"] = vp.preprocess(I[name], height=32, width=48).numpy()       # F.interpolate nearest (:resize)
+        out[f"{name}_default"] = vp.preprocess(I[name]).numpy()                            # 40 x 56: both multiples of 8
+    out["np_resized"] = vp.preprocess(I["arr"], height=32, width=48).numpy()
+    out["np_list"] = vp.preprocess([I["arr"], I["arr"][::-1].copy()], height=40, width=56).numpy()
+    pil = PIL.Image.fromarray(I["u8"])
+    out["pil_same"] = vp.preprocess(pil, height=40, width=56).numpy()
+    out["pil_resized"] = vp.preprocess(pil, height=32, width=48).numpy()                   # PIL lanczos
+    out["post_pt"] = vp.postprocess(I["post"], output_type="pt", do_denormalize=[True, True]).numpy()
+    out["post_np"] = vp.postprocess(I["post"], output_type="np", do_denormalize=[True, True])
+    out["post_pil"] = np.stack([np.array(im) for im in vp.postprocess(I["post"], output_type="pil", do_denormalize=[True, True])])
+    out["post_pt_mixed"] = vp.postprocess(I["post"], output_type="pt", do_denormalize=[True, False]).numpy()
+    np.savez_compressed(os.path.join(GOLD, "frontend.npz"), **out)
+    print("front-end fixture written:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only-config1", action="store_true")
@@ -825,6 +863,7 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
     ap.add_argument("--only-xl", action="store_true")
+    ap.add_argument("--only-frontend", action="store_true")
     ap.add_argument("--only-sdxl-full", action="store_true", help="one image of configs[4] (SDXL 1024^2) for 2 steps, full width (~5 min, ~25 GB)")
     ap.add_argument("--only-train", action="store_true")
     ap.add_argument("--only-layers", action="store_true")
@@ -840,6 +879,9 @@ if __name__ == "__main__":
     if a.only_xl:
         tiny_xl()
         sys.exit(0)
+    if a.only_frontend:
+        frontend()
+        sys.exit(0)
     if a.only_sdxl_full:
         sdxl_full()
         sys.exit(0)
@@ -854,6 +896,7 @@ if __name__ == "__main__":
         sys.exit(0)
     if not a.only_full:
         tiny()
+        frontend()
         tiny_guess_mode()
         tiny_train()
         layers_full()
