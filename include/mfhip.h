@@ -293,6 +293,25 @@ int mf_postprocess(const float* x, float* out_f32, void* out_u8, int32_t batch, 
 int mf_depth_normalize(const float* depth, const float* mask, float* out, int64_t n, float max_scene_depth, float delta,
                        int32_t signed_range, float* ws, void* stream);
 
+/* apply_transforms_depth(normalization_method="percentile") (dataset.py:115-127): the order statistics np.percentile
+ * interpolates between, by a two-level radix select (no sort; integer atomics, order-independent).  mf_select_ranks: the nr <= 4
+ * order statistics x_(ranks[i]) (0-based ranks in DEVICE memory) -> vals[i] (device); ws: mf_select_ws_bytes() bytes.
+ * mf_depth_percentile_normalize: ranks4 = {floor, ceil of 0.02 (n - 1); floor, ceil of 0.98 (n - 1)}, t_lo / t_hi the
+ * fractional parts; d2 / d98 interpolated like numpy's 'linear' method, out = (clip(d, d2, d98) - d2) / (d98 - d2), mapped to
+ * [-1, 1] when signed_range; vals4: 4 floats of device scratch. */
+int64_t mf_select_ws_bytes(void);
+int mf_select_ranks(const float* x, int64_t n, const int64_t* ranks, int32_t nr, float* vals, void* ws, void* stream);
+int mf_depth_percentile_normalize(const float* depth, float* out, int64_t n, const int64_t* ranks4, float t_lo, float t_hi,
+                                  int32_t signed_range, float* vals4, void* ws, void* stream);
+/* torchvision Resize(interpolation=BICUBIC) + CenterCrop (+ Normalize) of dataset.py:150-164,184-192 on fp32 planes: PyTorch's
+ * bicubic kernel (align_corners = False, A = -0.75, NO antialiasing: identical to torchvision when upsampling; torchvision >= 0.17
+ * additionally low-pass filters tensors when DOWN-sampling) evaluated inside the crop window only:
+ * dst[p][y][x] = a * bicubic(src[p] resized to h_res x w_res)[y + crop_top][x + crop_left] + b */
+int mf_bicubic_resize_crop(const float* src, float* dst, int32_t planes, int32_t h_in, int32_t w_in, int32_t h_res, int32_t w_res,
+                           int32_t crop_top, int32_t crop_left, int32_t h_out, int32_t w_out, float a, float b, void* stream);
+/* y[c][p] = a * x[p][c] + b: HWC -> CHW with Normalize([0.5], [0.5]) (apply_transforms_normals, dataset.py:184-192) */
+int mf_hwc_to_chw_affine(const float* x, float* y, int64_t hw, int32_t channels, float a, float b, void* stream);
+
 /* ============================================================================================
  * Training: the backward pass and the optimizer of examples/brushnet/train_brushnet_mirror.py:1459-1466
  * (accelerator.backward -> ATen autograd in the reference; clip_grad_norm_ :1463; torch.optim.AdamW :1188-1200).

@@ -770,18 +770,48 @@ def training_steps(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, sched_c
 # the build container, so it cannot be imported to check this restatement; it follows the numpy statements of
 # :122-145 line by line (the torchvision Resize / CenterCrop of :150-164 are the identity at the native resolution).
 # ---------------------------------------------------------------------------------------------
-def apply_transforms_depth_ref(depth_map, mask=None, max_scene_depth: float = 5.0, norm_range=(-1, 1), delta: float = 0.5):
+def _resize_center_crop_ref(t: torch.Tensor, resolution: int) -> torch.Tensor:
+    """transforms.Resize(resolution, BICUBIC) + CenterCrop(resolution) on a [C, H, W] tensor WITHOUT antialiasing (torchvision
+    < 0.17 for tensors; every version when up-sampling): smaller edge -> resolution, aspect kept (truncated), centre crop."""
+    _, h, w = t.shape
+    nh, nw = (resolution, int(resolution * w / h)) if h <= w else (int(resolution * h / w), resolution)
+    if (nh, nw) != (h, w):
+        t = F.interpolate(t[None], size=(nh, nw), mode="bicubic", align_corners=False)[0]
+    top, left = int(round((nh - resolution) / 2.0)), int(round((nw - resolution) / 2.0))
+    return t[:, top:top + resolution, left:left + resolution]
+
+
+def apply_transforms_depth_ref(depth_map, mask=None, max_scene_depth: float = 5.0, norm_range=(-1, 1), delta: float = 0.5,
+                               normalization_method: str = "max_scene_depth", resolution: Optional[int] = None):
     import numpy as np
     depth_map = np.copy(depth_map)
     if mask is not None and mask.ndim == 3:
         mask = mask[:, :, 0]                                                              # :111-112
-    if mask is not None:
-        max_scene_depth = np.max(depth_map[mask > 0]) + delta                             # :129-134
-    clipped = np.clip(depth_map, 0, max_scene_depth)                                      # :137
-    if list(norm_range) == [0, 1]:
-        out = clipped / max_scene_depth                                                   # :141
-    elif list(norm_range) == [-1, 1]:
-        out = 2.0 * (clipped / max_scene_depth) - 1.0                                     # :143
+    if normalization_method == "percentile":
+        d_2, d_98 = np.percentile(depth_map, 2), np.percentile(depth_map, 98)             # :116-117
+        clipped = np.clip(depth_map, d_2, d_98)                                           # :120
+        if list(norm_range) == [0, 1]:
+            out = (clipped - d_2) / (d_98 - d_2)                                          # :124
+        elif list(norm_range) == [-1, 1]:
+            out = 2.0 * (clipped - d_2) / (d_98 - d_2) - 1.0                              # :126
+        else:
+            raise ValueError("Unsupported normalization range. Use [0, 1] or [-1, 1].")
     else:
-        raise ValueError("Unsupported normalization range. Use [0, 1] or [-1, 1].")
-    return torch.tensor(out, dtype=torch.float32).unsqueeze(0)                            # :150
+        if mask is not None:
+            max_scene_depth = np.max(depth_map[mask > 0]) + delta                         # :129-134
+        clipped = np.clip(depth_map, 0, max_scene_depth)                                  # :137
+        if list(norm_range) == [0, 1]:
+            out = clipped / max_scene_depth                                               # :141
+        elif list(norm_range) == [-1, 1]:
+            out = 2.0 * (clipped / max_scene_depth) - 1.0                                 # :143
+        else:
+            raise ValueError("Unsupported normalization range. Use [0, 1] or [-1, 1].")
+    t = torch.tensor(out, dtype=torch.float32).unsqueeze(0)                               # :150
+    return t if resolution is None else _resize_center_crop_ref(t, resolution)           # :152-164
+
+
+def apply_transforms_normals_ref(normals_map, resolution: int = 512):
+    """dataset.py:184-192 (the map-valued modes): permute to CHW, Resize / CenterCrop, Normalize([0.5], [0.5]).  PARITY
+    UNPINNED like apply_transforms_depth_ref (same module)."""
+    t = torch.tensor(normals_map, dtype=torch.float32).permute(2, 0, 1)
+    return (_resize_center_crop_ref(t, resolution) - 0.5) / 0.5

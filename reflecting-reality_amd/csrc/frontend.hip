@@ -120,6 +120,125 @@ __global__ __launch_bounds__(256) void depth_normalize_kernel(const float* d, fl
     }
 }
 
+
+// ---- order statistics for apply_transforms_depth(normalization_method="percentile") (dataset.py:115-127) ---------------------
+// np.percentile(d, q) = linear interpolation between the two order statistics around q/100 * (n - 1).  A two-level radix
+// select on the order-preserving integer image of the floats finds up to four ranks without sorting: 65536-bin histogram of
+// the high halves -> the bin that holds each rank -> 65536-bin histogram of the low halves inside that bin -> the exact key.
+// Integer atomics only: the result does not depend on the order of the adds.
+__device__ __forceinline__ unsigned ord_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_val(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+constexpr int SEL_MAX = 4;
+
+__global__ __launch_bounds__(256) void sel_hist_hi_kernel(const float* x, int64_t n, unsigned* hist) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) atomicAdd(&hist[ord_key(x[i]) >> 16], 1u);
+}
+
+// one block of 1024 threads: for each rank, the bin whose cumulative count first exceeds it, and the rank inside that bin
+__global__ __launch_bounds__(1024) void sel_pick_kernel(const unsigned* hist, int nsets, const int64_t* ranks, int nr, unsigned* bin_out,
+                                                        int64_t* rem_out) {
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x;
+    for (int r = 0; r < nr; ++r) {
+        const unsigned* h = hist + (nsets > 1 ? (int64_t)r * 65536 : 0);
+        unsigned long long s = 0;
+        for (int j = 0; j < 64; ++j) s += h[t * 64 + j];
+        part[t] = s;
+        __syncthreads();
+        if (t == 0) {
+            const unsigned long long want = (unsigned long long)(nsets > 1 ? rem_out[r] : ranks[r]);
+            unsigned long long acc = 0;
+            int blk = 0;
+            while (blk < 1023 && acc + part[blk] <= want) { acc += part[blk]; ++blk; }
+            int b = blk * 64;
+            while (b < blk * 64 + 63 && acc + h[b] <= want) { acc += h[b]; ++b; }
+            bin_out[r] = (unsigned)b;
+            rem_out[r] = (int64_t)(want - acc);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void sel_hist_lo_kernel(const float* x, int64_t n, const unsigned* bins, int nr, unsigned* hist2) {
+    unsigned b[SEL_MAX];
+    for (int r = 0; r < SEL_MAX; ++r) b[r] = r < nr ? bins[r] : 0xffffffffu;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned k = ord_key(x[i]);
+        for (int r = 0; r < nr; ++r)
+            if ((k >> 16) == b[r]) atomicAdd(&hist2[(int64_t)r * 65536 + (k & 0xffffu)], 1u);
+    }
+}
+
+__global__ void sel_value_kernel(const unsigned* bins_hi, const unsigned* bins_lo, int nr, float* vals) {
+    const int r = threadIdx.x;
+    if (r < nr) vals[r] = ord_val((bins_hi[r] << 16) | bins_lo[r]);
+}
+
+// out = clip(d, d2, d98) mapped to [0, 1] or [-1, 1]; d2 / d98 interpolated from the four order statistics like numpy's
+// 'linear' method (a + (b - a) * t, taken from the b side for t >= 0.5)
+__global__ __launch_bounds__(256) void depth_percentile_kernel(const float* d, float* out, int64_t n, const float* v4, float t_lo, float t_hi,
+                                                               int signed_range) {
+    auto lerp = [](float a, float b, float t) { return t >= 0.5f ? b - (b - a) * (1.0f - t) : a + (b - a) * t; };
+    const float d2 = lerp(v4[0], v4[1], t_lo), d98 = lerp(v4[2], v4[3], t_hi);
+    const float inv = 1.0f / (d98 - d2);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = (fminf(fmaxf(d[i], d2), d98) - d2) * inv;
+        out[i] = signed_range ? 2.0f * v - 1.0f : v;
+    }
+}
+
+// ---- torchvision Resize(bicubic) + CenterCrop (dataset.py:150-164, 184-192) ------------------------------------------------------
+// PyTorch's upsample_bicubic2d (align_corners = False, A = -0.75, no antialiasing) evaluated only inside the crop window:
+// out[p][y][x] = bicubic(src[p], (y + oy + 0.5) * sh - 0.5, (x + ox + 0.5) * sw - 0.5), then y = a * v + b (Normalize).
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; }
+__global__ __launch_bounds__(256) void bicubic_crop_kernel(const float* src, float* dst, int planes, int h_in, int w_in, int h_res, int w_res,
+                                                           int oy, int ox, int h_out, int w_out, float a, float b) {
+    const float A = -0.75f;
+    const float sh = (float)h_in / (float)h_res, sw = (float)w_in / (float)w_res;
+    const int64_t total = (int64_t)planes * h_out * w_out;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w_out);
+        const int64_t t = i / w_out;
+        const int y = (int)(t % h_out);
+        const int pl = (int)(t / h_out);
+        const float fy = ((float)(y + oy) + 0.5f) * sh - 0.5f, fx = ((float)(x + ox) + 0.5f) * sw - 0.5f;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        const float ty = fy - (float)iy, tx = fx - (float)ix;
+        const float wy[4] = {cubic2(ty + 1.0f, A), cubic1(ty, A), cubic1(1.0f - ty, A), cubic2(2.0f - ty, A)};
+        const float wx[4] = {cubic2(tx + 1.0f, A), cubic1(tx, A), cubic1(1.0f - tx, A), cubic2(2.0f - tx, A)};
+        const float* sp = src + (int64_t)pl * h_in * w_in;
+        float acc = 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            int yy = iy - 1 + j;
+            yy = yy < 0 ? 0 : (yy > h_in - 1 ? h_in - 1 : yy);
+            float row = 0.0f;
+            for (int k = 0; k < 4; ++k) {
+                int xx = ix - 1 + k;
+                xx = xx < 0 ? 0 : (xx > w_in - 1 ? w_in - 1 : xx);
+                row += sp[(int64_t)yy * w_in + xx] * wx[k];
+            }
+            acc += row * wy[j];
+        }
+        dst[i] = a * acc + b;
+    }
+}
+
+// y[c][p] = a * x[p][c] + b: HWC -> CHW with an affine map (apply_transforms_normals at the native resolution)
+__global__ __launch_bounds__(256) void hwc_to_chw_affine_kernel(const float* x, float* y, int64_t hw, int c, float a, float b) {
+    const int64_t total = hw * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % hw;
+        const int cc = (int)(i / hw);
+        y[i] = a * x[p * c + cc] + b;
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t mf_minmax_ws_floats(void) { return 2 * MM_BLOCKS; }
@@ -185,5 +304,61 @@ extern "C" int mf_depth_normalize(const float* depth, const float* mask, float* 
     hipLaunchKernelGGL(depth_normalize_kernel, dim3(fgrid(n)), dim3(256), 0, s, depth, out, n, mm, mask != nullptr, max_scene_depth, delta,
                        signed_range);
     MF_CHECK_LAUNCH("mf_depth_normalize");
+    return MF_OK;
+}
+
+
+extern "C" int64_t mf_select_ws_bytes(void) { return (int64_t)(65536 * (1 + SEL_MAX)) * 4 + SEL_MAX * (4 + 4 + 8) + 64; }
+
+// the nr (<= 4) order statistics x_(ranks[i]) (0-based, ascending) of x[0..n) -> vals[i]; ranks / vals in device memory
+static int select_ranks(const float* x, int64_t n, const int64_t* ranks_dev, int nr, float* vals, void* ws, hipStream_t s) {
+    unsigned* hist = (unsigned*)ws;
+    unsigned* hist2 = hist + 65536;
+    unsigned* bin_hi = hist2 + (int64_t)SEL_MAX * 65536;
+    unsigned* bin_lo = bin_hi + SEL_MAX;
+    int64_t* rem = (int64_t*)(((uintptr_t)(bin_lo + SEL_MAX) + 7) & ~(uintptr_t)7);
+    if (hipMemsetAsync(hist, 0, (size_t)65536 * (1 + SEL_MAX) * 4, s) != hipSuccess) return MF_ELAUNCH;
+    hipLaunchKernelGGL(sel_hist_hi_kernel, dim3(fgrid(n)), dim3(256), 0, s, x, n, hist);
+    hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(1024), 0, s, hist, 1, ranks_dev, nr, bin_hi, rem);
+    hipLaunchKernelGGL(sel_hist_lo_kernel, dim3(fgrid(n)), dim3(256), 0, s, x, n, bin_hi, nr, hist2);
+    hipLaunchKernelGGL(sel_pick_kernel, dim3(1), dim3(1024), 0, s, hist2, SEL_MAX, ranks_dev, nr, bin_lo, rem);
+    hipLaunchKernelGGL(sel_value_kernel, dim3(1), dim3(64), 0, s, bin_hi, bin_lo, nr, vals);
+    return MF_OK;
+}
+
+extern "C" int mf_select_ranks(const float* x, int64_t n, const int64_t* ranks, int32_t nr, float* vals, void* ws, void* stream) {
+    MF_CHECK_ARG(x && ranks && vals && ws && n >= 1 && nr >= 1 && nr <= SEL_MAX, "mf_select_ranks: bad arguments");
+    const int rc = select_ranks(x, n, ranks, nr, vals, ws, (hipStream_t)stream);
+    if (rc != MF_OK) { mf_set_error("mf_select_ranks: memset failed"); return rc; }
+    MF_CHECK_LAUNCH("mf_select_ranks");
+    return MF_OK;
+}
+
+extern "C" int mf_depth_percentile_normalize(const float* depth, float* out, int64_t n, const int64_t* ranks4, float t_lo, float t_hi,
+                                             int32_t signed_range, float* vals4, void* ws, void* stream) {
+    MF_CHECK_ARG(depth && out && ranks4 && vals4 && ws && n >= 2, "mf_depth_percentile_normalize: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = select_ranks(depth, n, ranks4, 4, vals4, ws, s);
+    if (rc != MF_OK) { mf_set_error("mf_depth_percentile_normalize: memset failed"); return rc; }
+    hipLaunchKernelGGL(depth_percentile_kernel, dim3(fgrid(n)), dim3(256), 0, s, depth, out, n, vals4, t_lo, t_hi, signed_range);
+    MF_CHECK_LAUNCH("mf_depth_percentile_normalize");
+    return MF_OK;
+}
+
+extern "C" int mf_bicubic_resize_crop(const float* src, float* dst, int32_t planes, int32_t h_in, int32_t w_in, int32_t h_res, int32_t w_res,
+                                      int32_t crop_top, int32_t crop_left, int32_t h_out, int32_t w_out, float a, float b, void* stream) {
+    MF_CHECK_ARG(src && dst && planes >= 1 && h_in >= 1 && w_in >= 1 && h_res >= 1 && w_res >= 1 && h_out >= 1 && w_out >= 1 && crop_top >= 0 &&
+                     crop_left >= 0 && crop_top + h_out <= h_res && crop_left + w_out <= w_res,
+                 "mf_bicubic_resize_crop: the crop window must lie inside the resized image");
+    hipLaunchKernelGGL(bicubic_crop_kernel, dim3(fgrid((int64_t)planes * h_out * w_out)), dim3(256), 0, (hipStream_t)stream, src, dst, planes,
+                       h_in, w_in, h_res, w_res, crop_top, crop_left, h_out, w_out, a, b);
+    MF_CHECK_LAUNCH("mf_bicubic_resize_crop");
+    return MF_OK;
+}
+
+extern "C" int mf_hwc_to_chw_affine(const float* x, float* y, int64_t hw, int32_t channels, float a, float b, void* stream) {
+    MF_CHECK_ARG(x && y && hw >= 1 && channels >= 1, "mf_hwc_to_chw_affine: bad arguments");
+    hipLaunchKernelGGL(hwc_to_chw_affine_kernel, dim3(fgrid(hw * channels)), dim3(256), 0, (hipStream_t)stream, x, y, hw, channels, a, b);
+    MF_CHECK_LAUNCH("mf_hwc_to_chw_affine");
     return MF_OK;
 }

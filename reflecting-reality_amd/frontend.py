@@ -1,10 +1,18 @@
 """Dataset-side transforms of the reference on the device: examples/brushnet/dataset/dataset.py.
 
-`apply_transforms_depth` (:98-166), normalisation method "max_scene_depth": the scene depth is the maximum depth under the
-mirror mask plus `delta` (or the given `max_scene_depth` without a mask), depth is clipped to [0, scene] and mapped to
-[-1, 1] (or [0, 1]) — one masked max reduction and one streaming pass on the GPU (csrc/frontend.hip), no host round trip.
-The "percentile" method (a sort) and the bicubic Resize / CenterCrop of torchvision (only active when the depth map is
-not already `resolution` x `resolution`; SynMirror renders are 512 x 512) are not built and raise."""
+`apply_transforms_depth` (:98-166): normalisation "max_scene_depth" (scene depth = maximum depth under the mirror mask +
+`delta`, or the given `max_scene_depth`; one masked max reduction + one streaming pass) or "percentile" (clip to the
+[2 %, 98 %] percentiles: a two-level radix select finds the four order statistics np.percentile interpolates between — no
+sort), then torchvision's Resize(resolution, BICUBIC) + CenterCrop as ONE bicubic kernel evaluated inside the crop window.
+`apply_transforms_normals` (:168-192, the map-valued modes): HWC -> CHW, the same resize / crop, Normalize([0.5], [0.5]).
+All on the GPU (csrc/frontend.hip), no host round trip.
+
+Bicubic = PyTorch's kernel (align_corners=False, A = -0.75) WITHOUT antialiasing: what torchvision computes when it
+up-samples, and what torchvision < 0.17 computes for tensors in general; newer torchvision low-pass filters tensors when
+it DOWN-samples (antialias=True by default), which is not built: a down-sampling call must say antialias=False.  SynMirror
+renders are 512 x 512 = `resolution`, where Resize + CenterCrop are the identity.  The reference module itself imports
+h5py / torchvision / cv2 (absent here), so these transforms are checked against the oracle's numpy / torch restatement
+(oracle/mirrorfusion_ref.py, PARITY UNPINNED for this one module) — see tests/test_frontend_gpu.py."""
 from __future__ import annotations
 
 from typing import Optional, Sequence
@@ -15,13 +23,32 @@ import torch
 from . import hip
 
 
+def _resize_geometry(h: int, w: int, resolution: int):
+    """torchvision Resize(int): the smaller edge becomes `resolution`, the other keeps the aspect ratio (truncated);
+    CenterCrop((resolution, resolution)): offsets int(round((size - resolution) / 2))."""
+    if h <= w:
+        nh, nw = resolution, int(resolution * w / h)
+    else:
+        nh, nw = int(resolution * h / w), resolution
+    return (nh, nw), (int(round((nh - resolution) / 2.0)), int(round((nw - resolution) / 2.0)))
+
+
+def _resize_crop(planes: torch.Tensor, resolution: int, antialias: Optional[bool], a: float = 1.0, b: float = 0.0) -> torch.Tensor:
+    _, h, w = planes.shape
+    (nh, nw), (top, left) = _resize_geometry(h, w, resolution)
+    if (nh, nw) == (h, w) == (resolution, resolution):
+        return planes if (a, b) == (1.0, 0.0) else hip.axpby_affine(planes, a, b)
+    if (nh < h or nw < w) and antialias is not False:
+        raise NotImplementedError("bicubic DOWN-sampling with torchvision's antialias filter is not built: pass antialias=False for the "
+                                  "plain bicubic kernel (torchvision < 0.17 semantics), or feed maps of the target resolution")
+    return hip.bicubic_resize_crop(planes, (nh, nw), (top, left), (resolution, resolution), a, b)
+
+
 def apply_transforms_depth(depth_map, mask=None, normalization_method: str = "max_scene_depth", max_scene_depth: float = 5.0,
                            norm_range: Sequence[float] = (-1, 1), delta: float = 0.5, resolution: int = 512, device="cuda",
-                           **kwargs) -> torch.Tensor:
-    """Returns the [1, H, W] fp32 device tensor the reference's dataset hands to the collate function."""
-    if normalization_method == "percentile":
-        raise NotImplementedError("apply_transforms_depth: the 'percentile' normalisation (np.percentile) is not built")
-    if normalization_method != "max_scene_depth":
+                           antialias: Optional[bool] = None, **kwargs) -> torch.Tensor:
+    """Returns the [1, resolution, resolution] fp32 device tensor the reference's dataset hands to the collate function."""
+    if normalization_method not in ("percentile", "max_scene_depth"):
         raise ValueError("Unsupported normalization method. Use 'percentile' or 'max_scene_depth'.")
     rng = [float(v) for v in norm_range]
     if rng not in ([0.0, 1.0], [-1.0, 1.0]):
@@ -29,14 +56,30 @@ def apply_transforms_depth(depth_map, mask=None, normalization_method: str = "ma
     d = torch.as_tensor(np.ascontiguousarray(depth_map) if isinstance(depth_map, np.ndarray) else depth_map).to(device, torch.float32)
     if d.dim() != 2:
         raise ValueError("apply_transforms_depth takes an [H, W] depth map")
-    if tuple(d.shape) != (resolution, resolution):
-        raise NotImplementedError("apply_transforms_depth: torchvision's bicubic Resize + CenterCrop is not built; pass depth maps "
-                                  f"of {resolution} x {resolution}")
-    m = None
-    if mask is not None:
-        m = torch.as_tensor(np.ascontiguousarray(mask) if isinstance(mask, np.ndarray) else mask)
-        if m.dim() == 3:
-            m = m[:, :, 0]                                                    # dataset.py:111-112
-        m = m.to(device, torch.float32).contiguous()
-    out = hip.depth_normalize(d.contiguous(), m, max_scene_depth=max_scene_depth, delta=delta, signed_range=rng == [-1.0, 1.0])
-    return out.unsqueeze(0)
+    signed = rng == [-1.0, 1.0]
+    if normalization_method == "percentile":
+        out = hip.depth_percentile_normalize(d.contiguous(), signed_range=signed)                  # :115-127
+    else:
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(np.ascontiguousarray(mask) if isinstance(mask, np.ndarray) else mask)
+            if m.dim() == 3:
+                m = m[:, :, 0]                                                    # dataset.py:111-112
+            m = m.to(device, torch.float32).contiguous()
+        out = hip.depth_normalize(d.contiguous(), m, max_scene_depth=max_scene_depth, delta=delta, signed_range=signed)
+    return _resize_crop(out.unsqueeze(0), resolution, antialias)                                    # :150-164
+
+
+def apply_transforms_normals(normals_map, resolution: int = 512, mask=None, normals_conditioning_mode: str = "concat", device="cuda",
+                             antialias: Optional[bool] = None, **kwargs) -> torch.Tensor:
+    """dataset.py:168-192 for the map-valued modes: [H, W, 3] -> [3, resolution, resolution], (x - 0.5) / 0.5.  The
+    'ip_adapter' mode (one mean normal vector for the image encoder) belongs to the IP-Adapter path, which is out of scope."""
+    if normals_conditioning_mode == "ip_adapter":
+        raise NotImplementedError("normals_conditioning_mode='ip_adapter' (SURVEY.md §2 #14: IP-Adapter is outside the hot path)")
+    x = torch.as_tensor(np.ascontiguousarray(normals_map) if isinstance(normals_map, np.ndarray) else normals_map).to(device, torch.float32)
+    if x.dim() != 3 or x.shape[-1] != 3:
+        raise ValueError("apply_transforms_normals takes an [H, W, 3] normals map")
+    h, w, _ = x.shape
+    if (h, w) == (resolution, resolution):
+        return hip.hwc_to_chw_affine(x, 2.0, -1.0)                                                   # Normalize([0.5], [0.5])
+    return _resize_crop(hip.hwc_to_chw_affine(x, 1.0, 0.0), resolution, antialias, 2.0, -1.0)

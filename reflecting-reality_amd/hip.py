@@ -108,7 +108,8 @@ EXPORTS = [
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
     # image front-end (csrc/frontend.hip)
     "mf_minmax_ws_floats", "mf_minmax", "mf_image_normalize", "mf_mask_keep", "mf_concat_channels", "mf_postprocess",
-    "mf_depth_normalize",
+    "mf_depth_normalize", "mf_select_ws_bytes", "mf_select_ranks", "mf_depth_percentile_normalize", "mf_bicubic_resize_crop",
+    "mf_hwc_to_chw_affine",
     # training (csrc/train.hip)
     "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
     "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_layernorm_bwd", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
@@ -135,7 +136,7 @@ def load() -> C.CDLL:
     lib = C.CDLL(path)
     lib.mf_last_error.restype = C.c_char_p
     lib.mf_groupnorm_ws_floats.restype = C.c_int64
-    for fn in ("mf_conv_wgrad_ws_floats", "mf_colsum_ws_floats", "mf_sumsq_ws_doubles", "mf_minmax_ws_floats"):
+    for fn in ("mf_conv_wgrad_ws_floats", "mf_colsum_ws_floats", "mf_sumsq_ws_doubles", "mf_minmax_ws_floats", "mf_select_ws_bytes"):
         getattr(lib, fn).restype = C.c_int64
     if lib.mf_abi_version() != ABI_VERSION:
         raise MfhipError(f"libmfhip ABI {lib.mf_abi_version()} != binding ABI {ABI_VERSION}: rebuild the library")
@@ -974,6 +975,70 @@ def postprocess(x: torch.Tensor, denormalize: bool = True, uint8: bool = False) 
     _check(load().mf_postprocess(C.c_void_p(x.data_ptr()), C.c_void_p(None if uint8 else out.data_ptr()),
                                  C.c_void_p(out.data_ptr() if uint8 else None), b, c, C.c_int64(h * w), int(denormalize), _stream()),
            "mf_postprocess")
+    return out
+
+
+def _sel_ws(device) -> torch.Tensor:
+    return scratch("select", int(load().mf_select_ws_bytes()) // 4 + 8, device)
+
+
+def depth_percentile_normalize(depth: torch.Tensor, signed_range: bool = True) -> torch.Tensor:
+    """apply_transforms_depth(normalization_method="percentile"): clip to the [2 %, 98 %] percentiles and map to the range."""
+    import math
+    _f32(depth)
+    depth = depth.contiguous()
+    n = depth.numel()
+    ranks, ts = [], []
+    for q in (2.0, 98.0):
+        pos = q / 100.0 * (n - 1)
+        lo = math.floor(pos)
+        ranks += [lo, min(lo + 1, n - 1)]
+        ts.append(pos - lo)
+    rk = torch.tensor(ranks, dtype=torch.int64).to(depth.device)
+    vals = torch.empty(4, dtype=torch.float32, device=depth.device)
+    out = torch.empty_like(depth)
+    _check(load().mf_depth_percentile_normalize(C.c_void_p(depth.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int64(n), C.c_void_p(rk.data_ptr()),
+                                                C.c_float(ts[0]), C.c_float(ts[1]), int(signed_range), C.c_void_p(vals.data_ptr()),
+                                                C.c_void_p(_sel_ws(depth.device).data_ptr()), _stream()), "mf_depth_percentile_normalize")
+    return out
+
+
+def select_ranks(x: torch.Tensor, ranks) -> torch.Tensor:
+    """The order statistics x_(r) (0-based, ascending) for up to four ranks, on the device."""
+    _f32(x)
+    x = x.contiguous()
+    rk = torch.tensor(list(ranks), dtype=torch.int64).to(x.device)
+    vals = torch.empty(len(ranks), dtype=torch.float32, device=x.device)
+    _check(load().mf_select_ranks(C.c_void_p(x.data_ptr()), C.c_int64(x.numel()), C.c_void_p(rk.data_ptr()), len(ranks), C.c_void_p(vals.data_ptr()),
+                                  C.c_void_p(_sel_ws(x.device).data_ptr()), _stream()), "mf_select_ranks")
+    return vals
+
+
+def bicubic_resize_crop(x: torch.Tensor, resized: tuple, crop: tuple, out_hw: tuple, a: float = 1.0, b: float = 0.0) -> torch.Tensor:
+    """x [planes, H, W] fp32 -> a * bicubic(x -> resized)[crop window of out_hw at (top, left) = crop] + b."""
+    _f32(x)
+    x = x.contiguous()
+    planes, h, w = x.shape
+    out = torch.empty(planes, out_hw[0], out_hw[1], dtype=torch.float32, device=x.device)
+    _check(load().mf_bicubic_resize_crop(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), planes, h, w, int(resized[0]), int(resized[1]),
+                                         int(crop[0]), int(crop[1]), int(out_hw[0]), int(out_hw[1]), C.c_float(a), C.c_float(b), _stream()),
+           "mf_bicubic_resize_crop")
+    return out
+
+
+def axpby_affine(x: torch.Tensor, a: float, b: float) -> torch.Tensor:
+    """a * x + b on fp32 planes (the bicubic kernel at scale 1 is the identity: reuse it as the affine map)."""
+    planes, h, w = x.shape
+    return bicubic_resize_crop(x, (h, w), (0, 0), (h, w), a, b)
+
+
+def hwc_to_chw_affine(x: torch.Tensor, a: float, b: float) -> torch.Tensor:
+    _f32(x)
+    x = x.contiguous()
+    h, w, c = x.shape
+    out = torch.empty(c, h, w, dtype=torch.float32, device=x.device)
+    _check(load().mf_hwc_to_chw_affine(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int64(h * w), c, C.c_float(a), C.c_float(b),
+                                       _stream()), "mf_hwc_to_chw_affine")
     return out
 
 

@@ -1,5 +1,7 @@
-"""The image front-end on the device (csrc/frontend.hip) against the host path it replaces (the
-reference's torch / numpy statements) and, for the dataset depth transform, against the oracle's numpy restatement."""
+"""The image front-end on the device (csrc/frontend.hip): VaeImageProcessor against outputs of the REFERENCE's
+own class (tests/golden/frontend.npz) and the host path it replaces; the dataset transforms (dataset.py:98-192) against the
+oracle's numpy / torch restatement — PARITY UNPINNED for that one module: it imports h5py / torchvision / cv2, which this
+image lacks, so the reference staticmethods cannot be run to pin the restatement (stated in each test)."""
 import numpy as np
 import pytest
 import torch
@@ -84,9 +86,56 @@ def test_apply_transforms_depth_max_scene_depth(use_mask, rng):
     got = frontend.apply_transforms_depth(depth, mask if use_mask else None, max_scene_depth=5.0, norm_range=rng, delta=0.5)
     assert tuple(got.shape) == (1, 512, 512) and got.is_cuda
     assert float((got.cpu() - ref).abs().max()) < 2e-7
-    with pytest.raises(NotImplementedError):
-        frontend.apply_transforms_depth(depth, normalization_method="percentile")
-    with pytest.raises(NotImplementedError):
-        frontend.apply_transforms_depth(depth[:256, :256])
     with pytest.raises(ValueError):
         frontend.apply_transforms_depth(depth, norm_range=(0, 2))
+    with pytest.raises(ValueError):
+        frontend.apply_transforms_depth(depth, normalization_method="median")
+
+
+@pytest.mark.parametrize("rng", [(-1, 1), (0, 1)])
+def test_apply_transforms_depth_percentile(rng):
+    """dataset.py:115-127: clip to np.percentile(d, 2) / np.percentile(d, 98) and map to the range.  The device path finds the four
+    order statistics by a radix select (no sort) and interpolates like numpy's 'linear' method.  ORACLE UNPINNED: the
+    reference's dataset module cannot be imported here (h5py / torchvision / cv2), the numpy restatement is the checker."""
+    g = np.random.default_rng(4)
+    depth = (g.standard_normal((512, 512)).astype(np.float32) * 2.0 + 3.0).astype(np.float32)
+    depth[5, 7], depth[100, 3] = 1.0e4, -50.0                                             # outliers the percentiles exist to clip
+    ref = R.apply_transforms_depth_ref(depth, normalization_method="percentile", norm_range=rng)
+    got = frontend.apply_transforms_depth(depth, normalization_method="percentile", norm_range=rng)
+    assert tuple(got.shape) == (1, 512, 512) and got.is_cuda
+    assert float((got.cpu() - ref).abs().max()) < 2e-6
+    # the selection itself, exactly: order statistics of a tensor with ties, negatives and both zeros
+    x = torch.from_numpy(g.standard_normal(70001).astype(np.float32))
+    x[:500] = 0.25
+    x[500:600] = -0.0
+    x[600:700] = 0.0
+    srt = torch.sort(x).values
+    ranks = [0, 1400, 35000, 70000]
+    assert torch.equal(hip.select_ranks(x.to(DEV), ranks).cpu(), srt[ranks])
+
+
+@pytest.mark.parametrize("shape", [(384, 512), (512, 384), (300, 300), (512, 512), (600, 800)])
+def test_bicubic_resize_center_crop_and_normals(shape):
+    """torchvision's Resize(resolution, BICUBIC) + CenterCrop + Normalize of dataset.py:150-164,184-192 as one device kernel
+    against F.interpolate(mode='bicubic', align_corners=False) + slicing on the CPU (no antialiasing: down-sampling must ask
+    for it explicitly).  ORACLE UNPINNED (see above)."""
+    g = np.random.default_rng(5)
+    h, w = shape
+    res = 512
+    depth = (g.random((h, w), dtype=np.float32) * 4.0).astype(np.float32)
+    normals = g.random((h, w, 3), dtype=np.float32)
+    down = min(h, w) > res
+    kw = dict(antialias=False) if down else {}
+    if down:
+        with pytest.raises(NotImplementedError):
+            frontend.apply_transforms_depth(depth, max_scene_depth=5.0, resolution=res)
+    ref_d = R.apply_transforms_depth_ref(depth, max_scene_depth=5.0, resolution=res)
+    got_d = frontend.apply_transforms_depth(depth, max_scene_depth=5.0, resolution=res, **kw)
+    assert tuple(got_d.shape) == (1, res, res)
+    assert float((got_d.cpu() - ref_d).abs().max()) < 2e-5
+    ref_n = R.apply_transforms_normals_ref(normals, res)
+    got_n = frontend.apply_transforms_normals(normals, res, **kw)
+    assert tuple(got_n.shape) == (3, res, res)
+    assert float((got_n.cpu() - ref_n).abs().max()) < 2e-5
+    with pytest.raises(NotImplementedError):
+        frontend.apply_transforms_normals(normals, res, normals_conditioning_mode="ip_adapter")
