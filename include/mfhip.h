@@ -133,14 +133,14 @@ typedef struct mf_gemm_desc {
      * image sizes that tile by 8x16 / 16x16); 20-24: implicit GEMM with dx-tap reuse of the A window (3x3 / stride 1,
      * W divides or is divided by BM); 25-30: 16x16x32-MFMA forms (bf16); 31-36: deeper LDS rings; 37-40, 47: warp-specialised
      * dx-reuse convs (bf16: extra waves that only stage operands); 41-46, 48: the warp-specialised form of the plain ring
-     * (bf16, any call; with 49-50, their four-deep-ring forms, the only tiles that serve ln_colsum / vt_out).  A tile that does not apply to the call returns MF_EINVAL (the host autotuner skips it); nothing
+     * (bf16, any call; the only tiles that serve ln_colsum / vt_out).  A tile that does not apply to the call returns MF_EINVAL (the host autotuner skips it); nothing
      * is silently rerouted. */
     int32_t tile;
     /* LayerNorm folded into the GEMM (attention.py:203,233,261 -> the Linear that follows): ln_colsum[n] = sum_k W[n][k] of the
      * weight handed in, which the caller has already multiplied by the norm's gamma (and whose bias already holds W.beta):
      *   out = rstd[m] * (acc[m][n] - mean[m] * ln_colsum[n]) + bias ...  with mean / rstd of A row m over all K (eps = ln_eps),
      * gathered inside the kernel while the A tiles pass through LDS — the normalised tensor is never written.  bf16 1x1 GEMMs
-     * with one A segment and no split-K; served by the warp-specialised ring tiles (41-46, 48-50).  NULL = off. */
+     * with one A segment and no split-K; served by the warp-specialised ring tiles (41-46, 48).  NULL = off. */
     const float* ln_colsum; float ln_eps;
     /* Transposed output columns (a fused q | k | v projection whose V third attention wants as V^T): columns n >= vt_n0 are not
      * written to `out` but as vt_out[image][n - vt_n0][token] (bf16, row stride vt_ld elements), image = m / vt_tokens,

@@ -71,6 +71,9 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
     // is  log2(e)*scale*q.k - m  and the 32 v_fma per lane and tile disappear (the loop is VALU-issue bound: PMC round 2).  m only
     // moves when some score exceeds the offset by more than MJ_T (defer-max: P <= 2^MJ_T, exact in the fp32 sums), so the
     // rescale of O^T and the update of the Q~ slots are rare wave-uniform branches.
+    // (Round 3 also measured a 64-queries-per-wave form of this kernel — every K / V^T fragment feeding two MFMAs, 256-query blocks,
+    // a 2 / 3 / 4-deep K/V ring under counted vmcnt waits: 252 / 264 / 268 us against 247 us for this kernel on the same box
+    // (gpurun_out/r03e): neither the L2 -> LDS fill nor the LDS reads bound the d = 40 loop, so the form was removed.)
     constexpr bool MJ = !SP && (DK - HD >= 3);
     constexpr float MJ_T = 5.0f;
     static_assert(!MJ || HD % 16 == 8, "MJ: the pad k slots must be the whole last fragment of the h = 1 half-wave");
@@ -381,267 +384,6 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
 }
 
 
-// =====================================================================================================================
-// Round 3: the 64-queries-per-wave form for the dominant shape (bf16, head dim 40, thousands of keys).
-//
-// The kernel above turned out to be bound by the L2 -> LDS fill, not by the matrix pipe or the VALU: a block re-streams the
-// whole K / V^T of its (batch, head) for 128 queries, one 16-KB tile per 448 MFMA cycles and SIMD — ~76 GB/s per CU when
-// nothing waits, against the ~50 GB/s a CU sustains with 64 KB of DMA in flight (four double-buffered blocks; Little's law
-// with the ~1.2 us loaded L2 round trip, the same bound as the conv kernels).  Here a wave owns TWO 32-query
-// sub-blocks: every K and V^T fragment read from LDS feeds two MFMAs, a block covers 256 queries (half the fill bytes and half
-// the ds_reads per flop), and the tiles arrive through an NBUF-deep ring ordered by counted vmcnt waits (NBUF - 1 tiles =
-// 48 KB per block, 96 KB per CU in flight at two blocks per CU).  Softmax: the max-injected form (MJ) of the kernel above.
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-    // s_waitcnt takes an immediate: dispatch a wave-uniform count (<= N) to the constant forms
-    if constexpr (N == 0) { wait_vmcnt<0>(); }
-    else {
-        if (n >= N) wait_vmcnt<N>();
-        else wait_vmcnt_dyn<N - 1>(n);
-    }
-}
-
-template <int HD, int NBUF>
-__global__ __launch_bounds__(256, 2) void attn_fwd_q64_kernel(const AttnArgs p) {
-    constexpr int QW = 2;                     // 32-query sub-blocks per wave
-    constexpr int DK = (HD + 15) / 16 * 16, KS = DK / 16;
-    constexpr int DV = (HD + 31) / 32 * 32, DT = DV / 32;
-    constexpr int RBK = DK * 2 + 16, RBV = 144, RBO = DV * 2 + 16;
-    constexpr int KCPR = RBK / 16, VCPR = RBV / 16;
-    constexpr int KI = KCPR, VI = (HD * VCPR + 63) / 64;
-    constexpr int KPW = (KI + 3) / 4, VPW = (VI + 3) / 4;
-    constexpr int K_BYTES = 64 * RBK;
-    constexpr int V_BYTES = (DV * RBV > VI * 1024 ? DV * RBV : VI * 1024);
-    constexpr int O_BYTES = 4 * 32 * RBO;
-    constexpr int BUF_BYTES = K_BYTES + V_BYTES, V0 = K_BYTES;
-    constexpr int LDS_BYTES = (NBUF * BUF_BYTES) > O_BYTES ? (NBUF * BUF_BYTES) : O_BYTES;
-    static_assert(NBUF >= 2 && NBUF <= 4 && LDS_BYTES <= 80 * 1024, "two blocks per CU");
-    static_assert(DK - HD >= 3 && HD % 16 == 8, "max-injected softmax: the last K fragment of the h = 1 half-wave is all pad slots");
-    static_assert(DV > HD, "a pad row of V^T carries the ones that sum P on the matrix pipe");
-    constexpr float MJ_T = 5.0f;
-    constexpr int ONES_ROW = DV - 1;
-    constexpr int L_D = ONES_ROW / 32, L_RR = ONES_ROW % 32, L_E = (L_RR & 3) + 4 * (L_RR >> 3), L_H = (L_RR >> 2) & 1;
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    int bid = blockIdx.x;
-    if (!p.no_xcd_order) {
-        const int nblk = gridDim.x, q = nblk >> 3, rr = nblk & 7, x = bid & 7, j = bid >> 3;
-        bid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + j;
-    }
-    const int qblocks = (p.sq + 255) >> 8;
-    const int bx = bid % qblocks, bh = bid / qblocks;
-    const int b = bh / p.heads, head = bh - b * p.heads;
-    const int q0 = bx * 256 + wave * 64;
-
-    for (int i = tid * 16; i < NBUF * BUF_BYTES; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    for (int i = tid; i < NBUF * 32; i += 256)
-        *reinterpret_cast<uint32_t*>(smem + (i >> 5) * BUF_BYTES + V0 + ONES_ROW * RBV + (i & 31) * 4) = 0x3F803F80u;
-
-    // Q~ fragments of both sub-blocks, pre-multiplied by scale * log2(e)
-    uint4 qf[QW][KS];
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb) {
-        const int qi = q0 + 32 * qb + r;
-        const char* qrow = p.q + (((int64_t)b * p.sq + (qi < p.sq ? qi : 0)) * p.ldq + head * HD) * 2;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int kk = 16 * ks + 8 * h;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (kk < HD && qi < p.sq) v = ldg16(qrow + kk * 2);
-            unsigned* w = reinterpret_cast<unsigned*>(&v);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                w[e] = pack_bf16x2(__uint_as_float(w[e] << 16) * p.c, __uint_as_float(w[e] & 0xffff0000u) * p.c);
-            qf[qb][ks] = v;
-        }
-    }
-
-    const int64_t kb_off = ((int64_t)b * p.skv * p.ldk + head * HD) * 2;
-    const int64_t vb_off = ((int64_t)(b * p.heads + head) * HD) * p.ldvt * 2;
-    const int64_t k_left = ((int64_t)(p.batch - b) * p.skv * p.ldk - head * HD) * 2;
-    const int64_t v_left = ((int64_t)((p.batch - b) * p.heads - head) * HD * p.ldvt) * 2;
-    const srd_t srdK = make_srd(p.k + kb_off, (unsigned)(k_left < 0x7fffffff ? k_left : 0x7fffffff));
-    const srd_t srdV = make_srd(p.vt + vb_off, (unsigned)(v_left < 0x7fffffff ? v_left : 0x7fffffff));
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    unsigned koff[KPW], voff[VPW];
-    int my_dmas = 0;                                   // wave-instructions this wave issues per tile (wave-uniform)
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        const int g = (wv + 4 * i) * 64 + lane;
-        const int R = g / KCPR, c = g - R * KCPR;
-        const int kr = (R & ~12) | ((R & 4) << 1) | ((R & 8) >> 1);
-        const int64_t off = ((int64_t)kr * p.ldk + c * 8) * 2;
-        koff[i] = (c < HD / 8 && off < 0x7fffffff) ? (unsigned)off : 0x80000000u;
-        if (wv + 4 * i < KI) ++my_dmas;
-    }
-#pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-        const int g = (wv + 4 * i) * 64 + lane;
-        const int row = g / VCPR, c = g - row * VCPR;
-        const int64_t off = ((int64_t)row * p.ldvt + c * 8) * 2;
-        voff[i] = (row < HD && c < 8 && off < 0x7fffffff) ? (unsigned)off : 0x80000000u;
-        if (wv + 4 * i < VI) ++my_dmas;
-    }
-    my_dmas = __builtin_amdgcn_readfirstlane(my_dmas);
-    const unsigned kstep = (unsigned)(64 * p.ldk * 2);
-    auto issue_tile = [&](int buf) {
-        const unsigned lk = lds0 + buf * BUF_BYTES;
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            if (wv + 4 * i < KI) dma16_buf(koff[i], srdK, lk + (wv + 4 * i) * 1024);
-            koff[i] += kstep;
-        }
-#pragma unroll
-        for (int i = 0; i < VPW; ++i) {
-            if (wv + 4 * i < VI) dma16_buf(voff[i], srdV, lk + V0 + (wv + 4 * i) * 1024);
-            voff[i] += 128;
-        }
-    };
-
-    f32x16_t o[QW][DT];
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb)
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[qb][d][e] = 0.0f;
-    float m[QW] = {0.0f, 0.0f};
-    const unsigned ones_x = h ? 0x3F803F80u : 0u, ones_y = h ? 0x00003F80u : 0u;
-
-    const int ntiles = (p.skv + 63) / 64;
-    __syncthreads();                                   // zero fill and ones rows are in place
-    for (int t0 = 0; t0 < NBUF - 1 && t0 < ntiles; ++t0) issue_tile(t0);
-    int buf_c = 0, buf_i = NBUF - 1;
-    for (int t = 0; t < ntiles; ++t) {
-        {   // tile t has landed once at most the newer tiles' DMAs of this wave are outstanding
-            int newer = ntiles - 1 - t;
-            if (newer > NBUF - 2) newer = NBUF - 2;
-            wait_vmcnt_dyn<(NBUF - 2) * (KPW + VPW)>(newer * my_dmas);
-        }
-        __syncthreads();                               // ... for every wave; and everyone has finished reading tile t - 1
-        if (t + NBUF - 1 < ntiles) issue_tile(buf_i);  // into the buffer of tile t - 1
-        const int kv0 = t * 64;
-        const char* Ks = smem + buf_c * BUF_BYTES;
-        const char* Vs = Ks + V0;
-        buf_c = buf_c == NBUF - 1 ? 0 : buf_c + 1;
-        buf_i = buf_i == NBUF - 1 ? 0 : buf_i + 1;
-
-        // ---- S^T = K~ . Q~^T for both sub-blocks: every K fragment feeds two MFMAs ----
-        f32x16_t st[QW][2];
-        const f32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                uint4 a = *reinterpret_cast<const uint4*>(Ks + (32 * tt + r) * RBK + (16 * ks + 8 * h) * 2);
-                if (ks == KS - 1) { a.x |= ones_x; a.y |= ones_y; }
-#pragma unroll
-                for (int qb = 0; qb < QW; ++qb) st[qb][tt] = mfma16(a, qf[qb][ks], ks == 0 ? zero16 : st[qb][tt], false);
-            }
-        if (kv0 + 64 > p.skv) {
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = kv0 + 32 * tt + (e & 3) + 4 * (e >> 2 & 1) + 16 * (e >> 3) + 8 * h;
-                    if (key >= p.skv) {
-#pragma unroll
-                        for (int qb = 0; qb < QW; ++qb) st[qb][tt][e] = -INFINITY;
-                    }
-                }
-        }
-        // ---- softmax per sub-block (st already is score - m) ----
-        uint4 pf[QW][4];
-#pragma unroll
-        for (int qb = 0; qb < QW; ++qb) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(fmaxf(mx, st[qb][0][e]), st[qb][1][e]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (t == 0 || __builtin_amdgcn_ballot_w64(mx > MJ_T) != 0) {
-                const float want = m[qb] + (t == 0 ? mx : fmaxf(mx, 0.0f));
-                const unsigned b0 = pack_bf16x2(want, 0.0f) & 0xffffu;
-                const float r1 = want - __uint_as_float(b0 << 16);
-                const unsigned b1 = pack_bf16x2(r1, 0.0f) & 0xffffu;
-                const float r2 = r1 - __uint_as_float(b1 << 16);
-                const unsigned b2 = pack_bf16x2(r2, 0.0f) & 0xffffu;
-                const float m_rep = __uint_as_float(b0 << 16) + __uint_as_float(b1 << 16) + __uint_as_float(b2 << 16);
-                const float dlt = m_rep - m[qb];
-                m[qb] = m_rep;
-                if (h) {
-                    qf[qb][KS - 1].x = (b0 | (b1 << 16)) ^ 0x80008000u;
-                    qf[qb][KS - 1].y = b2 ^ 0x8000u;
-                }
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) st[qb][tt][e] -= dlt;
-                if (t != 0) {
-                    const float alpha = __builtin_amdgcn_exp2f(-dlt);
-#pragma unroll
-                    for (int d = 0; d < DT; ++d)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) o[qb][d][e] *= alpha;
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    uint4 u;
-                    u.x = pack_bf16x2(__builtin_amdgcn_exp2f(st[qb][tt][8 * s + 0]), __builtin_amdgcn_exp2f(st[qb][tt][8 * s + 1]));
-                    u.y = pack_bf16x2(__builtin_amdgcn_exp2f(st[qb][tt][8 * s + 2]), __builtin_amdgcn_exp2f(st[qb][tt][8 * s + 3]));
-                    u.z = pack_bf16x2(__builtin_amdgcn_exp2f(st[qb][tt][8 * s + 4]), __builtin_amdgcn_exp2f(st[qb][tt][8 * s + 5]));
-                    u.w = pack_bf16x2(__builtin_amdgcn_exp2f(st[qb][tt][8 * s + 6]), __builtin_amdgcn_exp2f(st[qb][tt][8 * s + 7]));
-                    pf[qb][2 * tt + s] = u;
-                }
-        }
-        // ---- O^T += V^T . P^T: every V^T fragment feeds two MFMAs ----
-#pragma unroll
-        for (int kst = 0; kst < 4; ++kst)
-#pragma unroll
-            for (int d = 0; d < DT; ++d) {
-                const uint4 a = *reinterpret_cast<const uint4*>(Vs + (32 * d + r) * RBV + (16 * kst + 8 * h) * 2);
-#pragma unroll
-                for (int qb = 0; qb < QW; ++qb) o[qb][d] = mfma16(a, pf[qb][kst], o[qb][d], false);
-            }
-    }
-    __syncthreads();                                   // every wave is done with the ring: reuse it for the output transposition
-
-    char* Os = smem + wave * 32 * RBO;
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb) {
-        const float l = __shfl(o[qb][L_D][L_E], (lane & 31) + 32 * L_H, 64);
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 u;
-                u.x = pack_bf16x2(o[qb][d][4 * g + 0] * inv, o[qb][d][4 * g + 1] * inv);
-                u.y = pack_bf16x2(o[qb][d][4 * g + 2] * inv, o[qb][d][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 2) = u;
-            }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        constexpr int OV = 32 * (HD / 8);
-        for (int v = lane; v < OV; v += 64) {
-            const int row = v / (HD / 8), cv = v - row * (HD / 8);
-            const int qq = q0 + 32 * qb + row;
-            if (qq < p.sq) {
-                const uint4 val = *reinterpret_cast<const uint4*>(Os + row * RBO + cv * 16);
-                *reinterpret_cast<uint4*>(p.out + (((int64_t)b * p.sq + qq) * p.ldo + head * HD + cv * 8) * 2) = val;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);            // the slab is read before the next sub-block overwrites it
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 template <int HD, bool SP = false>
 void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
     dim3 grid((unsigned)(((a.sq + 127) / 128) * a.heads * batch));
@@ -692,20 +434,7 @@ extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int6
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
         case 8: launch_attn<8>(a, batch, s); break;
-        case 40: {
-            // >= 1024 blocks of 256 queries: the 64-queries-per-wave form (A/B switch MFHIP_ATTN_Q64=0 / ring depth =2,3,4)
-            static const int q64 = getenv("MFHIP_ATTN_Q64") ? atoi(getenv("MFHIP_ATTN_Q64")) : 4;
-            const int64_t blocks256 = (int64_t)((sq + 255) / 256) * heads * batch;
-            if (q64 >= 2 && blocks256 >= 512) {
-                dim3 grid((unsigned)blocks256);
-                if (q64 == 2) hipLaunchKernelGGL((attn_fwd_q64_kernel<40, 2>), grid, dim3(256), 0, s, a);
-                else if (q64 == 3) hipLaunchKernelGGL((attn_fwd_q64_kernel<40, 3>), grid, dim3(256), 0, s, a);
-                else hipLaunchKernelGGL((attn_fwd_q64_kernel<40, 4>), grid, dim3(256), 0, s, a);
-            } else {
-                launch_attn<40>(a, batch, s);
-            }
-            break;
-        }
+        case 40: launch_attn<40>(a, batch, s); break;
         case 64: launch_attn<64>(a, batch, s); break;
         case 80: launch_attn<80>(a, batch, s); break;
         case 160: launch_attn<160>(a, batch, s); break;

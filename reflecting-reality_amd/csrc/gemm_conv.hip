@@ -248,7 +248,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 + (WS ? 256 : 0),
 void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;      // compute threads (also the staging threads unless WS)
     constexpr int NSTG = WS ? 256 : NTHR;             // staging threads: WS adds four producer waves, one per SIMD
-    static_assert(!WS || (DT == MF_BF16 && !A_F32 && (STAGES == 3 || (STAGES == 4 && !DXR))), "warp specialisation: bf16, LDS-DMA staging, 3-deep ring (4 for the plain ring)");
+    static_assert(!WS || (DT == MF_BF16 && !A_F32 && STAGES == 3), "warp specialisation: bf16, LDS-DMA staging, 3-deep ring");
     static_assert(!M16 || (DT == MF_BF16 && !A_F32), "the 16x16x32 form is instantiated for bf16 only");
     constexpr bool X1 = DT == MF_BF16X1;      // fp32 operands rounded to bf16 (RNE) in registers, ONE MFMA per product
     constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3 || X1);
@@ -2010,10 +2010,8 @@ const TileCfg kTiles[] = {
     {256, 128, 256, 3},        // 46  = 45 on 16x16x32 MFMAs
     {128, 160, 256, 2, 0, 1},  // 47  = 38 / 40 with EIGHT compute waves (4x2 of 32x80, 16x16x32 MFMAs only) + 4 staging
     {128, 160, 256, 3},        // 48  = 41 / 43 with eight compute waves of 32x80 + 4 staging
-    // 49-50: FOUR-deep rings of 48 / 41 (147 KB: three K tiles = 108 KB of DMA in flight per CU instead of 72 KB; the L2 -> LDS fill
-    // of these one-block-per-CU kernels is what Little's law allows for the bytes in flight)
-    {128, 160, 256, 4},        // 49
-    {128, 160, 256, 4},        // 50
+    // (round 3: FOUR-deep rings of 48 / 41 — 147 KB, three K tiles in flight — were built, parity-tested and offered to the tuner
+    // over the whole step: picked for none of 100 shapes, gpurun_out/r03e/tune_user.json; removed again)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -2127,8 +2125,6 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
                 case 46: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, true, true>(a, grid, s); break;
                 case 47: launch_one<DT, 128, 160, 4, 2, false, 3, true, false, false, true, true>(a, grid, s); break;
                 case 48: launch_one<DT, 128, 160, 4, 2, false, 3, false, false, false, true, true>(a, grid, s); break;
-                case 49: launch_one<DT, 128, 160, 4, 2, false, 4, false, false, false, true, true>(a, grid, s); break;
-                case 50: launch_one<DT, 128, 160, 4, 1, false, 4, false, false, false, true>(a, grid, s); break;
                 default: break;
             }
         }
@@ -2285,7 +2281,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         MF_CHECK_ARG(d->dtype == MF_BF16 && d->a_dtype == MF_BF16 && d->kh == 1 && d->kw == 1 && d->c1 == 0 && d->nz == 1 &&
                          (d->splitk == 0 || d->splitk == 1) && d->a_scale == nullptr && d->w_scale == nullptr,
                      "mf_gemm_conv: ln_colsum / vt_out need a plain bf16 1x1 GEMM (one A segment, no batching, no split-K, no scales)");
-        MF_CHECK_ARG(d->tile == 0 || (d->tile >= 41 && d->tile <= 50 && d->tile != 47), "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (tiles 41-46, 48-50 do)", d->tile);
+        MF_CHECK_ARG(d->tile == 0 || (d->tile >= 41 && d->tile <= 48 && d->tile != 47), "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (tiles 41-46, 48 do)", d->tile);
         MF_CHECK_ARG(!d->ln_colsum || (mf_aligned16(d->ln_colsum) && d->n % 8 == 0 && d->ln_eps > 0.0f), "mf_gemm_conv: ln_colsum must be 16-byte aligned, n %% 8 == 0, ln_eps > 0");
         if (d->vt_out) {
             MF_CHECK_ARG(d->out_dtype == MF_BF16 && mf_aligned16(d->vt_out) && d->vt_tokens > 0 && d->vt_tokens % 8 == 0 && a.M % d->vt_tokens == 0 &&

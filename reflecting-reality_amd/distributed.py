@@ -114,6 +114,15 @@ class GradBuckets:
         if pi is None:
             return
         p, st = self._plan[pi], self._state[pi]
+        # a bucket's countdown assumes ONE "gradient final" signal per parameter and step.  A parameter used by two tape ops
+        # (weight sharing, a module called twice, recomputation) would be signalled twice and release its bucket while a later
+        # contribution is still being accumulated into it: refuse that loudly instead of all-reducing a partial gradient
+        done = st.setdefault("done", set())
+        if param.name in done:
+            raise RuntimeError(f"GradBuckets: the gradient of {param.name!r} was reported final twice in one step (a parameter "
+                               "shared by several operators): per-use counting is not built — keep such parameters out of the "
+                               "bucketed exchange")
+        done.add(param.name)
         for b in p["where"].get(param.name, ()):
             st["pending"][b] -= 1
             if st["pending"][b] == 0 and not st["sent"][b]:

@@ -414,11 +414,17 @@ class StableDiffusionBrushNetPipeline:
                     noise = torch.randn(batch, lat_c, hl, wl, dtype=torch.float32).repeat(2, 1, 1, 1)
                 else:
                     noise = torch.randn(dup * batch, lat_c, hl, wl, dtype=torch.float32)   # global RNG, like vae.py:782-791
-            noise = noise.to(self.device, torch.float32)
+                    self._cond_halves_identical = False     # two independent draws: never identical
             if noise.shape[0] != dup * batch:
                 raise ValueError(f"conditioning_noise must have batch {dup * batch}")
+            if dup == 2 and self._cond_halves_identical:
+                # whether both CFG halves get the same sample is decided HERE, from how the noise was made (a host compare of a
+                # host tensor; a device tensor costs one read-back) — not by comparing the built conditioning on the device
+                self._cond_halves_identical = bool(torch.equal(noise[:batch], noise[batch:]))
+            noise = noise.to(self.device, torch.float32)
             return [hip.vae_sample(moments, noise[i * batch:(i + 1) * batch].contiguous(), lat_c, sf) for i in range(dup)]
 
+        self._cond_halves_identical = dup == 2
         halves = encode_sample(img, noises[0])
         parts = [[h] for h in halves]
         mask_l = hip.nearest_resize(hip.h2d(original_mask, self.device), hl, wl)                   # :1189-1195
@@ -599,7 +605,9 @@ class StableDiffusionBrushNetPipeline:
         if not (do_cfg and self.share_brushnet_cfg and self.brushnet.config.get("addition_embed_type") is None
                 and self.brushnet.config.get("class_embed_type") is None):
             return False
-        return bool(torch.equal(cond[:nb], cond[nb:]))
+        # identical halves <=> every VAE posterior sample that went into `cond` was the same for both halves (mask, depth and
+        # normals maps are deterministic functions of the inputs): recorded by build_conditioning, no device compare / sync
+        return bool(getattr(self, "_cond_halves_identical", False))
 
     def _overlap(self, on: bool):
         """Turn the BrushNet || UNet stream overlap (models._RESIDUAL_EVENTS) on or off for the next forward calls."""

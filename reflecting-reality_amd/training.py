@@ -133,7 +133,18 @@ class AdamW:
                     exp_avg=[t.cpu() for t in self.exp_avg], exp_avg_sq=[t.cpu() for t in self.exp_avg_sq])
 
     def load_state_dict(self, sd: dict) -> None:
+        """Restores the step count, the hyper-parameters and the moments.  NOT interchangeable with the reference's
+        `optimizer.bin` (a torch.optim.AdamW state_dict keyed by parameter index, written by accelerate): the moments here are
+        the flat arenas in the kernels' weight layout ([N][kh][kw][Cin_pad], fused time_emb_proj rows).  Model weights ARE
+        interchangeable (checkpoint-N/{brushnet,unet}); accelerate's scheduler.bin / random_states are not written."""
+        if not isinstance(sd, dict) or "exp_avg" not in sd or "step" not in sd:
+            raise ValueError("optimizer.bin is not an mfhip AdamW state (a torch.optim / accelerate optimizer state cannot be "
+                             "loaded: the moments are stored as flat arenas in the kernels' layout)")
         self.step_count = int(sd["step"])
+        self.lr = float(sd.get("lr", self.lr))
+        self.betas = tuple(sd.get("betas", self.betas))
+        self.weight_decay = float(sd.get("weight_decay", self.weight_decay))
+        self.eps = float(sd.get("eps", self.eps))
         for dst, src in zip(self.exp_avg + self.exp_avg_sq, list(sd["exp_avg"]) + list(sd["exp_avg_sq"])):
             if dst.numel() != src.numel():
                 raise ValueError("optimizer state does not match the models' arenas")
@@ -255,10 +266,15 @@ def load_state(path: str, model: MirrorFusionModel, optimizer: Optional[AdamW] =
     for m in model.get_trainable_modules():
         sub = "brushnet" if m is model.brushnet else "unet"
         m.load_state_dict(load_file(os.path.join(path, sub, m.weights_name)))
-    if optimizer is not None and os.path.exists(os.path.join(path, "optimizer.bin")):
-        if [m for m in model.get_trainable_modules()] != optimizer.models:
-            optimizer.models = model.get_trainable_modules()
-        optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.bin")))
+    if optimizer is not None:
+        if not os.path.exists(os.path.join(path, "optimizer.bin")):
+            import warnings
+            warnings.warn(f"load_state: {path} has no optimizer.bin — the weights are restored, AdamW restarts from zero moments "
+                          "(the next steps will differ from the uninterrupted run)")
+        else:
+            if [m for m in model.get_trainable_modules()] != optimizer.models:
+                optimizer.models = model.get_trainable_modules()
+            optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.bin")))
     with open(os.path.join(path, "trainer_state.json")) as f:
         return int(json.load(f)["global_step"])
 

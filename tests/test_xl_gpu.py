@@ -141,7 +141,10 @@ def test_baseline_config4_sdxl_full_width_against_reference(prec, tol):
     trace, final, pipe = _run_xl_full(prec)
     assert pipe.scheduler.timesteps.tolist() == G["timesteps"].tolist() and len(G["timesteps"]) == 30
     assert tuple(final.shape) == (2, 4, 128, 128) and torch.isfinite(final).all()
-    FP8_K_LINF, FP8_K_MEAN = 6.0, 6.0
+    # measured on MI355X at full width (gpurun_out/r03e): 3.0 x / 4.7 x after step 1, 3.8 x / 6.1 x after step 2 (e4m3 carries 3
+    # mantissa bits against bf16's 7 — 16 x per product — in the transformer Linears only; the convolutions, attention and the
+    # residual stream stay bf16 and the reduction over K = 640 ... 5120 averages): bounds with ~30 % headroom over the worst seen
+    FP8_K_LINF, FP8_K_MEAN = 5.0, 8.0
     for i, l in enumerate(trace):
         ref = G[f"latents_{i}"]
         if prec == "fp8":

@@ -8,16 +8,16 @@ for d in sorted(glob.glob(f"{root}/pmca_*")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "attn_fwd_kernel" in r["Kernel_Name"]:
+            if "attn_fwd" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             vals[k] = sum(v) / len(v)
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
-        t = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "attn_fwd_kernel" in r["Kernel_Name"]]
+        t = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if "attn_fwd" in r["Kernel_Name"]]
         if t:
             dur = sum(t) / len(t) / 1e3
 flop = 4.0 * 8 * 8 * 4096 * 4096 * 40
-print(f"attn_fwd_kernel<40>: self-attention B_eff 8 x 8 heads x 4096 tokens x d 40 ({flop / 1e9:.1f} GFLOP); kernel duration under the counters "
+print(f"attention kernel (d = 40): self-attention B_eff 8 x 8 heads x 4096 tokens x d 40 ({flop / 1e9:.1f} GFLOP); kernel duration under the counters "
       f"{dur:.1f} us = {flop / dur / 1e6:.0f} TF/s")
 for k, v in vals.items():
     print(f"  {k:32s} {v:14.4g}")
