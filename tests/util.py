@@ -41,6 +41,11 @@ _ENV = None
 # Round 3: cut from 2.0 / 1.5 to 1.25 / 1.1 — every ratio observed on MI355X is <= 0.85 (printed by report_env as
 # "ratio linf / mean"), so a regression that doubles the bf16 error now fails.
 ENV_K_LINF, ENV_K_MEAN = 1.25, 1.1
+# L-inf over a few hundred elements is an extreme-value statistic of two INDEPENDENT rounding-error draws (ours and the
+# reference's): on the tiny fixtures' 2 x 2-pixel tensors (512 elements) it scatters up to 1.53 x while the mean stays at 0.89 x
+# (gpurun_out/r03f).  Small tensors get 1.75 x on the maximum; the mean bound — the one a doubled error cannot pass — is the
+# same 1.1 x everywhere.
+ENV_K_LINF_SMALL, ENV_SMALL_NUMEL = 1.75, 8192
 
 
 def envelope(key):
@@ -51,12 +56,14 @@ def envelope(key):
     return _ENV[key]
 
 
-def report_env(name, got, ref, key, k_linf=ENV_K_LINF, k_mean=ENV_K_MEAN):
+def report_env(name, got, ref, key, k_linf=None, k_mean=ENV_K_MEAN):
     """bf16 mode: |got - ref| (ref = the reference's fp32 result) against the reference's own bf16 envelope for this case."""
     got = torch.as_tensor(np.asarray(got) if not torch.is_tensor(got) else got).float().cpu()
     ref = torch.as_tensor(ref).float()
     err = (got - ref).abs()
     env = envelope(key)
+    if k_linf is None:
+        k_linf = ENV_K_LINF if ref.numel() >= ENV_SMALL_NUMEL else ENV_K_LINF_SMALL
     linf, mean = err.max().item(), err.mean().item()
     print(f"{name}: max_abs_err={linf:.3e} (reference bf16: {env['linf']:.3e}) mean_abs_err={mean:.3e} "
           f"(reference bf16: {env['mean']:.3e}) ref_absmax={ref.abs().max().item():.3e} "
