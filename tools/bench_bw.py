@@ -1,8 +1,8 @@
 """HBM GB/s of the bandwidth-bound helper kernels of the denoise step at their production shapes (batch 4 x 512x512, CFG:
 B_eff = 8), HIP events over graph-free back-to-back launches.  Algorithmic bytes = every input read once + every output
-written once (GroupNorm: the input twice — statistics, then apply).  Prints a markdown table (profiles/r02_hbm_bandwidth.md).
+written once (GroupNorm: the input twice — statistics, then apply).  Prints a markdown table (profiles/r03_hbm_bandwidth.md).
 
-    python3 tools/bench_bw.py > gpurun_out/r02_hbm_bandwidth.md
+    python3 tools/bench_bw.py > gpurun_out/r03_hbm_bandwidth.md
 """
 import os
 import sys
