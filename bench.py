@@ -377,12 +377,12 @@ def main():
             a_px = m * stride * stride / (4.0 if ups else 1.0)
             alg_bytes += nz * 2.0 * (a_px * k / (kh * kh) + n * k + m * n)
         traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_gemm_family.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_gemm_family.json")
         if os.path.exists(pmc) and a.batch == 4 and a.size == 512 and a.precision == "bf16" and not xl:
             with open(pmc) as f:
                 pj = json.load(f)
             traffic = pj["traffic_bytes_per_launch"]          # separate rocprofv3 --pmc passes (tools/pmc_step.sh)
-            traffic_src = "profiles/r02_pmc_gemm_family.json: " + pj["method"]
+            traffic_src = "profiles/r03_pmc_gemm_family.json: " + pj["method"]
         roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel (all tile instantiations)",
                     "achieved": round(flops / secs / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(flops / secs / 1e12 / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
@@ -460,8 +460,11 @@ def main():
         parity = {"precision": "f16x3", "value": round(a.batch * a.steps / tp, 4), "unit": "images/sec",
                   "ms_per_step": round(tp / a.steps * 1e3, 2), "denoise_step_ms": round(pstep * 1e3, 3),
                   "denoise_step_tflops": round(a.batch * gflop * 1e9 / pstep / 1e12, 2) if gflop else None,
-                  "tolerance": "latent L-inf <= 1e-3 vs the reference on BASELINE configs[0] and the tiny pipelines "
-                               "(tests/test_pipeline_gpu.py, __graft_entry__.smoke)",
+                  "tolerance": "latent L-inf <= 1e-3 vs the reference: on THIS workload over all 50 DDIM steps (image 0 of the batch, "
+                               "5.4e-4 at step 50 where |latents| reach 71; the reference's own fp32 arithmetic is 1.8e-4 from the "
+                               "float64 value there), on BASELINE configs[0] and the tiny pipelines "
+                               "(tests/test_pipeline_gpu.py::test_baseline_config1_all_50_steps_against_reference, __graft_entry__.smoke); "
+                               "`value` (bf16) is NOT inside 1e-3: it is asserted inside the reference's own bf16 deviation instead",
                   "note": "same workload and inputs as `value`; fp32 activations, GEMM operands split into two fp16 halves, "
                           "three v_mfma_f32_32x32x16_f16 per product (ceiling 1/3 of the 16-bit MFMA peak)"}
         del ppipe, pipe

@@ -227,29 +227,15 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
     const int b = blockIdx.y, t = threadIdx.x;
     const int lcol = t % p.tpr, trow = t / p.tpr;
     __shared__ float gm[64], gr[64];
-    const int r0 = blockIdx.x * rows_per_block;
-    int r1 = r0 + rows_per_block;
-    if (r1 > p.HW) r1 = p.HW;
-    const int esz = p.in_dt == MF_F32 ? 4 : 2, osz = p.out_dt == MF_F32 ? 4 : 2;
-    // The first four rows of this thread are requested BEFORE the statistics are combined: the combine is a chain of
-    // dependent L2 reads + double arithmetic (~1.5 us) that every block pays, and the rows do not depend on it
-    float pre[4][VW];
-    const bool pre_ok = p.fuse_finalize && trow < p.rif && lcol < p.cvn && r0 + trow + 3 * p.rif < r1;
-    if (pre_ok) {
-        const int c = lcol * VW;
-        const char* base; int64_t ld; int cc;
-        if (c < p.C0) { base = p.x0; ld = p.C0; cc = c; }
-        else { base = p.x1; ld = p.C1; cc = c - p.C0; }
-        const int64_t step = (int64_t)p.rif * ld * esz;
-        const char* ptr = base + (((int64_t)b * p.HW + r0 + trow) * ld + cc) * esz;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) loadv<VW>(ptr + i * step, p.in_dt, pre[i]);
-    }
     if (p.fuse_finalize) {       // every block combines the chunk statistics itself: one launch (and its gap) less
         gn_group_mean_rstd(p, b, gm, gr);
         __syncthreads();
     }
     if (trow >= p.rif) return;
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > p.HW) r1 = p.HW;
+    const int esz = p.in_dt == MF_F32 ? 4 : 2, osz = p.out_dt == MF_F32 ? 4 : 2;
     const float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
     const bool fast_silu = p.out_dt == MF_BF16;         // bf16 output: __expf is far inside the rounding
     for (int col = lcol; col < p.cvn; col += p.tpr) {
@@ -285,13 +271,6 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
             else store4(o, p.out_dt, 0, make_float4(v[0], v[1], v[2], v[3]));
         };
         int r = r0 + trow;
-        if (pre_ok && col == lcol) {          // the batch fetched ahead of the combine
-            finish(pre[0], optr);
-            finish(pre[1], optr + ostep);
-            finish(pre[2], optr + 2 * ostep);
-            finish(pre[3], optr + 3 * ostep);
-            r += 4 * p.rif; ptr += 4 * step; optr += 4 * ostep;
-        }
         for (; r + 3 * p.rif < r1; r += 4 * p.rif, ptr += 4 * step, optr += 4 * ostep) {
             float v0[VW], v1[VW], v2[VW], v3[VW];
             loadv<VW>(ptr, p.in_dt, v0);
@@ -574,9 +553,9 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     MF_CHECK_ARG(d->groups <= 64, "mf_groupnorm: at most 64 groups");
     static const bool gn3 = getenv("MFHIP_GN3") != nullptr;     // A/B switch: separate finalize launch
     // measured (tools/bench_gn.py): -1.5...2 us per GroupNorm up to 32x32, +1 us at 64x64 (64 chunks combined by 256 blocks)
-    // round 3: with the first rows prefetched ahead of the combine (gn_apply_kernel) the fused form also wins at 64x64
-    static const bool gn_fuse_small = getenv("MFHIP_GN_FUSE_SMALL") != nullptr;     // A/B switch: the round-2 rule (<= 32x32 only)
-    a.fuse_finalize = !gn3 && (d->hw <= 1024 || !gn_fuse_small) && mf_aligned16(d->gamma) && mf_aligned16(d->beta);
+    // (round 3: fetching a thread's first rows AHEAD of the combine, so that the fused form could also serve 64x64, was
+    // measured neutral there — 26.3 vs 25.6 us, tools/bench_gn.py, and 16.70 vs 16.75 ms per denoise step — and removed)
+    a.fuse_finalize = !gn3 && d->hw <= 1024 && mf_aligned16(d->gamma) && mf_aligned16(d->beta);
     const int vw = (d->c0 % 8 == 0 && d->c1 % 8 == 0) ? 8 : 4;
     hipStream_t s = (hipStream_t)stream;
     {   // one-launch slab kernel for the low-resolution levels
