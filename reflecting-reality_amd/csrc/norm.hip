@@ -87,7 +87,7 @@ __device__ __forceinline__ void loadv(const char* p, int dt, float* o) {
 //
 // Pass 1, grid (nchunks, batch): per-(thread-row, channel) fp32 sums -> LDS -> one (mean, M2) per group of the
 // chunk, in double.  No atomics: bitwise reproducible.
-template <int VW>
+template <int VW, int U = 4>
 __global__ __launch_bounds__(GN_BLK) void gn_stats_kernel(const GnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* chan = reinterpret_cast<float2*>(smem_raw);   // [rif][C] (sum, sum of squares)
@@ -109,17 +109,17 @@ __global__ __launch_bounds__(GN_BLK) void gn_stats_kernel(const GnArgs p) {
             const int64_t step = (int64_t)p.rif * ld * esz;
             const char* ptr = base + (((int64_t)b * p.HW + r0 + trow) * ld + cc) * esz;
             int r = r0 + trow;
-            for (; r + 3 * p.rif < r1; r += 4 * p.rif, ptr += 4 * step) {
-                float v0[VW], v1[VW], v2[VW], v3[VW];
-                loadv<VW>(ptr, p.in_dt, v0);
-                loadv<VW>(ptr + step, p.in_dt, v1);
-                loadv<VW>(ptr + 2 * step, p.in_dt, v2);
-                loadv<VW>(ptr + 3 * step, p.in_dt, v3);
+            for (; r + (U - 1) * p.rif < r1; r += U * p.rif, ptr += U * step) {
+                float v[U][VW];
 #pragma unroll
-                for (int e = 0; e < VW; ++e) {
-                    s[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
-                    ss[e] += (v0[e] * v0[e] + v1[e] * v1[e]) + (v2[e] * v2[e] + v3[e] * v3[e]);
-                }
+                for (int u = 0; u < U; ++u) loadv<VW>(ptr + u * step, p.in_dt, v[u]);
+#pragma unroll
+                for (int u = 0; u < U; u += 4)
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) {
+                        s[e] += (v[u][e] + v[u + 1][e]) + (v[u + 2][e] + v[u + 3][e]);
+                        ss[e] += (v[u][e] * v[u][e] + v[u + 1][e] * v[u + 1][e]) + (v[u + 2][e] * v[u + 2][e] + v[u + 3][e] * v[u + 3][e]);
+                    }
             }
             for (; r < r1; r += p.rif, ptr += step) {
                 float v0[VW];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
 }
 
 // Pass 2, grid (row blocks, batch): pure streaming y = silu(x*a[c] + b[c]) with the thread's a/b in registers.
-template <int VW>
+template <int VW, int U = 4>
 __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int rows_per_block) {
     const int b = blockIdx.y, t = threadIdx.x;
     const int lcol = t % p.tpr, trow = t / p.tpr;
@@ -271,16 +271,12 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
             else store4(o, p.out_dt, 0, make_float4(v[0], v[1], v[2], v[3]));
         };
         int r = r0 + trow;
-        for (; r + 3 * p.rif < r1; r += 4 * p.rif, ptr += 4 * step, optr += 4 * ostep) {
-            float v0[VW], v1[VW], v2[VW], v3[VW];
-            loadv<VW>(ptr, p.in_dt, v0);
-            loadv<VW>(ptr + step, p.in_dt, v1);
-            loadv<VW>(ptr + 2 * step, p.in_dt, v2);
-            loadv<VW>(ptr + 3 * step, p.in_dt, v3);
-            finish(v0, optr);
-            finish(v1, optr + ostep);
-            finish(v2, optr + 2 * ostep);
-            finish(v3, optr + 3 * ostep);
+        for (; r + (U - 1) * p.rif < r1; r += U * p.rif, ptr += U * step, optr += U * ostep) {
+            float v[U][VW];
+#pragma unroll
+            for (int u = 0; u < U; ++u) loadv<VW>(ptr + u * step, p.in_dt, v[u]);      // U independent 16-byte loads in flight
+#pragma unroll
+            for (int u = 0; u < U; ++u) finish(v[u], optr + u * ostep);
         }
         for (; r < r1; r += p.rif, ptr += step, optr += ostep) {
             float v0[VW];
@@ -544,7 +540,9 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     a.x0 = (const char*)d->x0; a.x1 = (const char*)d->x1;
     a.C0 = d->c0; a.C1 = d->c1; a.C = C; a.in_dt = d->in_dtype; a.HW = d->hw; a.G = d->groups;
     a.cpg = C / d->groups;
-    a.rows_per_chunk = (d->hw + GN_MAX_CHUNKS - 1) / GN_MAX_CHUNKS;
+    static const int gn_chunks = getenv("MFHIP_GN_CHUNKS") ? atoi(getenv("MFHIP_GN_CHUNKS")) : GN_MAX_CHUNKS;      // developer sweep
+    const int want_chunks = gn_chunks >= 1 && gn_chunks <= GN_MAX_CHUNKS ? gn_chunks : GN_MAX_CHUNKS;
+    a.rows_per_chunk = (d->hw + want_chunks - 1) / want_chunks;
     if (a.rows_per_chunk < 16) a.rows_per_chunk = 16;
     a.nchunks = (d->hw + a.rows_per_chunk - 1) / a.rows_per_chunk;
     a.eps = d->eps; a.gamma = d->gamma; a.beta = d->beta; a.silu = d->silu;
@@ -584,14 +582,19 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
                              ? (size_t)a.rif * C * sizeof(float2) : (size_t)2 * d->groups * sizeof(float);
     MF_CHECK_ARG(smem1 <= 64 * 1024, "mf_groupnorm: C=%d too large", C);
     // ~4 row blocks per CU, at least 4 rows per thread
-    int rows_per_block = (int)(((int64_t)d->hw * d->batch + 1023) / 1024);
+    static const int gn_blocks = getenv("MFHIP_GN_APPLY_BLOCKS") ? atoi(getenv("MFHIP_GN_APPLY_BLOCKS")) : 1024;   // developer sweep
+    const int tgt = gn_blocks >= 64 ? gn_blocks : 1024;
+    int rows_per_block = (int)(((int64_t)d->hw * d->batch + tgt - 1) / tgt);
     if (rows_per_block < 4 * a.rif) rows_per_block = 4 * a.rif;
     const int nblk = (d->hw + rows_per_block - 1) / rows_per_block;
+    static const int gn_u = getenv("MFHIP_GN_UNROLL") ? atoi(getenv("MFHIP_GN_UNROLL")) : 4;      // developer sweep: 4 or 8 rows in flight
     if (vw == 8) {
-        hipLaunchKernelGGL(gn_stats_kernel<8>, dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
+        if (gn_u == 8) hipLaunchKernelGGL((gn_stats_kernel<8, 8>), dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
+        else hipLaunchKernelGGL((gn_stats_kernel<8, 4>), dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
         MF_CHECK_LAUNCH("mf_groupnorm(stats)");
         if (!a.fuse_finalize) hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
-        hipLaunchKernelGGL(gn_apply_kernel<8>, dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
+        if (gn_u == 8) hipLaunchKernelGGL((gn_apply_kernel<8, 8>), dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
+        else hipLaunchKernelGGL((gn_apply_kernel<8, 4>), dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<4>, dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
         MF_CHECK_LAUNCH("mf_groupnorm(stats)");
