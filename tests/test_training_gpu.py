@@ -486,14 +486,17 @@ def test_data_parallel_training_two_ranks_equal_one_process_on_the_joint_batch(t
     assert r0["max_w_diff"] < 3e-5       # 2 steps x lr 1e-5: a flipped near-zero gradient could move a weight by 2e-5 (measured 2e-6)
 
 
-def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync():
+@pytest.mark.parametrize("train_unet,b", [(False, 8), (True, 4)])
+def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync(train_unet, b):
     """BASELINE.json configs[3] at its own size: the MirrorFusion fine-tune step at per-GPU batch 8 x 512 x 512 (64 x 64 latents),
     full-size SD1.5 UNet (frozen) + BrushNet (trainable), f16x3 contractions, clip 1.0, AdamW (train_brushnet_mirror.py:1407-1466).
     No reference gradient exists at this size (the reference's autograd on the CPU would take hours), so the step is pinned by
     size-independent properties: (1) finite loss / gradient norm, every trainable tensor moves; (2) two identical runs are
     BIT-identical (fixed-order reductions, no atomics); (3) the same step with the bucketed gradient all-reduce forced through
     RCCL on this single rank (MF_FORCE_GRAD_SYNC=1: world size 1, sum of one = identity, divide by 1) is bit-identical to the
-    unsynchronised step — the DDP path of distributed.GradBuckets changes nothing but the exchange."""
+    unsynchronised step — the DDP path of distributed.GradBuckets changes nothing but the exchange.
+    train_unet=True is --train_base_unet (train_brushnet_mirror.py:1073-1075) at full size: both nets train (batch 4 here; the
+    exchange then carries both gradient arenas, 2.48 + 3.44 GB), and the UNet's weights must move too."""
     import socket
     import torch.distributed as dist
     from reflecting_reality_amd import distributed as D
@@ -504,18 +507,18 @@ def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync():
         unet.load_state_dict(synth.state_dict_for(unet.param_shapes(), 0))
         bn = M.BrushNetModel(dict(brushnet_config(SD15_UNET, 6)), precision="f16x3", device=DEV)
         bn.load_state_dict(synth.state_dict_for(bn.param_shapes(), 1))
-        return MirrorFusionModel(unet, bn).prepare_training(train_base_unet=False)
+        return MirrorFusionModel(unet, bn).prepare_training(train_base_unet=train_unet)
 
     g = torch.Generator().manual_seed(303)
-    b = 8
     lat, noi = torch.randn(b, 4, 64, 64, generator=g).to(DEV) * 0.8, torch.randn(b, 4, 64, 64, generator=g).to(DEV)
     cond, ehs = torch.randn(b, 6, 64, 64, generator=g).to(DEV), torch.randn(b, 77, 768, generator=g).to(DEV)
-    ts = torch.tensor([981, 3, 500, 250, 751, 17, 640, 111])
+    ts = torch.tensor([981, 3, 500, 250, 751, 17, 640, 111])[:b]
     ns = DDPMScheduler(**SD_SCHED)
 
     def run(sync_factory=None):
         model = build()
         w0 = model.brushnet.flat_w.clone()
+        u0 = model.unet.flat_w[: model.unet.num_arena_floats()].clone() if train_unet else None
         opt = AdamW(model.get_trainable_modules(), lr=1e-5)
         sync = sync_factory(model) if sync_factory else None
         out = []
@@ -524,12 +527,17 @@ def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync():
             out.append((float(loss), float(norm)))
         w = model.brushnet.flat_w.clone()
         n_used = model.brushnet.num_arena_floats()
+        if train_unet:          # the UNet's arena trains too: fold a digest of it into the comparison
+            u = model.unet.flat_w[: model.unet.num_arena_floats()]
+            out.append((float(u.double().sum()), float((u.double() ** 2).sum())))
+            assert (u != u0).float().mean().item() > 0.99, "the UNet's weights did not move under --train_base_unet"
+            assert model.unet.flat_g is not None and len(model.get_trainable_modules()) == 2
         del model, opt
         torch.cuda.empty_cache()
         return out, w, w0, n_used
 
     a_out, a_w, w0, n_used = run()
-    print("configs[3] step at batch 8 x 512^2: (loss, grad norm) per step", a_out)
+    print(f"configs[3] step at batch {b} x 512^2 (train_base_unet={train_unet}): (loss, grad norm) per step", a_out)
     assert all(np.isfinite(v) for pair in a_out for v in pair) and a_out[0][1] > 0
     moved = (a_w[:n_used] != w0[:n_used]).float().mean().item()
     assert moved > 0.99, f"only {moved:.3f} of the trainable floats moved"
