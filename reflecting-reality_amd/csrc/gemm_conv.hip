@@ -248,7 +248,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 + (WS ? 256 : 0),
 void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;      // compute threads (also the staging threads unless WS)
     constexpr int NSTG = WS ? 256 : NTHR;             // staging threads: WS adds four producer waves, one per SIMD
-    static_assert(!WS || (DT == MF_BF16 && !A_F32 && STAGES == 3), "warp specialisation: bf16, LDS-DMA staging, 3-deep ring");
+    static_assert(!WS || ((DT == MF_BF16 || (DT == MF_F16X3 && WPK && !M16 && !P16)) && !A_F32 && STAGES == 3),
+                  "warp specialisation: bf16 (or the parity mode with a pre-split W), LDS-DMA staging, 3-deep ring");
     static_assert(!M16 || (DT == MF_BF16 && !A_F32), "the 16x16x32 form is instantiated for bf16 only");
     constexpr bool X1 = DT == MF_BF16X1;      // fp32 operands rounded to bf16 (RNE) in registers, ONE MFMA per product
     constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3 || X1);
@@ -2044,6 +2045,16 @@ bool launch_tile_split(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
         case 6: launch_one<DT, 64, 128, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
         default: break;
     }
+    if constexpr (WPK && DT == MF_F16X3) {
+        // round 3: the warp-specialised forms in the parity mode (fp32 operands: the staging bytes are the bf16 kernels' bytes)
+        switch (tile) {
+            case 37: launch_one<DT, 256, 160, 8, 1, false, 3, true, true, false, true>(a, grid, s); return true;
+            case 38: launch_one<DT, 128, 160, 4, 1, false, 3, true, true, false, true>(a, grid, s); return true;
+            case 41: launch_one<DT, 128, 160, 4, 1, false, 3, false, true, false, true>(a, grid, s); return true;
+            case 44: launch_one<DT, 128, 128, 2, 2, false, 3, false, true, false, true>(a, grid, s); return true;
+            default: break;       // (256 x 128 with 8 + 4 waves spills at the 170-register budget of three waves per SIMD: not offered)
+        }
+    }
     if constexpr (WPK) {
         switch (tile) {
             case 7: launch_one<DT, 128, 128, 2, 2, false, 3, false, true>(a, grid, s); return true;
@@ -2316,7 +2327,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     }
     MF_CHECK_ARG(tile < 25 || tile > 30 || (d->dtype == MF_BF16 && !a_f32), "mf_gemm_conv: tile %d (16x16x32 MFMA form) does not apply: bf16 only", tile);
     MF_CHECK_ARG(tile < 31 || (!a_f32 && !split && d->dtype != MF_FP8), "mf_gemm_conv: tile %d (deep ring) does not apply to this precision", tile);
-    MF_CHECK_ARG(tile < 37 || d->dtype == MF_BF16, "mf_gemm_conv: tile %d (warp-specialised) does not apply: bf16 only", tile);
+    MF_CHECK_ARG(tile < 37 || d->dtype == MF_BF16 || (d->dtype == MF_F16X3 && d->w_split == 1),
+                 "mf_gemm_conv: tile %d (warp-specialised) does not apply: bf16, or f16x3 with a pre-split weight", tile);
     const TileCfg& tc = kTiles[tile - 1];
     if (tc.halo) {
         // conv3x3_halo_kernel: bf16, 3x3 / stride 1 / pad 1, whole TH x 16 tiles, 32-channel chunks

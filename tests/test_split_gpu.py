@@ -39,7 +39,8 @@ def test_split_linear_all_tiles(prec_name, m, k, n):
     ref = F.linear(x.double(), w.double(), b.double())
     xd = x.to(DEV)
     raw_tiles = (0, 1, 2, 3, 6, 14) if prec_name == "f16x3" else (0, 1, 2, 3, 6)     # f16x3 keeps the big-conv tile for raw weights (training)
-    for raw, tiles in ((False, (0, 1, 2, 3, 6, 7, 14)), (True, raw_tiles)):
+    ws_tiles = (41, 44) if prec_name == "f16x3" else ()      # round 3: the warp-specialised ring tiles serve the parity mode too
+    for raw, tiles in ((False, (0, 1, 2, 3, 6, 7, 14) + ws_tiles), (True, raw_tiles)):
         lw = ops.ConvWeight(w, b, prec, DEV, raw=raw)
         assert lw.w_split == (0 if raw else 1)
         for tile in tiles:
@@ -127,11 +128,17 @@ def test_split_conv_variants(prec_name, case):
 
 
 @pytest.mark.parametrize("prec_name", ["f16x3", "bf16x3"])
-@pytest.mark.parametrize("tile", [20, 21, 22])
+@pytest.mark.parametrize("tile", [20, 21, 22, 37, 38])
 @pytest.mark.parametrize("case", ["ragged", "cat_big", "splitk"])
 def test_split_conv3x3_dx_reuse_tiles(prec_name, tile, case):
-    """dx-tap reuse tiles (one staged A window for the three kx taps) in split precision."""
+    """dx-tap reuse tiles (one staged A window for the three kx taps) in split precision; 37 / 38: their warp-specialised forms
+    (f16x3 with a pre-split weight only: refused for bf16x3, never rerouted)."""
     prec = ops.Precision.get(prec_name)
+    if tile >= 37 and prec_name != "f16x3":
+        x0 = torch.zeros(1, 7, 16, 64, device=DEV)
+        with pytest.raises(hip.MfhipError, match="not instantiated|does not apply"):
+            ops.conv2d(x0, ops.ConvWeight(torch.zeros(40, 64, 3, 3), None, prec, DEV), tile=tile)
+        return
     g = torch.Generator().manual_seed(34)
     b, h, w_, c0, c1, n = {"ragged": (3, 7, 16, 64, 0, 40), "cat_big": (2, 32, 64, 64, 32, 160),
                            "splitk": (1, 16, 16, 256, 0, 200)}[case]
