@@ -2326,9 +2326,10 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         MF_CHECK_ARG(tile <= 6, "mf_gemm_conv: tile %d does not apply to fp32 activations with bf16 compute (tiles 1-12 do)", tile);
     }
     MF_CHECK_ARG(tile < 25 || tile > 30 || (d->dtype == MF_BF16 && !a_f32), "mf_gemm_conv: tile %d (16x16x32 MFMA form) does not apply: bf16 only", tile);
-    MF_CHECK_ARG(tile < 31 || (!a_f32 && !split && d->dtype != MF_FP8), "mf_gemm_conv: tile %d (deep ring) does not apply to this precision", tile);
-    MF_CHECK_ARG(tile < 37 || d->dtype == MF_BF16 || (d->dtype == MF_F16X3 && d->w_split == 1),
-                 "mf_gemm_conv: tile %d (warp-specialised) does not apply: bf16, or f16x3 with a pre-split weight", tile);
+    const bool split_ws = d->dtype == MF_F16X3 && d->w_split == 1 && (tile == 37 || tile == 38 || tile == 41 || tile == 44);
+    MF_CHECK_ARG(tile < 31 || split_ws || (!a_f32 && !split && d->dtype != MF_FP8), "mf_gemm_conv: tile %d (deep ring) does not apply to this precision", tile);
+    MF_CHECK_ARG(tile < 37 || d->dtype == MF_BF16 || split_ws,
+                 "mf_gemm_conv: tile %d (warp-specialised) does not apply: bf16, or f16x3 with a pre-split weight on tiles 37 / 38 / 41 / 44", tile);
     const TileCfg& tc = kTiles[tile - 1];
     if (tc.halo) {
         // conv3x3_halo_kernel: bf16, 3x3 / stride 1 / pad 1, whole TH x 16 tiles, 32-channel chunks
