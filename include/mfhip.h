@@ -200,6 +200,38 @@ int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ldq, const void* k_hi, const void* k_lo, int64_t ldk,
                        const void* vt_hi, const void* vt_lo, int64_t ldvt, float* out, int64_t ldo, int32_t batch,
                        int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream);
+/* The same with the row statistics the backward pass needs: lse[b][head][i] = log2 of row i's softmax denominator in the exp2
+ * domain (max + log2 sum, with scale * log2 e folded in), fp32 [B][heads][Sq]; lse may be NULL. */
+int mf_attention_f16x3_lse(const void* q_hi, const void* q_lo, int64_t ldq, const void* k_hi, const void* k_lo, int64_t ldk,
+                           const void* vt_hi, const void* vt_lo, int64_t ldvt, float* out, int64_t ldo, float* lse, int32_t batch,
+                           int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream);
+
+/* Flash-style attention BACKWARD in split precision (the training step's backward through
+ * F.scaled_dot_product_attention, attention_processor.py:1266-1268 under train_brushnet_mirror.py:1459): dQ, dK, dV from Q, K, V,
+ * dO, the forward's lse and dd[b][head][i] = sum_c dO[b][i][head*d + c] * O[b][i][head*d + c] (mf_rowdot_heads).  P is recomputed
+ * tile by tile; nothing of size Sq x Skv is written; no atomics (dK / dV and dQ are two passes of one kernel), so the result is
+ * bit-reproducible.  Every operand is given as two fp16 planes (mf_split_halves) — row-major [B][S][ld] for Q, K, V, dO and
+ * transposed [B][heads*d][ldt] (ldt >= S, a multiple of 8, pad columns finite) for Q, K, dO.  head_dim 8 / 40 (the 4096-token
+ * layers of the path; head dims 64 / 80 exceed the LDS of the double-buffered dK / dV pass and keep the unfused backward). */
+typedef struct mf_attn_bwd_desc {
+    const void* q_hi; const void* q_lo; int64_t ldq;
+    const void* k_hi; const void* k_lo; int64_t ldk;
+    const void* v_hi; const void* v_lo; int64_t ldv;
+    const void* do_hi; const void* do_lo; int64_t lddo;
+    const void* qt_hi; const void* qt_lo; int64_t ldqt;
+    const void* kt_hi; const void* kt_lo; int64_t ldkt;
+    const void* dot_hi; const void* dot_lo; int64_t lddot;
+    const float* lse; const float* dd;
+    float* dq; float* dk; float* dv; int64_t ldo;      /* fp32 [B][S][ldo] */
+    int32_t batch, heads, sq, skv, head_dim;
+    float scale;
+} mf_attn_bwd_desc;
+int mf_sizeof_attn_bwd_desc(void);
+int mf_attention_bwd_f16x3(const mf_attn_bwd_desc* d, void* stream);
+/* out[b][head][i] = sum_c a[b][i][head*d + c] * b[b][i][head*d + c]  (fp32 [B][S][ld] inputs) */
+int mf_rowdot_heads(const float* a, const float* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
+                    void* stream);
+
 /* x (n fp32, n % 4 == 0) -> fp16 planes hi = x rounded toward zero, lo = (x - hi) rounded toward zero */
 int mf_split_halves(const float* x, void* hi, void* lo, int64_t n, void* stream);
 /* Range guard of MF_F16X3.  The fp16 halves hold |x| <= 65504 only and v_cvt_pkrtz_f16_f32 SATURATES above that (no inf, no

@@ -265,3 +265,32 @@ def record_attention(tape: Tape, q, k, v, out, heads: int, skv: int, scale: floa
         tape.add(v, dv)
 
     tape.record(bwd)
+
+
+def record_attention_flash(tape: Tape, q, k, v, out, lse, heads: int, scale: float, q_planes, k_planes) -> None:
+    """Backward of the flash forward (ops.attention_train on the split-precision path): mf_attention_bwd_f16x3 recomputes P tile by
+    tile from q, k and the forward's row statistics `lse`; dK / dV and dQ are two passes of one kernel, no atomics, nothing of
+    size Sq x Skv is written.  The (hi, lo) planes of q and k made for the forward are kept; v, dO and the transposed operands
+    are split here."""
+    from . import ops
+    b, sq, c = q.shape
+    skv = k.shape[1]
+
+    def bwd():
+        g = tape.take(out)
+        if g is None:
+            return
+        g = g.view(b, sq, c).contiguous()
+        dd = hip.rowdot_heads(g, out, heads)
+        ldq, ldk = (sq + 7) // 8 * 8, (skv + 7) // 8 * 8
+        vs, gs = hip.split_halves(v.contiguous()), hip.split_halves(g)
+        qt = hip.split_halves(ops.transpose_tokens(q, ldq))
+        kt = hip.split_halves(ops.transpose_tokens(k, ldk))
+        gt = hip.split_halves(ops.transpose_tokens(g, ldq))
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        hip.attention_bwd_f16x3(q_planes, k_planes, vs, gs, qt, kt, gt, lse, dd, dq, dk, dv, heads=heads, scale=scale)
+        tape.add(q, dq)
+        tape.add(k, dk)
+        tape.add(v, dv)
+
+    tape.record(bwd)

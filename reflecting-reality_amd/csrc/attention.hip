@@ -29,10 +29,13 @@ struct AttnArgs {
     const char* vt; int64_t ldvt;
     const char* q2; const char* k2; const char* vt2;   // SP: the low-half planes (same layout as q / k / vt)
     char* out; int64_t ldo;
+    float* lse;   // optional [batch][heads][sq]: log2 of the row's softmax denominator in the exp2 domain (m + log2 l), for the backward pass
     int heads, sq, skv, batch;
     float c;   // softmax scale * log2(e)
     int no_xcd_order;   // A/B switch (MFHIP_ATTN_NOXCD=1): keep the hardware's round-robin block order
 };
+
+__device__ unsigned g_split_ovf_attn;     // raised when an fp16-split operand of this file exceeded the fp16 range (mf_common.h)
 
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
     if (ONES) l = __shfl(o[L_D][L_E], (lane & 31) + 32 * L_H, 64);      // the half-wave that holds accumulator row ONES_ROW
     else l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    if (p.lse && h == 0 && qi < p.sq) p.lse[((int64_t)b * p.heads + head) * p.sq + qi] = m + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
     char* Os = smem + wave * 32 * RBO;   // safe: the loop ended on a barrier
 #pragma unroll
     for (int d = 0; d < DT; ++d)
@@ -384,6 +388,316 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
 }
 
 
+
+// =====================================================================================================================
+// Flash-style attention BACKWARD in split precision (round 3).  Replaces the unfused backward of the training step
+// (autograd.record_attention: scores / softmax / softmax-backward over [B*heads][Sq][Skv] fp32 tensors, two of them transposed:
+// ~60 GB of HBM traffic per 4096-token layer) by two launches of ONE kernel that recompute P tile by tile from Q, K and the
+// forward's row statistics (lse, in the exp2 domain) — nothing of size Sq x Skv is ever written:
+//   KV = false: a wave owns 32 QUERIES (lanes), streams key tiles:   dQ^T += K^T . dS^T
+//   KV = true : a wave owns 32 KEYS (lanes), streams query tiles:    dK^T += Q^T . dS,  dV^T += dO^T . P
+// with  T = (row tile) . (column fragments) = q.k,   U = (second row tile) . (second fragments) = dO.v = dP,
+//       P = exp2(T c - lse),   dS = scale * P * (U - D),   D[q] = sum_c dO[q][c] O[q][c]   (mf_rowdot_heads).
+// The operand roles are the forward kernel's: a row-major tile with permuted rows is the MFMA A operand against register-resident
+// column fragments (accumulator rows = tile rows in natural order, lane = column item), and the accumulator, split into
+// (hi, lo) fp16 halves, is directly the B operand of the product with a TRANSPOSED tile (channels x items).  Every operand is
+// given as two fp16 planes (mf_split_halves); three MFMAs per product.  Deterministic: no atomics (dQ has its own pass).
+struct AttnBwdArgs {
+    const char* c1[2]; int64_t ldc1;      // column-side fragments, operand 1: dQ pass Q, dK/dV pass K      [B][Sc][ld] planes (hi, lo)
+    const char* c2[2]; int64_t ldc2;      // column-side fragments, operand 2: dQ pass dO, dK/dV pass V
+    const char* r1[2]; int64_t ldr1;      // streamed row-major tiles, operand 1: dQ pass K, dK/dV pass Q       [B][Sr][ld]
+    const char* r2[2]; int64_t ldr2;      // streamed row-major tiles, operand 2: dQ pass V, dK/dV pass dO
+    const char* t1[2]; int64_t ldt1;      // streamed transposed tiles for out1: dQ pass K^T, dK/dV pass Q^T       [B][heads*d][ldt]
+    const char* t2[2]; int64_t ldt2;      // dK/dV pass only: dO^T (for out2 = dV)
+    const float* lse; const float* dd;    // [B][heads][Sq]
+    float* out1; float* out2; int64_t ldo;   // fp32 [B][Sc][ldo]: dQ, or dK and dV
+    int heads, sc, sr, batch, sq;         // sc / sr: items on the column / row side; sq: queries (lse / dd row length)
+    float c, scale;                       // scale * log2(e), scale
+};
+
+template <int HD, bool KV>
+__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
+    constexpr int NP = 2;
+    constexpr int DK = (HD + 15) / 16 * 16, KS = DK / 16;
+    constexpr int DV = (HD + 31) / 32 * 32, DT = DV / 32;
+    constexpr int RBK = DK * 2 + 16, RBV = 144, RBO = DV * 4 + 16;
+    constexpr int KCPR = RBK / 16, VCPR = RBV / 16;
+    constexpr int KI = KCPR, VI = (HD * VCPR + 63) / 64;
+    constexpr int KPW = (KI + 3) / 4, VPW = (VI + 3) / 4;
+    constexpr int K_BYTES = 64 * RBK;
+    constexpr int V_BYTES = (DV * RBV > VI * 1024 ? DV * RBV : VI * 1024);
+    constexpr int NT = KV ? 2 : 1;                            // transposed operands per tile
+    constexpr int ST_BYTES = KV ? 2 * 1024 : 0;                // lse | dd of the 64 tile rows (dK/dV pass): one 1-KB DMA span each
+    constexpr int R2_OFF = NP * K_BYTES, T1_OFF = 2 * NP * K_BYTES, T2_OFF = T1_OFF + NP * V_BYTES, ST_OFF = T1_OFF + NT * NP * V_BYTES;
+    constexpr int BUF_BYTES = ST_OFF + ST_BYTES;
+    constexpr int O_BYTES = 4 * 32 * RBO;
+    constexpr int LDS_BYTES = 2 * BUF_BYTES > O_BYTES ? 2 * BUF_BYTES : O_BYTES;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int cblocks = (p.sc + 127) >> 7;
+    const int bx = blockIdx.x % cblocks, bh = blockIdx.x / cblocks;
+    const int b = bh / p.heads, head = bh - b * p.heads;
+    const int c0 = bx * 128 + wave * 32;
+    const int ci = c0 + r;                                    // this lane's column item (query or key)
+
+    for (int i = tid * 16; i < 2 * BUF_BYTES; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+    // column-side fragments: lane (item r, half h) holds X[item][16 ks + 8 h + j] of both planes
+    uint4 f1[NP][KS], f2[NP][KS];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+        const char* row1 = p.c1[pl] + (((int64_t)b * p.sc + (ci < p.sc ? ci : 0)) * p.ldc1 + head * HD) * 2;
+        const char* row2 = p.c2[pl] + (((int64_t)b * p.sc + (ci < p.sc ? ci : 0)) * p.ldc2 + head * HD) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kk = 16 * ks + 8 * h;
+            const bool on = kk < HD && ci < p.sc;
+            f1[pl][ks] = on ? ldg16(row1 + kk * 2) : make_uint4(0, 0, 0, 0);
+            f2[pl][ks] = on ? ldg16(row2 + kk * 2) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    float lse_l = 0.0f, dd_l = 0.0f;                           // dQ pass: the lane's own query
+    if (!KV && ci < p.sc) {
+        lse_l = p.lse[((int64_t)b * p.heads + head) * p.sq + ci];
+        dd_l = p.dd[((int64_t)b * p.heads + head) * p.sq + ci];
+    }
+
+    // LDS-DMA staging of the streamed tiles (the forward kernel's scheme: permuted rows for the row-major tiles, natural
+    // order for the transposed ones; out-of-range lanes write zeros)
+    srd_t srdR1[NP], srdR2[NP], srdT1[NP], srdT2[NP];
+    {
+        const int64_t rb1 = ((int64_t)b * p.sr * p.ldr1 + head * HD) * 2, rl1 = ((int64_t)(p.batch - b) * p.sr * p.ldr1 - head * HD) * 2;
+        const int64_t rb2 = ((int64_t)b * p.sr * p.ldr2 + head * HD) * 2, rl2 = ((int64_t)(p.batch - b) * p.sr * p.ldr2 - head * HD) * 2;
+        const int64_t tb1 = ((int64_t)(b * p.heads + head) * HD) * p.ldt1 * 2, tl1 = ((int64_t)((p.batch - b) * p.heads - head) * HD * p.ldt1) * 2;
+        const int64_t tb2 = KV ? ((int64_t)(b * p.heads + head) * HD) * p.ldt2 * 2 : 0;
+        const int64_t tl2 = KV ? ((int64_t)((p.batch - b) * p.heads - head) * HD * p.ldt2) * 2 : 0;
+        auto lim = [](int64_t v) { return (unsigned)(v < 0x7fffffff ? v : 0x7fffffff); };
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+            srdR1[pl] = make_srd(p.r1[pl] + rb1, lim(rl1));
+            srdR2[pl] = make_srd(p.r2[pl] + rb2, lim(rl2));
+            srdT1[pl] = make_srd(p.t1[pl] + tb1, lim(tl1));
+            srdT2[pl] = make_srd((KV ? p.t2[pl] : p.t1[pl]) + tb2, lim(KV ? tl2 : tl1));
+        }
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned roff1[KPW], roff2[KPW], toff1[VPW], toff2[VPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int g = (wv + 4 * i) * 64 + lane;
+        const int R = g / KCPR, c = g - R * KCPR;
+        const int kr = (R & ~12) | ((R & 4) << 1) | ((R & 8) >> 1);
+        const int64_t o1 = ((int64_t)kr * p.ldr1 + c * 8) * 2, o2 = ((int64_t)kr * p.ldr2 + c * 8) * 2;
+        roff1[i] = (c < HD / 8 && o1 < 0x7fffffff) ? (unsigned)o1 : 0x80000000u;
+        roff2[i] = (c < HD / 8 && o2 < 0x7fffffff) ? (unsigned)o2 : 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const int g = (wv + 4 * i) * 64 + lane;
+        const int row = g / VCPR, c = g - row * VCPR;
+        const int64_t o1 = ((int64_t)row * p.ldt1 + c * 8) * 2, o2 = ((int64_t)row * p.ldt2 + c * 8) * 2;
+        toff1[i] = (row < HD && c < 8 && o1 < 0x7fffffff) ? (unsigned)o1 : 0x80000000u;
+        toff2[i] = (KV && row < HD && c < 8 && o2 < 0x7fffffff) ? (unsigned)o2 : 0x80000000u;
+    }
+    const unsigned rstep1 = (unsigned)(64 * p.ldr1 * 2), rstep2 = (unsigned)(64 * p.ldr2 * 2);
+    // the tile's 64 lse / dd values arrive by DMA too (lanes 0..15 of wave 0 fetch 16 bytes each; rows past the end read zeros)
+    const int64_t st_base = ((int64_t)b * p.heads + head) * p.sq;
+    const srd_t srdL = make_srd(reinterpret_cast<const char*>(p.lse + st_base), (unsigned)(p.sq * 4));
+    const srd_t srdD = make_srd(reinterpret_cast<const char*>(p.dd + st_base), (unsigned)(p.sq * 4));
+    unsigned soff = lane < 16 ? (unsigned)(lane * 16) : 0x80000000u;
+    auto issue_tile = [&](int buf, int row0) {
+        const unsigned lb = lds0 + buf * BUF_BYTES;
+        if (KV && wv == 0) {
+            dma16_buf(soff, srdL, lb + ST_OFF);
+            dma16_buf(soff, srdD, lb + ST_OFF + 1024);
+            soff += 256;
+        }
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                if (wv + 4 * i < KI) {
+                    dma16_buf(roff1[i], srdR1[pl], lb + pl * K_BYTES + (wv + 4 * i) * 1024);
+                    dma16_buf(roff2[i], srdR2[pl], lb + R2_OFF + pl * K_BYTES + (wv + 4 * i) * 1024);
+                }
+            roff1[i] += rstep1;
+            roff2[i] += rstep2;
+        }
+#pragma unroll
+        for (int i = 0; i < VPW; ++i) {
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+                if (wv + 4 * i < VI) {
+                    dma16_buf(toff1[i], srdT1[pl], lb + T1_OFF + pl * V_BYTES + (wv + 4 * i) * 1024);
+                    if (KV) dma16_buf(toff2[i], srdT2[pl], lb + T2_OFF + pl * V_BYTES + (wv + 4 * i) * 1024);
+                }
+            toff1[i] += 128;
+            toff2[i] += 128;
+        }
+        (void)row0;
+    };
+
+    f32x16_t acc1[DT], acc2[KV ? DT : 1];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc1[d][e] = 0.0f; if (KV) acc2[d][e] = 0.0f; }
+    float amax = 0.0f;                                         // range guard of the fp16 split (dS can be large)
+
+    const int ntiles = (p.sr + 63) / 64;
+    __syncthreads();
+    issue_tile(0, 0);
+    wait_vmcnt<0>();
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int row0 = t * 64;
+        const char* B0 = smem + (t & 1) * BUF_BYTES;
+        if (t + 1 < ntiles) issue_tile((t + 1) & 1, row0 + 64);
+
+        // ---- T = R1 . f1^T and U = R2 . f2^T : [64 tile rows (registers)] x [32 column items (lanes)] ----
+        f32x16_t T[2], U[2];
+        const f32x16_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int fo = (32 * tt + r) * RBK + (16 * ks + 8 * h) * 2;
+                const uint4 ah = *reinterpret_cast<const uint4*>(B0 + fo);
+                const uint4 al = *reinterpret_cast<const uint4*>(B0 + K_BYTES + fo);
+                T[tt] = mfma16(al, f1[0][ks], ks == 0 ? zero16 : T[tt], true);
+                T[tt] = mfma16(ah, f1[1][ks], T[tt], true);
+                T[tt] = mfma16(ah, f1[0][ks], T[tt], true);
+                const uint4 bh_ = *reinterpret_cast<const uint4*>(B0 + R2_OFF + fo);
+                const uint4 bl_ = *reinterpret_cast<const uint4*>(B0 + R2_OFF + K_BYTES + fo);
+                U[tt] = mfma16(bl_, f2[0][ks], ks == 0 ? zero16 : U[tt], true);
+                U[tt] = mfma16(bh_, f2[1][ks], U[tt], true);
+                U[tt] = mfma16(bh_, f2[0][ks], U[tt], true);
+            }
+        // ---- P = exp2(T c - lse), dS = scale P (U - D); accumulator register e of sub-tile tt is tile row
+        //      32 tt + (e & 3) + 4 ((e >> 2) & 1) + 16 (e >> 3) + 8 h (natural order: the tile's rows are stored permuted) ----
+        uint4 ph[4], plo[4], sh[4], slo[4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float lv[16], dv[16];
+            if (KV) {
+                const float* stl = reinterpret_cast<const float*>(B0 + ST_OFF);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = 32 * tt + (e & 7) + 16 * (e >> 3) + 8 * h;
+                    lv[e] = stl[n];
+                    dv[e] = stl[256 + n];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { lv[e] = lse_l; dv[e] = dd_l; }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = row0 + 32 * tt + (e & 7) + 16 * (e >> 3) + 8 * h;
+                float pv = __builtin_amdgcn_exp2f(fmaf(T[tt][e], p.c, -lv[e]));
+                if (n >= p.sr) pv = 0.0f;
+                const float ds = p.scale * pv * (U[tt][e] - dv[e]);
+                amax = mf_amax3(amax, ds, 0.0f);
+                T[tt][e] = pv;
+                U[tt][e] = ds;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                unsigned a_h[4], a_l[4], b_h[4], b_l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p0 = T[tt][8 * s2 + 2 * e], p1 = T[tt][8 * s2 + 2 * e + 1];
+                    const auto hh = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+                    const auto ll = __builtin_amdgcn_cvt_pkrtz(p0 - (float)hh[0], p1 - (float)hh[1]);
+                    a_h[e] = __builtin_bit_cast(unsigned, hh); a_l[e] = __builtin_bit_cast(unsigned, ll);
+                    const float d0 = U[tt][8 * s2 + 2 * e], d1 = U[tt][8 * s2 + 2 * e + 1];
+                    const auto gh = __builtin_amdgcn_cvt_pkrtz(d0, d1);
+                    const auto gl = __builtin_amdgcn_cvt_pkrtz(d0 - (float)gh[0], d1 - (float)gh[1]);
+                    b_h[e] = __builtin_bit_cast(unsigned, gh); b_l[e] = __builtin_bit_cast(unsigned, gl);
+                }
+                ph[2 * tt + s2] = uint4{a_h[0], a_h[1], a_h[2], a_h[3]};
+                plo[2 * tt + s2] = uint4{a_l[0], a_l[1], a_l[2], a_l[3]};
+                sh[2 * tt + s2] = uint4{b_h[0], b_h[1], b_h[2], b_h[3]};
+                slo[2 * tt + s2] = uint4{b_l[0], b_l[1], b_l[2], b_l[3]};
+            }
+        }
+        // ---- out1^T += T1 . dS   (and out2^T += T2 . P): [channels (registers)] x [32 column items (lanes)] ----
+#pragma unroll
+        for (int kst = 0; kst < 4; ++kst)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                const int fo = (32 * d + r) * RBV + (16 * kst + 8 * h) * 2;
+                const uint4 ah = *reinterpret_cast<const uint4*>(B0 + T1_OFF + fo);
+                const uint4 al = *reinterpret_cast<const uint4*>(B0 + T1_OFF + V_BYTES + fo);
+                acc1[d] = mfma16(al, sh[kst], acc1[d], true);
+                acc1[d] = mfma16(ah, slo[kst], acc1[d], true);
+                acc1[d] = mfma16(ah, sh[kst], acc1[d], true);
+                if (KV) {
+                    const uint4 bh_ = *reinterpret_cast<const uint4*>(B0 + T2_OFF + fo);
+                    const uint4 bl_ = *reinterpret_cast<const uint4*>(B0 + T2_OFF + V_BYTES + fo);
+                    acc2[d] = mfma16(bl_, ph[kst], acc2[d], true);
+                    acc2[d] = mfma16(bh_, plo[kst], acc2[d], true);
+                    acc2[d] = mfma16(bh_, ph[kst], acc2[d], true);
+                }
+            }
+        wait_vmcnt<0>();
+        __syncthreads();
+    }
+    mf_raise_if_over(&g_split_ovf_attn, amax);
+
+    // ---- epilogue: transpose through LDS, row-contiguous fp32 stores ----
+    char* Os = smem + wave * 32 * RBO;
+#pragma unroll
+    for (int which = 0; which < (KV ? 2 : 1); ++which) {
+        float* outp = which == 0 ? p.out1 : p.out2;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16_t& a = (which == 0 || !KV) ? acc1[d] : acc2[d];
+                *reinterpret_cast<float4*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 4) =
+                    make_float4(a[4 * g + 0], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        constexpr int OV = 32 * (HD / 4);
+        for (int v = lane; v < OV; v += 64) {
+            const int row = v / (HD / 4), cv = v - row * (HD / 4);
+            const int cc = c0 + row;
+            if (cc < p.sc) {
+                const uint4 val = *reinterpret_cast<const uint4*>(Os + row * RBO + cv * 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(outp) + (((int64_t)b * p.sc + cc) * p.ldo + head * HD + cv * 4) * 4) = val;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// D[b][head][q] = sum_c dO[b][q][head*d + c] * O[b][q][head*d + c]
+__global__ __launch_bounds__(256) void rowdot_heads_kernel(const float* a, const float* bb, float* out, int batch, int sq, int heads, int hd,
+                                                           int64_t ld) {
+    const int64_t total = (int64_t)batch * sq * heads;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int hh = (int)(i % heads);
+        const int64_t t = i / heads;
+        const int q = (int)(t % sq);
+        const int b = (int)(t / sq);
+        const float* pa = a + ((int64_t)b * sq + q) * ld + hh * hd;
+        const float* pb = bb + ((int64_t)b * sq + q) * ld + hh * hd;
+        float s0 = 0.0f;
+        for (int c = 0; c < hd; c += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(pa + c), y = *reinterpret_cast<const float4*>(pb + c);
+            s0 += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        }
+        out[((int64_t)b * heads + hh) * sq + q] = s0;
+    }
+}
+
 template <int HD, bool SP = false>
 void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
     dim3 grid((unsigned)(((a.sq + 127) / 128) * a.heads * batch));
@@ -391,8 +705,6 @@ void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
 }
 
 // fp32 [rows][ld] (first `cols` columns) -> two fp16 planes of the same layout: hi toward zero, lo = x - hi
-__device__ unsigned g_split_ovf_attn;     // raised when a value handed to mf_split_halves exceeded the fp16 range (mf_common.h)
-
 __global__ __launch_bounds__(256) void split_halves_kernel(const float* x, unsigned short* hi, unsigned short* lo, int64_t n4) {
     float amax = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -461,9 +773,20 @@ extern "C" int mf_split_halves(const float* x, void* hi, void* lo, int64_t n, vo
     return MF_OK;
 }
 
+extern "C" int mf_attention_f16x3_lse(const void* q_hi, const void* q_lo, int64_t ldq, const void* k_hi, const void* k_lo, int64_t ldk,
+                                      const void* vt_hi, const void* vt_lo, int64_t ldvt, float* out, int64_t ldo, float* lse, int32_t batch,
+                                      int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream);
+
 extern "C" int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ldq, const void* k_hi, const void* k_lo, int64_t ldk,
                                   const void* vt_hi, const void* vt_lo, int64_t ldvt, float* out, int64_t ldo, int32_t batch,
                                   int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream) {
+    return mf_attention_f16x3_lse(q_hi, q_lo, ldq, k_hi, k_lo, ldk, vt_hi, vt_lo, ldvt, out, ldo, nullptr, batch, heads, sq, skv, head_dim, scale,
+                                  stream);
+}
+
+extern "C" int mf_attention_f16x3_lse(const void* q_hi, const void* q_lo, int64_t ldq, const void* k_hi, const void* k_lo, int64_t ldk,
+                                      const void* vt_hi, const void* vt_lo, int64_t ldvt, float* out, int64_t ldo, float* lse, int32_t batch,
+                                      int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream) {
     MF_CHECK_ARG(q_hi && q_lo && k_hi && k_lo && vt_hi && vt_lo && out, "mf_attention_f16x3: null pointer");
     MF_CHECK_ARG(batch >= 1 && heads >= 1 && sq >= 1 && skv >= 1, "mf_attention_f16x3: bad sizes");
     MF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && ldvt >= skv,
@@ -478,6 +801,7 @@ extern "C" int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ld
     a.k = (const char*)k_hi; a.k2 = (const char*)k_lo; a.ldk = ldk;
     a.vt = (const char*)vt_hi; a.vt2 = (const char*)vt_lo; a.ldvt = ldvt;
     a.out = (char*)out; a.ldo = ldo; a.heads = heads; a.sq = sq; a.skv = skv; a.batch = batch;
+    a.lse = lse;
     a.c = scale * 1.44269504088896340736f;
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
@@ -490,5 +814,81 @@ extern "C" int mf_attention_f16x3(const void* q_hi, const void* q_lo, int64_t ld
             return MF_EINVAL;
     }
     MF_CHECK_LAUNCH("mf_attention_f16x3");
+    return MF_OK;
+}
+
+template <int HD>
+static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
+    const float c = d->scale * 1.44269504088896340736f;
+    {   // dK, dV: a wave owns 32 keys and streams the query tiles
+        AttnBwdArgs a{};
+        a.c1[0] = (const char*)d->k_hi; a.c1[1] = (const char*)d->k_lo; a.ldc1 = d->ldk;
+        a.c2[0] = (const char*)d->v_hi; a.c2[1] = (const char*)d->v_lo; a.ldc2 = d->ldv;
+        a.r1[0] = (const char*)d->q_hi; a.r1[1] = (const char*)d->q_lo; a.ldr1 = d->ldq;
+        a.r2[0] = (const char*)d->do_hi; a.r2[1] = (const char*)d->do_lo; a.ldr2 = d->lddo;
+        a.t1[0] = (const char*)d->qt_hi; a.t1[1] = (const char*)d->qt_lo; a.ldt1 = d->ldqt;
+        a.t2[0] = (const char*)d->dot_hi; a.t2[1] = (const char*)d->dot_lo; a.ldt2 = d->lddot;
+        a.lse = d->lse; a.dd = d->dd; a.out1 = d->dk; a.out2 = d->dv; a.ldo = d->ldo;
+        a.heads = d->heads; a.sc = d->skv; a.sr = d->sq; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
+        dim3 grid((unsigned)(((d->skv + 127) / 128) * d->heads * d->batch));
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, true>), grid, dim3(256), 0, s, a);
+    }
+    {   // dQ: a wave owns 32 queries and streams the key tiles
+        AttnBwdArgs a{};
+        a.c1[0] = (const char*)d->q_hi; a.c1[1] = (const char*)d->q_lo; a.ldc1 = d->ldq;
+        a.c2[0] = (const char*)d->do_hi; a.c2[1] = (const char*)d->do_lo; a.ldc2 = d->lddo;
+        a.r1[0] = (const char*)d->k_hi; a.r1[1] = (const char*)d->k_lo; a.ldr1 = d->ldk;
+        a.r2[0] = (const char*)d->v_hi; a.r2[1] = (const char*)d->v_lo; a.ldr2 = d->ldv;
+        a.t1[0] = (const char*)d->kt_hi; a.t1[1] = (const char*)d->kt_lo; a.ldt1 = d->ldkt;
+        a.t2[0] = a.t1[0]; a.t2[1] = a.t1[1]; a.ldt2 = d->ldkt;
+        a.lse = d->lse; a.dd = d->dd; a.out1 = d->dq; a.out2 = nullptr; a.ldo = d->ldo;
+        a.heads = d->heads; a.sc = d->sq; a.sr = d->skv; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
+        dim3 grid((unsigned)(((d->sq + 127) / 128) * d->heads * d->batch));
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, false>), grid, dim3(256), 0, s, a);
+    }
+}
+
+extern "C" int mf_sizeof_attn_bwd_desc(void) { return (int)sizeof(mf_attn_bwd_desc); }
+
+extern "C" int mf_attention_bwd_f16x3(const mf_attn_bwd_desc* d, void* stream) {
+    MF_CHECK_ARG(d && d->q_hi && d->q_lo && d->k_hi && d->k_lo && d->v_hi && d->v_lo && d->do_hi && d->do_lo && d->qt_hi && d->qt_lo && d->kt_hi &&
+                     d->kt_lo && d->dot_hi && d->dot_lo && d->lse && d->dd && d->dq && d->dk && d->dv,
+                 "mf_attention_bwd_f16x3: null pointer");
+    MF_CHECK_ARG(d->batch >= 1 && d->heads >= 1 && d->sq >= 1 && d->skv >= 1, "mf_attention_bwd_f16x3: bad sizes");
+    MF_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->lddo % 8 == 0 && d->ldqt % 8 == 0 && d->ldkt % 8 == 0 &&
+                     d->lddot % 8 == 0 && d->ldo % 4 == 0 && d->ldqt >= d->sq && d->lddot >= d->sq && d->ldkt >= d->skv && d->sq % 4 == 0,
+                 "mf_attention_bwd_f16x3: leading dims must be multiples of 8 (ldo: 4), transposed rows at least as long as the sequence, sq %% 4 == 0");
+    const void* ptrs[] = {d->q_hi, d->q_lo, d->k_hi, d->k_lo, d->v_hi, d->v_lo, d->do_hi, d->do_lo, d->qt_hi, d->qt_lo, d->kt_hi, d->kt_lo,
+                          d->dot_hi, d->dot_lo, d->dq, d->dk, d->dv, d->lse, d->dd};
+    for (const void* q : ptrs)
+        if (!mf_aligned16(q)) {
+            mf_set_error("mf_attention_bwd_f16x3: pointers must be 16-byte aligned");
+            return MF_EALIGN;
+        }
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->head_dim) {
+        case 8: launch_attn_bwd<8>(d, s); break;
+        case 40: launch_attn_bwd<40>(d, s); break;
+        default:       // 64 / 80 would need 204 KB of LDS for the double-buffered dK/dV pass; their layers (<= 1024 tokens) keep the unfused backward
+            mf_set_error("mf_attention_bwd_f16x3: unsupported head_dim %d (have 8, 40)", d->head_dim);
+            return MF_EINVAL;
+    }
+    MF_CHECK_LAUNCH("mf_attention_bwd_f16x3");
+    return MF_OK;
+}
+
+extern "C" int mf_rowdot_heads(const float* a, const float* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
+                               void* stream) {
+    MF_CHECK_ARG(a && b && out && batch >= 1 && sq >= 1 && heads >= 1 && head_dim >= 4 && head_dim % 4 == 0 && ld % 4 == 0 && ld >= heads * head_dim,
+                 "mf_rowdot_heads: bad arguments (head_dim and ld multiples of 4)");
+    if (!mf_aligned16(a) || !mf_aligned16(b)) {
+        mf_set_error("mf_rowdot_heads: pointers must be 16-byte aligned");
+        return MF_EALIGN;
+    }
+    const int64_t total = (int64_t)batch * sq * heads;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rowdot_heads_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, batch, sq, heads, head_dim, ld);
+    MF_CHECK_LAUNCH("mf_rowdot_heads");
     return MF_OK;
 }

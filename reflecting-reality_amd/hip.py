@@ -83,6 +83,22 @@ class GroupNormBwdDesc(C.Structure):
     ]
 
 
+class AttnBwdDesc(C.Structure):
+    _fields_ = [
+        ("q_hi", C.c_void_p), ("q_lo", C.c_void_p), ("ldq", C.c_int64),
+        ("k_hi", C.c_void_p), ("k_lo", C.c_void_p), ("ldk", C.c_int64),
+        ("v_hi", C.c_void_p), ("v_lo", C.c_void_p), ("ldv", C.c_int64),
+        ("do_hi", C.c_void_p), ("do_lo", C.c_void_p), ("lddo", C.c_int64),
+        ("qt_hi", C.c_void_p), ("qt_lo", C.c_void_p), ("ldqt", C.c_int64),
+        ("kt_hi", C.c_void_p), ("kt_lo", C.c_void_p), ("ldkt", C.c_int64),
+        ("dot_hi", C.c_void_p), ("dot_lo", C.c_void_p), ("lddot", C.c_int64),
+        ("lse", C.c_void_p), ("dd", C.c_void_p),
+        ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("ldo", C.c_int64),
+        ("batch", C.c_int32), ("heads", C.c_int32), ("sq", C.c_int32), ("skv", C.c_int32), ("head_dim", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
 class GroupNormDesc(C.Structure):
     _fields_ = [
         ("x0", C.c_void_p), ("x1", C.c_void_p),
@@ -103,7 +119,8 @@ EXPORTS = [
     "mf_abi_version", "mf_last_error", "mf_sizeof_gemm_desc", "mf_sizeof_groupnorm_desc",
     "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape", "mf_gemm_tile_table_version",
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
-    "mf_attention_f16x3", "mf_split_halves", "mf_split_overflow", "mf_quantize_rows_fp8",
+    "mf_attention_f16x3", "mf_attention_f16x3_lse", "mf_sizeof_attn_bwd_desc", "mf_attention_bwd_f16x3", "mf_rowdot_heads",
+    "mf_split_halves", "mf_split_overflow", "mf_quantize_rows_fp8",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
     # image front-end (csrc/frontend.hip)
@@ -142,6 +159,8 @@ def load() -> C.CDLL:
         raise MfhipError(f"libmfhip ABI {lib.mf_abi_version()} != binding ABI {ABI_VERSION}: rebuild the library")
     if lib.mf_sizeof_gemm_desc() != C.sizeof(GemmDesc) or lib.mf_sizeof_groupnorm_desc() != C.sizeof(GroupNormDesc):
         raise MfhipError("descriptor struct layout mismatch between mfhip.h and the ctypes binding")
+    if lib.mf_sizeof_attn_bwd_desc() != C.sizeof(AttnBwdDesc):
+        raise MfhipError("mf_attn_bwd_desc layout mismatch between mfhip.h and the ctypes binding")
     if lib.mf_sizeof_wgrad_desc() != C.sizeof(WgradDesc) or lib.mf_sizeof_groupnorm_bwd_desc() != C.sizeof(GroupNormBwdDesc):
         raise MfhipError("training descriptor struct layout mismatch between mfhip.h and the ctypes binding")
     _lib = lib
@@ -586,15 +605,46 @@ def split_halves(x: torch.Tensor):
 
 
 def attention_f16x3(q, k, vt, out: torch.Tensor, *, ldq: int, ldk: int, ldvt: int, ldo: int, batch: int, heads: int,
-                    sq: int, skv: int, head_dim: int, scale: float) -> torch.Tensor:
-    """q / k / vt: (hi, lo) pairs from split_halves; out fp32."""
-    _req_cuda(*q, *k, *vt, out)
-    _check(load().mf_attention_f16x3(C.c_void_p(q[0].data_ptr()), C.c_void_p(q[1].data_ptr()), C.c_int64(ldq),
-                                     C.c_void_p(k[0].data_ptr()), C.c_void_p(k[1].data_ptr()), C.c_int64(ldk),
-                                     C.c_void_p(vt[0].data_ptr()), C.c_void_p(vt[1].data_ptr()), C.c_int64(ldvt),
-                                     C.c_void_p(out.data_ptr()), C.c_int64(ldo), batch, heads, sq, skv, head_dim,
-                                     C.c_float(scale), _stream()), "mf_attention_f16x3")
+                    sq: int, skv: int, head_dim: int, scale: float, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q / k / vt: (hi, lo) pairs from split_halves; out fp32.  lse (optional, fp32 [batch, heads, sq]): the row statistics the
+    flash backward needs."""
+    _req_cuda(*q, *k, *vt, out, lse)
+    _check(load().mf_attention_f16x3_lse(C.c_void_p(q[0].data_ptr()), C.c_void_p(q[1].data_ptr()), C.c_int64(ldq),
+                                         C.c_void_p(k[0].data_ptr()), C.c_void_p(k[1].data_ptr()), C.c_int64(ldk),
+                                         C.c_void_p(vt[0].data_ptr()), C.c_void_p(vt[1].data_ptr()), C.c_int64(ldvt),
+                                         C.c_void_p(out.data_ptr()), C.c_int64(ldo), C.c_void_p(_ptr(lse)), batch, heads, sq, skv, head_dim,
+                                         C.c_float(scale), _stream()), "mf_attention_f16x3")
     return out
+
+
+def rowdot_heads(a: torch.Tensor, b: torch.Tensor, heads: int) -> torch.Tensor:
+    """[B, S, C] x [B, S, C] -> [B, heads, S]: per-head dot products of the rows (the D term of the attention backward)."""
+    _f32(a, b)
+    bsz, s, c = a.shape
+    out = torch.empty(bsz, heads, s, dtype=torch.float32, device=a.device)
+    _check(load().mf_rowdot_heads(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), bsz, s, heads, c // heads,
+                                  C.c_int64(c), _stream()), "mf_rowdot_heads")
+    return out
+
+
+def attention_bwd_f16x3(q, k, v, do, qt, kt, dot, lse: torch.Tensor, dd: torch.Tensor, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, *,
+                        heads: int, scale: float) -> None:
+    """Flash attention backward (mf_attention_bwd_f16x3).  q / k / v / do: (hi, lo) planes [B, S, C]; qt / kt / dot: (hi, lo) planes of
+    the transposed tensors [B, C, ld]; lse / dd fp32 [B, heads, Sq]; dq / dk / dv fp32 [B, S, C] (written)."""
+    b, sq, c = q[0].shape
+    skv = k[0].shape[1]
+    d = AttnBwdDesc()
+    d.q_hi, d.q_lo, d.ldq = q[0].data_ptr(), q[1].data_ptr(), c
+    d.k_hi, d.k_lo, d.ldk = k[0].data_ptr(), k[1].data_ptr(), c
+    d.v_hi, d.v_lo, d.ldv = v[0].data_ptr(), v[1].data_ptr(), c
+    d.do_hi, d.do_lo, d.lddo = do[0].data_ptr(), do[1].data_ptr(), c
+    d.qt_hi, d.qt_lo, d.ldqt = qt[0].data_ptr(), qt[1].data_ptr(), qt[0].shape[-1]
+    d.kt_hi, d.kt_lo, d.ldkt = kt[0].data_ptr(), kt[1].data_ptr(), kt[0].shape[-1]
+    d.dot_hi, d.dot_lo, d.lddot = dot[0].data_ptr(), dot[1].data_ptr(), dot[0].shape[-1]
+    d.lse, d.dd = lse.data_ptr(), dd.data_ptr()
+    d.dq, d.dk, d.dv, d.ldo = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), c
+    d.batch, d.heads, d.sq, d.skv, d.head_dim, d.scale = b, heads, sq, skv, c // heads, scale
+    _check(load().mf_attention_bwd_f16x3(C.byref(d), _stream()), "mf_attention_bwd_f16x3")
 
 
 def pack_nhwc(src0: torch.Tensor, src1: Optional[torch.Tensor], c_pad: int, out_dtype: torch.dtype) -> torch.Tensor:

@@ -399,6 +399,17 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
         return hip.softmax_rows(scores, skv, torch.float32)
 
     vt = transpose_tokens(v, ld)
+    if (prec.code == hip.MF_F16X3 and d in FLASH_BWD_HEAD_DIMS and sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS and tape is not None
+            and FLASH_BWD):
+        # flash forward WITH the row statistics, flash backward (autograd.record_attention_flash): nothing of size Sq x Skv is
+        # ever written in either direction
+        qs, ks, vs = hip.split_halves(q.contiguous()), hip.split_halves(k.contiguous()), hip.split_halves(vt)
+        out = torch.empty(b, sq, c, dtype=torch.float32, device=q.device)
+        lse = torch.empty(b, heads, sq, dtype=torch.float32, device=q.device)
+        hip.attention_f16x3(qs, ks, vs, out, ldq=c, ldk=c, ldvt=vt.shape[-1], ldo=c, batch=b, heads=heads, sq=sq, skv=skv, head_dim=d,
+                            scale=scale, lse=lse)
+        autograd.record_attention_flash(tape, q, k, v, out, lse, heads, scale, qs, ks)
+        return out
     if prec.code == hip.MF_F16X3 and d in FLASH_SPLIT_HEAD_DIMS:
         # forward on the flash kernel (split precision): P is not materialised here at all; backward recomputes it once
         out = attention(q, k, vt, heads, skv, scale, prec, c=c)
@@ -434,6 +445,10 @@ def attention_unfused(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads:
     return out
 
 
+FLASH_BWD_HEAD_DIMS = (8, 40)                    # mf_attention_bwd_f16x3
+FLASH_BWD_MIN_TOKENS = 256                       # shorter sequences keep the unfused backward (its S x S tensors are small there)
+import os as _os
+FLASH_BWD = _os.environ.get("MFHIP_NO_FLASH_BWD") != "1"       # A/B switch
 FLASH_HEAD_DIMS = (8, 40, 64, 80, 160)
 FLASH_SPLIT_HEAD_DIMS = (8, 40, 64, 80)          # 160 (two split K / V^T planes, double buffered) does not fit in LDS
 

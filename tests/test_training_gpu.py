@@ -351,8 +351,12 @@ def test_layernorm_softmax_geglu_silu_backward():
 
 
 @pytest.mark.parametrize("code_name", ["fp32", "f16x3"])
-@pytest.mark.parametrize("heads,d,sq,skv", [(2, 40, 96, 96), (4, 8, 64, 77), (8, 40, 1024, 1024)])
+@pytest.mark.parametrize("heads,d,sq,skv", [(2, 40, 96, 96), (4, 8, 64, 77), (8, 40, 1024, 1024), (2, 40, 4096, 4096), (4, 40, 1024, 77),
+                                            (3, 8, 260, 300)])
 def test_attention_backward(code_name, heads, d, sq, skv):
+    """f16x3 with >= 256 queries and head dim 8 / 40 runs the FLASH backward (mf_attention_bwd_f16x3: two passes of one kernel
+    that recompute P from the forward's row statistics); everything else the unfused one.  Both against torch autograd in
+    float64."""
     from reflecting_reality_amd import autograd as AG
     prec = ops.Precision.get(code_name)
     g = torch.Generator().manual_seed(54)
@@ -375,7 +379,8 @@ def test_attention_backward(code_name, heads, d, sq, skv):
     tape.add = lambda t, gg: got.__setitem__(t.data_ptr(), gg)
     tape.backward()
     e = [_rel(got[t.data_ptr()].view(t.shape), r.grad) for t, r in ((qd, q), (kd, k), (vd, v))]
-    print(f"attention backward[{code_name}, h{heads} d{d} {sq}x{skv}]: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
+    flash = code_name == "f16x3" and d in ops.FLASH_BWD_HEAD_DIMS and sq >= ops.FLASH_BWD_MIN_TOKENS and sq % 4 == 0
+    print(f"attention backward[{code_name}, h{heads} d{d} {sq}x{skv}, {'flash' if flash else 'unfused'}]: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
     assert max(e) < 3e-5
 
 
