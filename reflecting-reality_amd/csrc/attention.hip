@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
     // a 2 / 3 / 4-deep K/V ring under counted vmcnt waits: 252 / 264 / 268 us against 247 us for this kernel on the same box
     // (gpurun_out/r03e): neither the L2 -> LDS fill nor the LDS reads bound the d = 40 loop, so the form was removed.)
     constexpr bool MJ = !SP && (DK - HD >= 3);
+    constexpr int SP_SHIFT = 8;
     constexpr float MJ_T = 5.0f;
     static_assert(!MJ || HD % 16 == 8, "MJ: the pad k slots must be the whole last fragment of the h = 1 half-wave");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -287,11 +288,14 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
             const float m_new = fmaxf(m, mx * p.c);
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             m = m_new;
+            // SP: P * 2^SP_SHIFT (<= 256), so that the low fp16 half of a small probability is not an fp16 subnormal with a
+            // handful of bits; l and O^T carry the same factor and it cancels in O = O^T / l (lse takes it back out)
+            const float m_sub = SP ? m_new - (float)SP_SHIFT : m_new;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[tt][e], p.c, -m_new));
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[tt][e], p.c, -m_sub));
                     st[tt][e] = pv;
                     if (!ONES) rs += pv;
                 }
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 if constexpr (SP) {
-                    // P = hi + lo in fp16 halves (hi toward zero, lo = P - hi exact in fp32); P <= 1, and fp16
+                    // P = hi + lo in fp16 halves (hi toward zero, lo = P - hi exact in fp32); P <= 2^SP_SHIFT, and fp16
                     // subnormals survive both v_cvt_pkrtz_f16_f32 and the matrix pipe (tools/micro/f16_denorm.hip)
                     unsigned hw[4], lw[4];
 #pragma unroll
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
     if (ONES) l = __shfl(o[L_D][L_E], (lane & 31) + 32 * L_H, 64);      // the half-wave that holds accumulator row ONES_ROW
     else l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    if (p.lse && h == 0 && qi < p.sq) p.lse[((int64_t)b * p.heads + head) * p.sq + qi] = m + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
+    if (p.lse && h == 0 && qi < p.sq) p.lse[((int64_t)b * p.heads + head) * p.sq + qi] = m + __builtin_amdgcn_logf(l) - (SP ? (float)SP_SHIFT : 0.0f);   // v_log_f32 = log2
     char* Os = smem + wave * 32 * RBO;   // safe: the loop ended on a barrier
 #pragma unroll
     for (int d = 0; d < DT; ++d)
@@ -413,6 +417,10 @@ struct AttnBwdArgs {
     float* out1; float* out2; int64_t ldo;   // fp32 [B][Sc][ldo]: dQ, or dK and dV
     int heads, sc, sr, batch, sq;         // sc / sr: items on the column / row side; sq: queries (lse / dd row length)
     float c, scale;                       // scale * log2(e), scale
+    // P and dS are split into fp16 halves whose low half is an fp16 SUBNORMAL for the small probabilities of a long row
+    // (P ~ 1 / 4096 keeps ~12 bits): both are computed times 2^pshift (folded into the exp2 argument, exact) and the
+    // accumulators are scaled back by 2^-pshift in the epilogue
+    float pshift, inv_pscale;
 };
 
 template <int HD, bool KV>
@@ -461,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
     }
     float lse_l = 0.0f, dd_l = 0.0f;                           // dQ pass: the lane's own query
     if (!KV && ci < p.sc) {
-        lse_l = p.lse[((int64_t)b * p.heads + head) * p.sq + ci];
+        lse_l = p.lse[((int64_t)b * p.heads + head) * p.sq + ci] - p.pshift;
         dd_l = p.dd[((int64_t)b * p.heads + head) * p.sq + ci];
     }
 
@@ -588,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int n = 32 * tt + (e & 7) + 16 * (e >> 3) + 8 * h;
-                    lv[e] = stl[n];
+                    lv[e] = stl[n] - p.pshift;
                     dv[e] = stl[256 + n];
                 }
             } else {
@@ -659,8 +667,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x16_t& a = (which == 0 || !KV) ? acc1[d] : acc2[d];
+                const float k2 = p.inv_pscale;
                 *reinterpret_cast<float4*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 4) =
-                    make_float4(a[4 * g + 0], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                    make_float4(a[4 * g + 0] * k2, a[4 * g + 1] * k2, a[4 * g + 2] * k2, a[4 * g + 3] * k2);
             }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -820,6 +829,9 @@ extern "C" int mf_attention_f16x3_lse(const void* q_hi, const void* q_lo, int64_
 template <int HD>
 static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
     const float c = d->scale * 1.44269504088896340736f;
+    int sh = 0;
+    while (sh < 8 && (2 << sh) <= d->skv) ++sh;                // 2^sh <= skv, at most 2^8: P * 2^sh <= 256, far inside fp16
+    const float pshift = (float)sh, inv_pscale = 1.0f / (float)(1 << sh);
     {   // dK, dV: a wave owns 32 keys and streams the query tiles
         AttnBwdArgs a{};
         a.c1[0] = (const char*)d->k_hi; a.c1[1] = (const char*)d->k_lo; a.ldc1 = d->ldk;
@@ -830,6 +842,7 @@ static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
         a.t2[0] = (const char*)d->dot_hi; a.t2[1] = (const char*)d->dot_lo; a.ldt2 = d->lddot;
         a.lse = d->lse; a.dd = d->dd; a.out1 = d->dk; a.out2 = d->dv; a.ldo = d->ldo;
         a.heads = d->heads; a.sc = d->skv; a.sr = d->sq; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
+        a.pshift = pshift; a.inv_pscale = inv_pscale;
         dim3 grid((unsigned)(((d->skv + 127) / 128) * d->heads * d->batch));
         hipLaunchKernelGGL((attn_bwd_kernel<HD, true>), grid, dim3(256), 0, s, a);
     }
@@ -843,6 +856,7 @@ static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
         a.t2[0] = a.t1[0]; a.t2[1] = a.t1[1]; a.ldt2 = d->ldkt;
         a.lse = d->lse; a.dd = d->dd; a.out1 = d->dq; a.out2 = nullptr; a.ldo = d->ldo;
         a.heads = d->heads; a.sc = d->sq; a.sr = d->skv; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
+        a.pshift = pshift; a.inv_pscale = inv_pscale;
         dim3 grid((unsigned)(((d->sq + 127) / 128) * d->heads * d->batch));
         hipLaunchKernelGGL((attn_bwd_kernel<HD, false>), grid, dim3(256), 0, s, a);
     }
