@@ -54,7 +54,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 12
+#define MF_ABI_VERSION 13
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -394,12 +394,15 @@ typedef struct mf_groupnorm_bwd_desc {
     float* dgamma_part; float* dbeta_part;
     int32_t batch, hw, groups, silu;
     float eps;
+    float* ws;      /* mf_groupnorm_bwd_ws_floats() floats, 16-byte aligned; null = the one-block-per-group kernel only */
 } mf_groupnorm_bwd_desc;
 int mf_sizeof_groupnorm_bwd_desc(void);
+int64_t mf_groupnorm_bwd_ws_floats(int32_t batch, int32_t hw, int32_t channels, int32_t groups);
 int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream);
 
-/* LayerNorm backward over [rows][c] (c <= 2048): dx, and per-64-row-block dgamma / dbeta partials
- * [(rows+63)/64][c] (nullable) */
+/* LayerNorm backward over [rows][c] (c <= 2048): dx, and per-block dgamma / dbeta partials
+ * [mf_layernorm_bwd_parts(rows)][c] (nullable) */
+int64_t mf_layernorm_bwd_parts(int64_t rows);
 int mf_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma_part, float* dbeta_part,
                      int64_t rows, int32_t c, float eps, void* stream);
 /* ds = scale * p * (dp - sum_j dp*p) per row of [rows][ld] (valid length cols, pad written 0): softmax backward */

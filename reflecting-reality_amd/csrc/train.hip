@@ -328,58 +328,232 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const GnBwdArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// LayerNorm backward: one wave per row, 64 rows per block; per-block dgamma / dbeta partials
-// ------------------------------------------------------------------------------------------------------------
-constexpr int LN_MAXK = 32;      // channels per lane: c <= 2048
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, const float* dy, const float* gamma, float* dx,
-                                                            float* dg_part, float* db_part, int64_t rows, int c, float eps) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nk = (c + 63) / 64;
-    float ag[LN_MAXK], ab[LN_MAXK];
+// ---- the streaming form for hw >= 256: five launches, every load a coalesced float4 over channels --------------------
+// A: per (image, pixel chunk) per-channel  sum x, sum x^2            -> part      R1: per (image, group) mean, rstd
+// B: per (image, pixel chunk) per-channel  sum dz, sum dz * xhat     -> part      R2: dgamma / dbeta partials, m1, m2
+// C: dx = rstd * (dz * gamma - m1 - xhat * m2)
+// One block per (image, group) as above leaves one block per CU and 40-byte runs per pixel at 320 channels (10 per group):
+// ~125 us on average over the step's GroupNorms; the sums are fp32 over the <= 64 pixels of a chunk, double across chunks.
+struct GnBwd2Args {
+    GnBwdArgs a;
+    float* part;        // [batch][chunks][2][C]
+    float* stats;       // [batch][groups][4]: mean, rstd, m1, m2
+    int chunks, rpc;    // pixel rows per chunk
+};
+
+__device__ __forceinline__ float4 gn_ld4(const GnBwdArgs& p, int b, int px, int q) {
+    const int c = 4 * q;
+    return c < p.c0 ? *reinterpret_cast<const float4*>(p.x0 + ((int64_t)b * p.hw + px) * p.c0 + c)
+                    : *reinterpret_cast<const float4*>(p.x1 + ((int64_t)b * p.hw + px) * p.c1 + (c - p.c0));
+}
+
+template <int PHASE>      // 0: sums of x, x^2; 1: sums of dz, dz * xhat; 2: dx
+__global__ __launch_bounds__(256) void gn_bwd2_kernel(const GnBwd2Args q2) {
+    const GnBwdArgs& p = q2.a;
+    __shared__ float red[2][4][256];
+    const int C = p.c0 + p.c1, Q = C >> 2, cpg = C / p.groups;
+    const int b = blockIdx.x / q2.chunks, chunk = blockIdx.x - b * q2.chunks;
+    const int px0 = chunk * q2.rpc, px1 = min(p.hw, px0 + q2.rpc);
+    const int t = threadIdx.x;
+    const int rif = Q >= 256 ? 1 : 256 / Q;
+    const int rl = Q >= 256 ? 0 : t / Q;
+    for (int q = Q >= 256 ? t : t - rl * Q; q < Q; q += 256) {         // Q < 256: one pass, rif pixel rows in flight
+        const bool active = rl < rif;
+        float mean[4], rstd[4], gam[4], bet[4], m1[4], m2[4];
+        if (PHASE >= 1) {
 #pragma unroll
-    for (int k = 0; k < LN_MAXK; ++k) { ag[k] = 0.0f; ab[k] = 0.0f; }
-    const int64_t rb = (int64_t)blockIdx.x * 64;
-    for (int i = 0; i < 16; ++i) {
-        const int64_t row = rb + wave * 16 + i;
-        if (row >= rows) break;
-        const float* xr = x + row * c;
-        const float* dr = dy + row * c;
-        float s = 0.0f, ss = 0.0f;
-        for (int k = 0; k < nk; ++k) {
-            const int ch = lane + 64 * k;
-            const float v = ch < c ? xr[ch] : 0.0f;
-            s += v; ss += v * v;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
-        const float mean = s / c;
-        float var = ss / c - mean * mean;
-        if (var < 0.0f) var = 0.0f;
-        const float rstd = 1.0f / sqrtf(var + eps);
-        float a1 = 0.0f, a2 = 0.0f;
-        for (int k = 0; k < nk; ++k) {
-            const int ch = lane + 64 * k;
-            if (ch < c) {
-                const float xh = (xr[ch] - mean) * rstd, d = dr[ch], dgm = d * gamma[ch];
-                a1 += dgm; a2 += dgm * xh;
-                if (k < LN_MAXK) { ag[k] += d * xh; ab[k] += d; }
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * q + j, g = c / cpg;
+                const float* st = q2.stats + ((int64_t)b * p.groups + g) * 4;
+                mean[j] = st[0]; rstd[j] = st[1];
+                if (PHASE == 2) { m1[j] = st[2]; m2[j] = st[3]; }
+                gam[j] = p.gamma[c]; bet[j] = p.beta[c];
             }
         }
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+        if (active)
+            for (int px = px0 + rl; px < px1; px += rif) {
+                const float4 xv4 = gn_ld4(p, b, px, q);
+                const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+                if (PHASE == 0) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
-        a1 /= c; a2 /= c;
-        for (int k = 0; k < nk; ++k) {
-            const int ch = lane + 64 * k;
-            if (ch < c) {
-                const float xh = (xr[ch] - mean) * rstd;
-                dx[row * c + ch] = rstd * (dr[ch] * gamma[ch] - a1 - xh * a2);
+                    for (int j = 0; j < 4; ++j) { s0[j] += xv[j]; s1[j] += xv[j] * xv[j]; }
+                } else {
+                    const float4 dy4 = *reinterpret_cast<const float4*>(p.dy + ((int64_t)b * p.hw + px) * C + 4 * q);
+                    const float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xhat = (xv[j] - mean[j]) * rstd[j];
+                        float dz = dyv[j];
+                        if (p.silu) {
+                            const float z = xhat * gam[j] + bet[j];
+                            const float sg = 1.0f / (1.0f + expf(-z));
+                            dz = dyv[j] * (sg * (1.0f + z * (1.0f - sg)));
+                        }
+                        if (PHASE == 1) { s0[j] += dz; s1[j] += dz * xhat; }
+                        else o[j] = rstd[j] * (dz * gam[j] - m1[j] - xhat * m2[j]);
+                    }
+                    if (PHASE == 2) {
+                        const int c = 4 * q;
+                        float* dst = c < p.c0 ? p.dx0 + ((int64_t)b * p.hw + px) * p.c0 + c : p.dx1 + ((int64_t)b * p.hw + px) * p.c1 + (c - p.c0);
+                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        if (PHASE < 2) {
+            float* dst = q2.part + (((int64_t)b * q2.chunks + chunk) * 2) * C + 4 * q;
+            if (rif == 1) {
+                if (active) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(s0[0], s0[1], s0[2], s0[3]);
+                    *reinterpret_cast<float4*>(dst + C) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                }
+            } else {                                                    // fixed-order sum over the rif row lanes of a quad
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { red[0][j][t] = s0[j]; red[1][j][t] = s1[j]; }
+                __syncthreads();
+                if (rl == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float a0 = 0.0f, a1 = 0.0f;
+                        for (int r = 0; r < rif; ++r) { a0 += red[0][j][r * Q + q]; a1 += red[1][j][r * Q + q]; }
+                        s0[j] = a0; s1[j] = a1;
+                    }
+                    *reinterpret_cast<float4*>(dst) = make_float4(s0[0], s0[1], s0[2], s0[3]);
+                    *reinterpret_cast<float4*>(dst + C) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                }
             }
         }
     }
+}
+
+// R1 / R2: one block per (image, group).  Each wave takes channels of the group in turn, its lanes the pixel chunks (double,
+// fixed order): PH 0 -> mean, rstd; PH 1 -> the image's dgamma / dbeta partials and m1, m2.
+template <int PH>
+__global__ __launch_bounds__(256) void gn_bwd2_reduce_kernel(const GnBwd2Args q2) {
+    const GnBwdArgs& p = q2.a;
+    __shared__ double red[2][4];
+    const int C = p.c0 + p.c1, cpg = C / p.groups;
+    const int b = blockIdx.x / p.groups, g = blockIdx.x - b * p.groups;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double ga = 0.0, gb = 0.0;                 // this wave's share of the group sums (identical in every lane)
+    for (int cc = wave; cc < cpg; cc += 4) {
+        const int c = g * cpg + cc;
+        double a = 0.0, bb = 0.0;
+        for (int ch = lane; ch < q2.chunks; ch += 64) {
+            const float* src = q2.part + (((int64_t)b * q2.chunks + ch) * 2) * C + c;
+            a += (double)src[0]; bb += (double)src[C];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); }
+        if (PH == 1) {
+            if (lane == 0 && p.dgamma_part) {
+                p.dbeta_part[(int64_t)b * C + c] = (float)a;
+                p.dgamma_part[(int64_t)b * C + c] = (float)bb;
+            }
+            const double gm = (double)p.gamma[c];
+            a *= gm; bb *= gm;
+        }
+        ga += a; gb += bb;
+    }
+    if (lane == 0) { red[0][wave] = ga; red[1][wave] = gb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double n = (double)p.hw * cpg;
+        float* st = q2.stats + ((int64_t)b * p.groups + g) * 4;
+        if (PH == 0) {
+            const double mean = s / n;
+            double var = ss / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            st[0] = (float)mean;
+            st[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+        } else {
+            st[2] = (float)(s / n);
+            st[3] = (float)(ss / n);
+        }
+    }
+}
+
+static inline int gn_bwd2_rpc(int batch, int hw) {
+    int64_t r = ((int64_t)hw * batch + 1023) / 1024;
+    return (int)(r < 8 ? 8 : (r > 64 ? 64 : r));
+}
+static inline bool gn_bwd2_applies(int hw, int c0, int c1) { return hw >= 256 && c0 % 4 == 0 && c1 % 4 == 0 && c0 + c1 <= 4096; }
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row, everything of a row in registers (NK channels per lane, one read of x and dy, the
+// next row's loads issued before this row's reductions); `rpw` consecutive rows per wave, per-block dgamma / dbeta partials
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXK = 32;      // channels per lane: c <= 2048
+template <int NK>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* dg_part, float* db_part, int64_t rows, int c, float eps, int rpw) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gm[NK], ag[NK], ab[NK], xv[NK], dv[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int ch = lane + 64 * k;
+        gm[k] = ch < c ? gamma[ch] : 0.0f;
+        ag[k] = 0.0f; ab[k] = 0.0f;
+    }
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * rpw;
+    auto load_row = [&](int64_t row, float (&xr)[NK], float (&dr)[NK]) {
+        const bool ok = row < rows;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int ch = lane + 64 * k;
+            const bool in = ok && ch < c;
+            xr[k] = in ? x[row * c + ch] : 0.0f;
+            dr[k] = in ? dy[row * c + ch] : 0.0f;
+        }
+    };
+    load_row(r0, xv, dv);
+    const float inv_c = 1.0f / (float)c;
+    for (int i = 0; i < rpw; ++i) {
+        const int64_t row = r0 + i;
+        if (row >= rows) break;
+        float xn[NK], dn[NK];
+        load_row(i + 1 < rpw ? row + 1 : rows, xn, dn);
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) s += xv[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * inv_c;
+        float ss = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float t = (lane + 64 * k < c) ? xv[k] - mean : 0.0f;
+            ss += t * t;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rstd = 1.0f / sqrtf(ss * inv_c + eps);
+        float a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float xh = (lane + 64 * k < c) ? (xv[k] - mean) * rstd : 0.0f, dgm = dv[k] * gm[k];
+            xv[k] = xh;
+            a1 += dgm; a2 += dgm * xh;
+            ag[k] += dv[k] * xh; ab[k] += dv[k];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        a1 *= inv_c; a2 *= inv_c;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < c) dx[row * c + ch] = rstd * (dv[k] * gm[k] - a1 - xv[k] * a2);
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { xv[k] = xn[k]; dv[k] = dn[k]; }
+    }
     if (dg_part) {
-        for (int k = 0; k < nk && k < LN_MAXK; ++k) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
             const int ch = lane + 64 * k;
             red[wave][lane] = ag[k];
             __syncthreads();
@@ -391,6 +565,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* x, cons
             __syncthreads();
         }
     }
+}
+
+// rows per wave: enough blocks to fill the chip (>= 1024 where the row count allows), at most 16 rows per wave
+static inline int ln_bwd_rpw(int64_t rows) {
+    int64_t r = (rows + 4095) / 4096;
+    return (int)(r < 2 ? 2 : (r > 16 ? 16 : r));
 }
 
 // dS = scale * P * (dP - sum_j dP P) per row (block per row)
@@ -643,17 +823,59 @@ extern "C" int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream) {
     a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1; a.dy = d->dy; a.gamma = d->gamma; a.beta = d->beta;
     a.dx0 = d->dx0; a.dx1 = d->dx1; a.dgamma_part = d->dgamma_part; a.dbeta_part = d->dbeta_part;
     a.batch = d->batch; a.hw = d->hw; a.groups = d->groups; a.silu = d->silu; a.eps = d->eps;
-    hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->ws && gn_bwd2_applies(d->hw, d->c0, d->c1)) {
+        MF_CHECK_ARG(mf_aligned16(d->x0) && mf_aligned16(d->x1) && mf_aligned16(d->dy) && mf_aligned16(d->dx0) && mf_aligned16(d->dx1) &&
+                     mf_aligned16(d->ws), "mf_groupnorm_bwd: tensors must be 16-byte aligned");
+        GnBwd2Args q{};
+        q.a = a;
+        q.rpc = gn_bwd2_rpc(d->batch, d->hw);
+        q.chunks = (d->hw + q.rpc - 1) / q.rpc;
+        q.stats = d->ws;
+        q.part = d->ws + (((int64_t)d->batch * d->groups * 4 + 3) & ~3ll);
+        const dim3 grid((unsigned)(d->batch * q.chunks));
+        hipLaunchKernelGGL(gn_bwd2_kernel<0>, grid, dim3(256), 0, s, q);
+        hipLaunchKernelGGL(gn_bwd2_reduce_kernel<0>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(gn_bwd2_kernel<1>, grid, dim3(256), 0, s, q);
+        hipLaunchKernelGGL(gn_bwd2_reduce_kernel<1>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(gn_bwd2_kernel<2>, grid, dim3(256), 0, s, q);
+        MF_CHECK_LAUNCH("mf_groupnorm_bwd(streaming)");
+        return MF_OK;
+    }
+    hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, a);
     MF_CHECK_LAUNCH("mf_groupnorm_bwd");
     return MF_OK;
+}
+
+extern "C" int64_t mf_groupnorm_bwd_ws_floats(int32_t batch, int32_t hw, int32_t channels, int32_t groups) {
+    if (batch < 1 || hw < 1 || channels < 1 || groups < 1) return 0;
+    const int rpc = gn_bwd2_rpc(batch, hw);
+    const int64_t chunks = (hw + rpc - 1) / rpc;
+    return (((int64_t)batch * groups * 4 + 3) & ~3ll) + (int64_t)batch * chunks * 2 * channels;
+}
+
+extern "C" int64_t mf_layernorm_bwd_parts(int64_t rows) {
+    const int rpw = ln_bwd_rpw(rows);
+    return (rows + 4 * rpw - 1) / (4 * rpw);
 }
 
 extern "C" int mf_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma_part, float* dbeta_part,
                                 int64_t rows, int32_t c, float eps, void* stream) {
     MF_CHECK_ARG(x && dy && gamma && dx && rows >= 1 && c >= 1 && c <= 64 * LN_MAXK, "mf_layernorm_bwd: bad arguments (c <= %d)", 64 * LN_MAXK);
     MF_CHECK_ARG((dgamma_part != nullptr) == (dbeta_part != nullptr), "mf_layernorm_bwd: dgamma / dbeta partials go together");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dx,
-                       dgamma_part, dbeta_part, rows, c, eps);
+    const int rpw = ln_bwd_rpw(rows);
+    const dim3 grid((unsigned)mf_layernorm_bwd_parts(rows));
+    const int nk = (c + 63) / 64;
+#define MF_LN_BWD(NK)                                                                                                              \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<NK>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dx, dgamma_part, dbeta_part, \
+                       rows, c, eps, rpw)
+    if (nk <= 1) MF_LN_BWD(1);
+    else if (nk <= 2) MF_LN_BWD(2);
+    else if (nk <= 5) MF_LN_BWD(5);
+    else if (nk <= 10) MF_LN_BWD(10);
+    else if (nk <= 20) MF_LN_BWD(20);
+    else MF_LN_BWD(32);
+#undef MF_LN_BWD
     MF_CHECK_LAUNCH("mf_layernorm_bwd");
     return MF_OK;
 }

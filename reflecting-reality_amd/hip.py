@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1 = 0, 1, 2, 3, 4, 5
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class MfhipError(RuntimeError):
@@ -80,6 +80,7 @@ class GroupNormBwdDesc(C.Structure):
         ("dgamma_part", C.c_void_p), ("dbeta_part", C.c_void_p),
         ("batch", C.c_int32), ("hw", C.c_int32), ("groups", C.c_int32), ("silu", C.c_int32),
         ("eps", C.c_float),
+        ("ws", C.c_void_p),
     ]
 
 
@@ -129,7 +130,7 @@ EXPORTS = [
     "mf_hwc_to_chw_affine",
     # training (csrc/train.hip)
     "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
-    "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_layernorm_bwd", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
+    "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_groupnorm_bwd_ws_floats", "mf_layernorm_bwd", "mf_layernorm_bwd_parts", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
     "mf_zero_insert2x", "mf_sumpool2x2", "mf_mse_grad", "mf_sumsq_ws_doubles", "mf_sumsq", "mf_clip_coef", "mf_adamw",
 ]
 
@@ -153,6 +154,9 @@ def load() -> C.CDLL:
     lib = C.CDLL(path)
     lib.mf_last_error.restype = C.c_char_p
     lib.mf_groupnorm_ws_floats.restype = C.c_int64
+    lib.mf_groupnorm_bwd_ws_floats.restype = C.c_int64
+    lib.mf_layernorm_bwd_parts.restype = C.c_int64
+    lib.mf_layernorm_bwd_parts.argtypes = [C.c_int64]
     for fn in ("mf_conv_wgrad_ws_floats", "mf_colsum_ws_floats", "mf_sumsq_ws_doubles", "mf_minmax_ws_floats", "mf_select_ws_bytes"):
         getattr(lib, fn).restype = C.c_int64
     if lib.mf_abi_version() != ABI_VERSION:
@@ -858,8 +862,9 @@ def colsum(x: torch.Tensor, n: int, *, segs: int = 1, rows_per_seg: Optional[int
 
 
 def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int, eps: float, silu: bool,
-                  x1: Optional[torch.Tensor] = None, want_param_grads: bool = True):
-    """Returns (dx0, dx1 or None, dgamma_part [B, C] or None, dbeta_part)."""
+                  x1: Optional[torch.Tensor] = None, want_param_grads: bool = True, streaming: bool = True):
+    """Returns (dx0, dx1 or None, dgamma_part [B, C] or None, dbeta_part).  streaming=False withholds the workspace, which keeps
+    the one-block-per-(image, group) kernel at every size (tests compare the two)."""
     _f32(x0, x1, dy, gamma, beta)
     b, c0 = x0.shape[0], x0.shape[-1]
     c1 = x1.shape[-1] if x1 is not None else 0
@@ -872,6 +877,8 @@ def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta:
     d.x0, d.x1, d.c0, d.c1, d.dy = _ptr(x0), _ptr(x1), c0, c1, _ptr(dy)
     d.gamma, d.beta, d.dx0, d.dx1, d.dgamma_part, d.dbeta_part = _ptr(gamma), _ptr(beta), _ptr(dx0), _ptr(dx1), _ptr(dg), _ptr(db)
     d.batch, d.hw, d.groups, d.silu, d.eps = b, hw, groups, int(silu), eps
+    if streaming:
+        d.ws = _ptr(scratch("gn_bwd", int(load().mf_groupnorm_bwd_ws_floats(b, hw, c0 + c1, groups)), x0.device))
     _check(load().mf_groupnorm_bwd(C.byref(d), _stream()), "mf_groupnorm_bwd")
     return dx0, dx1, dg, db
 
@@ -881,7 +888,7 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     c = x.shape[-1]
     rows = x.numel() // c
     dx = torch.empty_like(x)
-    nb = (rows + 63) // 64
+    nb = int(load().mf_layernorm_bwd_parts(rows))
     dg = torch.empty(nb, c, dtype=torch.float32, device=x.device) if want_param_grads else None
     db = torch.empty_like(dg) if want_param_grads else None
     _check(load().mf_layernorm_bwd(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(gamma.data_ptr()),

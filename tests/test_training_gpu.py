@@ -297,9 +297,15 @@ def test_conv_wgrad_and_dgrad(code_name, case):
 
 
 @pytest.mark.parametrize("silu", [True, False])
-@pytest.mark.parametrize("shape", [(2, 64, 0, 6, 10, 32), (2, 1280, 640, 8, 8, 32), (1, 320, 0, 64, 64, 32), (3, 32, 32, 5, 3, 16)])
+@pytest.mark.parametrize("shape", [(2, 64, 0, 6, 10, 32), (2, 1280, 640, 8, 8, 32), (1, 320, 0, 64, 64, 32), (3, 32, 32, 5, 3, 16),
+                                   (2, 1280, 1280, 16, 16, 32), (2, 320, 640, 32, 32, 32), (2, 640, 0, 17, 19, 32), (1, 64, 0, 40, 40, 32),
+                                   (1, 320, 0, 64, 64, 32, "blocks")])
 def test_groupnorm_backward(shape, silu):
-    b, c0, c1, h, w_, groups = shape
+    """hw >= 256 runs the streaming form (five launches, float4 over channels: 640 quads > 256 threads, 10 / 30 channels per group
+    straddling quads, a ragged last pixel chunk, 16 pixel rows in flight); "blocks" withholds the workspace = the one-block-per-
+    (image, group) kernel at the same size."""
+    streaming = len(shape) == 6
+    b, c0, c1, h, w_, groups = shape[:6]
     g = torch.Generator().manual_seed(52)
     x = (torch.randn(b, c0 + c1, h, w_, generator=g, dtype=torch.float64) * 1.7 + 0.3).requires_grad_(True)
     gamma = torch.randn(c0 + c1, generator=g, dtype=torch.float64).requires_grad_(True)
@@ -311,7 +317,7 @@ def test_groupnorm_backward(shape, silu):
     xa = x.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV)
     x0, x1 = (xa[..., :c0].contiguous(), xa[..., c0:].contiguous()) if c1 else (xa, None)
     dx0, dx1, dg, db = hip.groupnorm_bwd(x0, gy.float().permute(0, 2, 3, 1).contiguous().to(DEV), gamma.detach().float().to(DEV),
-                                         beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu, x1=x1)
+                                         beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu, x1=x1, streaming=streaming)
     dx = torch.cat([dx0, dx1], -1) if c1 else dx0
     e = (_rel(dx.permute(0, 3, 1, 2), x.grad), _rel(hip.colsum(dg, c0 + c1)[0], gamma.grad), _rel(hip.colsum(db, c0 + c1)[0], beta.grad))
     print(f"groupnorm_bwd{shape} silu={silu}: dx {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
@@ -320,7 +326,7 @@ def test_groupnorm_backward(shape, silu):
 
 def test_layernorm_softmax_geglu_silu_backward():
     g = torch.Generator().manual_seed(53)
-    for rows, c in ((130, 320), (64, 1280), (5, 32)):
+    for rows, c in ((130, 320), (64, 1280), (5, 32), (4100, 320), (1000, 640), (300, 2048), (77, 96), (70000, 64)):
         x = torch.randn(rows, c, generator=g, dtype=torch.float64).requires_grad_(True)
         gamma = torch.randn(c, generator=g, dtype=torch.float64).requires_grad_(True)
         beta = torch.randn(c, generator=g, dtype=torch.float64).requires_grad_(True)
