@@ -30,7 +30,21 @@ struct WgradArgs {
     float* out; int64_t ldo;            // dW (splitm == 1) or the slab workspace
     int64_t slab;                       // floats per slab
     int splitm, m_per_split, tiles_k_per_tap, tiles_n;
+    unsigned mul_howo, sh_howo, mul_wo, sh_wo;      // m / HoWo and rr / Wo by multiplication (wg_fastdiv)
 };
+
+// floor(x / d) for 0 <= x < 2^31 as (x * mul) >> sh with l = ceil(log2 d), mul = floor(2^(31+l) / d) + 1, sh = 31 + l
+// (Granlund-Montgomery: mul * d - 2^(31+l) <= d <= 2^l).  The 32-bit division it replaces expands to ~30 VALU instructions
+// and the staging loop needs eight of them per 32 pixels: more issue cycles than the tile's MFMAs.
+static inline void wg_fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    *mul = (unsigned)(((1ull << (31 + l)) / d) + 1);
+    *sh = 31 + l;
+}
+__device__ __forceinline__ int wg_fastdiv(int x, unsigned mul, unsigned sh) {
+    return (int)(((unsigned long long)(unsigned)x * mul) >> sh);
+}
 
 constexpr int WG_BN = 128, WG_BC = 128, WG_BP = 32, WG_PITCH = 132;   // LDS rows of 128 floats + 4 pad (16-byte aligned rows)
 
@@ -158,6 +172,194 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     if constexpr (DT == MF_F16X3) mf_raise_if_over(&g_split_ovf_train, wg_amax);
     // D[row = n (e & 3) + 8 (e >> 2) + 4 h][col = c r]
     float* out = p.out + (int64_t)blockIdx.y * p.slab;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wk * 64 + 32 * j + r;
+            if (c >= p.Ctot) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < p.N) out[(int64_t)n * p.ldo + (int64_t)tap * p.Ctot + c] = acc[i][j][e];
+            }
+        }
+}
+
+// ---- the 16-bit forms (MF_F16X3, MF_BF16X1), second version -------------------------------------------------------------
+// Same 128 (n) x 128 (c of one tap) tile and 64 x 64 per wave, but the operands are converted ONCE while they are staged
+// (above: every element is read from LDS as fp32 by two waves, one ds_read_b32 per element, and split in both) into 16-bit
+// planes [pixel][128 columns] (256-byte rows, 16-byte chunks XOR-swizzled), and the MFMA fragments — eight consecutive PIXELS of
+// one column — come out of two ds_read_b64_tr_b16 (the hardware's transposing read: a quarter of the read instructions, twice
+// the LDS bytes per clock of ds_read_b32).  Two LDS stages: the global loads of tile t+1 are in flight during the MFMAs of
+// tile t and are converted and written behind them; one barrier per 32 pixels.
+constexpr int WT_PLANE = WG_BP * 256;     // one 16-bit plane of a 32-pixel x 128-column tile: 8 KB
+
+__device__ __forceinline__ int wt_off(int row, int ch) {      // byte offset of 16-byte chunk ch of pixel row `row`
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+typedef __attribute__((ext_vector_type(4))) short wt_s4;
+__device__ __forceinline__ f16x8_t wt_frag(const char* base, int a0, int a1) {
+    // two transposed reads = pixels 0..3 and 4..7 of this lane's column
+    const wt_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wt_s4*)(base + a0));
+    const wt_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wt_s4*)(base + a1));
+    struct { wt_s4 a, b; } v{lo, hi};
+    return __builtin_bit_cast(f16x8_t, v);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p) {
+    constexpr int NPL = DT == MF_F16X3 ? 2 : 1;              // planes per operand: (hi, lo) or the one bf16 plane
+    constexpr int STAGE = 2 * NPL * WT_PLANE;                // Y planes, then A planes
+    extern __shared__ __attribute__((aligned(16))) char wt_smem[];
+    float wg_amax = 0.0f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    // 1-D grid, workgroups go to the 8 XCDs round-robin: with the pixel slabs a multiple of 8, XCD x takes slabs x, x + 8, ... and
+    // all the tiles of a slab run side by side on ONE XCD, marching through the same pixels: each dy / x tile crosses the fabric
+    // once per XCD and the other (tiles - 1) reads hit that XCD's L2 (a slab's dy + x do not fit in 4 MB, the moving window does)
+    const int tiles_all = p.tiles_n * p.tiles_k_per_tap * p.taps;
+    int bid, slab_id;
+    if ((p.splitm & 7) == 0) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        slab_id = xcd + 8 * (idx / tiles_all);
+        bid = idx % tiles_all;
+    } else {
+        slab_id = blockIdx.x / tiles_all;
+        bid = blockIdx.x - slab_id * tiles_all;
+    }
+    const int tile_n = bid % p.tiles_n;
+    bid /= p.tiles_n;
+    const int tile_k = bid % p.tiles_k_per_tap;
+    const int tap = bid / p.tiles_k_per_tap;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int n0 = tile_n * WG_BN, c0 = tile_k * WG_BC;
+    const int m_begin = slab_id * p.m_per_split;
+    int m_end = m_begin + p.m_per_split;
+    if (m_end > p.M) m_end = p.M;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // staging: thread -> (row = tid / 32 (+8 per pass), 4 consecutive columns of 128)
+    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    const int Hlim = p.Hin << p.ups, Wlim = p.Win << p.ups;
+    float4 vy0[4], va0[4], vy1[4], va1[4];        // two register sets: the loads of tile t+2 are issued before the MFMAs of tile t
+    auto load_tile = [&](int m0, float4 (&vy)[4], float4 (&va)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + srow + 8 * i;
+            vy[i] = make_float4(0, 0, 0, 0); va[i] = make_float4(0, 0, 0, 0);
+            if (m < m_end) {
+                const int n = n0 + scol;
+                if (n + 4 <= p.N) vy[i] = *reinterpret_cast<const float4*>(p.dy + (int64_t)m * p.lddy + n);
+                else if (n < p.N) {
+                    float t[4] = {0, 0, 0, 0};
+                    for (int j = 0; j < 4 && n + j < p.N; ++j) t[j] = p.dy[(int64_t)m * p.lddy + n + j];
+                    vy[i] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+                const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
+                const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
+                const int c = c0 + scol;
+                if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim && c < p.Ctot) {
+                    const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+                    const float* src = c < p.C0 ? p.a0 + pix * p.lda0 + c : p.a1 + pix * p.lda1 + (c - p.C0);
+                    va[i] = *reinterpret_cast<const float4*>(src);       // channel counts are multiples of 4: no straddle
+                }
+            }
+        }
+    };
+    auto put = [&](char* dst, const float4 v) {
+        if constexpr (DT == MF_BF16X1) {
+            *reinterpret_cast<uint2*>(dst) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+        } else {
+            wg_amax = mf_amax3(mf_amax3(wg_amax, v.x, v.y), v.z, v.w);
+            const auto h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+            const auto l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
+            const auto l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
+            *reinterpret_cast<uint2*>(dst) = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+            *reinterpret_cast<uint2*>(dst + WT_PLANE) = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+        }
+    };
+    auto write_tile = [&](char* st, const float4 (&vy)[4], const float4 (&va)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 8 * i;
+            const int off = wt_off(row, scol >> 3) + 8 * ((scol >> 2) & 1);
+            put(st + off, vy[i]);
+            put(st + NPL * WT_PLANE + off, va[i]);
+        }
+    };
+    // transposed-read addresses: lane 4q + pp of the 16-lane group g supplies row q of the group's 4-pixel x 16-column block,
+    // columns 4pp..4pp+3; group g = (pixel half h = g >> 1, column half g & 1) of the 32-column operand block
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int ay[2][2], aa[2][2];                                   // [32-column block][pixels 0..3 / 4..7]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * (g >> 1) + 4 * j + q;
+            ay[i][j] = wt_off(row, ((wn * 64 + 32 * i + 16 * (g & 1)) >> 3) + (pp >> 1)) + 8 * (pp & 1);
+            aa[i][j] = wt_off(row, ((wk * 64 + 32 * i + 16 * (g & 1)) >> 3) + (pp >> 1)) + 8 * (pp & 1) + NPL * WT_PLANE;
+        }
+
+    const int tiles = (m_end - m_begin + WG_BP - 1) / WG_BP;
+    auto compute = [&](const char* st) {
+#pragma unroll
+        for (int s = 0; s < WG_BP / 16; ++s) {
+            const char* sb = st + s * 16 * 256;               // 16 pixel rows further: the swizzle repeats every 16 rows
+            f16x8_t Y[NPL][2], A[NPL][2];
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    Y[pl][i] = wt_frag(sb + pl * WT_PLANE, ay[i][0], ay[i][1]);
+                    A[pl][i] = wt_frag(sb + pl * WT_PLANE, aa[i][0], aa[i][1]);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (DT == MF_BF16X1) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Y[0][i]),
+                                                                            __builtin_bit_cast(bf16x8_t, A[0][j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Y[NPL - 1][i], A[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Y[0][i], A[NPL - 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Y[0][i], A[0][j], acc[i][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+    if (tiles > 0) {
+        load_tile(m_begin, vy0, va0);
+        write_tile(wt_smem, vy0, va0);
+        if (tiles > 1) load_tile(m_begin + WG_BP, vy0, va0);
+    }
+    __syncthreads();
+    for (int t = 0; t < tiles; t += 2) {
+        // even tile t: stage 0; its successor t+1 sits in set 0, t+2 goes to set 1
+        if (t + 2 < tiles) load_tile(m_begin + (t + 2) * WG_BP, vy1, va1);
+        compute(wt_smem);
+        if (t + 1 < tiles) write_tile(wt_smem + STAGE, vy0, va0);
+        __syncthreads();
+        if (t + 1 >= tiles) break;
+        // odd tile t+1: stage 1; t+2 sits in set 1, t+3 goes to set 0
+        if (t + 3 < tiles) load_tile(m_begin + (t + 3) * WG_BP, vy0, va0);
+        compute(wt_smem + STAGE);
+        if (t + 2 < tiles) write_tile(wt_smem, vy1, va1);
+        __syncthreads();
+    }
+    if constexpr (DT == MF_F16X3) mf_raise_if_over(&g_split_ovf_train, wg_amax);
+    // D[row = n (e & 3) + 8 (e >> 2) + 4 h][col = c r]
+    float* out = p.out + (int64_t)slab_id * p.slab;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -732,11 +934,14 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
         mf_set_error("mf_conv_wgrad: a0/a1/dy must be 16-byte aligned, lddy a multiple of 4");
         return MF_EALIGN;
     }
+    static const bool wgrad_xcd = getenv("MFHIP_WGRAD_NO_XCD") == nullptr;            // developer A/B
     WgradArgs a{};
     a.a0 = d->a0; a.a1 = d->a1; a.C0 = d->c0; a.Ctot = d->c0 + d->c1; a.lda0 = d->lda0; a.lda1 = d->lda1;
     a.Hin = d->h_in; a.Win = d->w_in; a.Ho = d->h_out; a.Wo = d->w_out; a.HoWo = d->h_out * d->w_out;
     a.KW = d->kw; a.taps = d->kh * d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.ups = d->upsample;
     a.dy = d->dy; a.lddy = d->lddy;
+    wg_fastdiv_make((unsigned)a.HoWo, &a.mul_howo, &a.sh_howo);
+    wg_fastdiv_make((unsigned)a.Wo, &a.mul_wo, &a.sh_wo);
     const int64_t M64 = (int64_t)d->batch * d->h_out * d->w_out;
     MF_CHECK_ARG(M64 < (1ll << 31), "mf_conv_wgrad: M too large");
     a.M = (int)M64; a.N = d->n;
@@ -751,6 +956,7 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
         const int cap = a.M / 256 < 1 ? 1 : a.M / 256;
         if (sm > cap) sm = cap;
         if (sm > 64) sm = 64;
+        if (sm > 8 && d->dtype != MF_F32 && wgrad_xcd) sm = (sm + 4) / 8 * 8;            // whole slabs per XCD (conv_wgrad_tr_kernel)
         if (sm > 1 && (d->ws == nullptr || (int64_t)sm * a.N * K > d->ws_floats)) {
             sm = d->ws ? (int)(d->ws_floats / ((int64_t)a.N * K)) : 1;
             if (sm < 1) sm = 1;
@@ -760,6 +966,7 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
                  (long long)sm * a.N * K);
     a.m_per_split = ((a.M + sm - 1) / sm + WG_BP - 1) / WG_BP * WG_BP;
     a.splitm = (a.M + a.m_per_split - 1) / a.m_per_split;
+    if (a.splitm < sm && (sm & 7) == 0 && sm >= 8) a.splitm = sm;                       // keep the multiple of 8 (empty tail slabs write zeros)
     const bool direct = a.splitm == 1 && !d->accumulate;
     a.out = direct ? d->dw : d->ws;
     a.ldo = direct ? d->lddw : K;
@@ -767,9 +974,23 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     MF_CHECK_ARG(direct || d->ws, "mf_conv_wgrad: accumulate needs a workspace");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)a.splitm);
+    const dim3 grid1((unsigned)(tiles * a.splitm));
+    static const bool old_form = getenv("MFHIP_WGRAD_V1") != nullptr;        // developer A/B: the first version of the 16-bit forms
     if (d->dtype == MF_F32) hipLaunchKernelGGL(conv_wgrad_kernel<MF_F32>, grid, dim3(256), 0, s, a);
-    else if (d->dtype == MF_BF16X1) hipLaunchKernelGGL(conv_wgrad_kernel<MF_BF16X1>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<MF_F16X3>, grid, dim3(256), 0, s, a);
+    else if (old_form) {
+        if (d->dtype == MF_BF16X1) hipLaunchKernelGGL(conv_wgrad_kernel<MF_BF16X1>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv_wgrad_kernel<MF_F16X3>, grid, dim3(256), 0, s, a);
+    } else if (d->dtype == MF_BF16X1) {
+        hipLaunchKernelGGL(conv_wgrad_tr_kernel<MF_BF16X1>, grid1, dim3(256), 2 * 2 * WT_PLANE, s, a);
+    } else {
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tr_kernel<MF_F16X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * 4 * WT_PLANE);
+            return true;
+        }();
+        (void)attr;
+        hipLaunchKernelGGL(conv_wgrad_tr_kernel<MF_F16X3>, grid1, dim3(256), 2 * 4 * WT_PLANE, s, a);
+    }
     MF_CHECK_LAUNCH("mf_conv_wgrad");
     if (!direct) {
         hipLaunchKernelGGL(sum_slabs_kernel, dim3(grid_for((int64_t)a.N * K)), dim3(256), 0, s, d->ws, a.splitm, a.slab, d->dw, d->lddw, a.N,
