@@ -31,6 +31,8 @@ struct WgradArgs {
     int64_t slab;                       // floats per slab
     int splitm, m_per_split, tiles_k_per_tap, tiles_n;
     unsigned mul_howo, sh_howo, mul_wo, sh_wo;      // m / HoWo and rr / Wo by multiplication (wg_fastdiv)
+    int slabs_xcd;                                  // the first slabs_xcd (a multiple of 8) slabs are pinned to XCDs
+    int acc_out;                                    // out += (one slab accumulating into dW)
 };
 
 // floor(x / d) for 0 <= x < 2^31 as (x * mul) >> sh with l = ceil(log2 d), mul = floor(2^(31+l) / d) + 1, sh = 31 + l
@@ -222,11 +224,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
     // once per XCD and the other (tiles - 1) reads hit that XCD's L2 (a slab's dy + x do not fit in 4 MB, the moving window does)
     const int tiles_all = p.tiles_n * p.tiles_k_per_tap * p.taps;
     int bid, slab_id;
-    if ((p.splitm & 7) == 0) {
+    if ((int)blockIdx.x < p.slabs_xcd * tiles_all) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         slab_id = xcd + 8 * (idx / tiles_all);
         bid = idx % tiles_all;
-    } else {
+    } else {                                                  // the remaining (< 8) slabs: spread over all XCDs
         slab_id = blockIdx.x / tiles_all;
         bid = blockIdx.x - slab_id * tiles_all;
     }
@@ -248,53 +250,64 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    // staging: thread -> (row = tid / 32 (+8 per pass), 4 consecutive columns of 128)
-    const int srow = tid >> 5, scol = (tid & 31) * 4;
+    // staging: thread -> (pixel row tid / 8 of the 32, 16 consecutive columns of 128): ONE row's coordinates per thread and tile
+    const int srow = tid >> 3, scol = (tid & 7) * 16;
     const int Hlim = p.Hin << p.ups, Wlim = p.Win << p.ups;
     float4 vy0[4], va0[4], vy1[4], va1[4];        // two register sets: the loads of tile t+2 are issued before the MFMAs of tile t
     auto load_tile = [&](int m0, float4 (&vy)[4], float4 (&va)[4]) {
+        const int m = m0 + srow;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + srow + 8 * i;
-            vy[i] = make_float4(0, 0, 0, 0); va[i] = make_float4(0, 0, 0, 0);
-            if (m < m_end) {
-                const int n = n0 + scol;
-                if (n + 4 <= p.N) vy[i] = *reinterpret_cast<const float4*>(p.dy + (int64_t)m * p.lddy + n);
+        for (int k = 0; k < 4; ++k) { vy[k] = make_float4(0, 0, 0, 0); va[k] = make_float4(0, 0, 0, 0); }
+        if (m < m_end) {
+            const float* yrow = p.dy + (int64_t)m * p.lddy;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = n0 + scol + 4 * k;
+                if (n + 4 <= p.N) vy[k] = *reinterpret_cast<const float4*>(yrow + n);
                 else if (n < p.N) {
                     float t[4] = {0, 0, 0, 0};
-                    for (int j = 0; j < 4 && n + j < p.N; ++j) t[j] = p.dy[(int64_t)m * p.lddy + n + j];
-                    vy[i] = make_float4(t[0], t[1], t[2], t[3]);
+                    for (int j = 0; j < 4 && n + j < p.N; ++j) t[j] = yrow[n + j];
+                    vy[k] = make_float4(t[0], t[1], t[2], t[3]);
                 }
-                const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
-                const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
-                const int c = c0 + scol;
-                if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim && c < p.Ctot) {
-                    const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
-                    const float* src = c < p.C0 ? p.a0 + pix * p.lda0 + c : p.a1 + pix * p.lda1 + (c - p.C0);
-                    va[i] = *reinterpret_cast<const float4*>(src);       // channel counts are multiples of 4: no straddle
+            }
+            const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
+            const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
+            if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
+                const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+                const float* r0 = p.a0 + pix * p.lda0;
+                const float* r1 = p.a1 + pix * p.lda1 - p.C0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + scol + 4 * k;
+                    if (c < p.Ctot) va[k] = *reinterpret_cast<const float4*>((c < p.C0 ? r0 : r1) + c);   // channel counts are multiples of 4
                 }
             }
         }
     };
-    auto put = [&](char* dst, const float4 v) {
+    auto cvt = [&](const float4 v, uint2& hi, uint2& lo) {
         if constexpr (DT == MF_BF16X1) {
-            *reinterpret_cast<uint2*>(dst) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+            hi = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
         } else {
             wg_amax = mf_amax3(mf_amax3(wg_amax, v.x, v.y), v.z, v.w);
             const auto h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
             const auto l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
             const auto l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
-            *reinterpret_cast<uint2*>(dst) = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-            *reinterpret_cast<uint2*>(dst + WT_PLANE) = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+            hi = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+            lo = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
         }
+    };
+    auto put2 = [&](char* dst, const float4 u, const float4 v) {          // eight consecutive columns = one 16-byte chunk per plane
+        uint2 h0, l0, h1, l1;
+        cvt(u, h0, l0); cvt(v, h1, l1);
+        *reinterpret_cast<uint4*>(dst) = uint4{h0.x, h0.y, h1.x, h1.y};
+        if constexpr (NPL == 2) *reinterpret_cast<uint4*>(dst + WT_PLANE) = uint4{l0.x, l0.y, l1.x, l1.y};
     };
     auto write_tile = [&](char* st, const float4 (&vy)[4], const float4 (&va)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 8 * i;
-            const int off = wt_off(row, scol >> 3) + 8 * ((scol >> 2) & 1);
-            put(st + off, vy[i]);
-            put(st + NPL * WT_PLANE + off, va[i]);
+        for (int k = 0; k < 2; ++k) {
+            const int off = wt_off(srow, (scol >> 3) + k);
+            put2(st + off, vy[2 * k], vy[2 * k + 1]);
+            put2(st + NPL * WT_PLANE + off, va[2 * k], va[2 * k + 1]);
         }
     };
     // transposed-read addresses: lane 4q + pp of the 16-lane group g supplies row q of the group's 4-pixel x 16-column block,
@@ -369,7 +382,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = n0 + wn * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (n < p.N) out[(int64_t)n * p.ldo + (int64_t)tap * p.Ctot + c] = acc[i][j][e];
+                if (n < p.N) {
+                    float* o = out + (int64_t)n * p.ldo + (int64_t)tap * p.Ctot + c;
+                    *o = p.acc_out ? *o + acc[i][j][e] : acc[i][j][e];
+                }
             }
         }
 }
@@ -951,26 +967,40 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     a.tiles_k_per_tap = (a.Ctot + WG_BC - 1) / WG_BC;
     const int64_t tiles = (int64_t)a.tiles_n * a.tiles_k_per_tap * a.taps;
     int sm = d->splitm;
+    const bool tr_form = d->dtype != MF_F32 && getenv("MFHIP_WGRAD_V1") == nullptr;
     if (sm <= 0) {
-        sm = (int)((1024 + tiles - 1) / tiles);
-        const int cap = a.M / 256 < 1 ? 1 : a.M / 256;
-        if (sm > cap) sm = cap;
-        if (sm > 64) sm = 64;
-        if (sm > 8 && d->dtype != MF_F32 && wgrad_xcd) sm = (sm + 4) / 8 * 8;            // whole slabs per XCD (conv_wgrad_tr_kernel)
-        if (sm > 1 && (d->ws == nullptr || (int64_t)sm * a.N * K > d->ws_floats)) {
-            sm = d->ws ? (int)(d->ws_floats / ((int64_t)a.N * K)) : 1;
-            if (sm < 1) sm = 1;
+        int cap = a.M / 256 < 1 ? 1 : a.M / 256;
+        if (cap > 64) cap = 64;
+        if (d->ws == nullptr) cap = 1;
+        else if ((int64_t)cap * a.N * K > d->ws_floats) cap = (int)(d->ws_floats / ((int64_t)a.N * K)) < 1 ? 1 : (int)(d->ws_floats / ((int64_t)a.N * K));
+        if (!tr_form) {
+            sm = (int)((1024 + tiles - 1) / tiles);
+            if (sm > cap) sm = cap;
+        } else {
+            // cost in units of one 32-pixel tile step of one resident block (~1.3 us): rounds of 512 resident blocks (2 per CU) x
+            // steps per block, plus the slabs' write + read (N K floats each way per slab, ~4 TB/s) unless one slab writes dW itself
+            double best = 1e300;
+            sm = 1;
+            for (int c = 1; c <= cap; ++c) {
+                const int64_t blocks = tiles * c, rounds = (blocks + 511) / 512;
+                const int64_t steps = (((int64_t)a.M + c - 1) / c + WG_BP - 1) / WG_BP;
+                const double slab_us = c == 1 ? 0.0 : (double)c * a.N * K * 8.0 / 4.0e6;
+                const double cost = (double)rounds * steps * 1.3 + slab_us + 4.0;     // + launch of the slab sum
+                if (cost < best * 0.98) { best = cost; sm = c; }                      // a larger split has to pay for itself
+            }
         }
     }
     MF_CHECK_ARG(sm == 1 || (d->ws && (int64_t)sm * a.N * K <= d->ws_floats), "mf_conv_wgrad: split-M=%d needs %lld workspace floats", sm,
                  (long long)sm * a.N * K);
     a.m_per_split = ((a.M + sm - 1) / sm + WG_BP - 1) / WG_BP * WG_BP;
     a.splitm = (a.M + a.m_per_split - 1) / a.m_per_split;
-    if (a.splitm < sm && (sm & 7) == 0 && sm >= 8) a.splitm = sm;                       // keep the multiple of 8 (empty tail slabs write zeros)
-    const bool direct = a.splitm == 1 && !d->accumulate;
+    // one slab: the 16-bit kernel adds into dW itself (single writer per element: still deterministic)
+    const bool direct = a.splitm == 1 && (!d->accumulate || tr_form);
+    a.acc_out = direct && d->accumulate;
     a.out = direct ? d->dw : d->ws;
     a.ldo = direct ? d->lddw : K;
     a.slab = (int64_t)a.N * K;
+    a.slabs_xcd = wgrad_xcd ? a.splitm / 8 * 8 : 0;
     MF_CHECK_ARG(direct || d->ws, "mf_conv_wgrad: accumulate needs a workspace");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)tiles, (unsigned)a.splitm);
