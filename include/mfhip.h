@@ -372,6 +372,13 @@ int mf_sizeof_wgrad_desc(void);
 int64_t mf_conv_wgrad_ws_floats(const mf_wgrad_desc* d);
 int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream);
 
+/* fp32 weight [rows][k] (row stride ldw) -> mf_gemm_desc's w_split layout for MF_F16X3 / MF_BF16X3: out = 16-bit
+ * [rows][2 * kp], kp = round_up(k, 32), per 32 k the 32 high halves then the 32 low halves (hi = RNE(w), lo = RNE(w - hi)),
+ * zero padded.  The device form of what the inference weights get once on the host: training re-splits the weights the
+ * optimizer just changed (models.py / autograd.py), the frozen network's once.  An |w| > 65504 under MF_F16X3 raises the
+ * flag mf_split_overflow() reports. */
+int mf_split_pack(const float* w, int64_t ldw, void* out, int64_t rows, int32_t k, int32_t dtype, void* stream);
+
 /* y[z][c][r] = x[z][r][c] for nz matrices: element strides ldx / ldy between rows, zsx / zsy between matrices (signed:
  * a negative zsy with y pointing at the last matrix writes the batch in reverse — the tap flip of a dgrad weight) */
 int mf_transpose(const float* x, float* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,

@@ -104,6 +104,12 @@ def _dgrad_weight(cw, tape: Tape) -> torch.Tensor:
         wd = torch.empty(ct, taps * n, dtype=torch.float32, device=cw.w.device)
         # per tap t: x_t[n][c] = w[n][t*ct + c] (ld taps*ct)  ->  y[c][(taps-1-t)*n + n'] (ld taps*n): zsy < 0 flips the taps
         hip.transpose(cw.w, n, ct, nz=taps, ldx=taps * ct, ldy=taps * n, zsx=ct, zsy=-n, out=wd, y_offset=(taps - 1) * n)
+        cw._wd_split, cw._wd_ld = 0, taps * n
+        from . import ops
+        if ops.PRESPLIT_TRAINING and tape.code in (hip.MF_F16X3, hip.MF_BF16X3):
+            # (hi, lo) halves packed once per weight generation: the pre-split GEMM forms (ConvWeight.operand)
+            wd, cw._wd_ld = hip.split_pack(wd, tape.code)
+            cw._wd_split = 1
         cw._wd, cw._wd_gen = wd, cw.generation()
     return cw._wd
 
@@ -152,9 +158,9 @@ def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, 
                 continue
             if tape.needs(seg):
                 dx = torch.empty(batch, hu, wu, cs, dtype=torch.float32, device=x.device)
-                hip.gemm_conv(a, wd[off:off + cs], dx, dtype=tape.code, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw, h_out=hu,
-                              w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l, ldw=taps * n,
-                              n=cs)
+                hip.gemm_conv(a, wd[off:off + cs], dx, dtype=tape.code, w_split=cw._wd_split, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
+                              h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
+                              ldw=cw._wd_ld, n=cs)
                 outs.append((seg, hip.sumpool2x2(dx) if upsample else dx))
             off += cs
         for seg, dx in outs:

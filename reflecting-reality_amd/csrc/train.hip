@@ -390,6 +390,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
         }
 }
 
+// fp32 [rows][k] (row stride ldw) -> mf_gemm_desc's w_split layout: per 32 k, [32 high halves | 32 low halves], rows zero-padded
+// to kp = round_up(k, 32); hi = RNE(w), lo = RNE(w - hi) (bit-identical to the host's torch split).  The trainable weights
+// change every optimizer step: one pass over them buys the pre-split GEMM forms for the step's forward and data gradients.
+template <int DT>      // MF_F16X3 or MF_BF16X3
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, int64_t ldw, unsigned short* __restrict__ out, int64_t rows,
+                                                         int k, int kp) {
+    const int64_t quads = rows * (kp >> 2);
+    float amax = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / (kp >> 2);
+        const int c = (int)(i - row * (kp >> 2)) * 4;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = c + j < k ? w[row * ldw + c + j] : 0.0f;
+        unsigned short hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (DT == MF_F16X3) {
+                amax = fmaxf(amax, fabsf(v[j]));
+                const _Float16 h = (_Float16)v[j];
+                const _Float16 l = (_Float16)(v[j] - (float)h);
+                hi[j] = __builtin_bit_cast(unsigned short, h); lo[j] = __builtin_bit_cast(unsigned short, l);
+            } else {
+                hi[j] = f32_to_bf16(v[j]);
+                lo[j] = f32_to_bf16(v[j] - bf16_to_f32(hi[j]));
+            }
+        }
+        unsigned short* dst = out + row * 2 * (int64_t)kp + (c >> 5) * 64 + (c & 31);
+        *reinterpret_cast<uint2*>(dst) = uint2{(unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16)};
+        *reinterpret_cast<uint2*>(dst + 32) = uint2{(unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16)};
+    }
+    if constexpr (DT == MF_F16X3) mf_raise_if_over(&g_split_ovf_train, amax);
+}
+
 // out[i] (+)= sum_z slabs[z][i]   (rows of `cols` floats, output row stride ldo)
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* ws, int nslab, int64_t slab, float* out, int64_t ldo,
                                                         int rows, int cols, int accumulate) {
@@ -1027,6 +1061,20 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
                            (int)K, d->accumulate);
         MF_CHECK_LAUNCH("mf_conv_wgrad(sum slabs)");
     }
+    return MF_OK;
+}
+
+extern "C" int mf_split_pack(const float* w, int64_t ldw, void* out, int64_t rows, int32_t k, int32_t dtype, void* stream) {
+    MF_CHECK_ARG(w && out && rows >= 1 && k >= 1 && ldw >= k, "mf_split_pack: bad arguments");
+    MF_CHECK_ARG(dtype == MF_F16X3 || dtype == MF_BF16X3, "mf_split_pack: dtype must be MF_F16X3 or MF_BF16X3");
+    MF_CHECK_ARG((((uintptr_t)out) & 7) == 0, "mf_split_pack: out must be 8-byte aligned");
+    const int kp = (k + 31) / 32 * 32;
+    const unsigned blocks = grid_for(rows * (kp / 4));
+    if (dtype == MF_F16X3)
+        hipLaunchKernelGGL(split_pack_kernel<MF_F16X3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ldw, (unsigned short*)out, rows, k, kp);
+    else
+        hipLaunchKernelGGL(split_pack_kernel<MF_BF16X3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ldw, (unsigned short*)out, rows, k, kp);
+    MF_CHECK_LAUNCH("mf_split_pack");
     return MF_OK;
 }
 

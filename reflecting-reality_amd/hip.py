@@ -129,7 +129,7 @@ EXPORTS = [
     "mf_depth_normalize", "mf_select_ws_bytes", "mf_select_ranks", "mf_depth_percentile_normalize", "mf_bicubic_resize_crop",
     "mf_hwc_to_chw_affine",
     # training (csrc/train.hip)
-    "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
+    "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_split_pack", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
     "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_groupnorm_bwd_ws_floats", "mf_layernorm_bwd", "mf_layernorm_bwd_parts", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
     "mf_zero_insert2x", "mf_sumpool2x2", "mf_mse_grad", "mf_sumsq_ws_doubles", "mf_sumsq", "mf_clip_coef", "mf_adamw",
 ]
@@ -594,6 +594,24 @@ def split_pack_check(w: torch.Tensor, code: int) -> None:
     """Weights are split once on the host: refuse an fp16 split of a weight outside the fp16 range."""
     if code == MF_F16X3 and w.numel() and float(w.abs().max()) > 65504.0:
         raise SplitRangeError("f16x3: a weight exceeds the fp16 range (|w| > 65504); use precision 'bf16x3' or 'fp32'")
+
+
+def split_pack(w: torch.Tensor, code: int, out: Optional[torch.Tensor] = None):
+    """fp32 [rows, k] (row stride w.stride(0)) -> (16-bit [rows, 2 * kp] in mf_gemm_desc's w_split layout, kp) on the device
+    (mf_split_pack; ops.split_pack is the host-side twin the inference weights go through once)."""
+    _req_cuda(w, out)
+    if w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+        raise MfhipError("split_pack: fp32 [rows, k] with unit column stride")
+    rows, k = w.shape
+    kp = (k + 31) // 32 * 32
+    half = torch.float16 if code == MF_F16X3 else torch.bfloat16
+    if out is None:
+        out = torch.empty(rows, 2 * kp, dtype=half, device=w.device)
+    elif out.dtype != half or out.numel() != rows * 2 * kp or not out.is_contiguous():
+        raise MfhipError("split_pack: out must be a contiguous 16-bit [rows, 2 * kp] tensor")
+    _check(load().mf_split_pack(C.c_void_p(w.data_ptr()), C.c_int64(w.stride(0)), C.c_void_p(out.data_ptr()), C.c_int64(rows), k, code,
+                                _stream()), "mf_split_pack")
+    return out, kp
 
 
 def split_halves(x: torch.Tensor):

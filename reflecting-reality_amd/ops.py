@@ -15,6 +15,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional, Tuple, Union
 
+import os
+
 import torch
 
 from . import autograd, hip
@@ -137,9 +139,25 @@ class ConvWeight:
         self.p_w, self.p_bias, self._gen_src = p_w, p_bias, gen_src
         return self
 
+    def operand(self):
+        """(weight tensor, w_split, ldw) for mf_gemm_conv.  A weight that lives in a training arena is fp32 (the optimizer updates
+        it in place); under a split precision its (hi, lo) halves are packed on the device once per weight generation — every
+        step for a network that trains, once for a frozen one — because the pre-split GEMM forms are 25-30 % faster than
+        splitting the weight tile in registers (profiles/r03_presplit_weights_microbench.txt)."""
+        if self.p_w is None or not PRESPLIT_TRAINING or self.prec.code not in (hip.MF_F16X3, hip.MF_BF16X3):
+            return self.w, self.w_split, self.ldw
+        gen = self.generation()
+        if getattr(self, "_wp_gen", None) != gen or getattr(self, "_wp", None) is None:
+            self._wp, self._wp_ld = hip.split_pack(self.w.view(self.n, self.ldw), self.prec.code, out=getattr(self, "_wp", None))
+            self._wp_gen = gen
+        return self._wp, 1, self._wp_ld
+
     def generation(self) -> int:
         """Changes whenever the underlying weights do (layouts derived from them are rebuilt then)."""
         return self._gen_src._weights_gen if self._gen_src is not None else 0
+
+
+PRESPLIT_TRAINING = os.environ.get("MFHIP_NO_PRESPLIT", "0") != "1"      # developer A/B: split arena weights in registers
 
 
 def split_pack(w: torch.Tensor, code: int):
@@ -191,7 +209,8 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
     ho = (hu + pt + pb - cw.kh) // stride + 1
     wo = (wu + pl + pr - cw.kw) // stride + 1
     out = torch.empty(b, ho, wo, cw.n, dtype=out_dtype or cw.prec.act, device=x.device)
-    hip.gemm_conv(x, cw.w, out, dtype=cw.prec.code, w_split=cw.w_split, ldw=cw.ldw, c0=c0, lda0=c0, a1=x1, c1=c1, lda1=c1,
+    wt, wsp, wld = cw.operand()
+    hip.gemm_conv(x, wt, out, dtype=cw.prec.code, w_split=wsp, ldw=wld, c0=c0, lda0=c0, a1=x1, c1=c1, lda1=c1,
                   batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, kh=cw.kh, kw=cw.kw, stride=stride,
                   pad_t=pt, pad_l=pl, upsample=upsample, n=cw.n, bias=cw.bias,
                   temb=temb, ld_temb=(temb.stride(0) if temb is not None else 0),
@@ -217,7 +236,8 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
     m = x.numel() // k
     if out is None:
         out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
-    hip.gemm_conv(x, lw.w, out, dtype=lw.prec.code, w_split=lw.w_split, ldw=lw.ldw, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
+    wt, wsp, wld = lw.operand()
+    hip.gemm_conv(x, wt, out, dtype=lw.prec.code, w_split=wsp, ldw=wld, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
                   h_out=1, w_out=1, n=lw.n, bias=lw.bias, res0=res0, res1=res1, res1_rows=_shared_rows(res1, m, lw.n), alpha=alpha,
                   act=act, splitk=splitk, tile=tile, ln_colsum=lw.ln_colsum, ln_eps=lw.ln_eps)
     if TAPE is not None:

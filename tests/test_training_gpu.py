@@ -296,6 +296,26 @@ def test_conv_wgrad_and_dgrad(code_name, case):
         assert _rel(got[x1a.data_ptr()].view(x1a.shape).permute(0, 3, 1, 2), xs[1].grad) < tol
 
 
+@pytest.mark.parametrize("code_name", ["f16x3", "bf16x3"])
+def test_device_split_pack_matches_the_host_split(code_name):
+    """mf_split_pack (the per-step split of the weights the optimizer just changed) is bit-identical to ops.split_pack (the split the
+    inference weights get once on the host), including the zero padding of K to whole 32-blocks and a strided source."""
+    code = {"f16x3": hip.MF_F16X3, "bf16x3": hip.MF_BF16X3}[code_name]
+    g = torch.Generator().manual_seed(61)
+    for rows, k, ld in ((7, 36, 36), (320, 2880, 2880), (5, 31, 40), (64, 64, 64)):
+        buf = (torch.randn(rows, ld, generator=g) * torch.logspace(-6, 2, ld)[None, :]).to(DEV)
+        w = buf[:, :k]
+        got, kp = hip.split_pack(w, code)
+        ref, kp_ref = ops.split_pack(w.contiguous(), code)
+        assert kp == kp_ref and got.shape == ref.shape and got.dtype == ref.dtype
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    if code == hip.MF_F16X3:
+        hip.split_overflow(reset=True)
+        big = torch.full((4, 32), 7.0e4, device=DEV)
+        hip.split_pack(big, code)
+        assert hip.split_overflow(reset=True) != 0
+
+
 @pytest.mark.parametrize("silu", [True, False])
 @pytest.mark.parametrize("shape", [(2, 64, 0, 6, 10, 32), (2, 1280, 640, 8, 8, 32), (1, 320, 0, 64, 64, 32), (3, 32, 32, 5, 3, 16),
                                    (2, 1280, 1280, 16, 16, 32), (2, 320, 640, 32, 32, 32), (2, 640, 0, 17, 19, 32), (1, 64, 0, 40, 40, 32),
