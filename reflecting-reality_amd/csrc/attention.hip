@@ -423,35 +423,38 @@ struct AttnBwdArgs {
     float pshift, inv_pscale;
 };
 
+// Eight waves per block (256 column items against one streamed tile): two waves per SIMD, so one wave's exp2 / split VALU work
+// runs under the other's MFMAs, and each staged tile feeds twice the products of the first version's four waves.
+constexpr int BWD_NW = 8;
 template <int HD, bool KV>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
-    constexpr int NP = 2;
+__global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
+    constexpr int NP = 2, NW = BWD_NW;
     constexpr int DK = (HD + 15) / 16 * 16, KS = DK / 16;
     constexpr int DV = (HD + 31) / 32 * 32, DT = DV / 32;
     constexpr int RBK = DK * 2 + 16, RBV = 144, RBO = DV * 4 + 16;
     constexpr int KCPR = RBK / 16, VCPR = RBV / 16;
     constexpr int KI = KCPR, VI = (HD * VCPR + 63) / 64;
-    constexpr int KPW = (KI + 3) / 4, VPW = (VI + 3) / 4;
+    constexpr int KPW = (KI + NW - 1) / NW, VPW = (VI + NW - 1) / NW;
     constexpr int K_BYTES = 64 * RBK;
     constexpr int V_BYTES = (DV * RBV > VI * 1024 ? DV * RBV : VI * 1024);
     constexpr int NT = KV ? 2 : 1;                            // transposed operands per tile
     constexpr int ST_BYTES = KV ? 2 * 1024 : 0;                // lse | dd of the 64 tile rows (dK/dV pass): one 1-KB DMA span each
     constexpr int R2_OFF = NP * K_BYTES, T1_OFF = 2 * NP * K_BYTES, T2_OFF = T1_OFF + NP * V_BYTES, ST_OFF = T1_OFF + NT * NP * V_BYTES;
     constexpr int BUF_BYTES = ST_OFF + ST_BYTES;
-    constexpr int O_BYTES = 4 * 32 * RBO;
+    constexpr int O_BYTES = NW * 32 * RBO;
     constexpr int LDS_BYTES = 2 * BUF_BYTES > O_BYTES ? 2 * BUF_BYTES : O_BYTES;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int cblocks = (p.sc + 127) >> 7;
+    const int cblocks = (p.sc + NW * 32 - 1) / (NW * 32);
     const int bx = blockIdx.x % cblocks, bh = blockIdx.x / cblocks;
     const int b = bh / p.heads, head = bh - b * p.heads;
-    const int c0 = bx * 128 + wave * 32;
+    const int c0 = bx * (NW * 32) + wave * 32;
     const int ci = c0 + r;                                    // this lane's column item (query or key)
 
-    for (int i = tid * 16; i < 2 * BUF_BYTES; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+    for (int i = tid * 16; i < 2 * BUF_BYTES; i += NW * 64 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
 
     // column-side fragments: lane (item r, half h) holds X[item][16 ks + 8 h + j] of both planes
     uint4 f1[NP][KS], f2[NP][KS];
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
     unsigned roff1[KPW], roff2[KPW], toff1[VPW], toff2[VPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
-        const int g = (wv + 4 * i) * 64 + lane;
+        const int g = (wv + NW * i) * 64 + lane;
         const int R = g / KCPR, c = g - R * KCPR;
         const int kr = (R & ~12) | ((R & 4) << 1) | ((R & 8) >> 1);
         const int64_t o1 = ((int64_t)kr * p.ldr1 + c * 8) * 2, o2 = ((int64_t)kr * p.ldr2 + c * 8) * 2;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < VPW; ++i) {
-        const int g = (wv + 4 * i) * 64 + lane;
+        const int g = (wv + NW * i) * 64 + lane;
         const int row = g / VCPR, c = g - row * VCPR;
         const int64_t o1 = ((int64_t)row * p.ldt1 + c * 8) * 2, o2 = ((int64_t)row * p.ldt2 + c * 8) * 2;
         toff1[i] = (row < HD && c < 8 && o1 < 0x7fffffff) ? (unsigned)o1 : 0x80000000u;
@@ -528,9 +531,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
         for (int i = 0; i < KPW; ++i) {
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                if (wv + 4 * i < KI) {
-                    dma16_buf(roff1[i], srdR1[pl], lb + pl * K_BYTES + (wv + 4 * i) * 1024);
-                    dma16_buf(roff2[i], srdR2[pl], lb + R2_OFF + pl * K_BYTES + (wv + 4 * i) * 1024);
+                if (wv + NW * i < KI) {
+                    dma16_buf(roff1[i], srdR1[pl], lb + pl * K_BYTES + (wv + NW * i) * 1024);
+                    dma16_buf(roff2[i], srdR2[pl], lb + R2_OFF + pl * K_BYTES + (wv + NW * i) * 1024);
                 }
             roff1[i] += rstep1;
             roff2[i] += rstep2;
@@ -539,9 +542,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
         for (int i = 0; i < VPW; ++i) {
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl)
-                if (wv + 4 * i < VI) {
-                    dma16_buf(toff1[i], srdT1[pl], lb + T1_OFF + pl * V_BYTES + (wv + 4 * i) * 1024);
-                    if (KV) dma16_buf(toff2[i], srdT2[pl], lb + T2_OFF + pl * V_BYTES + (wv + 4 * i) * 1024);
+                if (wv + NW * i < VI) {
+                    dma16_buf(toff1[i], srdT1[pl], lb + T1_OFF + pl * V_BYTES + (wv + NW * i) * 1024);
+                    if (KV) dma16_buf(toff2[i], srdT2[pl], lb + T2_OFF + pl * V_BYTES + (wv + NW * i) * 1024);
                 }
             toff1[i] += 128;
             toff2[i] += 128;
@@ -843,8 +846,8 @@ static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
         a.lse = d->lse; a.dd = d->dd; a.out1 = d->dk; a.out2 = d->dv; a.ldo = d->ldo;
         a.heads = d->heads; a.sc = d->skv; a.sr = d->sq; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
         a.pshift = pshift; a.inv_pscale = inv_pscale;
-        dim3 grid((unsigned)(((d->skv + 127) / 128) * d->heads * d->batch));
-        hipLaunchKernelGGL((attn_bwd_kernel<HD, true>), grid, dim3(256), 0, s, a);
+        dim3 grid((unsigned)(((d->skv + BWD_NW * 32 - 1) / (BWD_NW * 32)) * d->heads * d->batch));
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, true>), grid, dim3(BWD_NW * 64), 0, s, a);
     }
     {   // dQ: a wave owns 32 queries and streams the key tiles
         AttnBwdArgs a{};
@@ -857,8 +860,8 @@ static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
         a.lse = d->lse; a.dd = d->dd; a.out1 = d->dq; a.out2 = nullptr; a.ldo = d->ldo;
         a.heads = d->heads; a.sc = d->sq; a.sr = d->skv; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
         a.pshift = pshift; a.inv_pscale = inv_pscale;
-        dim3 grid((unsigned)(((d->sq + 127) / 128) * d->heads * d->batch));
-        hipLaunchKernelGGL((attn_bwd_kernel<HD, false>), grid, dim3(256), 0, s, a);
+        dim3 grid((unsigned)(((d->sq + BWD_NW * 32 - 1) / (BWD_NW * 32)) * d->heads * d->batch));
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, false>), grid, dim3(BWD_NW * 64), 0, s, a);
     }
 }
 
