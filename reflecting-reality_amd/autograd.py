@@ -39,6 +39,7 @@ class Tape:
         self.grads: Dict[int, torch.Tensor] = {}
         self.stop = set()                      # storages that need no gradient (the batch's inputs)
         self.on_param_grad: Optional[Callable[[Param], None]] = None   # gradient-bucket hook (distributed.GradBuckets)
+        self.dgrad_rebuilt: list = []          # trainable weights whose data-gradient layout this backward had to rebuild
 
     # ---- bookkeeping ---------------------------------------------------------------------------------------
     def no_grad(self, *ts: Optional[torch.Tensor]) -> None:
@@ -95,22 +96,29 @@ class Tape:
 # =====================================================================================================================
 # backward closures
 # =====================================================================================================================
-def _dgrad_weight(cw, tape: Tape) -> torch.Tensor:
+def _dgrad_weight(cw, tape) -> torch.Tensor:
     """[Ctot][taps (flipped)][N]: the weight of the data-gradient convolution, laid out by mf_transpose once per
-    optimizer step (the master weight changes every step)."""
+    optimizer step (the master weight changes every step) into buffers the weight keeps (no allocation after the first
+    step: training.train_step rebuilds them on a side stream under the forward pass).  `tape`: a Tape or its compute code."""
+    code = tape if isinstance(tape, int) else tape.code
     gen = getattr(cw, "_wd_gen", None)
-    if gen != cw.generation() or getattr(cw, "_wd", None) is None:
+    if gen != cw.generation() or getattr(cw, "_wd", None) is None or getattr(cw, "_wd_code", None) != code:
         taps, n, ct = cw.kh * cw.kw, cw.n, cw.cin_pad
-        wd = torch.empty(ct, taps * n, dtype=torch.float32, device=cw.w.device)
+        wd = getattr(cw, "_wd_f32", None)
+        if wd is None:
+            wd = cw._wd_f32 = torch.empty(ct, taps * n, dtype=torch.float32, device=cw.w.device)
         # per tap t: x_t[n][c] = w[n][t*ct + c] (ld taps*ct)  ->  y[c][(taps-1-t)*n + n'] (ld taps*n): zsy < 0 flips the taps
         hip.transpose(cw.w, n, ct, nz=taps, ldx=taps * ct, ldy=taps * n, zsx=ct, zsy=-n, out=wd, y_offset=(taps - 1) * n)
         cw._wd_split, cw._wd_ld = 0, taps * n
         from . import ops
-        if ops.PRESPLIT_TRAINING and tape.code in (hip.MF_F16X3, hip.MF_BF16X3):
+        if ops.PRESPLIT_TRAINING and code in (hip.MF_F16X3, hip.MF_BF16X3):
             # (hi, lo) halves packed once per weight generation: the pre-split GEMM forms (ConvWeight.operand)
-            wd, cw._wd_ld = hip.split_pack(wd, tape.code)
+            prev = getattr(cw, "_wd", None)
+            wd, cw._wd_ld = hip.split_pack(wd, code, out=prev if (prev is not None and prev.dtype != torch.float32) else None)
             cw._wd_split = 1
-        cw._wd, cw._wd_gen = wd, cw.generation()
+        cw._wd, cw._wd_gen, cw._wd_code = wd, cw.generation(), code
+        if not isinstance(tape, int) and cw.p_w is not None and cw.p_w.grad is not None:
+            tape.dgrad_rebuilt.append(cw)              # a weight that trains: next step's prefetch list
     return cw._wd
 
 

@@ -159,6 +159,7 @@ class _ClipState:
 
 
 _clip_states: dict = {}
+DGRAD_PREFETCH = os.environ.get("MFHIP_NO_DGRAD_PREFETCH", "0") != "1"     # developer A/B
 
 
 def clip_grad_norm_(models: Sequence, max_norm: float, loss_scale: float = 1.0):
@@ -192,6 +193,21 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     tape = autograd.Tape(prec.tape_code)
     if grad_sync is not None:
         grad_sync.begin(tape)
+    # The data-gradient layouts of the weights that train (transposed, tap-flipped, split: ~540 small launches) depend only on
+    # the weights the optimizer left behind: rebuild them on a side stream under the forward pass instead of inside the backward
+    # (the list is what the previous step's backward had to rebuild; the first step builds them lazily).
+    dgrad_ready = None
+    prefetch = getattr(model, "_dgrad_prefetch", None)
+    if prefetch and DGRAD_PREFETCH:
+        dev = mods[0].device
+        side = getattr(model, "_side_stream", None)
+        if side is None:
+            side = model._side_stream = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for cw in prefetch:
+                autograd._dgrad_weight(cw, prec.tape_code)
+            dgrad_ready = side.record_event()
     ops.TAPE = tape
     try:
         loss, pred, target, weights = training_loss(model, noise_scheduler, latents, noise, timesteps, encoder_hidden_states,
@@ -211,7 +227,12 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     if prec.code == hip.MF_F16X3 and check_overflow:
         hip.split_overflow(reset=True)         # flags raised by earlier, unrelated work do not count against this step
     tape.add(pred, d_pred)
+    if dgrad_ready is not None:
+        torch.cuda.current_stream(mods[0].device).wait_event(dgrad_ready)
     tape.backward()
+    if tape.dgrad_rebuilt:
+        known = {id(c) for c in (prefetch or [])}
+        model._dgrad_prefetch = list(prefetch or []) + [c for c in tape.dgrad_rebuilt if id(c) not in known]
     if grad_sync is not None:
         grad_sync.finish()
     norm, coef = clip_grad_norm_(mods, max_grad_norm, loss_scale=scale)
