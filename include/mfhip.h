@@ -402,8 +402,11 @@ typedef struct mf_groupnorm_bwd_desc {
     int32_t batch, hw, groups, silu;
     float eps;
     float* ws;      /* mf_groupnorm_bwd_ws_floats() floats, 16-byte aligned; null = the one-block-per-group kernel only */
+    float* dgamma_acc; float* dbeta_acc;   /* [c0 + c1], nullable, INSTEAD of the partials: the gradients summed over the batch
+                                            * are ADDED here (needs mf_groupnorm_bwd_streams(...) != 0 and ws) */
 } mf_groupnorm_bwd_desc;
 int mf_sizeof_groupnorm_bwd_desc(void);
+int mf_groupnorm_bwd_streams(int32_t batch, int32_t hw, int32_t c0, int32_t c1);   /* 1: this shape runs the streaming form */
 int64_t mf_groupnorm_bwd_ws_floats(int32_t batch, int32_t hw, int32_t channels, int32_t groups);
 int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream);
 

@@ -14,9 +14,13 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional
 
+import os
+
 import torch
 
 from . import hip
+
+GN_GRAD_ACC = os.environ.get("MFHIP_NO_GN_ACC", "0") != "1"      # developer A/B: per-image partials + mf_colsum instead
 
 
 class Param:
@@ -184,11 +188,12 @@ def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, gro
             return
         want = p_gamma.grad is not None
         dx0, dx1, dg, db = hip.groupnorm_bwd(x0, g.view(out.shape), p_gamma.data, p_beta.data, groups=groups, eps=eps, silu=silu,
-                                             x1=x1, want_param_grads=want)
+                                             x1=x1, want_param_grads=want, grad_acc=(p_gamma.grad, p_beta.grad) if (want and GN_GRAD_ACC) else None)
         if want:
-            c = dg.shape[1]
-            hip.colsum(dg, c, out=p_gamma.grad.view(1, c), accumulate=True)
-            hip.colsum(db, c, out=p_beta.grad.view(1, c), accumulate=True)
+            if dg is not None:                     # small maps: per-image partials (the streaming form adds into the arena itself)
+                c = dg.shape[1]
+                hip.colsum(dg, c, out=p_gamma.grad.view(1, c), accumulate=True)
+                hip.colsum(db, c, out=p_beta.grad.view(1, c), accumulate=True)
             tape.param_grad_done(p_gamma)
             tape.param_grad_done(p_beta)
         tape.add(x0, dx0)

@@ -586,6 +586,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const GnBwdArgs p) {
 // C: dx = rstd * (dz * gamma - m1 - xhat * m2)
 // One block per (image, group) as above leaves one block per CU and 40-byte runs per pixel at 320 channels (10 per group):
 // ~125 us on average over the step's GroupNorms; the sums are fp32 over the <= 64 pixels of a chunk, double across chunks.
+constexpr int GN_BWD_MAX_BATCH = 64;          // images per call of the fused parameter-gradient form (gn_bwd2_reduce_acc_kernel)
 struct GnBwd2Args {
     GnBwdArgs a;
     float* part;        // [batch][chunks][2][C]
@@ -724,6 +725,48 @@ __global__ __launch_bounds__(256) void gn_bwd2_reduce_kernel(const GnBwd2Args q2
             st[2] = (float)(s / n);
             st[3] = (float)(ss / n);
         }
+    }
+}
+
+// R2 with the parameter gradients finished in the same launch: one block per GROUP, images in turn; dgamma / dbeta of a channel are
+// summed over the images in a register (fixed order) and ADDED to the gradient arena — the per-image partials and the two
+// mf_colsum calls (four launches) that used to follow every GroupNorm backward are gone.
+__global__ __launch_bounds__(256) void gn_bwd2_reduce_acc_kernel(const GnBwd2Args q2, float* dgamma_acc, float* dbeta_acc) {
+    const GnBwdArgs& p = q2.a;
+    __shared__ double red[2][4][GN_BWD_MAX_BATCH];
+    const int C = p.c0 + p.c1, cpg = C / p.groups;
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * 4 * GN_BWD_MAX_BATCH; i += 256) (&red[0][0][0])[i] = 0.0;
+    __syncthreads();
+    for (int cc = wave; cc < cpg; cc += 4) {
+        const int c = g * cpg + cc;
+        const double gm = (double)p.gamma[c];
+        double da = 0.0, db = 0.0;
+        for (int b = 0; b < p.batch; ++b) {
+            double a = 0.0, bb = 0.0;
+            for (int ch = lane; ch < q2.chunks; ch += 64) {
+                const float* src = q2.part + (((int64_t)b * q2.chunks + ch) * 2) * C + c;
+                a += (double)src[0]; bb += (double)src[C];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); }
+            da += a; db += bb;
+            if (lane == 0) { red[0][wave][b] += a * gm; red[1][wave][b] += bb * gm; }     // this wave's share of image b's group sums
+        }
+        if (lane == 0) {
+            dbeta_acc[c] += (float)da;
+            dgamma_acc[c] += (float)db;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < p.batch; b += 256) {
+        const double s = (red[0][0][b] + red[0][1][b]) + (red[0][2][b] + red[0][3][b]);
+        const double ss = (red[1][0][b] + red[1][1][b]) + (red[1][2][b] + red[1][3][b]);
+        const double n = (double)p.hw * cpg;
+        float* st = q2.stats + ((int64_t)b * p.groups + g) * 4;
+        st[2] = (float)(s / n);
+        st[3] = (float)(ss / n);
     }
 }
 
@@ -1111,6 +1154,10 @@ extern "C" int mf_colsum(const float* x, int64_t ldx, float* out, int64_t ldo, i
     return MF_OK;
 }
 
+extern "C" int mf_groupnorm_bwd_streams(int32_t batch, int32_t hw, int32_t c0, int32_t c1) {
+    return gn_bwd2_applies(hw, c0, c1) && batch <= GN_BWD_MAX_BATCH;
+}
+
 extern "C" int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream) {
     MF_CHECK_ARG(d && d->x0 && d->dy && d->gamma && d->beta && d->dx0, "mf_groupnorm_bwd: null pointer");
     const int C = d->c0 + d->c1;
@@ -1118,6 +1165,10 @@ extern "C" int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream) {
                  "mf_groupnorm_bwd: bad segments");
     MF_CHECK_ARG(d->groups >= 1 && C % d->groups == 0 && C / d->groups <= 256, "mf_groupnorm_bwd: groups must divide channels, <= 256 channels per group");
     MF_CHECK_ARG((d->dgamma_part != nullptr) == (d->dbeta_part != nullptr), "mf_groupnorm_bwd: dgamma / dbeta partials go together");
+    MF_CHECK_ARG((d->dgamma_acc != nullptr) == (d->dbeta_acc != nullptr) && !(d->dgamma_acc && d->dgamma_part),
+                 "mf_groupnorm_bwd: dgamma_acc / dbeta_acc go together and replace the partials");
+    MF_CHECK_ARG(!d->dgamma_acc || (d->ws && mf_groupnorm_bwd_streams(d->batch, d->hw, d->c0, d->c1)),
+                 "mf_groupnorm_bwd: dgamma_acc / dbeta_acc need the streaming form (mf_groupnorm_bwd_streams) and its workspace");
     GnBwdArgs a{};
     a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1; a.dy = d->dy; a.gamma = d->gamma; a.beta = d->beta;
     a.dx0 = d->dx0; a.dx1 = d->dx1; a.dgamma_part = d->dgamma_part; a.dbeta_part = d->dbeta_part;
@@ -1136,7 +1187,8 @@ extern "C" int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream) {
         hipLaunchKernelGGL(gn_bwd2_kernel<0>, grid, dim3(256), 0, s, q);
         hipLaunchKernelGGL(gn_bwd2_reduce_kernel<0>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
         hipLaunchKernelGGL(gn_bwd2_kernel<1>, grid, dim3(256), 0, s, q);
-        hipLaunchKernelGGL(gn_bwd2_reduce_kernel<1>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
+        if (d->dgamma_acc) hipLaunchKernelGGL(gn_bwd2_reduce_acc_kernel, dim3((unsigned)d->groups), dim3(256), 0, s, q, d->dgamma_acc, d->dbeta_acc);
+        else hipLaunchKernelGGL(gn_bwd2_reduce_kernel<1>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
         hipLaunchKernelGGL(gn_bwd2_kernel<2>, grid, dim3(256), 0, s, q);
         MF_CHECK_LAUNCH("mf_groupnorm_bwd(streaming)");
         return MF_OK;

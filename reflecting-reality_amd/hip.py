@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -81,6 +81,7 @@ class GroupNormBwdDesc(C.Structure):
         ("batch", C.c_int32), ("hw", C.c_int32), ("groups", C.c_int32), ("silu", C.c_int32),
         ("eps", C.c_float),
         ("ws", C.c_void_p),
+        ("dgamma_acc", C.c_void_p), ("dbeta_acc", C.c_void_p),
     ]
 
 
@@ -130,7 +131,7 @@ EXPORTS = [
     "mf_hwc_to_chw_affine",
     # training (csrc/train.hip)
     "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_split_pack", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
-    "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_groupnorm_bwd_ws_floats", "mf_layernorm_bwd", "mf_layernorm_bwd_parts", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
+    "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_groupnorm_bwd_ws_floats", "mf_groupnorm_bwd_streams", "mf_layernorm_bwd", "mf_layernorm_bwd_parts", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
     "mf_zero_insert2x", "mf_sumpool2x2", "mf_mse_grad", "mf_sumsq_ws_doubles", "mf_sumsq", "mf_clip_coef", "mf_adamw",
 ]
 
@@ -880,18 +881,25 @@ def colsum(x: torch.Tensor, n: int, *, segs: int = 1, rows_per_seg: Optional[int
 
 
 def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int, eps: float, silu: bool,
-                  x1: Optional[torch.Tensor] = None, want_param_grads: bool = True, streaming: bool = True):
+                  x1: Optional[torch.Tensor] = None, want_param_grads: bool = True, streaming: bool = True,
+                  grad_acc: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """Returns (dx0, dx1 or None, dgamma_part [B, C] or None, dbeta_part).  streaming=False withholds the workspace, which keeps
-    the one-block-per-(image, group) kernel at every size (tests compare the two)."""
+    the one-block-per-(image, group) kernel at every size (tests compare the two).  grad_acc = (dgamma, dbeta) fp32 [C]: where
+    the shape runs the streaming form the parameter gradients are ADDED there by the kernel itself and the partials come back
+    None; elsewhere it is ignored (sum the partials with colsum)."""
     _f32(x0, x1, dy, gamma, beta)
     b, c0 = x0.shape[0], x0.shape[-1]
     c1 = x1.shape[-1] if x1 is not None else 0
     hw = x0.numel() // (b * c0)
     dx0 = torch.empty_like(x0)
     dx1 = torch.empty_like(x1) if x1 is not None else None
-    dg = torch.empty(b, c0 + c1, dtype=torch.float32, device=x0.device) if want_param_grads else None
-    db = torch.empty_like(dg) if want_param_grads else None
+    fused = bool(grad_acc is not None and want_param_grads and streaming and load().mf_groupnorm_bwd_streams(b, hw, c0, c1))
+    dg = torch.empty(b, c0 + c1, dtype=torch.float32, device=x0.device) if (want_param_grads and not fused) else None
+    db = torch.empty_like(dg) if dg is not None else None
     d = GroupNormBwdDesc()
+    if fused:
+        _f32(*grad_acc)
+        d.dgamma_acc, d.dbeta_acc = _ptr(grad_acc[0]), _ptr(grad_acc[1])
     d.x0, d.x1, d.c0, d.c1, d.dy = _ptr(x0), _ptr(x1), c0, c1, _ptr(dy)
     d.gamma, d.beta, d.dx0, d.dx1, d.dgamma_part, d.dbeta_part = _ptr(gamma), _ptr(beta), _ptr(dx0), _ptr(dx1), _ptr(dg), _ptr(db)
     d.batch, d.hw, d.groups, d.silu, d.eps = b, hw, groups, int(silu), eps

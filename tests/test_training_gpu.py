@@ -342,6 +342,13 @@ def test_groupnorm_backward(shape, silu):
     e = (_rel(dx.permute(0, 3, 1, 2), x.grad), _rel(hip.colsum(dg, c0 + c1)[0], gamma.grad), _rel(hip.colsum(db, c0 + c1)[0], beta.grad))
     print(f"groupnorm_bwd{shape} silu={silu}: dx {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
     assert max(e) < 2e-5
+    if streaming and h * w_ >= 256:
+        # the form the training tape uses: parameter gradients ADDED to the arena by the kernel (no partials, no colsum)
+        acc = (torch.full((c0 + c1,), 0.5, device=DEV), torch.full((c0 + c1,), -0.25, device=DEV))
+        dx0b, dx1b, dg2, db2 = hip.groupnorm_bwd(x0, gy.float().permute(0, 2, 3, 1).contiguous().to(DEV), gamma.detach().float().to(DEV),
+                                                 beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu, x1=x1, grad_acc=acc)
+        assert dg2 is None and db2 is None and torch.equal(dx0b, dx0)
+        assert _rel(acc[0] - 0.5, gamma.grad) < 2e-5 and _rel(acc[1] + 0.25, beta.grad) < 2e-5
 
 
 def test_layernorm_softmax_geglu_silu_backward():
