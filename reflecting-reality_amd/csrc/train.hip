@@ -424,6 +424,177 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     if constexpr (DT == MF_F16X3) mf_raise_if_over(&g_split_ovf_train, amax);
 }
 
+// ---- 160 x 160 tiles, five waves ------------------------------------------------------------------------------------------
+// The same scheme on a 160 (n) x 160 (c) tile: wave w owns the 32 columns w of the c side and all five 32-row blocks of the n
+// side (5 accumulator blocks; one A fragment feeds five products).  The step's channel counts are multiples of 160 (320, 640,
+// 960, 1280, 1920, 2560): no padded third tile as with 128 (320 = 2.5 x 128), and 320 staged columns feed 160 x 160 products
+// per pixel where 256 fed 128 x 128 (1.56 x the products per byte: the kernel is bound by its operand traffic).  Planes are
+// [32 pixels][160 columns] with a 320-byte pitch: row q of a transposed read's 4-row block starts 16 banks after row q - 1, so
+// the reads are conflict-free without a swizzle.  80 KB of LDS (two stages) = two blocks per CU.
+constexpr int W160 = 160, W160_PITCH = 2 * W160, W160_PLANE = WG_BP * W160_PITCH;     // 10 KB per plane
+
+template <int DT, int NST>
+__global__ __launch_bounds__(320, 2) void conv_wgrad_tr160_kernel(const WgradArgs p) {
+    constexpr int NPL = DT == MF_F16X3 ? 2 : 1;
+    constexpr int STAGE = 2 * NPL * W160_PLANE;
+    extern __shared__ __attribute__((aligned(16))) char wt_smem[];
+    float wg_amax = 0.0f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_all = p.tiles_n * p.tiles_k_per_tap * p.taps;
+    int bid, slab_id;
+    if ((int)blockIdx.x < p.slabs_xcd * tiles_all) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        slab_id = xcd + 8 * (idx / tiles_all);
+        bid = idx % tiles_all;
+    } else {
+        slab_id = blockIdx.x / tiles_all;
+        bid = blockIdx.x - slab_id * tiles_all;
+    }
+    const int tile_n = bid % p.tiles_n;
+    bid /= p.tiles_n;
+    const int tile_k = bid % p.tiles_k_per_tap;
+    const int tap = bid / p.tiles_k_per_tap;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int n0 = tile_n * W160, c0 = tile_k * W160;
+    const int m_begin = slab_id * p.m_per_split;
+    int m_end = m_begin + p.m_per_split;
+    if (m_end > p.M) m_end = p.M;
+
+    f32x16_t acc[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+
+    // staging: 32 pixel rows x 20 chunks of 8 columns per operand = 640 slots, two per thread (rows 16 apart)
+    const int srow = tid / 20, sch = tid - srow * 20;
+    const int Hlim = p.Hin << p.ups, Wlim = p.Win << p.ups;
+    float4 vy[2][2], va[2][2];
+    auto load_tile = [&](int m0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int m = m0 + srow + 16 * k;
+            vy[k][0] = vy[k][1] = va[k][0] = va[k][1] = make_float4(0, 0, 0, 0);
+            if (m < m_end) {
+                const float* yrow = p.dy + (int64_t)m * p.lddy;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + 8 * sch + 4 * j;
+                    if (n + 4 <= p.N) vy[k][j] = *reinterpret_cast<const float4*>(yrow + n);
+                    else if (n < p.N) {
+                        float t[4] = {0, 0, 0, 0};
+                        for (int u = 0; u < 4 && n + u < p.N; ++u) t[u] = yrow[n + u];
+                        vy[k][j] = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+                const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
+                const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
+                if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
+                    const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+                    const float* r0 = p.a0 + pix * p.lda0;
+                    const float* r1 = p.a1 + pix * p.lda1 - p.C0;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int c = c0 + 8 * sch + 4 * j;
+                        if (c < p.Ctot) va[k][j] = *reinterpret_cast<const float4*>((c < p.C0 ? r0 : r1) + c);
+                    }
+                }
+            }
+        }
+    };
+    auto cvt = [&](const float4 v, uint2& hi, uint2& lo) {
+        if constexpr (DT == MF_BF16X1) {
+            hi = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+        } else {
+            wg_amax = mf_amax3(mf_amax3(wg_amax, v.x, v.y), v.z, v.w);
+            const auto h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+            const auto l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
+            const auto l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
+            hi = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+            lo = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+        }
+    };
+    auto put2 = [&](char* dst, const float4 u, const float4 v) {
+        uint2 h0, l0, h1, l1;
+        cvt(u, h0, l0); cvt(v, h1, l1);
+        *reinterpret_cast<uint4*>(dst) = uint4{h0.x, h0.y, h1.x, h1.y};
+        if constexpr (NPL == 2) *reinterpret_cast<uint4*>(dst + W160_PLANE) = uint4{l0.x, l0.y, l1.x, l1.y};
+    };
+    auto write_tile = [&](char* st) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int off = (srow + 16 * k) * W160_PITCH + 16 * sch;
+            put2(st + off, vy[k][0], vy[k][1]);
+            put2(st + NPL * W160_PLANE + off, va[k][0], va[k][1]);
+        }
+    };
+    // transposed-read addresses (see conv_wgrad_tr_kernel): lane 4q + pp of group g -> row 8 (g >> 1) + 4 j + q, columns 4 pp ..
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int ay[2], aa[2];                                         // pixels 0..3 / 4..7; n-block i adds 64 bytes
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 8 * (g >> 1) + 4 * j + q;
+        ay[j] = row * W160_PITCH + 2 * (16 * (g & 1) + 4 * pp);
+        aa[j] = ay[j] + 64 * wave + NPL * W160_PLANE;
+    }
+
+    const int tiles = (m_end - m_begin + WG_BP - 1) / WG_BP;
+    if (tiles > 0) {
+        load_tile(m_begin);
+        write_tile(wt_smem);
+    }
+    __syncthreads();
+    for (int t = 0; t < tiles; ++t) {
+        const char* st = wt_smem + (NST == 2 ? (t & 1) * STAGE : 0);
+        if (t + 1 < tiles) load_tile(m_begin + (t + 1) * WG_BP);
+#pragma unroll
+        for (int s = 0; s < WG_BP / 16; ++s) {
+            const char* sb = st + s * 16 * W160_PITCH;
+            f16x8_t A[NPL], Y[2][NPL];        // the n-block i + 1 fragments are read while block i's MFMAs run (left to itself the
+                                              // compiler reuses one register set: read, wait, three MFMAs, read, wait ...)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                A[pl] = wt_frag(sb + pl * W160_PLANE, aa[0], aa[1]);
+                Y[0][pl] = wt_frag(sb + pl * W160_PLANE, ay[0], ay[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (i + 1 < 5) {
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) Y[(i + 1) & 1][pl] = wt_frag(sb + pl * W160_PLANE + 64 * (i + 1), ay[0], ay[1]);
+                }
+                const f16x8_t* Yc = Y[i & 1];
+                if constexpr (DT == MF_BF16X1) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Yc[0]), __builtin_bit_cast(bf16x8_t, A[0]), acc[i], 0, 0, 0);
+                } else {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yc[NPL - 1], A[0], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yc[0], A[NPL - 1], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Yc[0], A[0], acc[i], 0, 0, 0);
+                }
+            }
+        }
+        if (NST == 1) __syncthreads();                        // one stage: every wave is done reading before the tile is replaced
+        if (t + 1 < tiles) write_tile(wt_smem + (NST == 2 ? ((t + 1) & 1) * STAGE : 0));
+        __syncthreads();
+    }
+    if constexpr (DT == MF_F16X3) mf_raise_if_over(&g_split_ovf_train, wg_amax);
+    float* out = p.out + (int64_t)slab_id * p.slab;
+    const int c = c0 + 32 * wave + r;
+    if (c < p.Ctot) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < p.N) {
+                    float* o = out + (int64_t)n * p.ldo + (int64_t)tap * p.Ctot + c;
+                    *o = p.acc_out ? *o + acc[i][e] : acc[i][e];
+                }
+            }
+    }
+}
+
 // out[i] (+)= sum_z slabs[z][i]   (rows of `cols` floats, output row stride ldo)
 __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* ws, int nslab, int64_t slab, float* out, int64_t ldo,
                                                         int rows, int cols, int accumulate) {
@@ -1040,31 +1211,44 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     a.M = (int)M64; a.N = d->n;
     const int64_t K = (int64_t)a.taps * a.Ctot;
     MF_CHECK_ARG(d->lddw >= K, "mf_conv_wgrad: lddw < K");
-    a.tiles_n = (a.N + WG_BN - 1) / WG_BN;
-    a.tiles_k_per_tap = (a.Ctot + WG_BC - 1) / WG_BC;
-    const int64_t tiles = (int64_t)a.tiles_n * a.tiles_k_per_tap * a.taps;
-    int sm = d->splitm;
     const bool tr_form = d->dtype != MF_F32 && getenv("MFHIP_WGRAD_V1") == nullptr;
+    static const bool no160 = getenv("MFHIP_WGRAD_128") != nullptr;                   // developer A/B
+    // Tile form (128 x 128 / four waves, or 160 x 160 / five waves) and pixel split are chosen together by a cost model: rounds of
+    // 512 resident blocks (2 per CU) x 32-pixel steps per block x the measured step time of the form (2.3 / 3.7 us: the 160 form
+    // does 1.56 x the products per step and pads 320-multiples less, but has fewer, longer blocks to spread), plus the slabs'
+    // write + read (N K floats each way per slab at ~4 TB/s) unless one slab adds into dW itself.
+    int cap = a.M / 256 < 1 ? 1 : a.M / 256;
+    if (cap > 64) cap = 64;
+    if (d->ws == nullptr) cap = 1;
+    else if ((int64_t)cap * a.N * K > d->ws_floats) cap = (int)(d->ws_floats / ((int64_t)a.N * K)) < 1 ? 1 : (int)(d->ws_floats / ((int64_t)a.N * K));
+    auto tiles_of = [&](int w) { return (int64_t)((a.N + w - 1) / w) * ((a.Ctot + w - 1) / w) * a.taps; };
+    auto model = [&](int w, double step_us, int* best_c) {
+        double best = 1e300;
+        *best_c = 1;
+        for (int c = 1; c <= cap; ++c) {
+            const int64_t blocks = tiles_of(w) * c, rounds = (blocks + 511) / 512;
+            const int64_t steps = (((int64_t)a.M + c - 1) / c + WG_BP - 1) / WG_BP;
+            const double slab_us = c == 1 ? 0.0 : (double)c * a.N * K * 8.0 / 4.0e6 + 4.0;
+            const double cost = (double)rounds * steps * step_us + slab_us;
+            if (cost < best * 0.98) { best = cost; *best_c = c; }                        // a larger split has to pay for itself
+        }
+        return best;
+    };
+    int c128 = 1, c160 = 1;
+    const double cost128 = model(WG_BN, 2.3, &c128);
+    const double cost160 = tr_form && !no160 ? model(W160, 3.7, &c160) : 1e300;
+    const bool t160 = cost160 < cost128;
+    const int tile_w = t160 ? W160 : WG_BN;
+    a.tiles_n = (a.N + tile_w - 1) / tile_w;
+    a.tiles_k_per_tap = (a.Ctot + tile_w - 1) / tile_w;
+    const int64_t tiles = tiles_of(tile_w);
+    int sm = d->splitm;
     if (sm <= 0) {
-        int cap = a.M / 256 < 1 ? 1 : a.M / 256;
-        if (cap > 64) cap = 64;
-        if (d->ws == nullptr) cap = 1;
-        else if ((int64_t)cap * a.N * K > d->ws_floats) cap = (int)(d->ws_floats / ((int64_t)a.N * K)) < 1 ? 1 : (int)(d->ws_floats / ((int64_t)a.N * K));
         if (!tr_form) {
             sm = (int)((1024 + tiles - 1) / tiles);
             if (sm > cap) sm = cap;
         } else {
-            // cost in units of one 32-pixel tile step of one resident block (~1.3 us): rounds of 512 resident blocks (2 per CU) x
-            // steps per block, plus the slabs' write + read (N K floats each way per slab, ~4 TB/s) unless one slab writes dW itself
-            double best = 1e300;
-            sm = 1;
-            for (int c = 1; c <= cap; ++c) {
-                const int64_t blocks = tiles * c, rounds = (blocks + 511) / 512;
-                const int64_t steps = (((int64_t)a.M + c - 1) / c + WG_BP - 1) / WG_BP;
-                const double slab_us = c == 1 ? 0.0 : (double)c * a.N * K * 8.0 / 4.0e6;
-                const double cost = (double)rounds * steps * 1.3 + slab_us + 4.0;     // + launch of the slab sum
-                if (cost < best * 0.98) { best = cost; sm = c; }                      // a larger split has to pay for itself
-            }
+            sm = t160 ? c160 : c128;
         }
     }
     MF_CHECK_ARG(sm == 1 || (d->ws && (int64_t)sm * a.N * K <= d->ws_floats), "mf_conv_wgrad: split-M=%d needs %lld workspace floats", sm,
@@ -1087,6 +1271,17 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     else if (old_form) {
         if (d->dtype == MF_BF16X1) hipLaunchKernelGGL(conv_wgrad_kernel<MF_BF16X1>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_wgrad_kernel<MF_F16X3>, grid, dim3(256), 0, s, a);
+    } else if (t160) {
+        static const bool attr160 = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tr160_kernel<MF_F16X3, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * W160_PLANE);
+            return true;
+        }();
+        (void)attr160;
+        static const bool one_stage = getenv("MFHIP_WGRAD_STAGES1") != nullptr;         // developer A/B
+        if (d->dtype == MF_BF16X1) hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_BF16X1, 2>), grid1, dim3(320), 2 * 2 * W160_PLANE, s, a);
+        else if (one_stage) hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_F16X3, 1>), grid1, dim3(320), 4 * W160_PLANE, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_F16X3, 2>), grid1, dim3(320), 2 * 4 * W160_PLANE, s, a);
     } else if (d->dtype == MF_BF16X1) {
         hipLaunchKernelGGL(conv_wgrad_tr_kernel<MF_BF16X1>, grid1, dim3(256), 2 * 2 * WT_PLANE, s, a);
     } else {
