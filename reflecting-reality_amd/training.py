@@ -197,6 +197,9 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     # the weights the optimizer left behind: rebuild them on a side stream under the forward pass instead of inside the backward
     # (the list is what the previous step's backward had to rebuild; the first step builds them lazily).
     dgrad_ready = None
+    arena_key = tuple(m.flat_w.data_ptr() for m in (model.brushnet, model.unet) if getattr(m, "flat_w", None) is not None)
+    if getattr(model, "_dgrad_prefetch_key", None) != arena_key:        # prepare_training() rebuilt an arena: the list is stale
+        model._dgrad_prefetch, model._dgrad_prefetch_key = None, arena_key
     prefetch = getattr(model, "_dgrad_prefetch", None)
     if prefetch and DGRAD_PREFETCH:
         dev = mods[0].device
