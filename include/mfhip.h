@@ -404,6 +404,8 @@ typedef struct mf_groupnorm_bwd_desc {
     float* ws;      /* mf_groupnorm_bwd_ws_floats() floats, 16-byte aligned; null = the one-block-per-group kernel only */
     float* dgamma_acc; float* dbeta_acc;   /* [c0 + c1], nullable, INSTEAD of the partials: the gradients summed over the batch
                                             * are ADDED here (needs mf_groupnorm_bwd_streams(...) != 0 and ws) */
+    const float* add0; const float* add1;  /* nullable, laid out like dx0 / dx1: dx = gradient + add (the gradient a residual
+                                            * connection already left for the same tensor: no separate accumulation pass) */
 } mf_groupnorm_bwd_desc;
 int mf_sizeof_groupnorm_bwd_desc(void);
 int mf_groupnorm_bwd_streams(int32_t batch, int32_t hw, int32_t c0, int32_t c1);   /* 1: this shape runs the streaming form */
@@ -414,7 +416,7 @@ int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream);
  * [mf_layernorm_bwd_parts(rows)][c] (nullable) */
 int64_t mf_layernorm_bwd_parts(int64_t rows);
 int mf_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma_part, float* dbeta_part,
-                     int64_t rows, int32_t c, float eps, void* stream);
+                     int64_t rows, int32_t c, float eps, const float* add /* nullable [rows][c]: dx = gradient + add */, void* stream);
 /* ds = scale * p * (dp - sum_j dp*p) per row of [rows][ld] (valid length cols, pad written 0): softmax backward */
 int mf_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int32_t cols, int32_t ld, float scale, void* stream);
 int mf_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);

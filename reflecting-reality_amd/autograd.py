@@ -20,6 +20,7 @@ import torch
 
 from . import hip
 
+FUSE_GRAD_ADD = os.environ.get("MFHIP_NO_FUSED_GRAD_ADD", "0") != "1"   # developer A/B: norm backwards add the residual's gradient
 GN_GRAD_ACC = os.environ.get("MFHIP_NO_GN_ACC", "0") != "1"      # developer A/B: per-image partials + mf_colsum instead
 
 
@@ -67,6 +68,21 @@ class Tape:
         k = _key(t)
         old = self.grads.get(k)
         self.grads[k] = g if old is None else hip.axpby_n([old, g.view(old.shape)], [1.0, 1.0])
+
+    def peek(self, t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """The gradient t has accumulated so far (or None): a backward kernel that can add it into its own output (put) saves
+        the separate accumulation pass add() would launch."""
+        if not (FUSE_GRAD_ADD and self.needs(t)):
+            return None
+        g = self.grads.get(_key(t))
+        return g if (g is not None and g.is_contiguous() and g.numel() == t.numel()) else None
+
+    def put(self, t: Optional[torch.Tensor], g: torch.Tensor, fused: bool) -> None:
+        """fused: g already contains what peek(t) returned — replace t's gradient by it; otherwise accumulate as add() does."""
+        if not fused:
+            return self.add(t, g)
+        if self.needs(t):
+            self.grads[_key(t)] = g
 
     def add_cols(self, view: torch.Tensor, g_rows: torch.Tensor, n: int, segs: int) -> None:
         """view = parent[:, a:b] (a column slice of a 2-D fp32 tensor): add the per-segment column sums of g_rows
@@ -187,8 +203,10 @@ def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, gro
         if g is None:
             return
         want = p_gamma.grad is not None
+        a0, a1 = tape.peek(x0), (tape.peek(x1) if x1 is not None else None)
         dx0, dx1, dg, db = hip.groupnorm_bwd(x0, g.view(out.shape), p_gamma.data, p_beta.data, groups=groups, eps=eps, silu=silu,
-                                             x1=x1, want_param_grads=want, grad_acc=(p_gamma.grad, p_beta.grad) if (want and GN_GRAD_ACC) else None)
+                                             x1=x1, want_param_grads=want, grad_acc=(p_gamma.grad, p_beta.grad) if (want and GN_GRAD_ACC) else None,
+                                             add0=a0, add1=a1)
         if want:
             if dg is not None:                     # small maps: per-image partials (the streaming form adds into the arena itself)
                 c = dg.shape[1]
@@ -196,9 +214,9 @@ def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, gro
                 hip.colsum(db, c, out=p_beta.grad.view(1, c), accumulate=True)
             tape.param_grad_done(p_gamma)
             tape.param_grad_done(p_beta)
-        tape.add(x0, dx0)
+        tape.put(x0, dx0, a0 is not None)        # fused: dx already holds what the residual path left (peek above)
         if x1 is not None:
-            tape.add(x1, dx1)
+            tape.put(x1, dx1, a1 is not None)
 
     tape.record(bwd)
 
@@ -209,14 +227,15 @@ def record_layernorm(tape: Tape, x, p_gamma: Param, p_beta: Param, out, eps: flo
         if g is None:
             return
         want = p_gamma.grad is not None
-        dx, dg, db = hip.layernorm_bwd(x, g.view(x.shape), p_gamma.data, eps, want_param_grads=want)
+        ax = tape.peek(x)
+        dx, dg, db = hip.layernorm_bwd(x, g.view(x.shape), p_gamma.data, eps, want_param_grads=want, add=ax)
         if want:
             c = dg.shape[1]
             hip.colsum(dg, c, out=p_gamma.grad.view(1, c), accumulate=True)
             hip.colsum(db, c, out=p_beta.grad.view(1, c), accumulate=True)
             tape.param_grad_done(p_gamma)
             tape.param_grad_done(p_beta)
-        tape.add(x, dx)
+        tape.put(x, dx, ax is not None)
 
     tape.record(bwd)
 

@@ -671,6 +671,7 @@ struct GnBwdArgs {
     const float* dy;                       // [b][hw][c0 + c1]
     const float* gamma; const float* beta;
     float* dx0; float* dx1;                // [b][hw][c0], [b][hw][c1]
+    const float* add0; const float* add1;  // nullable, laid out like dx0 / dx1: dx = (the gradient) + add (a residual's gradient)
     float* dgamma_part; float* dbeta_part; // [b][c0 + c1] or null
     int batch, hw, groups, silu; float eps;
 };
@@ -743,10 +744,13 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const GnBwdArgs p) {
     // ---- dx ----
     if (active) {
         float* dxb = seg1 ? p.dx1 + (int64_t)b * p.hw * p.c1 + (c - p.c0) : p.dx0 + (int64_t)b * p.hw * p.c0 + c;
+        const float* adb = seg1 ? (p.add1 ? p.add1 + (int64_t)b * p.hw * p.c1 + (c - p.c0) : nullptr)
+                                : (p.add0 ? p.add0 + (int64_t)b * p.hw * p.c0 + c : nullptr);
         for (int px = rl; px < p.hw; px += rif) {
             float xhat;
             const float dz = dz_of(xb[(int64_t)px * ldx], dyb[(int64_t)px * C], xhat);
-            dxb[(int64_t)px * ldx] = rstd * (dz * gam - m1 - xhat * m2);
+            const float v = rstd * (dz * gam - m1 - xhat * m2);
+            dxb[(int64_t)px * ldx] = adb ? v + adb[(int64_t)px * ldx] : v;
         }
     }
 }
@@ -820,8 +824,13 @@ __global__ __launch_bounds__(256) void gn_bwd2_kernel(const GnBwd2Args q2) {
                     }
                     if (PHASE == 2) {
                         const int c = 4 * q;
-                        float* dst = c < p.c0 ? p.dx0 + ((int64_t)b * p.hw + px) * p.c0 + c : p.dx1 + ((int64_t)b * p.hw + px) * p.c1 + (c - p.c0);
-                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                        const int64_t off = c < p.c0 ? ((int64_t)b * p.hw + px) * p.c0 + c : ((int64_t)b * p.hw + px) * p.c1 + (c - p.c0);
+                        const float* ad = c < p.c0 ? p.add0 : p.add1;
+                        if (ad) {
+                            const float4 a4 = *reinterpret_cast<const float4*>(ad + off);
+                            o[0] += a4.x; o[1] += a4.y; o[2] += a4.z; o[3] += a4.w;
+                        }
+                        *reinterpret_cast<float4*>((c < p.c0 ? p.dx0 : p.dx1) + off) = make_float4(o[0], o[1], o[2], o[3]);
                     }
                 }
             }
@@ -955,7 +964,8 @@ constexpr int LN_MAXK = 32;      // channels per lane: c <= 2048
 template <int NK>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
-                                                            float* dg_part, float* db_part, int64_t rows, int c, float eps, int rpw) {
+                                                            float* dg_part, float* db_part, int64_t rows, int c, float eps, int rpw,
+                                                            const float* __restrict__ add) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float gm[NK], ag[NK], ab[NK], xv[NK], dv[NK];
@@ -1012,7 +1022,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int ch = lane + 64 * k;
-            if (ch < c) dx[row * c + ch] = rstd * (dv[k] * gm[k] - a1 - xv[k] * a2);
+            if (ch < c) {
+                const float v = rstd * (dv[k] * gm[k] - a1 - xv[k] * a2);
+                dx[row * c + ch] = add ? v + add[row * c + ch] : v;
+            }
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) { xv[k] = xn[k]; dv[k] = dn[k]; }
@@ -1366,12 +1379,12 @@ extern "C" int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream) {
                  "mf_groupnorm_bwd: dgamma_acc / dbeta_acc need the streaming form (mf_groupnorm_bwd_streams) and its workspace");
     GnBwdArgs a{};
     a.x0 = d->x0; a.x1 = d->x1; a.c0 = d->c0; a.c1 = d->c1; a.dy = d->dy; a.gamma = d->gamma; a.beta = d->beta;
-    a.dx0 = d->dx0; a.dx1 = d->dx1; a.dgamma_part = d->dgamma_part; a.dbeta_part = d->dbeta_part;
+    a.dx0 = d->dx0; a.dx1 = d->dx1; a.add0 = d->add0; a.add1 = d->add1; a.dgamma_part = d->dgamma_part; a.dbeta_part = d->dbeta_part;
     a.batch = d->batch; a.hw = d->hw; a.groups = d->groups; a.silu = d->silu; a.eps = d->eps;
     hipStream_t s = (hipStream_t)stream;
     if (d->ws && gn_bwd2_applies(d->hw, d->c0, d->c1)) {
         MF_CHECK_ARG(mf_aligned16(d->x0) && mf_aligned16(d->x1) && mf_aligned16(d->dy) && mf_aligned16(d->dx0) && mf_aligned16(d->dx1) &&
-                     mf_aligned16(d->ws), "mf_groupnorm_bwd: tensors must be 16-byte aligned");
+                     mf_aligned16(d->ws) && mf_aligned16(d->add0) && mf_aligned16(d->add1), "mf_groupnorm_bwd: tensors must be 16-byte aligned");
         GnBwd2Args q{};
         q.a = a;
         q.rpc = gn_bwd2_rpc(d->batch, d->hw);
@@ -1406,7 +1419,7 @@ extern "C" int64_t mf_layernorm_bwd_parts(int64_t rows) {
 }
 
 extern "C" int mf_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma_part, float* dbeta_part,
-                                int64_t rows, int32_t c, float eps, void* stream) {
+                                int64_t rows, int32_t c, float eps, const float* add, void* stream) {
     MF_CHECK_ARG(x && dy && gamma && dx && rows >= 1 && c >= 1 && c <= 64 * LN_MAXK, "mf_layernorm_bwd: bad arguments (c <= %d)", 64 * LN_MAXK);
     MF_CHECK_ARG((dgamma_part != nullptr) == (dbeta_part != nullptr), "mf_layernorm_bwd: dgamma / dbeta partials go together");
     const int rpw = ln_bwd_rpw(rows);
@@ -1414,7 +1427,7 @@ extern "C" int mf_layernorm_bwd(const float* x, const float* dy, const float* ga
     const int nk = (c + 63) / 64;
 #define MF_LN_BWD(NK)                                                                                                              \
     hipLaunchKernelGGL(layernorm_bwd_kernel<NK>, grid, dim3(256), 0, (hipStream_t)stream, x, dy, gamma, dx, dgamma_part, dbeta_part, \
-                       rows, c, eps, rpw)
+                       rows, c, eps, rpw, add)
     if (nk <= 1) MF_LN_BWD(1);
     else if (nk <= 2) MF_LN_BWD(2);
     else if (nk <= 5) MF_LN_BWD(5);

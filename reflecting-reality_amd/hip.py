@@ -82,6 +82,7 @@ class GroupNormBwdDesc(C.Structure):
         ("eps", C.c_float),
         ("ws", C.c_void_p),
         ("dgamma_acc", C.c_void_p), ("dbeta_acc", C.c_void_p),
+        ("add0", C.c_void_p), ("add1", C.c_void_p),
     ]
 
 
@@ -882,7 +883,8 @@ def colsum(x: torch.Tensor, n: int, *, segs: int = 1, rows_per_seg: Optional[int
 
 def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int, eps: float, silu: bool,
                   x1: Optional[torch.Tensor] = None, want_param_grads: bool = True, streaming: bool = True,
-                  grad_acc: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+                  grad_acc: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, add0: Optional[torch.Tensor] = None,
+                  add1: Optional[torch.Tensor] = None):
     """Returns (dx0, dx1 or None, dgamma_part [B, C] or None, dbeta_part).  streaming=False withholds the workspace, which keeps
     the one-block-per-(image, group) kernel at every size (tests compare the two).  grad_acc = (dgamma, dbeta) fp32 [C]: where
     the shape runs the streaming form the parameter gradients are ADDED there by the kernel itself and the partials come back
@@ -900,6 +902,11 @@ def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta:
     if fused:
         _f32(*grad_acc)
         d.dgamma_acc, d.dbeta_acc = _ptr(grad_acc[0]), _ptr(grad_acc[1])
+    for t, ref in ((add0, x0), (add1, x1)):       # dx = gradient + add: add is laid out like the matching input
+        if t is not None and (ref is None or t.numel() != ref.numel() or not t.is_contiguous()):
+            raise MfhipError("groupnorm_bwd: add0 / add1 must be contiguous and sized like x0 / x1")
+    _f32(add0, add1)
+    d.add0, d.add1 = _ptr(add0), _ptr(add1)
     d.x0, d.x1, d.c0, d.c1, d.dy = _ptr(x0), _ptr(x1), c0, c1, _ptr(dy)
     d.gamma, d.beta, d.dx0, d.dx1, d.dgamma_part, d.dbeta_part = _ptr(gamma), _ptr(beta), _ptr(dx0), _ptr(dx1), _ptr(dg), _ptr(db)
     d.batch, d.hw, d.groups, d.silu, d.eps = b, hw, groups, int(silu), eps
@@ -909,8 +916,12 @@ def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta:
     return dx0, dx1, dg, db
 
 
-def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, want_param_grads: bool = True):
-    _f32(x, dy, gamma)
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: float, want_param_grads: bool = True,
+                  add: Optional[torch.Tensor] = None):
+    """add (optional, sized like x): dx = gradient + add."""
+    _f32(x, dy, gamma, add)
+    if add is not None and (add.numel() != x.numel() or not add.is_contiguous()):
+        raise MfhipError("layernorm_bwd: add must be contiguous and sized like x")
     c = x.shape[-1]
     rows = x.numel() // c
     dx = torch.empty_like(x)
@@ -919,7 +930,7 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, eps: f
     db = torch.empty_like(dg) if want_param_grads else None
     _check(load().mf_layernorm_bwd(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), C.c_void_p(gamma.data_ptr()),
                                    C.c_void_p(dx.data_ptr()), C.c_void_p(_ptr(dg)), C.c_void_p(_ptr(db)), C.c_int64(rows), c,
-                                   C.c_float(eps), _stream()), "mf_layernorm_bwd")
+                                   C.c_float(eps), C.c_void_p(_ptr(add)), _stream()), "mf_layernorm_bwd")
     return dx, dg, db
 
 

@@ -349,6 +349,15 @@ def test_groupnorm_backward(shape, silu):
                                                  beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu, x1=x1, grad_acc=acc)
         assert dg2 is None and db2 is None and torch.equal(dx0b, dx0)
         assert _rel(acc[0] - 0.5, gamma.grad) < 2e-5 and _rel(acc[1] + 0.25, beta.grad) < 2e-5
+    # dx = gradient + add (the gradient a residual connection already left): both kernel forms
+    add0 = torch.randn_like(x0)
+    add1 = torch.randn_like(x1) if c1 else None
+    ex0, ex1, _, _ = hip.groupnorm_bwd(x0, gy.float().permute(0, 2, 3, 1).contiguous().to(DEV), gamma.detach().float().to(DEV),
+                                       beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu, x1=x1, streaming=streaming,
+                                       add0=add0, add1=add1)
+    assert torch.allclose(ex0, dx0 + add0, rtol=0, atol=2e-6 * float(dx0.abs().max() + add0.abs().max()))
+    if c1:
+        assert torch.allclose(ex1, dx1 + add1, rtol=0, atol=2e-6 * float(dx1.abs().max() + add1.abs().max()))
 
 
 def test_layernorm_softmax_geglu_silu_backward():
@@ -361,6 +370,9 @@ def test_layernorm_softmax_geglu_silu_backward():
         gy = torch.randn(rows, c, generator=g, dtype=torch.float64)
         y.backward(gy)
         dx, dg, db = hip.layernorm_bwd(x.detach().float().to(DEV), gy.float().to(DEV), gamma.detach().float().to(DEV), 1e-5)
+        ad = torch.randn(rows, c, generator=g).to(DEV)
+        dxa, _, _ = hip.layernorm_bwd(x.detach().float().to(DEV), gy.float().to(DEV), gamma.detach().float().to(DEV), 1e-5, add=ad)
+        assert torch.allclose(dxa, dx + ad, rtol=0, atol=2e-6 * float(dx.abs().max() + ad.abs().max()))
         e = (_rel(dx, x.grad), _rel(hip.colsum(dg, c)[0], gamma.grad), _rel(hip.colsum(db, c)[0], beta.grad))
         print(f"layernorm_bwd {rows}x{c}: {e}")
         assert max(e) < 2e-5
