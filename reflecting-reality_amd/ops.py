@@ -419,10 +419,11 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
         return hip.softmax_rows(scores, skv, torch.float32)
 
     vt = transpose_tokens(v, ld)
-    if (prec.code == hip.MF_F16X3 and d in FLASH_BWD_HEAD_DIMS and sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS and tape is not None
-            and FLASH_BWD):
+    if (prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and d in FLASH_BWD_HEAD_DIMS and sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS
+            and tape is not None and FLASH_BWD):
         # flash forward WITH the row statistics, flash backward (autograd.record_attention_flash): nothing of size Sq x Skv is
-        # ever written in either direction
+        # ever written in either direction.  The bf16x1 mode (fp32 storage, bf16 products) takes the same split-precision kernels:
+        # finer than its own arithmetic, and the S x S tensors of the unfused form are what bounds it at 64 x 64 latents.
         qs, ks, vs = hip.split_halves(q.contiguous()), hip.split_halves(k.contiguous()), hip.split_halves(vt)
         out = torch.empty(b, sq, c, dtype=torch.float32, device=q.device)
         lse = torch.empty(b, heads, sq, dtype=torch.float32, device=q.device)
