@@ -165,7 +165,7 @@ def train_main(a, D):
     backward pass.  Secondary workload: reported with its own metric, never as the inference number."""
     from reflecting_reality_amd import (BrushNetModel, DDPMScheduler, UNet2DConditionModel, hip, synth)
     from reflecting_reality_amd.configs import SD15_SCHED, SD15_UNET, brushnet_config
-    from reflecting_reality_amd.training import AdamW, MirrorFusionModel, train_step
+    from reflecting_reality_amd.training import AdamW, GraphedTrainStep, MirrorFusionModel, train_step
     backend = os.environ.get("MF_BENCH_BACKEND") or None
     rank, world, local = D.init_process_group(backend)
     if world != a.gpus:
@@ -192,9 +192,19 @@ def train_main(a, D):
     lat, noi = torch.randn(b, 4, hl, hl, generator=g).to(device) * 0.8, torch.randn(b, 4, hl, hl, generator=g).to(device)
     cond, ehs = torch.randn(b, 6, hl, hl, generator=g).to(device), torch.randn(b, 77, 768, generator=g).to(device)
 
+    # one process, no gradient sync: zero_grad + forward + backward + clip replayed from one hipGraph (training.GraphedTrainStep;
+    # its first two calls are the eager step — run them inside the warm-up).  MF_TRAIN_GRAPH=0: the eager step throughout.
+    graphed = GraphedTrainStep(model, ns, opt, max_grad_norm=1.0) if (sync is None and os.environ.get("MF_TRAIN_GRAPH", "1") != "0") else None
+
     def one_step(i):
         ts = torch.randint(0, 1000, (b,), generator=g)
+        if graphed is not None:
+            return graphed(lat, noi, ts, ehs, cond)
         return train_step(model, ns, opt, lat, noi, ts, ehs, cond, max_grad_norm=1.0, grad_sync=sync)
+
+    if graphed is not None and a.warmup < 3:
+        for i in range(3 - a.warmup):            # untimed: the graph is captured on the third call
+            one_step(i)
 
     for i in range(a.warmup):
         one_step(i)
@@ -222,7 +232,8 @@ def train_main(a, D):
             "vs_baseline": None, "dtype": prec, "data": "synthetic",
             "config": {"workload": f"train_brushnet_mirror.py step, per-GPU batch {b} x {a.size}x{a.size}, BrushNet(6 cond ch) trainable / UNet "
                                    f"{'trainable' if a.train_base_unet else 'frozen'}, clip 1.0, AdamW lr 1e-5, random-init weights", "per_gpu_batch": b, "global_batch": b * world,
-                       "parallelism": f"data-parallel x{world}" + (" (bucketed gradient all-reduce over RCCL)" if world > 1 else "")},
+                       "parallelism": f"data-parallel x{world}" + (" (bucketed gradient all-reduce over RCCL)" if world > 1 else ""),
+                       "launch": "hipGraph replay (forward + backward + clip), eager noising / optimizer" if graphed is not None else "eager"},
             "all_reduce": ({"ms": round(ar_ms, 2), "bytes": ar_bytes, "GB/s_per_rank": round(2 * (world - 1) / max(world, 1) * ar_bytes / (ar_ms * 1e-3) / 1e9, 1),
                             "note": "one un-overlapped bucketed all-reduce of the gradient arenas (64 Mi-float buckets), measured after the timed steps; "
                                     "in the step it runs on a side stream under the backward pass"} if ar_ms else None),

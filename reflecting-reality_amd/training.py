@@ -258,6 +258,124 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     return loss, norm
 
 
+class GraphedTrainStep:
+    """train_step() with zero_grad + forward + loss + backward + clip captured ONCE in a hipGraph and replayed every step.
+
+    A training step is ~5000 kernel launches; each costs ~25 us of Python + ctypes on the host, so the host's launch rate
+    (not the GPU) bounds the bf16x1 step and eats into the f16x3 one.  What depends on host values stays outside the graph
+    and runs eagerly around the replay: the noising of the latents (per-sample schedule coefficients looked up by timestep on
+    the host, :1416), the SNR weights (:1437-1449), the range-guard read-back, and the optimizer (its bias corrections are
+    host scalars).  Inputs are copied into static device buffers; shapes are fixed at the first call.  The first `warmup`
+    calls run the eager train_step (they tune GEMM tiles, build the frozen network's derived weights and learn which
+    data-gradient layouts to prefetch); the next call captures.  Single-process only: with a GradBuckets gradient sync the
+    eager step is used (RCCL calls are not captured).  The arithmetic and its order are the eager step's: weights are
+    bit-identical after the same number of steps (tests/test_training_gpu.py)."""
+
+    def __init__(self, model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, snr_gamma: Optional[float] = None,
+                 max_grad_norm: float = 1.0, check_overflow: bool = True, warmup: int = 2):
+        self.model, self.ns, self.opt = model, noise_scheduler, optimizer
+        self.snr_gamma, self.max_grad_norm, self.check_overflow = snr_gamma, max_grad_norm, check_overflow
+        self.warmup, self.calls, self.graph = max(int(warmup), 1), 0, None
+
+    # -- eager, host-dependent staging ----------------------------------------------------------------------------------
+    def _stage(self, latents, noise, timesteps, ehs, cond):
+        dev = self.noisy.device
+        self.noisy.copy_(self.ns.add_noise(latents, noise, timesteps))                                   # :1416
+        ptype = self.ns.config["prediction_type"]
+        if ptype == "epsilon":                                                                           # :1427-1432
+            self.target.copy_(noise.to(dev, torch.float32))
+        elif ptype == "v_prediction":
+            self.target.copy_(self.ns.get_velocity(latents, noise, timesteps))
+        else:
+            raise ValueError(f"Unknown prediction type {ptype}")
+        self.t_dev.copy_(hip.h2d(timesteps.reshape(-1).float().contiguous(), dev))
+        self.ehs.copy_(ehs.to(dev, torch.float32))
+        self.cond.copy_(cond.to(dev, torch.float32))
+        if self.snr_gamma is not None:                                                                   # :1437-1449
+            snr = compute_snr(self.ns, timesteps)
+            w = torch.stack([snr, self.snr_gamma * torch.ones_like(snr)], dim=1).min(dim=1)[0]
+            w = w / snr if ptype == "epsilon" else w / (snr + 1)
+            self.weights.copy_(hip.h2d(w.float().contiguous(), dev))
+
+    def _body(self):
+        model, prec = self.model, self.model.brushnet.prec
+        mods = model.get_trainable_modules()
+        self.opt.zero_grad()
+        tape = autograd.Tape(prec.tape_code)
+        dgrad_ready = None
+        prefetch = getattr(model, "_dgrad_prefetch", None)
+        cur = torch.cuda.current_stream(mods[0].device)
+        if prefetch and DGRAD_PREFETCH:
+            side = getattr(model, "_side_stream", None)
+            if side is None:
+                side = model._side_stream = torch.cuda.Stream(device=mods[0].device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for cw in prefetch:
+                    autograd._dgrad_weight(cw, prec.tape_code)
+                dgrad_ready = side.record_event()
+        ops.TAPE = tape
+        try:
+            pred = model(self.noisy, self.t_dev, self.ehs, self.cond)
+            loss, _ = hip.mse_loss(pred.float(), self.target, self.weights if self.snr_gamma is not None else None)
+        finally:
+            ops.TAPE = None
+        d_pred = hip.mse_grad(pred.contiguous(), self.target, self.weights if self.snr_gamma is not None else None)
+        scale = 1.0
+        if prec.split:
+            scale = float(2 ** int(pred.numel() - 1).bit_length())
+            d_pred = hip.axpby_n([d_pred], [scale], out=d_pred)
+        model.loss_scale = scale
+        tape.add(pred, d_pred)
+        if dgrad_ready is not None:
+            cur.wait_event(dgrad_ready)
+        tape.backward()
+        norm, coef = clip_grad_norm_(mods, self.max_grad_norm, loss_scale=scale)
+        return loss, norm, coef
+
+    def __call__(self, latents, noise, timesteps, encoder_hidden_states, conditioning_latents):
+        model = self.model
+        mods = model.get_trainable_modules()
+        if not mods:
+            raise RuntimeError("GraphedTrainStep: call model.prepare_training() first")
+        if self.graph is None and self.calls < self.warmup:
+            self.calls += 1
+            return train_step(model, self.ns, self.opt, latents, noise, timesteps, encoder_hidden_states, conditioning_latents,
+                              snr_gamma=self.snr_gamma, max_grad_norm=self.max_grad_norm, check_overflow=self.check_overflow)
+        dev = mods[0].device
+        prec = model.brushnet.prec
+        if self.graph is None:
+            f32 = dict(dtype=torch.float32, device=dev)
+            self.noisy, self.target = torch.empty(latents.shape, **f32), torch.empty(latents.shape, **f32)
+            self.t_dev = torch.empty(latents.shape[0], **f32)
+            self.ehs, self.cond = torch.empty(encoder_hidden_states.shape, **f32), torch.empty(conditioning_latents.shape, **f32)
+            self.weights = torch.ones(latents.shape[0], **f32)
+            self._stage(latents, noise, timesteps, encoder_hidden_states, conditioning_latents)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss, self.norm, self.coef = self._body()
+        else:
+            for t, ref in ((latents, self.noisy), (encoder_hidden_states, self.ehs), (conditioning_latents, self.cond)):
+                if tuple(t.shape) != tuple(ref.shape):
+                    raise ValueError(f"GraphedTrainStep: input shape {tuple(t.shape)} != the captured {tuple(ref.shape)}")
+            self._stage(latents, noise, timesteps, encoder_hidden_states, conditioning_latents)
+        guard = prec.code == hip.MF_F16X3 and self.check_overflow
+        if guard:
+            hip.split_overflow(reset=True)
+        self.graph.replay()
+        self.calls += 1
+        if guard and hip.split_overflow(reset=True):
+            import warnings
+            model.overflow_steps = getattr(model, "overflow_steps", 0) + 1
+            warnings.warn(f"GraphedTrainStep: an f16x3 operand exceeded the fp16 range; optimizer step skipped "
+                          f"({model.overflow_steps} so far) — train with precision 'bf16x1' / 'fp32' if this persists")
+            self.opt.zero_grad()
+            return self.loss, self.norm
+        self.opt.step(grad_scale=self.coef)
+        return self.loss, self.norm
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # checkpoints: accelerator.save_state with the script's hooks (:997-1069) and its rotation (:1474-1498)
 # ---------------------------------------------------------------------------------------------------------------------

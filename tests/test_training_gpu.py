@@ -212,6 +212,36 @@ def test_training_step_is_deterministic_and_checkpoints_resume(tmp_path):
     assert set(bn.state_dict()) == set(a)
 
 
+@pytest.mark.parametrize("prec,snr_gamma", [("f16x3", None), ("fp32", 5.0), ("bf16x1", None)])
+def test_graphed_train_step_equals_the_eager_one(prec, snr_gamma):
+    """GraphedTrainStep (zero_grad + forward + loss + backward + clip replayed from one hipGraph; noising, SNR weights, range
+    guard and AdamW eager around it) leaves bit-identical weights, loss and gradient norm to train_step over five steps with
+    changing inputs and timesteps (two eager warm-up calls, the capture, two replays)."""
+    from reflecting_reality_amd.training import GraphedTrainStep
+    ns = DDPMScheduler(**SD_SCHED)
+    batches = _batches()
+
+    def run(graphed):
+        model = _model(prec).prepare_training()
+        opt = AdamW(model.get_trainable_modules())
+        step = GraphedTrainStep(model, ns, opt, snr_gamma=snr_gamma, warmup=2) if graphed else None
+        out = []
+        for i in range(5):
+            lat, noi, ts, ehs, cond = batches[i % len(batches)]
+            ts = (ts + 37 * i) % 1000
+            args = (lat.to(DEV) * (1.0 + 0.1 * i), noi.to(DEV), ts, ehs.to(DEV), cond.to(DEV))
+            loss, norm = step(*args) if graphed else train_step(model, ns, opt, *args, snr_gamma=snr_gamma)
+            out.append((float(loss), float(norm)))
+        if graphed:
+            assert step.graph is not None and step.calls == 5
+        return model.brushnet.state_dict(), out
+
+    (wa, la), (wb, lb) = run(False), run(True)
+    assert la == lb, (la, lb)
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), f"{k}: the graphed step differs from the eager one"
+
+
 def test_training_needs_fp32_class_precision_and_the_training_layout():
     model = _model("bf16")
     with pytest.raises(NotImplementedError, match="fp32 master"):
