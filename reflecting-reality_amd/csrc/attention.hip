@@ -322,10 +322,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float a0 = st[tt][8 * s + 2 * e], a1 = st[tt][8 * s + 2 * e + 1];
-                        const auto hh = __builtin_amdgcn_cvt_pkrtz(a0, a1);
-                        const auto ll = __builtin_amdgcn_cvt_pkrtz(a0 - (float)hh[0], a1 - (float)hh[1]);
-                        hw[e] = __builtin_bit_cast(unsigned, hh);
-                        lw[e] = __builtin_bit_cast(unsigned, ll);
+                        mf_split_f16x2(a0, a1, hw[e], lw[e]);
                     }
                     pf[0][2 * tt + s] = uint4{hw[0], hw[1], hw[2], hw[3]};
                     pf[1][2 * tt + s] = uint4{lw[0], lw[1], lw[2], lw[3]};
@@ -622,13 +619,9 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float p0 = T[tt][8 * s2 + 2 * e], p1 = T[tt][8 * s2 + 2 * e + 1];
-                    const auto hh = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-                    const auto ll = __builtin_amdgcn_cvt_pkrtz(p0 - (float)hh[0], p1 - (float)hh[1]);
-                    a_h[e] = __builtin_bit_cast(unsigned, hh); a_l[e] = __builtin_bit_cast(unsigned, ll);
+                    mf_split_f16x2(p0, p1, a_h[e], a_l[e]);
                     const float d0 = U[tt][8 * s2 + 2 * e], d1 = U[tt][8 * s2 + 2 * e + 1];
-                    const auto gh = __builtin_amdgcn_cvt_pkrtz(d0, d1);
-                    const auto gl = __builtin_amdgcn_cvt_pkrtz(d0 - (float)gh[0], d1 - (float)gh[1]);
-                    b_h[e] = __builtin_bit_cast(unsigned, gh); b_l[e] = __builtin_bit_cast(unsigned, gl);
+                    mf_split_f16x2(d0, d1, b_h[e], b_l[e]);
                 }
                 ph[2 * tt + s2] = uint4{a_h[0], a_h[1], a_h[2], a_h[3]};
                 plo[2 * tt + s2] = uint4{a_l[0], a_l[1], a_l[2], a_l[3]};
@@ -722,11 +715,11 @@ __global__ __launch_bounds__(256) void split_halves_kernel(const float* x, unsig
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         amax = mf_amax3(mf_amax3(amax, v.x, v.y), v.z, v.w);
-        const auto h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-        const auto l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
-        const auto l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
-        reinterpret_cast<uint2*>(hi)[i] = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-        reinterpret_cast<uint2*>(lo)[i] = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+        uint2 h, l;
+        mf_split_f16x2(v.x, v.y, h.x, l.x);
+        mf_split_f16x2(v.z, v.w, h.y, l.y);
+        reinterpret_cast<uint2*>(hi)[i] = h;
+        reinterpret_cast<uint2*>(lo)[i] = l;
     }
     mf_raise_if_over(&g_split_ovf_attn, amax);
 }

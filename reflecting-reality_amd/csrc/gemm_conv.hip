@@ -532,10 +532,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                 h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);                                   // nearest-even; no low half
                 l[e] = 0;
             } else if constexpr (DT == MF_F16X3) {
-                const auto hh = __builtin_amdgcn_cvt_pkrtz(x[2 * e], x[2 * e + 1]);          // v_cvt_pkrtz_f16_f32
-                const auto ll = __builtin_amdgcn_cvt_pkrtz(x[2 * e] - (float)hh[0], x[2 * e + 1] - (float)hh[1]);
-                h[e] = __builtin_bit_cast(unsigned, hh);
-                l[e] = __builtin_bit_cast(unsigned, ll);
+                mf_split_f16x2(x[2 * e], x[2 * e + 1], h[e], l[e]);                           // v_cvt_pkrtz + 2 v_fma_mix + v_cvt_pkrtz
             } else {
                 const unsigned ua = __float_as_uint(x[2 * e]), ub = __float_as_uint(x[2 * e + 1]);
                 h[e] = (ua >> 16) | (ub & 0xffff0000u);                                       // truncated bf16 pair

@@ -96,6 +96,16 @@ __device__ __forceinline__ float mf_amax3(float m, float a, float b) { return fm
 __device__ __forceinline__ void mf_raise_if_over(unsigned* flag, float amax) {
     if (amax > MF_F16_MAX) atomicOr(flag, 1u);
 }
+// (hi, lo) fp16 halves of two fp32 values: hi = x toward zero, lo = x - hi toward zero.  The low half comes from ONE
+// v_fma_mix_f32 per element (fp32 fma reading the f16 half of `hi` directly: x - hi, the same single rounding as
+// v_cvt_f32_f16 + v_sub_f32) — four instructions per pair instead of six; the compiler does not form it from C.
+__device__ __forceinline__ void mf_split_f16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(b));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+}
 unsigned* mf_ovf_flag_gemm();        // device addresses of the three translation units' flags (host functions)
 unsigned* mf_ovf_flag_attention();
 unsigned* mf_ovf_flag_train();

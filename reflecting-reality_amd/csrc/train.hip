@@ -289,11 +289,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
             hi = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
         } else {
             wg_amax = mf_amax3(mf_amax3(wg_amax, v.x, v.y), v.z, v.w);
-            const auto h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-            const auto l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
-            const auto l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
-            hi = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-            lo = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+            mf_split_f16x2(v.x, v.y, hi.x, lo.x);
+            mf_split_f16x2(v.z, v.w, hi.y, lo.y);
         }
     };
     auto put2 = [&](char* dst, const float4 u, const float4 v) {          // eight consecutive columns = one 16-byte chunk per plane
@@ -508,11 +505,8 @@ __global__ __launch_bounds__(320, 2) void conv_wgrad_tr160_kernel(const WgradArg
             hi = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
         } else {
             wg_amax = mf_amax3(mf_amax3(wg_amax, v.x, v.y), v.z, v.w);
-            const auto h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-            const auto l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
-            const auto l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
-            hi = uint2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
-            lo = uint2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+            mf_split_f16x2(v.x, v.y, hi.x, lo.x);
+            mf_split_f16x2(v.z, v.w, hi.y, lo.y);
         }
     };
     auto put2 = [&](char* dst, const float4 u, const float4 v) {
