@@ -269,7 +269,9 @@ class GraphedTrainStep:
     calls run the eager train_step (they tune GEMM tiles, build the frozen network's derived weights and learn which
     data-gradient layouts to prefetch); the next call captures.  Single-process only: with a GradBuckets gradient sync the
     eager step is used (RCCL calls are not captured).  The arithmetic and its order are the eager step's: weights are
-    bit-identical after the same number of steps (tests/test_training_gpu.py)."""
+    bit-identical after the same number of steps (tests/test_training_gpu.py).  The returned (loss, grad_norm) tensors live
+    in the graph's memory pool and are overwritten by the next call: read them (float(), .clone()) before stepping again.
+    Memory: the graph keeps one step's activations resident between calls (they are reused, not reallocated)."""
 
     def __init__(self, model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, snr_gamma: Optional[float] = None,
                  max_grad_norm: float = 1.0, check_overflow: bool = True, warmup: int = 2):
