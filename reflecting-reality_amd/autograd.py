@@ -122,7 +122,11 @@ def _dgrad_weight(cw, tape) -> torch.Tensor:
     step: training.train_step rebuilds them on a side stream under the forward pass).  `tape`: a Tape or its compute code."""
     code = tape if isinstance(tape, int) else tape.code
     gen = getattr(cw, "_wd_gen", None)
-    if gen != cw.generation() or getattr(cw, "_wd", None) is None or getattr(cw, "_wd_code", None) != code:
+    from . import ops
+    tok = ops.CAPTURE_TOKEN          # capturing a training graph: the rebuild of a weight that trains must be IN the graph
+    recapture = tok is not None and cw.p_w is not None and cw.p_w.grad is not None and getattr(cw, "_wd_tok", None) is not tok
+    if gen != cw.generation() or getattr(cw, "_wd", None) is None or getattr(cw, "_wd_code", None) != code or recapture:
+        cw._wd_tok = tok
         taps, n, ct = cw.kh * cw.kw, cw.n, cw.cin_pad
         wd = getattr(cw, "_wd_f32", None)
         if wd is None:
@@ -130,7 +134,6 @@ def _dgrad_weight(cw, tape) -> torch.Tensor:
         # per tap t: x_t[n][c] = w[n][t*ct + c] (ld taps*ct)  ->  y[c][(taps-1-t)*n + n'] (ld taps*n): zsy < 0 flips the taps
         hip.transpose(cw.w, n, ct, nz=taps, ldx=taps * ct, ldy=taps * n, zsx=ct, zsy=-n, out=wd, y_offset=(taps - 1) * n)
         cw._wd_split, cw._wd_ld = 0, taps * n
-        from . import ops
         if ops.PRESPLIT_TRAINING and code in (hip.MF_F16X3, hip.MF_BF16X3):
             # (hi, lo) halves packed once per weight generation: the pre-split GEMM forms (ConvWeight.operand)
             prev = getattr(cw, "_wd", None)

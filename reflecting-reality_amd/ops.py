@@ -147,10 +147,15 @@ class ConvWeight:
         if self.p_w is None or not PRESPLIT_TRAINING or self.prec.code not in (hip.MF_F16X3, hip.MF_BF16X3):
             return self.w, self.w_split, self.ldw
         gen = self.generation()
-        if getattr(self, "_wp_gen", None) != gen or getattr(self, "_wp", None) is None:
+        recapture = CAPTURE_TOKEN is not None and self.trains() and getattr(self, "_wp_tok", None) is not CAPTURE_TOKEN
+        if getattr(self, "_wp_gen", None) != gen or getattr(self, "_wp", None) is None or recapture:
             self._wp, self._wp_ld = hip.split_pack(self.w.view(self.n, self.ldw), self.prec.code, out=getattr(self, "_wp", None))
-            self._wp_gen = gen
+            self._wp_gen, self._wp_tok = gen, CAPTURE_TOKEN
         return self._wp, 1, self._wp_ld
+
+    def trains(self) -> bool:
+        """The weight lives in an arena the optimizer updates (its derived layouts go stale every step)."""
+        return self.p_w is not None and self.p_w.grad is not None
 
     def generation(self) -> int:
         """Changes whenever the underlying weights do (layouts derived from them are rebuilt then)."""
@@ -158,6 +163,10 @@ class ConvWeight:
 
 
 PRESPLIT_TRAINING = os.environ.get("MFHIP_NO_PRESPLIT", "0") != "1"      # developer A/B: split arena weights in registers
+# Set (to a fresh object) by training.GraphedTrainStep while it captures: every per-step re-layout of a weight that trains
+# (operand() here, autograd._dgrad_weight) is rebuilt once under the capture regardless of its generation stamp, so that the
+# rebuild is part of the graph.
+CAPTURE_TOKEN = None
 
 
 def split_pack(w: torch.Tensor, code: int):

@@ -180,18 +180,33 @@ def clip_grad_norm_(models: Sequence, max_norm: float, loss_scale: float = 1.0):
 
 def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, latents: torch.Tensor, noise: torch.Tensor,
                timesteps: torch.Tensor, encoder_hidden_states: torch.Tensor, conditioning_latents: torch.Tensor,
-               snr_gamma: Optional[float] = None, max_grad_norm: float = 1.0, grad_sync=None, check_overflow: bool = True):
-    """One optimisation step (:1407-1466).  Returns (loss, grad_norm) as one-element device tensors.
+               snr_gamma: Optional[float] = None, max_grad_norm: float = 1.0, grad_sync=None, check_overflow: bool = True,
+               gradient_accumulation_steps: int = 1, lr_scheduler=None):
+    """One pass of the training loop's body (:1349, 1407-1466).  Returns (loss, grad_norm) as one-element device tensors.
     `grad_sync`: a distributed.GradBuckets when several ranks train data-parallel (the DDP wrap of :1267-1269).
-    `check_overflow` (f16x3 only): read the split precision's range-guard flags after the backward pass and skip the
-    optimizer step when an operand left the fp16 range."""
+    `check_overflow` (split precisions): read the range-guard flags after the backward pass and skip the optimizer step when
+    an operand of the forward OR the backward pass left the fp16 range.
+    `gradient_accumulation_steps` = G (--gradient_accumulation_steps, `accelerator.accumulate`, :1349): the gradients of G
+    consecutive calls are summed in the arena (each loss scaled by 1 / G, accelerate's `backward`); only the G-th call
+    exchanges gradients between ranks (DDP's no_sync on the others), clips, steps the optimizer and the learning-rate
+    schedule and zeroes the arena — the other calls return (loss, None).
+    `lr_scheduler`: an optimization.LambdaLR (optimization.get_scheduler, :1257); stepped once per rank per optimizer step,
+    as accelerate's scheduler wrapper does (which is why the script scales its warm-up by num_processes, :1260)."""
     mods = model.get_trainable_modules()
     if not mods:
         raise RuntimeError("train_step: call model.prepare_training() first")
-    optimizer.zero_grad()
+    accum = max(int(gradient_accumulation_steps), 1)
+    micro = getattr(optimizer, "_micro", 0)
+    sync_step = micro + 1 >= accum
     prec = model.brushnet.prec
+    guard = prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and check_overflow      # bf16x1 runs the fp16 split flash attention
+    if micro == 0:
+        optimizer.zero_grad()
+        if guard:
+            hip.split_overflow(reset=True)     # flags raised by earlier, unrelated work do not count against this step; the
+                                               # forward pass that follows DOES (the flags are sticky until the read below)
     tape = autograd.Tape(prec.tape_code)
-    if grad_sync is not None:
+    if grad_sync is not None and sync_step:
         grad_sync.begin(tape)
     # The data-gradient layouts of the weights that train (transposed, tap-flipped, split: ~540 small launches) depend only on
     # the weights the optimizer left behind: rebuild them on a side stream under the forward pass instead of inside the backward
@@ -225,10 +240,9 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     scale = 1.0
     if prec.split:
         scale = float(2 ** int(pred.numel() - 1).bit_length())
-        d_pred = hip.axpby_n([d_pred], [scale], out=d_pred)
+    if scale != 1.0 or accum > 1:
+        d_pred = hip.axpby_n([d_pred], [scale / accum], out=d_pred)      # 1 / G: accelerator.backward under accumulate()
     model.loss_scale = scale
-    if prec.code == hip.MF_F16X3 and check_overflow:
-        hip.split_overflow(reset=True)         # flags raised by earlier, unrelated work do not count against this step
     tape.add(pred, d_pred)
     if dgrad_ready is not None:
         torch.cuda.current_stream(mods[0].device).wait_event(dgrad_ready)
@@ -236,10 +250,14 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     if tape.dgrad_rebuilt:
         known = {id(c) for c in (prefetch or [])}
         model._dgrad_prefetch = list(prefetch or []) + [c for c in tape.dgrad_rebuilt if id(c) not in known]
+    if not sync_step:
+        optimizer._micro = micro + 1
+        return loss, None
+    optimizer._micro = 0
     if grad_sync is not None:
         grad_sync.finish()
     norm, coef = clip_grad_norm_(mods, max_grad_norm, loss_scale=scale)
-    if prec.code == hip.MF_F16X3 and check_overflow:
+    if guard:
         # fp16 halves saturate above 65504 without producing inf / NaN (mfhip.h, mf_split_overflow): a step whose forward or
         # (loss-scaled) backward operands left that range has silently wrong gradients — it is SKIPPED, like a GradScaler
         # step with inf gradients.  One 12-byte read-back per step; every rank skips together (the flag is all-reduced).
@@ -250,11 +268,14 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
         if raised:
             import warnings
             model.overflow_steps = getattr(model, "overflow_steps", 0) + 1
-            warnings.warn(f"train_step: an f16x3 operand exceeded the fp16 range (flags {raised:#x}); optimizer step skipped "
-                          f"({model.overflow_steps} so far) — train with precision 'bf16x1' / 'fp32' if this persists")
+            warnings.warn(f"train_step: a split-precision operand exceeded the fp16 range (flags {raised:#x}); optimizer step "
+                          f"skipped ({model.overflow_steps} so far) — train with precision 'fp32' if this persists")
             optimizer.zero_grad()
             return loss, norm
     optimizer.step(grad_scale=coef)
+    if lr_scheduler is not None:
+        for _ in range(max(int(getattr(grad_sync, "world", 1) or 1), 1) if grad_sync is not None else 1):
+            lr_scheduler.step()
     return loss, norm
 
 
@@ -274,10 +295,17 @@ class GraphedTrainStep:
     Memory: the graph keeps one step's activations resident between calls (they are reused, not reallocated)."""
 
     def __init__(self, model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, snr_gamma: Optional[float] = None,
-                 max_grad_norm: float = 1.0, check_overflow: bool = True, warmup: int = 2):
+                 max_grad_norm: float = 1.0, check_overflow: bool = True, warmup: int = 2, lr_scheduler=None):
         self.model, self.ns, self.opt = model, noise_scheduler, optimizer
         self.snr_gamma, self.max_grad_norm, self.check_overflow = snr_gamma, max_grad_norm, check_overflow
         self.warmup, self.calls, self.graph = max(int(warmup), 1), 0, None
+        self.lr_scheduler = lr_scheduler
+        self._arena_key = None
+
+    def _arenas(self):
+        """What the captured kernels point into: the weight / gradient arenas of both networks."""
+        return tuple(t.data_ptr() for m in (self.model.brushnet, self.model.unet)
+                     for t in (getattr(m, "flat_w", None), getattr(m, "flat_g", None)) if t is not None)
 
     # -- eager, host-dependent staging ----------------------------------------------------------------------------------
     def _stage(self, latents, noise, timesteps, ehs, cond):
@@ -343,9 +371,13 @@ class GraphedTrainStep:
         if self.graph is None and self.calls < self.warmup:
             self.calls += 1
             return train_step(model, self.ns, self.opt, latents, noise, timesteps, encoder_hidden_states, conditioning_latents,
-                              snr_gamma=self.snr_gamma, max_grad_norm=self.max_grad_norm, check_overflow=self.check_overflow)
+                              snr_gamma=self.snr_gamma, max_grad_norm=self.max_grad_norm, check_overflow=self.check_overflow,
+                              lr_scheduler=self.lr_scheduler)
         dev = mods[0].device
         prec = model.brushnet.prec
+        if self.graph is not None and self._arenas() != self._arena_key:
+            # prepare_training() rebuilt an arena since the capture: the graph's kernels point at freed memory
+            self.graph = None
         if self.graph is None:
             f32 = dict(dtype=torch.float32, device=dev)
             self.noisy, self.target = torch.empty(latents.shape, **f32), torch.empty(latents.shape, **f32)
@@ -355,14 +387,23 @@ class GraphedTrainStep:
             self._stage(latents, noise, timesteps, encoder_hidden_states, conditioning_latents)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.loss, self.norm, self.coef = self._body()
+            # The per-step re-layouts of the weights that train (ConvWeight.operand: split-pack; autograd._dgrad_weight:
+            # transpose + split-pack) must be IN the graph, whatever their generation stamps say: a warm-up step skipped by the
+            # range guard leaves the stamps current, and a graph captured then would replay on frozen copies while AdamW keeps
+            # updating the arena.  The token makes each of them rebuild once during this capture.
+            ops.CAPTURE_TOKEN = object()
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.loss, self.norm, self.coef = self._body()
+            finally:
+                ops.CAPTURE_TOKEN = None
+            self._arena_key = self._arenas()
         else:
             for t, ref in ((latents, self.noisy), (encoder_hidden_states, self.ehs), (conditioning_latents, self.cond)):
                 if tuple(t.shape) != tuple(ref.shape):
                     raise ValueError(f"GraphedTrainStep: input shape {tuple(t.shape)} != the captured {tuple(ref.shape)}")
             self._stage(latents, noise, timesteps, encoder_hidden_states, conditioning_latents)
-        guard = prec.code == hip.MF_F16X3 and self.check_overflow
+        guard = prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and self.check_overflow
         if guard:
             hip.split_overflow(reset=True)
         self.graph.replay()
@@ -370,11 +411,13 @@ class GraphedTrainStep:
         if guard and hip.split_overflow(reset=True):
             import warnings
             model.overflow_steps = getattr(model, "overflow_steps", 0) + 1
-            warnings.warn(f"GraphedTrainStep: an f16x3 operand exceeded the fp16 range; optimizer step skipped "
-                          f"({model.overflow_steps} so far) — train with precision 'bf16x1' / 'fp32' if this persists")
+            warnings.warn(f"GraphedTrainStep: a split-precision operand exceeded the fp16 range; optimizer step skipped "
+                          f"({model.overflow_steps} so far) — train with precision 'fp32' if this persists")
             self.opt.zero_grad()
             return self.loss, self.norm
         self.opt.step(grad_scale=self.coef)
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
         return self.loss, self.norm
 
 

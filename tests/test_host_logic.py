@@ -413,3 +413,40 @@ def test_image_processor_host_path_matches_the_reference_vae_image_processor():
     assert np.array_equal(np.stack([np.array(im) for im in ip.postprocess(I["post"], output_type="pil", do_denormalize=[True, True])]),
                           G["post_pil"])
     assert np.array_equal(ip.postprocess(I["post"], output_type="pt", do_denormalize=[True, False]).numpy(), G["post_pt_mixed"])
+
+
+def test_lr_schedules_match_the_reference_get_scheduler():
+    """optimization.get_scheduler (train_brushnet_mirror.py:1257-1263) against the learning rates the REFERENCE's
+    diffusers.optimization.get_scheduler produced for every schedule name (tests/golden/lr_schedules.json,
+    tools/make_golden_r04.py --lr-schedules): the value after construction and after each step, exactly."""
+    import json
+    from reflecting_reality_amd import optimization as O
+
+    class Opt:
+        def __init__(self, lr):
+            self.lr = lr
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lr_schedules.json")) as f:
+        g = json.load(f)
+    for name, kw in g["_cases"].items():
+        o = Opt(g["_lr"])
+        sch = O.get_scheduler(name, o, **kw)
+        seq = [sch.get_last_lr()[0]]
+        for _ in range(g["_steps"]):
+            sch.step()
+            seq.append(o.lr)
+        assert seq == g[name], name
+    with pytest.raises(ValueError):
+        O.get_scheduler("linear", Opt(1e-5), num_warmup_steps=3)               # needs num_training_steps
+    with pytest.raises(ValueError):
+        O.get_scheduler("cosine", Opt(1e-5))
+    # a resumed schedule (state_dict round trip) continues where it stopped
+    o = Opt(1e-5)
+    a = O.get_scheduler("cosine", o, num_warmup_steps=2, num_training_steps=10)
+    for _ in range(4):
+        a.step()
+    o2 = Opt(1e-5)
+    b = O.get_scheduler("cosine", o2, num_warmup_steps=2, num_training_steps=10)
+    b.load_state_dict(a.state_dict())
+    a.step(); b.step()
+    assert o.lr == o2.lr

@@ -667,3 +667,144 @@ def test_bench_train_under_torchrun_with_rccl_reports_all_reduce():
     ar = rec["all_reduce"]
     assert ar is not None and ar["ms"] > 0 and ar["bytes"] > 1e9, ar
     print("single-rank RCCL all-reduce of the BrushNet gradient arena:", ar)
+
+
+# ---- round 4: range guard over the WHOLE step, capture after a skipped warm-up, accumulation, lr schedule ---------------
+def _skip_inputs(i, overflow=False):
+    lat, noi, ts, ehs, cond = _batches()[i % 2]
+    ts = (ts + 37 * i) % 1000
+    ehs = ehs * (3.0e6 if overflow else 1.0)        # the UNet's to_k / to_v operands leave the fp16 range IN THE FORWARD pass
+    return lat.to(DEV) * (1.0 + 0.1 * i), noi.to(DEV), ts, ehs.to(DEV), cond.to(DEV)
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_forward_overflow_skips_the_optimizer_step(graphed):
+    """an f16x3 operand above 65504 in the FORWARD pass must skip the step (v_cvt_pkrtz saturates silently).  The
+    guard flags are reset before the forward pass and read after the backward pass, in train_step and in GraphedTrainStep."""
+    import warnings
+    from reflecting_reality_amd.training import GraphedTrainStep
+    ns = DDPMScheduler(**SD_SCHED)
+    model = _model("f16x3").prepare_training()
+    opt = AdamW(model.get_trainable_modules())
+    step = GraphedTrainStep(model, ns, opt, warmup=1) if graphed else (lambda *a: train_step(model, ns, opt, *a))
+    for i in range(2):                                # (graphed: one eager warm-up, then the capture)
+        step(*_skip_inputs(i))
+    w = model.brushnet.flat_w.clone()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        step(*_skip_inputs(2, overflow=True))
+    assert any("exceeded the fp16 range" in str(r.message) for r in rec), "the overflowing step was not reported"
+    assert torch.equal(model.brushnet.flat_w, w), "weights moved although a forward operand left the fp16 range"
+    assert opt.step_count == 2 and getattr(model, "overflow_steps", 0) == 1
+    step(*_skip_inputs(3))                            # and training goes on
+    assert opt.step_count == 3 and not torch.equal(model.brushnet.flat_w, w)
+
+
+def test_flag_raised_between_forward_and_backward_counts(monkeypatch):
+    """The discriminating form of the test above: a range-guard flag raised after the forward pass and before the backward pass
+    (here by an unrelated overflowing split issued from the loss-gradient call) must still be set when train_step reads the
+    flags — round 3's train_step cleared them at exactly that point."""
+    import warnings
+    ns = DDPMScheduler(**SD_SCHED)
+    model = _model("f16x3").prepare_training()
+    opt = AdamW(model.get_trainable_modules())
+    orig = hip.mse_grad
+
+    def mse_grad_and_overflow(*a, **k):
+        hip.split_halves(torch.full((64,), 1.0e6, device=DEV))
+        return orig(*a, **k)
+
+    monkeypatch.setattr(hip, "mse_grad", mse_grad_and_overflow)
+    w = model.brushnet.flat_w.clone()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        train_step(model, ns, opt, *_skip_inputs(0))
+    assert any("exceeded the fp16 range" in str(r.message) for r in rec)
+    assert torch.equal(model.brushnet.flat_w, w) and opt.step_count == 0
+
+
+def test_capture_after_an_overflow_skipped_warmup_replays_on_live_weights():
+    """when the warm-up step of GraphedTrainStep is skipped by the range guard the weight generation does not move,
+    so the per-step re-layouts (split-pack of the forward weights, transpose + split-pack of the data-gradient weights) used to
+    be left OUT of the captured graph, and every replay ran on frozen copies while AdamW kept updating the arena.  The capture
+    now forces them in: the graphed run equals the eager run bit for bit over three optimizer steps after the skipped one."""
+    import warnings
+    from reflecting_reality_amd.training import GraphedTrainStep
+    ns = DDPMScheduler(**SD_SCHED)
+
+    def run(graphed):
+        model = _model("f16x3").prepare_training()
+        opt = AdamW(model.get_trainable_modules())
+        step = GraphedTrainStep(model, ns, opt, warmup=1) if graphed else (lambda *a: train_step(model, ns, opt, *a))
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            step(*_skip_inputs(0, overflow=True))     # the warm-up call: skipped
+            assert opt.step_count == 0
+            for i in range(1, 5):
+                loss, norm = step(*_skip_inputs(i))
+                out.append((float(loss), float(norm)))
+        assert opt.step_count == 4
+        return model.brushnet.flat_w.clone(), out
+
+    (wa, la), (wb, lb) = run(False), run(True)
+    assert la == lb, (la, lb)
+    assert torch.equal(wa, wb), "the graph captured after a skipped warm-up step trains on stale weight layouts"
+
+
+def test_graphed_step_recaptures_when_the_arenas_move():
+    """prepare_training() rebuilds the arenas: a graph captured before it points at freed memory and must not be replayed."""
+    from reflecting_reality_amd.training import GraphedTrainStep
+    ns = DDPMScheduler(**SD_SCHED)
+    model = _model("fp32").prepare_training()
+    opt = AdamW(model.get_trainable_modules())
+    step = GraphedTrainStep(model, ns, opt, warmup=1)
+    for i in range(3):
+        step(*_skip_inputs(i))
+    g0, key0 = step.graph, step._arena_key
+    keep = (model.brushnet.flat_w, model.brushnet.flat_g)          # keep the old arenas alive so the new ones get new addresses
+    model.prepare_training()
+    opt2 = AdamW(model.get_trainable_modules())
+    step.opt = opt2
+    loss, norm = step(*_skip_inputs(3))
+    assert step.graph is not g0 and step._arena_key != key0 and np.isfinite(float(loss)) and float(norm) > 0
+    del keep
+
+
+def test_gradient_accumulation_equals_the_joint_batch_and_the_lr_schedule_steps_with_the_optimizer():
+    """--gradient_accumulation_steps 2 (train_brushnet_mirror.py:474-478, :1349): two calls on 3 samples each leave the
+    gradients — and, after AdamW, the weights — of ONE call on the 6 samples (mean loss over 6 = mean of the two means; each
+    micro-loss scaled by 1 / 2); the first call returns no norm, takes no optimizer step and leaves the schedule alone.  The
+    schedule is optimization.get_scheduler's (pinned to the reference in tests/test_host_logic.py)."""
+    from reflecting_reality_amd.optimization import get_scheduler
+    ns = DDPMScheduler(**SD_SCHED)
+    (l0, n0, t0, e0, c0), (l1, n1, t1, e1, c1) = _batches()
+
+    model = _model("fp32").prepare_training()
+    opt = AdamW(model.get_trainable_modules(), lr=1e-5)
+    sch = get_scheduler("constant_with_warmup", opt, num_warmup_steps=2)
+    assert opt.lr == 0.0
+    sch.step()                                        # leave the zero-lr first step of the warm-up behind: lr = 5e-6
+    loss_a, norm_a = train_step(model, ns, opt, l0.to(DEV), n0.to(DEV), t0, e0.to(DEV), c0.to(DEV), gradient_accumulation_steps=2,
+                                lr_scheduler=sch)
+    assert norm_a is None and opt.step_count == 0 and opt.lr == 5e-6 and opt._micro == 1
+    g_half = model.brushnet.flat_g.clone()
+    loss_b, norm_b = train_step(model, ns, opt, l1.to(DEV), n1.to(DEV), t1, e1.to(DEV), c1.to(DEV), gradient_accumulation_steps=2,
+                                lr_scheduler=sch)
+    assert norm_b is not None and opt.step_count == 1 and opt.lr == 1e-5 and opt._micro == 0
+    assert float(g_half.abs().max()) > 0
+    w_acc = model.brushnet.flat_w.clone()
+
+    joint = _model("fp32").prepare_training()
+    opt2 = AdamW(joint.get_trainable_modules(), lr=5e-6)
+    cat = lambda a, b: torch.cat([a, b]).to(DEV)
+    loss_j, norm_j = train_step(joint, ns, opt2, cat(l0, l1), cat(n0, n1), torch.cat([t0, t1]), cat(e0, e1), cat(c0, c1))
+    print(f"accumulated: losses {float(loss_a):.7f} {float(loss_b):.7f} norm {float(norm_b):.6f} | joint: loss {float(loss_j):.7f} norm {float(norm_j):.6f}")
+    assert abs(0.5 * (float(loss_a) + float(loss_b)) - float(loss_j)) < 1e-6 * float(loss_j)
+    assert abs(float(norm_b) - float(norm_j)) < 1e-5 * float(norm_j)
+    n = joint.brushnet.num_arena_floats()
+    dw_acc, dw_j = w_acc[:n] - _model("fp32").prepare_training().brushnet.flat_w[:n], joint.brushnet.flat_w[:n] - _model("fp32").prepare_training().brushnet.flat_w[:n]
+    # Adam's first step moves every weight by ~lr * sign(g): compare the updates, not the weights
+    rel = float((dw_acc - dw_j).norm() / dw_j.norm())
+    print(f"   ||update(accumulated) - update(joint)|| / ||update|| = {rel:.3e}")
+    assert rel < 2e-3            # g / (|g| + eps) flips where a gradient element is ~0 (summation order differs)
