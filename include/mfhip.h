@@ -54,7 +54,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 13
+#define MF_ABI_VERSION 14
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -146,6 +146,13 @@ typedef struct mf_gemm_desc {
      * written to `out` but as vt_out[image][n - vt_n0][token] (bf16, row stride vt_ld elements), image = m / vt_tokens,
      * token = m % vt_tokens.  vt_n0 must be a multiple of 640; same tiles as ln_colsum.  NULL = off. */
     void* vt_out; int32_t vt_n0, vt_tokens; int64_t vt_ld;
+    /* In-launch split-K combine: sk_tickets = `sk_ticket_cap` 32-bit arrival counters owned by the caller, ALL ZERO when the call
+     * is issued (the kernel leaves them zero again; one buffer per stream, like `ws`).  With split-K > 1 and at most
+     * sk_ticket_cap output tiles, the K-slice block that arrives last at its tile's counter sums the tile's fp32 slabs in slice
+     * order (bit-reproducible) and runs the epilogue itself: the separate reduce launch and the kernel boundary behind the
+     * dirty partials disappear.  Built into the tiles small-M / deep-K calls use (1, 2, 3, 6 and the warp-specialised rings 41,
+     * 43, 44, 48 in bf16; 1, 2, 3, 6, 41, 44 in MF_F16X3); any other tile, or NULL, keeps the reduce launch — same result. */
+    uint32_t* sk_tickets; int32_t sk_ticket_cap;
 } mf_gemm_desc;
 
 int mf_gemm_conv(const mf_gemm_desc* d, void* stream);
@@ -335,12 +342,18 @@ int64_t mf_select_ws_bytes(void);
 int mf_select_ranks(const float* x, int64_t n, const int64_t* ranks, int32_t nr, float* vals, void* ws, void* stream);
 int mf_depth_percentile_normalize(const float* depth, float* out, int64_t n, const int64_t* ranks4, float t_lo, float t_hi,
                                   int32_t signed_range, float* vals4, void* ws, void* stream);
-/* torchvision Resize(interpolation=BICUBIC) + CenterCrop (+ Normalize) of dataset.py:150-164,184-192 on fp32 planes: PyTorch's
- * bicubic kernel (align_corners = False, A = -0.75, NO antialiasing: identical to torchvision when upsampling; torchvision >= 0.17
- * additionally low-pass filters tensors when DOWN-sampling) evaluated inside the crop window only:
+/* torchvision Resize(interpolation=BICUBIC, antialias=False) + CenterCrop (+ Normalize) of dataset.py:150-164,184-192 on fp32 planes:
+ * PyTorch's plain bicubic kernel (align_corners = False, A = -0.75, no antialiasing: torchvision < 0.17's default for tensors)
+ * evaluated inside the crop window only:
  * dst[p][y][x] = a * bicubic(src[p] resized to h_res x w_res)[y + crop_top][x + crop_left] + b */
 int mf_bicubic_resize_crop(const float* src, float* dst, int32_t planes, int32_t h_in, int32_t w_in, int32_t h_res, int32_t w_res,
                            int32_t crop_top, int32_t crop_left, int32_t h_out, int32_t w_out, float a, float b, void* stream);
+/* The same with PyTorch's ANTIALIASED bicubic (F.interpolate(mode="bicubic", align_corners=False, antialias=True): ATen's
+ * _upsample_bicubic2d_aa, Keys kernel a = -0.5 stretched by max(scale, 1), weights normalised per output pixel, width pass then
+ * height pass) — what torchvision 0.18 (the reference's pinned version) runs for transforms.Resize(BICUBIC) on a tensor at every
+ * scale (dataset.py:150-164,183-192: antialias defaults to True there). */
+int mf_bicubic_aa_resize_crop(const float* src, float* dst, int32_t planes, int32_t h_in, int32_t w_in, int32_t h_res, int32_t w_res,
+                              int32_t crop_top, int32_t crop_left, int32_t h_out, int32_t w_out, float a, float b, void* stream);
 /* y[c][p] = a * x[p][c] + b: HWC -> CHW with Normalize([0.5], [0.5]) (apply_transforms_normals, dataset.py:184-192) */
 int mf_hwc_to_chw_affine(const float* x, float* y, int64_t hw, int32_t channels, float a, float b, void* stream);
 

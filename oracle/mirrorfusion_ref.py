@@ -770,19 +770,22 @@ def training_steps(unet_sd: SD, unet_cfg: dict, bn_sd: SD, bn_cfg: dict, sched_c
 # the build container, so it cannot be imported to check this restatement; it follows the numpy statements of
 # :122-145 line by line (the torchvision Resize / CenterCrop of :150-164 are the identity at the native resolution).
 # ---------------------------------------------------------------------------------------------
-def _resize_center_crop_ref(t: torch.Tensor, resolution: int) -> torch.Tensor:
-    """transforms.Resize(resolution, BICUBIC) + CenterCrop(resolution) on a [C, H, W] tensor WITHOUT antialiasing (torchvision
-    < 0.17 for tensors; every version when up-sampling): smaller edge -> resolution, aspect kept (truncated), centre crop."""
+def _resize_center_crop_ref(t: torch.Tensor, resolution: int, antialias: bool = True) -> torch.Tensor:
+    """transforms.Resize(resolution, BICUBIC) + CenterCrop(resolution) on a [C, H, W] tensor: smaller edge -> resolution,
+    aspect kept (truncated), centre crop.  antialias=True is torchvision 0.18's default (the reference's pinned version):
+    its tensor path calls exactly this interpolate (torchvision/transforms/_functional_tensor.py `resize`) at every scale;
+    False is the plain kernel (torchvision < 0.17 for tensors)."""
     _, h, w = t.shape
     nh, nw = (resolution, int(resolution * w / h)) if h <= w else (int(resolution * h / w), resolution)
     if (nh, nw) != (h, w):
-        t = F.interpolate(t[None], size=(nh, nw), mode="bicubic", align_corners=False)[0]
+        t = F.interpolate(t[None], size=(nh, nw), mode="bicubic", align_corners=False, antialias=antialias)[0]
     top, left = int(round((nh - resolution) / 2.0)), int(round((nw - resolution) / 2.0))
     return t[:, top:top + resolution, left:left + resolution]
 
 
 def apply_transforms_depth_ref(depth_map, mask=None, max_scene_depth: float = 5.0, norm_range=(-1, 1), delta: float = 0.5,
-                               normalization_method: str = "max_scene_depth", resolution: Optional[int] = None):
+                               normalization_method: str = "max_scene_depth", resolution: Optional[int] = None,
+                               antialias: bool = True):
     import numpy as np
     depth_map = np.copy(depth_map)
     if mask is not None and mask.ndim == 3:
@@ -807,11 +810,11 @@ def apply_transforms_depth_ref(depth_map, mask=None, max_scene_depth: float = 5.
         else:
             raise ValueError("Unsupported normalization range. Use [0, 1] or [-1, 1].")
     t = torch.tensor(out, dtype=torch.float32).unsqueeze(0)                               # :150
-    return t if resolution is None else _resize_center_crop_ref(t, resolution)           # :152-164
+    return t if resolution is None else _resize_center_crop_ref(t, resolution, antialias)   # :152-164
 
 
-def apply_transforms_normals_ref(normals_map, resolution: int = 512):
+def apply_transforms_normals_ref(normals_map, resolution: int = 512, antialias: bool = True):
     """dataset.py:184-192 (the map-valued modes): permute to CHW, Resize / CenterCrop, Normalize([0.5], [0.5]).  PARITY
     UNPINNED like apply_transforms_depth_ref (same module)."""
     t = torch.tensor(normals_map, dtype=torch.float32).permute(2, 0, 1)
-    return (_resize_center_crop_ref(t, resolution) - 0.5) / 0.5
+    return (_resize_center_crop_ref(t, resolution, antialias) - 0.5) / 0.5

@@ -229,6 +229,57 @@ __global__ __launch_bounds__(256) void bicubic_crop_kernel(const float* src, flo
     }
 }
 
+// ---- the same with PyTorch's ANTIALIASED bicubic (F.interpolate(mode="bicubic", align_corners=False, antialias=True)) ------------
+// What torchvision 0.18 (the reference's pinned version, MirrorFusion/README.md:34) computes for transforms.Resize(BICUBIC) on a
+// tensor at EVERY scale: antialias defaults to True and _functional_tensor.resize hands it to interpolate unconditionally.
+// ATen's _upsample_bicubic2d_aa: separable; per output index i along a dimension of size n_in -> n_out, scale = n_in / n_out,
+// support = 2 * max(scale, 1), centre = scale * (i + 0.5); taps [xmin, xmin + xsize) with xmin = max(int(centre - support + 0.5), 0),
+// xsize = min(int(centre + support + 0.5), n_in) - xmin; weight_j = cubic_aa((j + xmin - centre + 0.5) / max(scale, 1)) with the Keys
+// kernel at a = -0.5 (NOT the -0.75 of the plain kernel), normalised by their sum.  Width first, then height, as ATen does.
+__device__ __forceinline__ float cubic_aa(float x) {
+    const float a = -0.5f;
+    x = fabsf(x);
+    if (x < 1.0f) return ((a + 2.0f) * x - (a + 3.0f)) * x * x + 1.0f;
+    if (x < 2.0f) return (((x - 5.0f) * x + 8.0f) * x - 4.0f) * a;
+    return 0.0f;
+}
+struct AaTaps { int lo, n; float centre, inv, total; };
+__device__ __forceinline__ AaTaps aa_taps(int i, int n_in, float scale) {
+    AaTaps t;
+    const float support = scale >= 1.0f ? 2.0f * scale : 2.0f;
+    t.inv = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    t.centre = scale * ((float)i + 0.5f);
+    t.lo = (int)(t.centre - support + 0.5f);
+    if (t.lo < 0) t.lo = 0;
+    int hi = (int)(t.centre + support + 0.5f);
+    if (hi > n_in) hi = n_in;
+    t.n = hi - t.lo;
+    t.total = 0.0f;
+    for (int j = 0; j < t.n; ++j) t.total += cubic_aa(((float)(j + t.lo) - t.centre + 0.5f) * t.inv);
+    return t;
+}
+__global__ __launch_bounds__(256) void bicubic_aa_crop_kernel(const float* src, float* dst, int planes, int h_in, int w_in, int h_res, int w_res,
+                                                              int oy, int ox, int h_out, int w_out, float a, float b) {
+    const float sh = (float)h_in / (float)h_res, sw = (float)w_in / (float)w_res;
+    const int64_t total = (int64_t)planes * h_out * w_out;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w_out);
+        const int64_t t = i / w_out;
+        const int y = (int)(t % h_out);
+        const int pl = (int)(t / h_out);
+        const AaTaps ty = aa_taps(y + oy, h_in, sh), tx = aa_taps(x + ox, w_in, sw);
+        const float* sp = src + (int64_t)pl * h_in * w_in;
+        float acc = 0.0f;
+        for (int j = 0; j < ty.n; ++j) {
+            const float* rowp = sp + (int64_t)(ty.lo + j) * w_in + tx.lo;
+            float row = 0.0f;                       // the width pass' output pixel (ATen's intermediate image)
+            for (int k = 0; k < tx.n; ++k) row += rowp[k] * (cubic_aa(((float)(k + tx.lo) - tx.centre + 0.5f) * tx.inv) / tx.total);
+            acc += row * (cubic_aa(((float)(j + ty.lo) - ty.centre + 0.5f) * ty.inv) / ty.total);
+        }
+        dst[i] = a * acc + b;
+    }
+}
+
 // y[c][p] = a * x[p][c] + b: HWC -> CHW with an affine map (apply_transforms_normals at the native resolution)
 __global__ __launch_bounds__(256) void hwc_to_chw_affine_kernel(const float* x, float* y, int64_t hw, int c, float a, float b) {
     const int64_t total = hw * c;
@@ -353,6 +404,17 @@ extern "C" int mf_bicubic_resize_crop(const float* src, float* dst, int32_t plan
     hipLaunchKernelGGL(bicubic_crop_kernel, dim3(fgrid((int64_t)planes * h_out * w_out)), dim3(256), 0, (hipStream_t)stream, src, dst, planes,
                        h_in, w_in, h_res, w_res, crop_top, crop_left, h_out, w_out, a, b);
     MF_CHECK_LAUNCH("mf_bicubic_resize_crop");
+    return MF_OK;
+}
+
+extern "C" int mf_bicubic_aa_resize_crop(const float* src, float* dst, int32_t planes, int32_t h_in, int32_t w_in, int32_t h_res, int32_t w_res,
+                                         int32_t crop_top, int32_t crop_left, int32_t h_out, int32_t w_out, float a, float b, void* stream) {
+    MF_CHECK_ARG(src && dst && planes >= 1 && h_in >= 1 && w_in >= 1 && h_res >= 1 && w_res >= 1 && h_out >= 1 && w_out >= 1 && crop_top >= 0 &&
+                     crop_left >= 0 && crop_top + h_out <= h_res && crop_left + w_out <= w_res,
+                 "mf_bicubic_aa_resize_crop: the crop window must lie inside the resized image");
+    hipLaunchKernelGGL(bicubic_aa_crop_kernel, dim3(fgrid((int64_t)planes * h_out * w_out)), dim3(256), 0, (hipStream_t)stream, src, dst, planes,
+                       h_in, w_in, h_res, w_res, crop_top, crop_left, h_out, w_out, a, b);
+    MF_CHECK_LAUNCH("mf_bicubic_aa_resize_crop");
     return MF_OK;
 }
 

@@ -34,6 +34,20 @@ namespace {
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];   // zero-initialised module global
 __device__ unsigned g_split_ovf_gemm;     // raised when an MF_F16X3 operand exceeded the fp16 range (mf_common.h)
 
+// Developer build only (-DMF_STAMPS: tools/stamps.py): wave 0 of every block (and the first staging wave of a warp-specialised
+// block, slots 8+) writes the 100 MHz real-time counter at its phase boundaries, so that a launch's time can be split into
+// ramp / prologue / first DMA round trip / main loop / epilogue per block.  Compiled out of the product library.
+#ifdef MF_STAMPS
+__device__ unsigned long long* g_stamps;   // [blocks][16]
+#define MF_STAMP(slot) do { if (g_stamps) { const int t_ = (int)threadIdx.x; \
+    if (t_ == 0) g_stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    else if (t_ == (int)blockDim.x - 256) g_stamps[(size_t)blockIdx.x * 16 + 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define MF_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")     // slot 5 = "the epilogue's stores have left"
+#else
+#define MF_STAMP(slot) do { } while (0)
+#define MF_STAMP_DRAIN() do { } while (0)
+#endif
+
 struct GemmArgs {
     const char* a0; const char* a1;
     int C0, Ctot;
@@ -44,6 +58,7 @@ struct GemmArgs {
     int zdiv; int64_t a_zs_o, a_zs_i, w_zs_o, w_zs_i, o_zs_o, o_zs_i;
     int splitk, kt_per_split, nkt, nz;
     float* ws;
+    unsigned* sk_tickets;    // in-launch split-K combine: one arrival counter per output tile (zero between launches), or nullptr
     const float* bias; int bias_mode;
     const float* rs; const float* cs; int64_t rs_zs, cs_zs;   // dequantisation: acc * rs[m] * cs[n]
     const float* temb; int64_t ld_temb;
@@ -53,6 +68,7 @@ struct GemmArgs {
     float alpha; int act;
     char* out; int out_dt; int64_t ldc;
     int tiles_n, tiles_m, ord_mfast, ord_pw, nblk, vec_ok, fast, dbg_no_res_pre;
+    int pointwise;           // kh = kw = 1, stride 1, no padding, no upsample, same extent: input pixel index == output row
     // LayerNorm folded into this GEMM (warp-specialised ring tiles): ln_cs[n] = sum_k W'[n][k] of the gamma-scaled weight;
     // the staging waves accumulate every A row's (sum, sum of squares) while they wait, the epilogue applies
     // rstd[m] * (acc - mean[m] * ln_cs[n]).  vt_out: columns n >= vt_n0 are written TRANSPOSED ([image][n - vt_n0][token]).
@@ -230,6 +246,60 @@ constexpr int min_waves(int bm, int bn, int stages, int nthr) {
     return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
+// In-launch split-K combine (mf_gemm_desc.sk_tickets).  Every K-slice block has written its fp32 slab; the block that arrives
+// LAST at the tile's ticket sums the slabs in slice order (s = 0 .. splitk-1: the result does not depend on which block that is)
+// and runs the epilogue — no second launch, and the kernel boundary behind ~10-20 MB of dirty partials goes with it.
+// Cross-workgroup visibility (cdna_hip_programming.md Guideline 16, the counter form): every storing wave drains vmcnt, the
+// block's barrier, ONE lane's agent-scope release + drain, the relaxed agent-scope ticket; the last arriver's ONE agent-scope
+// acquire + drain, a barrier, then plain loads by every wave.  Correct for any placement of a tile's slices over XCDs / CUs.
+// The last arriver re-arms the ticket, so the counters are zero again when the launch ends.
+template <int BM, int BN, int NT_ALL>
+__device__ __forceinline__ void splitk_combine_tail(const GemmArgs& p, char* smem, int tile_m, int tile_n, int z, int zq, int64_t zo, int t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's slab stores have left
+    __syncthreads();                                                     // ... and every other wave's (the LDS is free too)
+    unsigned* last_flag = reinterpret_cast<unsigned*>(smem);
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the compiler may drop the fence's own wait (Pitfall 12)
+        unsigned* tk = p.sk_tickets + ((int64_t)z * p.tiles_m + tile_m) * p.tiles_n + tile_n;
+        const unsigned prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = prev == (unsigned)p.splitk - 1u;
+        if (last) {
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *last_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*last_flag == 0u) return;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    constexpr int CPR = BN / 8;
+    const int64_t mn = (int64_t)p.M * p.N;
+    const bool vec = p.vec_ok && (p.N & 3) == 0;
+    for (int it = t; it < BM * CPR; it += NT_ALL) {
+        const int row = it / CPR, ec = (it - row * CPR) * 8;
+        const int m = m0 + row, n = n0 + ec;
+        if (m >= p.M || n >= p.N) continue;
+        const float* src = p.ws + (int64_t)z * mn + (int64_t)m * p.N + n;
+        if (vec && n + 8 <= p.N) {
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < p.splitk; ++s) {
+                const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)s * p.nz * mn);
+                const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)s * p.nz * mn + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+            epilogue_store8(p, zo, m, n, v, false, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, zq);
+        } else {
+            for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) {
+                float v = 0.0f;
+                for (int s = 0; s < p.splitk; ++s) v += src[(int64_t)s * p.nz * mn + jj];
+                epilogue_store(p, zo, m, n + jj, v, zq);
+            }
+        }
+    }
+}
+
 // DT: MF_BF16, MF_F32, or a split code (MF_F16X3 / MF_BF16X3: fp32 operands staged exactly like MF_F32, every 8-wide
 // fragment split in registers into 16-bit (hi, lo) halves, three 32x32x16 MFMAs per product).  WPK (split codes only):
 // the W operand was split ahead of time ([32 hi | 32 lo] 16-bit values per block of 32 k — the same 128 bytes as 32
@@ -241,8 +311,11 @@ constexpr int min_waves(int bm, int bn, int stages, int nthr) {
 // the last four (one per SIMD) only stage operands (LDS-DMA issue + counted waits), two taps ahead through a 3-deep W ring.  A wave's K
 // tile costs ~640 MFMA cycles AND ~1000 cycles of DMA issue when one wave does both; split over two waves of
 // the same SIMD the two streams issue from different ports and overlap.
+// SKF: the in-launch split-K combine (splitk_combine_tail) is compiled in.  A separate instantiation on purpose: these kernels
+// sit at their register / SGPR budget, and the tail's extra scalar state costs the 256 x 160 forms 368 bytes of scratch and
+// several others a wave per SIMD even when it never runs; only the tiles that small-M, deep-K calls use carry an SKF twin.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES, bool DXR = false, bool WPK = false, bool M16 = false,
-          bool WS = false, bool P16 = false>
+          bool WS = false, bool P16 = false, bool SKF = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 + (WS ? 256 : 0),
                              WS ? (WAVES_M * WAVES_N + 4) / 4 : min_waves(BM + (DXR ? 32 : 0), BN, STAGES, WAVES_M* WAVES_N * 64))
 void gemm_conv_kernel(const GemmArgs p) {
@@ -279,6 +352,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     static_assert(!A_F32 || DT == MF_BF16, "A_F32 only converts fp32 activations for bf16 compute");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MF_STAMP(0);
 
     // wave-uniform, and provably so (a scalar compare): the staging code keeps descriptors and loop state in SGPRs
     const bool producer = WS && __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= NTHR;
@@ -327,13 +401,19 @@ void gemm_conv_kernel(const GemmArgs p) {
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + lrow + i * RPP;
         if (m < p.M) {
-            const int b = m / p.HoWo;
-            const int r = m - b * p.HoWo;
-            const int oy = r / p.Wo;
-            const int ox = r - oy * p.Wo;
-            a_pix[i] = b * p.Hin * p.Win;
-            a_iy0[i] = oy * p.stride - p.pad_t;
-            a_ix0[i] = ox * p.stride - p.pad_l;
+            if (p.pointwise) {          // 1x1 / stride 1 / no padding / no upsample: output pixel m reads input pixel m
+                a_pix[i] = m;           // (two integer divisions per row less: ~0.4 us of every Linear's prologue)
+                a_iy0[i] = 0;
+                a_ix0[i] = 0;
+            } else {
+                const int b = m / p.HoWo;
+                const int r = m - b * p.HoWo;
+                const int oy = r / p.Wo;
+                const int ox = r - oy * p.Wo;
+                a_pix[i] = b * p.Hin * p.Win;
+                a_iy0[i] = oy * p.stride - p.pad_t;
+                a_ix0[i] = ox * p.stride - p.pad_l;
+            }
         } else {
             a_pix[i] = 0;
             a_iy0[i] = -(1 << 28);   // fails the bounds test -> zero page
@@ -729,6 +809,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     };
 
     // ---- main loop ------------------------------------------------------------------------
+    MF_STAMP(1);
     if (nt > 0) {
         if constexpr (DXR) {
             // 3x3 / stride 1 convolution with dx-tap reuse of the A tile.  K runs (ky, 128-byte-row chunk, kx): the
@@ -926,6 +1007,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                     for (int k = 0; k < PFD && k < nt; ++k) issue_next();
                     wait_for(0);
                     __builtin_amdgcn_s_barrier();                  // #0
+                    MF_STAMP(2);
                     for (int t = 0; t + 1 < nt; ++t) {
                         if (t + PFD < nt) issue_next();            // tap t + PFD
                         wait_for(t + 1);
@@ -934,6 +1016,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                 } else {
                     int c_kx = 0, c_grp = 0, c_st = 0;
                     __builtin_amdgcn_s_barrier();                  // #0
+                    MF_STAMP(2);
                     for (int t = 0; t < nt; ++t) {
                         compute3(c_grp & 1, c_st, c_kx);
                         c_st = c_st == WST - 1 ? 0 : c_st + 1;
@@ -1024,6 +1107,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                     for (int k = 0; k < PF && k < nt; ++k) issue_next();
                     wait_for(0);
                     __builtin_amdgcn_s_barrier();                  // #0
+                    MF_STAMP(2);
                     for (int t = 0; t + 1 < nt; ++t) {
                         if (t + PF < nt) issue_next();             // into the stage of tile t - 1: the DMA goes out FIRST ...
                         if (lnf) ln_tile();                        // ... and tile t is summed while it flies
@@ -1051,6 +1135,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                 } else {
                     int st_c = 0;
                     __builtin_amdgcn_s_barrier();                  // #0
+                    MF_STAMP(2);
                     for (int t = 0; t < nt; ++t) {
                         compute(st_c);
                         st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
@@ -1086,7 +1171,9 @@ void gemm_conv_kernel(const GemmArgs p) {
             }
         }
     }
+    MF_STAMP(3);
     __syncthreads();   // every wave is done reading the staging LDS: reuse it for the epilogue slabs
+    MF_STAMP(4);
     if constexpr (DT == MF_F16X3) mf_raise_if_over(&g_split_ovf_gemm, split_amax);
 
     // ---- epilogue ---------------------------------------------------------------------------
@@ -1234,6 +1321,12 @@ void gemm_conv_kernel(const GemmArgs p) {
                 __builtin_amdgcn_s_barrier();
             }
         }
+        MF_STAMP_DRAIN();
+        MF_STAMP(5);
+        if constexpr (SKF) {
+            if (ws) splitk_combine_tail<BM, BN, NTHR + 256>(p, smem, tile_m, tile_n, z, zq, zo, (int)threadIdx.x);
+        }
+        MF_STAMP(6);
         return;
     }
 #pragma unroll
@@ -1309,6 +1402,12 @@ void gemm_conv_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_waitcnt(0xc07f);          // slab reads done before the next slab overwrites it
         __builtin_amdgcn_wave_barrier();
     }
+    MF_STAMP_DRAIN();
+    MF_STAMP(5);
+    if constexpr (SKF) {
+        if (ws) splitk_combine_tail<BM, BN, NTHR>(p, smem, tile_m, tile_n, z, zq, zo, (int)threadIdx.x);
+    }
+    MF_STAMP(6);
 }
 
 // =====================================================================================================
@@ -2014,7 +2113,7 @@ const TileCfg kTiles[] = {
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false,
-          bool P16 = false>
+          bool P16 = false, bool SKF = false>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     // warp-specialised ring tiles keep BM (mean, rstd) pairs of a folded LayerNorm past the ring
     constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? ST : 2) * BN * 128 : ST * (BM + BN) * 128 + (WS ? BM * 8 : 0);
@@ -2024,17 +2123,42 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     const int smem = smem_k > smem_min ? smem_k : smem_min;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, SKF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16>), grid, dim3(WMv * WNv * 64 + (WS ? 256 : 0)), smem, s, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, SKF>), grid, dim3(WMv * WNv * 64 + (WS ? 256 : 0)), smem, s, a);
+}
+
+// a tile with an SKF twin: the twin when the call carries tickets, the plain kernel otherwise
+template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false,
+          bool P16 = false>
+void launch_skf(const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if (a.sk_tickets) launch_one<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, true>(a, grid, s);
+    else launch_one<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, false>(a, grid, s);
+}
+// tiles whose kernels have an in-launch split-K combine (keep in sync with the launch_skf cases below)
+bool tile_has_skf(int tile, int dtype, int w_split, bool a_f32) {
+    if (a_f32) return false;
+    const bool base = tile == 1 || tile == 2 || tile == 3 || tile == 6;
+    if (dtype == MF_BF16) return base || tile == 41 || tile == 43 || tile == 44 || tile == 48;   // (45 / 46, 256 x 128: the tail spills there)
+    if (dtype == MF_F16X3) return base || (w_split && (tile == 41 || tile == 44));
+    return false;
 }
 
 // Split codes: the tiles whose register budget holds the split fragments (see kTiles).  Returns false for a tile that
 // is not instantiated for them.
 template <int DT, bool WPK>
 bool launch_tile_split(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
+    if constexpr (DT == MF_F16X3) {
+        switch (tile) {
+            case 1: launch_skf<DT, 128, 128, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
+            case 2: launch_skf<DT, 128, 64, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
+            case 3: launch_skf<DT, 64, 64, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
+            case 6: launch_skf<DT, 64, 128, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
+            default: break;
+        }
+    }
     switch (tile) {
         case 1: launch_one<DT, 128, 128, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
         case 2: launch_one<DT, 128, 64, 2, 2, false, 2, false, WPK>(a, grid, s); return true;
@@ -2047,8 +2171,8 @@ bool launch_tile_split(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
         switch (tile) {
             case 37: launch_one<DT, 256, 160, 8, 1, false, 3, true, true, false, true>(a, grid, s); return true;
             case 38: launch_one<DT, 128, 160, 4, 1, false, 3, true, true, false, true>(a, grid, s); return true;
-            case 41: launch_one<DT, 128, 160, 4, 1, false, 3, false, true, false, true>(a, grid, s); return true;
-            case 44: launch_one<DT, 128, 128, 2, 2, false, 3, false, true, false, true>(a, grid, s); return true;
+            case 41: launch_skf<DT, 128, 160, 4, 1, false, 3, false, true, false, true>(a, grid, s); return true;
+            case 44: launch_skf<DT, 128, 128, 2, 2, false, 3, false, true, false, true>(a, grid, s); return true;
             default: break;       // (256 x 128 with 8 + 4 waves spills at the 170-register budget of three waves per SIMD: not offered)
         }
     }
@@ -2077,6 +2201,15 @@ template <int DT, bool AF>
 void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
     // AF (fp32 activations converted to bf16 on load) is register staged with 2 stages: mf_gemm_conv has already
     // resolved the tile to 1..6, so the grid it computed matches the kernel's BM x BN
+    if constexpr (DT == MF_BF16 && !AF) {
+        switch (tile) {
+            case 1: launch_skf<DT, 128, 128, 2, 2, false, 2>(a, grid, s); return;
+            case 2: launch_skf<DT, 128, 64, 2, 2, false, 2>(a, grid, s); return;
+            case 3: launch_skf<DT, 64, 64, 2, 2, false, 2>(a, grid, s); return;
+            case 6: launch_skf<DT, 64, 128, 2, 2, false, 2>(a, grid, s); return;
+            default: break;
+        }
+    }
     switch (tile) {
         case 1: launch_one<DT, 128, 128, 2, 2, AF, 2>(a, grid, s); break;
         case 2: launch_one<DT, 128, 64, 2, 2, AF, 2>(a, grid, s); break;
@@ -2125,14 +2258,14 @@ void launch_tile(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
                 case 38: launch_one<DT, 128, 160, 4, 1, false, 3, true, false, false, true>(a, grid, s); break;
                 case 39: launch_one<DT, 256, 160, 8, 1, false, 3, true, false, true, true>(a, grid, s); break;
                 case 40: launch_one<DT, 128, 160, 4, 1, false, 3, true, false, true, true>(a, grid, s); break;
-                case 41: launch_one<DT, 128, 160, 4, 1, false, 3, false, false, false, true>(a, grid, s); break;
+                case 41: launch_skf<DT, 128, 160, 4, 1, false, 3, false, false, false, true>(a, grid, s); break;
                 case 42: launch_one<DT, 256, 160, 8, 1, false, 3, false, false, true, true>(a, grid, s); break;
-                case 43: launch_one<DT, 128, 160, 4, 1, false, 3, false, false, true, true>(a, grid, s); break;
-                case 44: launch_one<DT, 128, 128, 2, 2, false, 3, false, false, false, true>(a, grid, s); break;
+                case 43: launch_skf<DT, 128, 160, 4, 1, false, 3, false, false, true, true>(a, grid, s); break;
+                case 44: launch_skf<DT, 128, 128, 2, 2, false, 3, false, false, false, true>(a, grid, s); break;
                 case 45: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, false, true>(a, grid, s); break;
                 case 46: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, true, true>(a, grid, s); break;
                 case 47: launch_one<DT, 128, 160, 4, 2, false, 3, true, false, false, true, true>(a, grid, s); break;
-                case 48: launch_one<DT, 128, 160, 4, 2, false, 3, false, false, false, true, true>(a, grid, s); break;
+                case 48: launch_skf<DT, 128, 160, 4, 2, false, 3, false, false, false, true, true>(a, grid, s); break;
                 default: break;
             }
         }
@@ -2213,6 +2346,12 @@ unsigned* mf_ovf_flag_gemm() {
     (void)hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_split_ovf_gemm));
     return p;
 }
+
+#ifdef MF_STAMPS
+extern "C" int mf_debug_set_stamps(void* ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ptr, sizeof(ptr)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int mf_gemm_num_tiles(void) { return kNumTiles; }
 extern "C" int mf_gemm_tile_table_version(void) { return 1; }
@@ -2411,6 +2550,9 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(a.splitk == 1 || (a.ws != nullptr && (int64_t)a.splitk * a.nz * a.M * a.N <= d->ws_floats),
                  "mf_gemm_conv: split-K=%d needs a workspace of %lld floats", a.splitk,
                  (long long)a.splitk * a.nz * a.M * a.N);
+    // in-launch combine: one ticket per output tile; a grid with more tiles than tickets keeps the reduce launch
+    a.sk_tickets = (a.splitk > 1 && d->sk_tickets != nullptr && tiles_mn <= (int64_t)d->sk_ticket_cap &&
+                    tile_has_skf(tile, d->dtype, d->w_split, a_f32)) ? (unsigned*)d->sk_tickets : nullptr;
     {   // fast staging: every K tile inside one (tap, segment) and every operand addressable with 31-bit offsets
         const int64_t npix = (int64_t)d->batch * d->h_in * d->w_in;
         const int64_t ext_a = (npix - 1) * (int64_t)(a.ld0b > a.ld1b ? a.ld0b : a.ld1b) + (int64_t)a.Ctot * aes;
@@ -2418,6 +2560,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         a.fast = (a.C0 % bk == 0) && (a.Ctot % bk == 0) && ext_a < (1ll << 31) - (1 << 20) && ext_w < (1ll << 31) - (1 << 20);
     }
     MF_CHECK_ARG(d->act != MF_ACT_GEGLU4 || a.vec_ok, "mf_gemm_conv: GEGLU epilogue needs 16-byte aligned bias/out");
+    a.pointwise = d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad_t == 0 && d->pad_l == 0 && !d->upsample && d->h_out == d->h_in &&
+                  d->w_out == d->w_in;
     a.tiles_n = cdiv(a.N, tc.bn);
     a.tiles_m = cdiv(a.M, tc.bm);
     const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * a.splitk;
@@ -2459,7 +2603,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         launch_tile<MF_F32, false>(tile, a, grid, s);
     }
     MF_CHECK_LAUNCH("mf_gemm_conv");
-    if (a.splitk > 1) {
+    if (a.splitk > 1 && a.sk_tickets == nullptr) {
         const int64_t total = (int64_t)a.M * a.N * a.nz / (a.vec_ok ? 8 : 1);
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;

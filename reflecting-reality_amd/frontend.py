@@ -7,12 +7,16 @@ sort), then torchvision's Resize(resolution, BICUBIC) + CenterCrop as ONE bicubi
 `apply_transforms_normals` (:168-192, the map-valued modes): HWC -> CHW, the same resize / crop, Normalize([0.5], [0.5]).
 All on the GPU (csrc/frontend.hip), no host round trip.
 
-Bicubic = PyTorch's kernel (align_corners=False, A = -0.75) WITHOUT antialiasing: what torchvision computes when it
-up-samples, and what torchvision < 0.17 computes for tensors in general; newer torchvision low-pass filters tensors when
-it DOWN-samples (antialias=True by default), which is not built: a down-sampling call must say antialias=False.  SynMirror
-renders are 512 x 512 = `resolution`, where Resize + CenterCrop are the identity.  The reference module itself imports
-h5py / torchvision / cv2 (absent here), so these transforms are checked against the oracle's numpy / torch restatement
-(oracle/mirrorfusion_ref.py, PARITY UNPINNED for this one module) — see tests/test_frontend_gpu.py."""
+Bicubic: the reference pins torchvision 0.18 (MirrorFusion/README.md:34), where transforms.Resize defaults to
+antialias=True and, for a tensor, hands it to torch.nn.functional.interpolate at EVERY scale (torchvision/transforms/
+_functional_tensor.py `resize`): ATen's antialiased bicubic (Keys kernel a = -0.5 stretched by max(scale, 1), normalised
+weights) — `antialias=None` / `True` here, mf_bicubic_aa_resize_crop.  `antialias=False` is the plain kernel (A = -0.75:
+torchvision < 0.17's default for tensors), mf_bicubic_resize_crop.  SynMirror renders are 512 x 512 = `resolution`, where
+Resize + CenterCrop are the identity in both.  The resize is checked against torch's own CPU interpolate (the arithmetic
+torchvision calls; torchvision itself is absent from this image).  The reference MODULE imports h5py / torchvision / cv2 and
+cannot be imported here, so the numpy statements around the resize (percentile / max-scene-depth normalisation) are checked
+against the oracle's restatement of dataset.py:98-192 (oracle/mirrorfusion_ref.py, PARITY UNPINNED for those lines) — see
+tests/test_frontend_gpu.py."""
 from __future__ import annotations
 
 from typing import Optional, Sequence
@@ -38,10 +42,8 @@ def _resize_crop(planes: torch.Tensor, resolution: int, antialias: Optional[bool
     (nh, nw), (top, left) = _resize_geometry(h, w, resolution)
     if (nh, nw) == (h, w) == (resolution, resolution):
         return planes if (a, b) == (1.0, 0.0) else hip.axpby_affine(planes, a, b)
-    if (nh < h or nw < w) and antialias is not False:
-        raise NotImplementedError("bicubic DOWN-sampling with torchvision's antialias filter is not built: pass antialias=False for the "
-                                  "plain bicubic kernel (torchvision < 0.17 semantics), or feed maps of the target resolution")
-    return hip.bicubic_resize_crop(planes, (nh, nw), (top, left), (resolution, resolution), a, b)
+    # antialias None = the reference's pinned torchvision (0.18): True, at every scale
+    return hip.bicubic_resize_crop(planes, (nh, nw), (top, left), (resolution, resolution), a, b, antialias=antialias is not False)
 
 
 def apply_transforms_depth(depth_map, mask=None, normalization_method: str = "max_scene_depth", max_scene_depth: float = 5.0,

@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1 = 0, 1, 2, 3, 4, 5
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class MfhipError(RuntimeError):
@@ -51,6 +51,7 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32),
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("vt_out", C.c_void_p), ("vt_n0", C.c_int32), ("vt_tokens", C.c_int32), ("vt_ld", C.c_int64),
+        ("sk_tickets", C.c_void_p), ("sk_ticket_cap", C.c_int32),
     ]
 
 
@@ -129,6 +130,7 @@ EXPORTS = [
     # image front-end (csrc/frontend.hip)
     "mf_minmax_ws_floats", "mf_minmax", "mf_image_normalize", "mf_mask_keep", "mf_concat_channels", "mf_postprocess",
     "mf_depth_normalize", "mf_select_ws_bytes", "mf_select_ranks", "mf_depth_percentile_normalize", "mf_bicubic_resize_crop",
+    "mf_bicubic_aa_resize_crop",
     "mf_hwc_to_chw_affine",
     # training (csrc/train.hip)
     "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_split_pack", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
@@ -140,7 +142,8 @@ _lib: Optional[C.CDLL] = None
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # MFHIP_LIB: a developer build of the same sources (e.g. the stamped one of tools/stamps.py); never set in production
+    return os.environ.get("MFHIP_LIB") or _build.LIB_PATH
 
 
 def load() -> C.CDLL:
@@ -216,6 +219,34 @@ def scratch(name: str, nfloats: int, device) -> torch.Tensor:
     return buf
 
 
+# tiles whose kernels carry the in-launch combine (csrc/gemm_conv.hip: tile_has_skf), per compute code
+SK_FUSED_TILES = {MF_BF16: (1, 2, 3, 6, 41, 43, 44, 48), MF_F16X3: (1, 2, 3, 6, 41, 44)}
+SK_TICKETS = 8192          # arrival counters of the in-launch split-K combine (mf_gemm_desc.sk_tickets), per stream
+SK_STREAMS = 64
+_tickets: dict = {}        # device index -> ([SK_STREAMS, SK_TICKETS] zeroed int32, {stream id: row})
+
+
+def sk_tickets(device) -> torch.Tensor:
+    """The zeroed ticket row of the current stream.  Launches on different streams may run concurrently, so every stream owns
+    a row of one per-device table; the kernels leave their tickets zeroed, so the table is cleared once, when it is allocated —
+    outside any graph capture (a capture stream only picks a row: no allocation, no memset node)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ent = _tickets.get(idx)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise MfhipError("the split-K ticket table must exist before a graph capture (run the step eagerly once)")
+        ent = _tickets[idx] = (torch.zeros(SK_STREAMS, SK_TICKETS, dtype=torch.int32, device=dev), {})
+    table, rows = ent
+    sid = torch.cuda.current_stream(dev).cuda_stream
+    row = rows.get(sid)
+    if row is None:
+        if len(rows) >= SK_STREAMS:
+            raise MfhipError(f"more than {SK_STREAMS} streams issued split-K GEMMs on device {idx}")
+        row = rows[sid] = len(rows)
+    return table[row]
+
+
 _staging: dict = {}
 
 
@@ -272,6 +303,7 @@ LAST_PROFILE = []
 # for grids that cannot fill 256 CUs) the first time a GEMM shape is seen and remembers the winner.  Winners
 # are persisted in tune_cache.json next to this file so later processes (and graph capture) start tuned.
 AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
+SK_FUSED = os.environ.get("MFHIP_NO_SK_FUSED", "0") != "1"   # developer A/B: offer the in-launch split-K combine to the tuner
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
 TUNE_GRAPH = os.environ.get("MFHIP_TUNE_GRAPH", "0") == "1"   # developer switch: time candidates from a hipGraph (see _tuned_config)
 # The package ships a cache tuned on MI355X (read-only); new winners go to a per-user file (MFHIP_TUNE_CACHE, default
@@ -368,12 +400,19 @@ def _tuned_config(d: "GemmDesc", key: tuple):
         if blocks < 512 and nkt >= 8 and not key[10]:
             sks += [s for s in (2, 3, 4, 6, 8, 12, 16, 24) if s <= nkt // 4 and blocks * s <= 2048
                     and s * key[9] * m * n <= d.ws_floats]
-        cands += [(t, s) for s in sks]
-    best, best_t = (0, 0), float("inf")
+        cands += [(t, s, 0) for s in sks]
+        # the in-launch combine (mode 1: the last-arriving K slice reduces; no second launch) makes a split of 2-4 cheap
+        # enough for grids of up to 512 tiles and K of 4+ tiles
+        if SK_FUSED and not key[10] and t in SK_FUSED_TILES.get(key[0], ()):
+            cands += [(t, s, 1) for s in (2, 3, 4, 6, 8, 12, 16) if s <= max(nkt // 2, 1) and blocks <= SK_TICKETS and blocks * s <= 2048
+                      and nkt >= 4 and s * key[9] * m * n <= d.ws_floats]
+    best, best_t = (0, 0, 0), float("inf")
     st = _stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for t, s in cands:
+    tk = sk_tickets(torch.device("cuda", torch.cuda.current_device()))
+    for t, s, mode in cands:
         d.tile, d.splitk = t, s
+        d.sk_tickets, d.sk_ticket_cap = (tk.data_ptr(), tk.numel()) if mode else (None, 0)
         if lib.mf_gemm_conv(C.byref(d), st) != 0:
             continue
         dt = float("inf")
@@ -402,7 +441,7 @@ def _tuned_config(d: "GemmDesc", key: tuple):
                 e1.synchronize()
                 dt = min(dt, e0.elapsed_time(e1))
         if dt < best_t:
-            best, best_t = (t, s), dt
+            best, best_t = (t, s, mode), dt
     cache[ks] = best
     _tune_new[ks] = best
     return best
@@ -421,7 +460,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
               nz: int = 1, zdiv: int = 1, a_zs=(0, 0), w_zs=(0, 0), o_zs=(0, 0),
               a_scale: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None, a_scale_zs: int = 0,
               w_scale_zs: int = 0, splitk: int = 0, tile: int = 0, ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-              vt_out: Optional[torch.Tensor] = None, vt_n0: int = 0, vt_tokens: int = 0) -> torch.Tensor:
+              vt_out: Optional[torch.Tensor] = None, vt_n0: int = 0, vt_tokens: int = 0, sk_fused: bool = False) -> torch.Tensor:
     """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements.  `dtype`: a torch
     dtype (bf16 / fp32 compute) or an MF_* compute code (the split codes take fp32 a0 and, with w_split=1, a weight
     from ops.split_pack)."""
@@ -484,7 +523,16 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         tkey = (code, d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), int(c1 > 0),
                 nz, int(splitk == 1) if not fused else 1, act, h_out, w_out) + ((w_split,) if code in (MF_F16X3, MF_BF16X3) else ()) \
             + ((("ln", "vt", "lnvt")[fused - 1],) if fused else ())
-        d.tile, d.splitk = _tuned_config(d, tkey)
+        cfg = _tuned_config(d, tkey)
+        d.tile, d.splitk = cfg[0], cfg[1]
+        if len(cfg) > 2 and cfg[2]:
+            tk = sk_tickets(out.device)
+            d.sk_tickets, d.sk_ticket_cap = tk.data_ptr(), tk.numel()
+        else:
+            d.sk_tickets, d.sk_ticket_cap = None, 0
+    elif sk_fused and splitk > 1:
+        tk = sk_tickets(out.device)
+        d.sk_tickets, d.sk_ticket_cap = tk.data_ptr(), tk.numel()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -497,7 +545,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     if rc != 0 and tkey is not None and d.tile != 0:
         # a cached (tile, split-K) the library no longer accepts for this call: forget it and let the heuristic choose
         _tune_forget(_tune_key(tkey))
-        d.tile, d.splitk = 0, splitk
+        d.tile, d.splitk, d.sk_tickets, d.sk_ticket_cap = 0, splitk, None, 0
         rc = load().mf_gemm_conv(C.byref(d), _stream())
     _check(rc, "mf_gemm_conv")
     return out
@@ -1108,15 +1156,17 @@ def select_ranks(x: torch.Tensor, ranks) -> torch.Tensor:
     return vals
 
 
-def bicubic_resize_crop(x: torch.Tensor, resized: tuple, crop: tuple, out_hw: tuple, a: float = 1.0, b: float = 0.0) -> torch.Tensor:
-    """x [planes, H, W] fp32 -> a * bicubic(x -> resized)[crop window of out_hw at (top, left) = crop] + b."""
+def bicubic_resize_crop(x: torch.Tensor, resized: tuple, crop: tuple, out_hw: tuple, a: float = 1.0, b: float = 0.0,
+                        antialias: bool = False) -> torch.Tensor:
+    """x [planes, H, W] fp32 -> a * bicubic(x -> resized)[crop window of out_hw at (top, left) = crop] + b.  antialias: PyTorch's
+    antialiased kernel (F.interpolate(..., antialias=True): torchvision 0.18's Resize on tensors) instead of the plain one."""
     _f32(x)
     x = x.contiguous()
     planes, h, w = x.shape
     out = torch.empty(planes, out_hw[0], out_hw[1], dtype=torch.float32, device=x.device)
-    _check(load().mf_bicubic_resize_crop(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), planes, h, w, int(resized[0]), int(resized[1]),
-                                         int(crop[0]), int(crop[1]), int(out_hw[0]), int(out_hw[1]), C.c_float(a), C.c_float(b), _stream()),
-           "mf_bicubic_resize_crop")
+    fn, name = (load().mf_bicubic_aa_resize_crop, "mf_bicubic_aa_resize_crop") if antialias else (load().mf_bicubic_resize_crop, "mf_bicubic_resize_crop")
+    _check(fn(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), planes, h, w, int(resized[0]), int(resized[1]),
+              int(crop[0]), int(crop[1]), int(out_hw[0]), int(out_hw[1]), C.c_float(a), C.c_float(b), _stream()), name)
     return out
 
 

@@ -204,7 +204,7 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
            x1: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None,
            res0: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None,
            alpha: float = 1.0, act: int = hip.ACT_NONE, out_dtype: Optional[torch.dtype] = None,
-           splitk: int = 0, tile: int = 0) -> torch.Tensor:
+           splitk: int = 0, tile: int = 0, sk_fused: bool = False) -> torch.Tensor:
     """Convolution over NHWC x (optionally cat([x, x1], C) and/or nearest-2x upsampled), fused epilogue
     alpha*(conv + bias + temb[b]) + res0 + res1.  padding = int or (top, left, bottom, right)."""
     b, h, w, c0 = x.shape
@@ -224,7 +224,7 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
                   pad_t=pt, pad_l=pl, upsample=upsample, n=cw.n, bias=cw.bias,
                   temb=temb, ld_temb=(temb.stride(0) if temb is not None else 0),
                   res0=res0, res1=res1, res1_rows=_shared_rows(res1, b * ho * wo, cw.n), alpha=alpha, act=act, splitk=splitk,
-                  tile=tile)
+                  tile=tile, sk_fused=sk_fused)
     if TAPE is not None:
         autograd.record_conv(TAPE, x, x1, cw, out, batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, pad_t=pt, pad_l=pl,
                              upsample=upsample, temb=temb, res0=res0, res1=res1, alpha=alpha, act=act)
@@ -234,7 +234,7 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
 def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = None,
            res1: Optional[torch.Tensor] = None, alpha: float = 1.0, act: int = hip.ACT_NONE,
            out_dtype: Optional[torch.dtype] = None, splitk: int = 0, tile: int = 0,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, sk_fused: bool = False) -> torch.Tensor:
     """y = x @ W^T + b over the last dim of x ([..., K] contiguous).  An fp8 weight takes x as an (fp8, row scales) pair
     from hip.quantize_rows_fp8 / ops.layernorm(..., fp8=True), or quantises a bf16 / fp32 x itself."""
     if lw.fp8:
@@ -248,7 +248,7 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
     wt, wsp, wld = lw.operand()
     hip.gemm_conv(x, wt, out, dtype=lw.prec.code, w_split=wsp, ldw=wld, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
                   h_out=1, w_out=1, n=lw.n, bias=lw.bias, res0=res0, res1=res1, res1_rows=_shared_rows(res1, m, lw.n), alpha=alpha,
-                  act=act, splitk=splitk, tile=tile, ln_colsum=lw.ln_colsum, ln_eps=lw.ln_eps)
+                  act=act, splitk=splitk, tile=tile, ln_colsum=lw.ln_colsum, ln_eps=lw.ln_eps, sk_fused=sk_fused)
     if TAPE is not None:
         if lw.ln_colsum is not None:
             raise hip.MfhipError("training: folded LayerNorms are inference only")

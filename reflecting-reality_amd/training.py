@@ -238,7 +238,11 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     # target) w / (n B)) to O(1) keeps every backward GEMM operand in the range where hi + lo carries 22 bits; it is
     # exact in fp32 and undone inside the clip coefficient.  fp32 MFMA needs none.
     scale = 1.0
-    if prec.split:
+    if prec.split or prec.code == hip.MF_BF16X1:
+        # (bf16x1 too: its d = 8 / 40 attention runs forward and backward on fp16 halves (ops.attention), and an unscaled dO of
+        # 1e-6 sits in the fp16 subnormals, where the toward-zero split loses it — found by the full-size reference gradients of
+        # round 4: every gradient behind the 64 x 64 attention layers came out 0.3-0.5 % short.  bf16 rounding is invariant under
+        # a power-of-two scale, so the mode's own arithmetic does not change.)
         scale = float(2 ** int(pred.numel() - 1).bit_length())
     if scale != 1.0 or accum > 1:
         d_pred = hip.axpby_n([d_pred], [scale / accum], out=d_pred)      # 1 / G: accelerator.backward under accumulate()
@@ -352,7 +356,7 @@ class GraphedTrainStep:
             ops.TAPE = None
         d_pred = hip.mse_grad(pred.contiguous(), self.target, self.weights if self.snr_gamma is not None else None)
         scale = 1.0
-        if prec.split:
+        if prec.split or prec.code == hip.MF_BF16X1:
             scale = float(2 ** int(pred.numel() - 1).bit_length())
             d_pred = hip.axpby_n([d_pred], [scale], out=d_pred)
         model.loss_scale = scale

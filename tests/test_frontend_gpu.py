@@ -114,28 +114,47 @@ def test_apply_transforms_depth_percentile(rng):
     assert torch.equal(hip.select_ranks(x.to(DEV), ranks).cpu(), srt[ranks])
 
 
-@pytest.mark.parametrize("shape", [(384, 512), (512, 384), (300, 300), (512, 512), (600, 800)])
-def test_bicubic_resize_center_crop_and_normals(shape):
-    """torchvision's Resize(resolution, BICUBIC) + CenterCrop + Normalize of dataset.py:150-164,184-192 as one device kernel
-    against F.interpolate(mode='bicubic', align_corners=False) + slicing on the CPU (no antialiasing: down-sampling must ask
-    for it explicitly).  ORACLE UNPINNED (see above)."""
+@pytest.mark.parametrize("antialias", [None, False])
+@pytest.mark.parametrize("shape", [(384, 512), (512, 384), (300, 300), (512, 512), (600, 800), (1024, 1536), (2048, 1100), (515, 512)])
+def test_bicubic_resize_center_crop_and_normals(shape, antialias):
+    """torchvision's Resize(resolution, BICUBIC) + CenterCrop + Normalize of dataset.py:150-164,184-192 as one device kernel.
+    antialias=None (the default) is the reference's pinned torchvision 0.18: Resize(antialias=True), whose tensor path calls
+    torch.nn.functional.interpolate(mode='bicubic', align_corners=False, antialias=True) at every scale — up-sampling
+    (384 -> 512), down-sampling by 1.2x ... 4x and the mixed case; antialias=False is the plain kernel.  The checker is that
+    very interpolate on the CPU (ATen: the arithmetic torchvision calls; torchvision itself is absent from this image) inside
+    the oracle's restatement of the two transforms, whose numpy lines stay PARITY UNPINNED (module header)."""
     g = np.random.default_rng(5)
     h, w = shape
     res = 512
     depth = (g.random((h, w), dtype=np.float32) * 4.0).astype(np.float32)
     normals = g.random((h, w, 3), dtype=np.float32)
-    down = min(h, w) > res
-    kw = dict(antialias=False) if down else {}
-    if down:
-        with pytest.raises(NotImplementedError):
-            frontend.apply_transforms_depth(depth, max_scene_depth=5.0, resolution=res)
-    ref_d = R.apply_transforms_depth_ref(depth, max_scene_depth=5.0, resolution=res)
-    got_d = frontend.apply_transforms_depth(depth, max_scene_depth=5.0, resolution=res, **kw)
+    aa = antialias is not False
+    ref_d = R.apply_transforms_depth_ref(depth, max_scene_depth=5.0, resolution=res, antialias=aa)
+    got_d = frontend.apply_transforms_depth(depth, max_scene_depth=5.0, resolution=res, antialias=antialias)
     assert tuple(got_d.shape) == (1, res, res)
-    assert float((got_d.cpu() - ref_d).abs().max()) < 2e-5
-    ref_n = R.apply_transforms_normals_ref(normals, res)
-    got_n = frontend.apply_transforms_normals(normals, res, **kw)
+    err_d = float((got_d.cpu() - ref_d).abs().max())
+    ref_n = R.apply_transforms_normals_ref(normals, res, antialias=aa)
+    got_n = frontend.apply_transforms_normals(normals, res, antialias=antialias)
     assert tuple(got_n.shape) == (3, res, res)
-    assert float((got_n.cpu() - ref_n).abs().max()) < 2e-5
+    err_n = float((got_n.cpu() - ref_n).abs().max())
+    print(f"{shape} antialias={antialias}: depth max err {err_d:.2e}, normals {err_n:.2e}")
+    assert err_d < 5e-6 and err_n < 5e-6           # values in [-1, 1]: fp32 rounding of a <= 17 x 17-tap weighted sum
+    if aa and min(h, w) > res:                     # the two kernels really differ when down-sampling (the low-pass filter)
+        plain = frontend.apply_transforms_depth(depth, max_scene_depth=5.0, resolution=res, antialias=False)
+        assert float((plain - got_d).abs().max()) > 1e-2
     with pytest.raises(NotImplementedError):
         frontend.apply_transforms_normals(normals, res, normals_conditioning_mode="ip_adapter")
+
+
+def test_antialiased_bicubic_kernel_against_aten_on_ragged_sizes():
+    """mf_bicubic_aa_resize_crop alone against F.interpolate(antialias=True) on the CPU: odd sizes, strong down-sampling (taps
+    clipped at every border), up-sampling, and a crop window that is not centred."""
+    g = torch.Generator().manual_seed(11)
+    for (h, w, nh, nw) in ((37, 53, 16, 23), (96, 128, 48, 64), (100, 75, 33, 25), (40, 60, 40, 25), (17, 19, 64, 80), (511, 257, 96, 64)):
+        x = torch.rand(2, h, w, generator=g) * 2.0 - 1.0
+        ref = torch.nn.functional.interpolate(x[None], size=(nh, nw), mode="bicubic", align_corners=False, antialias=True)[0]
+        got = hip.bicubic_resize_crop(x.to(DEV), (nh, nw), (0, 0), (nh, nw), antialias=True)
+        assert float((got.cpu() - ref).abs().max()) < 3e-6, (h, w, nh, nw)
+        top, left, ch, cw = nh // 5, nw // 7, nh // 2, nw // 2
+        got = hip.bicubic_resize_crop(x.to(DEV), (nh, nw), (top, left), (ch, cw), 2.0, -1.0, antialias=True)
+        assert float((got.cpu() - (2.0 * ref[:, top:top + ch, left:left + cw] - 1.0)).abs().max()) < 6e-6

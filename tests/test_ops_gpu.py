@@ -670,3 +670,81 @@ def test_fused_qkv_projection_with_transposed_v(tile, batch, tokens, c, with_ln)
     assert qk.shape == (batch, tokens, 2 * c) and vt.shape == (batch, c, tokens)
     check(f"qkv.qk[{batch}x{tokens}x{c},tile{tile}]", qk, ref[..., :2 * c], 3e-2, 2e-2)
     check(f"qkv.vt[{batch}x{tokens}x{c},tile{tile}]", vt.transpose(1, 2), ref[..., 2 * c:], 3e-2, 2e-2)
+
+
+# ---- round 4: the in-launch split-K combine ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec_name,tile", [("bf16", t) for t in (1, 2, 3, 6, 41, 43, 44, 48)] + [("f16x3", t) for t in (1, 2, 3, 6, 41, 44)]
+                         + [("bf16", 14), ("bf16", 45), ("fp32", 3)])
+def test_in_launch_split_k_combine_equals_the_reduce_launch(prec_name, tile):
+    """mf_gemm_desc.sk_tickets: the K-slice block that arrives last at its tile's ticket sums the slabs in slice order and runs the
+    epilogue inside the GEMM launch.  Same slabs, same order, same epilogue as the separate reduce launch => BIT-identical output,
+    for every tile that carries the tail (and for tiles / precisions that do not: they keep the reduce launch, (bf16, 14) and
+    (fp32, 3) here).  Cases: a deep-K 3x3 conv at 8 x 8 with a ragged M (tile rows past M), residual + temb + SiLU epilogue;
+    a Linear with an N tail and a shared residual; repeated launches (tickets re-armed) and two streams with their own tickets."""
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(100 + tile)
+    b, cin, cout, h, w = 3, 128, 200, 8, 8                                  # M = 192 (a 128-row tile and a half), N tail of 40
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.03
+    bias = torch.randn(cout, generator=g)
+    temb = torch.randn(b, cout, generator=g).to(DEV)
+    r0 = torch.randn(b, cout, h, w, generator=g)
+    cw = ops.ConvWeight(wt, bias, prec, DEV)
+    kw = dict(temb=temb, res0=nhwc(r0, prec.act), act=hip.ACT_SILU, tile=tile)
+    hip.sk_tickets(DEV)
+    table = lambda: hip._tickets[torch.cuda.current_device()][0]
+    for sk in (2, 3, 6):
+        ref = ops.conv2d(nhwc(x, prec.act), cw, splitk=sk, **kw)
+        for rep in range(3):
+            got = ops.conv2d(nhwc(x, prec.act), cw, splitk=sk, sk_fused=True, **kw)
+            assert torch.equal(got, ref), f"tile {tile} splitk {sk} rep {rep}: max diff {float((got.float() - ref.float()).abs().max()):.3e}"
+            assert int(table().abs().sum()) == 0, "tickets must be zero again after the launch"
+    xl = torch.randn(70, 512, generator=g)                                   # M = 70 (ragged), K = 512, N = 72 (scalar tail path when N % 8)
+    for n in (72, 77 if prec_name != "bf16" else 80):
+        wl = torch.randn(n, 512, generator=g) * 0.05
+        rl = torch.randn(35, n, generator=g)
+        lw = ops.ConvWeight(wl, None, prec, DEV)
+        ref = ops.linear(xl.to(DEV, prec.act), lw, res1=rl.to(DEV, prec.act), splitk=4, tile=tile)
+        got = ops.linear(xl.to(DEV, prec.act), lw, res1=rl.to(DEV, prec.act), splitk=4, tile=tile, sk_fused=True)
+        assert torch.equal(got, ref), f"linear n={n} tile {tile}"
+    # two streams at once, each with its own slabs and tickets
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ref = ops.conv2d(nhwc(x, prec.act), cw, splitk=3, **kw)
+    torch.cuda.synchronize()
+    outs = []
+    for st in (s1, s2):
+        with torch.cuda.stream(st):
+            xa = nhwc(x, prec.act)
+            for _ in range(4):
+                outs.append(ops.conv2d(xa, cw, splitk=3, sk_fused=True, **kw))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)
+    assert int(table().abs().sum()) == 0
+
+
+def test_in_launch_split_k_combine_under_uneven_load_and_graph_replay():
+    """The hand-off must not depend on timing, placement or cold caches (cdna_hip_programming.md Guideline 16, Pitfall 3): a
+    production-size split (512 x 1280 x 11520, 6 and 12 slices: 192 / 384 blocks over 8 XCDs) replayed 20 times from a hipGraph
+    back to back with an unrelated streaming kernel in between, every output compared bit for bit with the reduce-launch form."""
+    prec = ops.Precision.get("bf16")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 1280, 8, 8, generator=g)
+    wt = torch.randn(1280, 1280, 3, 3, generator=g) * 0.01
+    cw = ops.ConvWeight(wt, torch.randn(1280, generator=g), prec, DEV)
+    xa = nhwc(x, prec.act)
+    big = torch.randn(64 * 1024 * 1024, device=DEV)
+    for tile, sk in ((41, 6), (48, 12), (44, 4), (6, 3)):
+        ref = ops.conv2d(xa, cw, splitk=sk, tile=tile)
+        hip.sk_tickets(DEV)
+        out = torch.empty_like(ref)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(3):
+                y = ops.conv2d(xa, cw, splitk=sk, tile=tile, sk_fused=True)
+                big.mul_(1.0000001)
+            out.copy_(y)
+        for rep in range(20):
+            gr.replay()
+            assert torch.equal(out, ref), f"tile {tile} splitk {sk} replay {rep}"
+        assert int(hip._tickets[torch.cuda.current_device()][0].abs().sum()) == 0

@@ -525,3 +525,91 @@ def test_baseline_config1_all_50_steps_against_reference(prec, tol):
     st = G["image_stats"]
     check(f"config1 x 50 steps, image 0, decoded [{prec}]", strided_sample(res.images[:1], st[2], 4096), G["image_sample"], prec,
           dict(atol=2e-3), "sd15_config1_50steps/image")
+
+
+# ---- round 4: the schedulers the shipped scripts run, at configs[1]'s size; and a run at a trained checkpoint's magnitudes ------
+def _config1_pipe(unet, bn, vae, sched):
+    pipe = StableDiffusionBrushNetPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, brushnet=bn, scheduler=sched,
+                                           safety_checker=None, feature_extractor=None, requires_safety_checker=False,
+                                           depth_conditioning_mode="concat")
+    pipe.set_progress_bar_config(disable=True)
+    return pipe
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-3), ("bf16", None)])
+@pytest.mark.parametrize("name", ["pndm", "unipc"])
+def test_baseline_config1_shipped_schedulers_against_reference(prec, tol, name):
+    """What examples/brushnet/test_brushnet.py actually runs — UniPCMultistepScheduler.from_config(pipe.scheduler.config)
+    (:158) over the checkpoint's PNDM config — and that PNDM config itself, at BASELINE.json configs[1]'s size: batch 4 x 512 x
+    512, CFG 7.5, 10 steps through the captured model graph with the eager scheduler step after each replay, against the
+    REFERENCE pipeline's latents after EVERY step for image 0 of the same inputs (tests/golden/sd15_config1_sched.npz,
+    tools/make_golden_r04.py --config1-sched; scheduling_unipc_multistep.py:507-719, scheduling_pndm.py:225-430).  f16x3: the
+    north-star 1e-3 at every step; bf16: inside the reference's own bf16 deviation on this case."""
+    unet, bn, vae = build("sd15", prec)
+    G = golden("sd15_config1_sched.npz")
+    sched = PNDMScheduler(skip_prk_steps=True, **SD_SCHED)
+    if name == "unipc":
+        sched = UniPCMultistepScheduler.from_config(sched.config)
+    pipe = _config1_pipe(unet, bn, vae, sched)
+    inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+    trace = []
+    res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
+               mask=inp["mask"], depth=inp["depth"], num_inference_steps=10, guidance_scale=7.5, latents=inp["latents"].clone(),
+               output_type="pt", height=512, width=512, conditioning_noise=inp["vae_noise"],
+               callback_on_step_end=lambda p, i, t, kw: trace.append(kw["latents"][:1].clone()) or {})
+    assert pipe.scheduler.timesteps.tolist() == G[f"{name}_timesteps"].tolist()
+    assert len(trace) == len(G[f"{name}_timesteps"]) == (11 if name == "pndm" else 10)
+    assert tuple(res.images.shape) == (4, 3, 512, 512) and torch.isfinite(res.images).all()
+    for i, l in enumerate(trace):
+        check(f"config1 {name}, image 0, latents after step {i} [{prec}]", l, G[f"{name}_latents_{i}"], prec, dict(atol=tol),
+              f"sd15_config1_sched/{name}_latents_{i}")
+    st = G[f"{name}_image_stats"]
+    check(f"config1 {name}, image 0, decoded [{prec}]", strided_sample(res.images[:1], st[2], 4096), G[f"{name}_image_sample"], prec,
+          dict(atol=2e-3), f"sd15_config1_sched/{name}_image")
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-3), ("bf16", None)])
+def test_baseline_config1_50_steps_at_trained_checkpoint_magnitudes(prec, tol):
+    """The 50-step fixture of configs[1] again, in the range a TRAINED checkpoint works in.  With seeded random weights eps is
+    uncorrelated with the noise in x_t, DDIM's 1 / sqrt(alpha_t) rescaling is never cancelled and the latents of
+    sd15_config1_50steps.npz grow to |x| = 71; a trained model keeps |x| <~ 5.  Here the UNet's conv_out (weight and bias) is
+    scaled by `eps_scale` and the start latents by `start_scale` (both stored in the fixture): the same architecture, kernels and
+    50-step graph, max |latents| = 5.5 over the run in the REFERENCE (tests/golden/sd15_config1_bounded.npz,
+    tools/make_golden_r04.py --config1-bounded).  So the absolute 1e-3 bound of the north star and the bf16 envelopes are also
+    stated where real checkpoints live, and the f16x3 range guard sees realistic activations."""
+    unet, bn, vae = build("sd15", prec)
+    G = golden("sd15_config1_bounded.npz")
+    eps_scale, start_scale = float(G["eps_scale"]), float(G["start_scale"])
+    shapes = keys("sd15")["unet"]
+    sd = {k: synth.fill(k, shapes[k], 0) * eps_scale for k in ("conv_out.weight", "conv_out.bias")}
+    saved = unet.P["conv_out"]
+    unet.P["conv_out"] = unet._conv(sd, "conv_out")
+    unet._weights_gen += 1                               # captured graphs key on it
+    try:
+        pipe = _config1_pipe(unet, bn, vae, DDIMScheduler(clip_sample=False, **SD_SCHED))
+        inp = synth.pipeline_inputs(4, 512, 512, seed=77)
+        want = [int(n) for n in G["steps"]]
+        trace, absmax = {}, []
+
+        def cb(p, i, t, kw):
+            absmax.append(float(kw["latents"][:1].abs().max()))
+            if i + 1 in want:
+                trace[i + 1] = kw["latents"][:1].clone()
+            return {}
+
+        res = pipe(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
+                   mask=inp["mask"], depth=inp["depth"], num_inference_steps=50, guidance_scale=7.5,
+                   latents=(inp["latents"] * start_scale).clone(), output_type="pt", height=512, width=512,
+                   conditioning_noise=inp["vae_noise"], callback_on_step_end=cb)
+    finally:
+        unet.P["conv_out"] = saved
+        unet._weights_gen += 1
+    assert pipe.scheduler.timesteps.tolist() == G["timesteps"].tolist()
+    assert float(G["absmax"].max()) < 6.0 and max(absmax) < 6.0, "the fixture is meant to stay at trained-checkpoint magnitudes"
+    assert torch.isfinite(res.images).all()
+    for n in want:
+        check(f"config1 bounded, image 0, latents after step {n} [{prec}]", trace[n], G[f"latents_{n}"], prec, dict(atol=tol),
+              f"sd15_config1_bounded/latents_{n}")
+    st = G["image_stats"]
+    check(f"config1 bounded, image 0, decoded [{prec}]", strided_sample(res.images[:1], st[2], 4096), G["image_sample"], prec,
+          dict(atol=2e-3), "sd15_config1_bounded/image")
