@@ -202,12 +202,17 @@ def train_main(a, D):
             return graphed(lat, noi, ts, ehs, cond)
         return train_step(model, ns, opt, lat, noi, ts, ehs, cond, max_grad_norm=1.0, grad_sync=sync)
 
-    if graphed is not None and a.warmup < 3:
-        for i in range(3 - a.warmup):            # untimed: the graph is captured on the third call
+    def warm():
+        if graphed is not None and a.warmup < 3:
+            for i in range(3 - a.warmup):        # untimed: the graph is captured on the third call
+                one_step(i)
+        for i in range(a.warmup):
             one_step(i)
 
-    for i in range(a.warmup):
-        one_step(i)
+    if sync is None:
+        D.tuned_once(warm)                       # (with a gradient sync every rank must take part in every step's exchange)
+    else:
+        warm()
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -336,8 +341,8 @@ def main():
                     guidance_scale=7.5, latents=inp["latents"], output_type="pt", brushnet_conditioning_scale=1.0,
                     height=a.size, width=a.size, conditioning_noise=inp["vae_noise"], _timing=timing).images
 
-    for _ in range(a.warmup):
-        one_pass()
+    # several ranks and a cold tune cache: rank 0 warms (and tunes) first, the others read its winners (distributed.tuned_once)
+    D.tuned_once(lambda: [one_pass() for _ in range(a.warmup)])
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -38,10 +38,10 @@ __device__ unsigned g_split_ovf_gemm;     // raised when an MF_F16X3 operand exc
 // block, slots 8+) writes the 100 MHz real-time counter at its phase boundaries, so that a launch's time can be split into
 // ramp / prologue / first DMA round trip / main loop / epilogue per block.  Compiled out of the product library.
 #ifdef MF_STAMPS
-__device__ unsigned long long* g_stamps;   // [blocks][16]
+__device__ unsigned long long* g_stamps;   // [blocks][32]: wave 0 in slots 0-15, the first staging wave in 16-31
 #define MF_STAMP(slot) do { if (g_stamps) { const int t_ = (int)threadIdx.x; \
-    if (t_ == 0) g_stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
-    else if (t_ == (int)blockDim.x - 256) g_stamps[(size_t)blockIdx.x * 16 + 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+    if (t_ == 0) g_stamps[(size_t)blockIdx.x * 32 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    else if (t_ == (int)blockDim.x - 256) g_stamps[(size_t)blockIdx.x * 32 + 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define MF_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")     // slot 5 = "the epilogue's stores have left"
 #else
 #define MF_STAMP(slot) do { } while (0)
@@ -68,6 +68,7 @@ struct GemmArgs {
     float alpha; int act;
     char* out; int out_dt; int64_t ldc;
     int tiles_n, tiles_m, ord_mfast, ord_pw, nblk, vec_ok, fast, dbg_no_res_pre;
+    int dbg_epi;             // developer switch (MFHIP_DBG_EPI, stamped builds): bit 0 skip the epilogue's global stores, bit 1 skip its slab reads
     int pointwise;           // kh = kw = 1, stride 1, no padding, no upsample, same extent: input pixel index == output row
     // LayerNorm folded into this GEMM (warp-specialised ring tiles): ln_cs[n] = sum_k W'[n][k] of the gamma-scaled weight;
     // the staging waves accumulate every A row's (sum, sum of squares) while they wait, the epilogue applies
@@ -1247,8 +1248,10 @@ void gemm_conv_kernel(const GemmArgs p) {
                         }
                 }
             }
+            MF_STAMP(7 + 3 * ih);                         // (stamps: round ih — residuals requested, accumulators in the slab)
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's slab writes are done ...
             __builtin_amdgcn_s_barrier();                // ... and everybody else's
+            MF_STAMP(8 + 3 * ih);
 #pragma unroll
             for (int u = 0; u < MAXC; ++u) {
                 int sw, row, ec, m, n;
@@ -1289,8 +1292,17 @@ void gemm_conv_kernel(const GemmArgs p) {
                     continue;
                 }
                 float v[8];
-                float4 lo = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4);
-                float4 hi = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4 + 16);
+                float4 lo, hi;
+#ifdef MF_STAMPS
+                if (p.dbg_epi & 2) { lo = make_float4(1.0f, 2.0f, 3.0f, (float)u); hi = lo; } else
+#endif
+                {
+                    lo = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4);
+                    hi = *reinterpret_cast<const float4*>(sl + row * EP_RS + ec * 4 + 16);
+                }
+#ifdef MF_STAMPS
+                if (p.dbg_epi & 1) { asm volatile("" ::"v"(lo.x), "v"(hi.w)); continue; }
+#endif
                 if (p.ln_cs && m < p.M && n + 8 <= p.N) {            // LayerNorm fold: rstd * (acc - mean * colsum)
                     const float2 st = lnst[m - m0];
                     const float4 c0 = *reinterpret_cast<const float4*>(p.ln_cs + n);
@@ -1316,6 +1328,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                     }
                 }
             }
+            MF_STAMP(9 + 3 * ih);                         // (stamps: this wave's stores of round ih are issued)
             if (ih + 1 < MT * (32 / SR)) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);      // slab reads done before the next round overwrites the slabs
                 __builtin_amdgcn_s_barrier();
@@ -2586,6 +2599,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         }
     }
     { static const bool off = getenv("MFHIP_NO_RES_PRE") != nullptr; a.dbg_no_res_pre = off; }     // A/B switch
+    { static const int e = getenv("MFHIP_DBG_EPI") ? atoi(getenv("MFHIP_DBG_EPI")) : 0; a.dbg_epi = e; }
     dim3 grid((unsigned)nblk, 1, (unsigned)a.nz);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == MF_FP8) {

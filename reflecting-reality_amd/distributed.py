@@ -10,7 +10,7 @@ contract asks for (RCCL when the tensors are on the GPU, gloo on the CPU for tes
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Sequence, Tuple, TypeVar
+from typing import Callable, List, Optional, Sequence, Tuple, TypeVar
 
 import torch
 import torch.distributed as dist
@@ -51,6 +51,28 @@ def shard(items: Sequence[T], rank: int, world: int) -> List[T]:
 def barrier() -> None:
     if dist.is_initialized():
         dist.barrier()
+
+
+def tuned_once(warm: Callable[[], None], save: Optional[Callable[[], None]] = None, reload: Optional[Callable[[], None]] = None) -> None:
+    """Warm-up with a possibly cold GEMM tune cache on several ranks: rank 0 runs `warm` ALONE (it autotunes every new
+    (shape -> tile, split-K) once and persists the winners: hip.tune_save), the other ranks wait at a barrier, re-read the cache
+    (hip.tune_reload) and only then run `warm` themselves — one tuning pass per node instead of one per rank (an 8-rank start used
+    to time every candidate tile eight times, on eight GPUs contending for the host).  Ranks whose shapes differ from rank 0's (a
+    ragged last batch shard) still tune their own misses.  A single process just runs `warm`."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        warm()
+        return
+    if save is None or reload is None:
+        from . import hip
+        save, reload = save or hip.tune_save, reload or hip.tune_reload
+    if dist.get_rank() == 0:
+        warm()
+        save()
+    dist.barrier()
+    if dist.get_rank() != 0:
+        reload()
+        warm()
+    dist.barrier()
 
 
 def max_over_ranks(value: float, device="cpu") -> float:

@@ -303,7 +303,10 @@ LAST_PROFILE = []
 # for grids that cannot fill 256 CUs) the first time a GEMM shape is seen and remembers the winner.  Winners
 # are persisted in tune_cache.json next to this file so later processes (and graph capture) start tuned.
 AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
-SK_FUSED = os.environ.get("MFHIP_NO_SK_FUSED", "0") != "1"   # developer A/B: offer the in-launch split-K combine to the tuner
+# Offer the in-launch split-K combine (mf_gemm_desc.sk_tickets) to the tuner.  OFF by default: measured on MI355X (tools/bench_skf.py,
+# profiles/r04_splitk_in_launch.txt) the last-arriver form with an agent-scope release per block is 8-15 us SLOWER than the reduce
+# launch it replaces on every small-M shape of the step (each block's release writes back its XCD's L2: ~45 ns per block, serialised).
+SK_FUSED = os.environ.get("MFHIP_SK_FUSED", "0") == "1"
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
 TUNE_GRAPH = os.environ.get("MFHIP_TUNE_GRAPH", "0") == "1"   # developer switch: time candidates from a hipGraph (see _tuned_config)
 # The package ships a cache tuned on MI355X (read-only); new winners go to a per-user file (MFHIP_TUNE_CACHE, default
@@ -359,6 +362,13 @@ def tune_save(path: Optional[str] = None) -> None:
         os.replace(tmp, path)
     except OSError:
         pass
+
+
+def tune_reload() -> None:
+    """Drop the in-memory cache: the next lookup re-reads the shipped file and the per-user file (another rank of this node may
+    just have written its winners there: distributed.tuned_once)."""
+    global _tune
+    _tune = None
 
 
 def _tune_forget(ks: str) -> None:

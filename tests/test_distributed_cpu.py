@@ -144,3 +144,51 @@ def test_bucketed_gradient_allreduce_equals_the_mean_of_the_ranks(tmp_path):
     res = [json.load(open(tmp_path / f"grad{r}.json")) for r in range(2)]
     for r in res:
         assert r["err"] < 1e-6 and r["nb"][0] > 5 and abs(r["loss"] - 1.5) < 1e-6
+
+
+TUNE_WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch
+    from reflecting_reality_amd import distributed as D, hip
+    rank, world, local = D.init_process_group("gloo")
+    out = os.environ["RESULT_DIR"]
+    os.environ["MFHIP_TUNE_CACHE"] = os.path.join(out, "user_tune.json")
+    log = []
+
+    def warm():
+        # stands in for a warm-up pass: a rank that finds the shape untuned "tunes" it (and would time every candidate tile)
+        key = "9,9,7,77,777,1,1,0,0,1,0,0,1,1"
+        hit = hip._tune_load().get(key)
+        log.append(dict(rank=rank, t=time.time(), hit=hit is not None))
+        if hit is None:
+            time.sleep(0.3)
+            hip._tune_load()[key] = (44, 6, 0)
+            hip._tune_new[key] = (44, 6, 0)
+
+    D.tuned_once(warm)
+    with open(os.path.join(out, f"tune{rank}.json"), "w") as f:
+        json.dump(log, f)
+""") % ROOT
+
+
+def test_cold_tune_cache_is_filled_by_rank_zero_only(tmp_path):
+    """with several ranks and a cold tune cache only rank 0 tunes; it persists its winners, the other ranks
+    re-read the cache behind a barrier and find the shape tuned (distributed.tuned_once, what bench.py's warm-up goes through)."""
+    import json
+    script = tmp_path / "tune_worker.py"
+    script.write_text(TUNE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RESULT_DIR=str(tmp_path))
+    for attempt in range(3):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+        if out.returncode == 0:
+            break
+    assert out.returncode == 0, out.stderr[-2000:]
+    r0, r1 = (json.load(open(tmp_path / f"tune{r}.json")) for r in range(2))
+    assert len(r0) == 1 and len(r1) == 1
+    assert r0[0]["hit"] is False and r1[0]["hit"] is True, (r0, r1)            # rank 1 found rank 0's winner: it did not tune
+    assert r1[0]["t"] >= r0[0]["t"] + 0.3                                       # ... and only started after rank 0 had finished
+    saved = json.load(open(tmp_path / "user_tune.json"))
+    assert saved["entries"]["9,9,7,77,777,1,1,0,0,1,0,0,1,1"] == [44, 6, 0]

@@ -49,7 +49,7 @@ def run(label, b, h, w, ci, co, k, tile, sk, with_res, with_bias=True, with_temb
         fn()
     torch.cuda.synchronize()
     nblk = 8192
-    buf = torch.zeros(nblk, 16, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(nblk, 32, dtype=torch.int64, device="cuda")
     lib.mf_debug_set_stamps(C.c_void_p(buf.data_ptr()))
     # the launch under test sits between two other kernels of a replayed graph, like in the denoise step
     g = torch.cuda.CUDAGraph()
@@ -68,7 +68,7 @@ def run(label, b, h, w, ci, co, k, tile, sk, with_res, with_bias=True, with_temb
     t0 = st[:, 0].min()
     us = lambda a: (a - t0) / 100.0
     n = st.shape[0]
-    ws = (st[:, 8] > 0).any()
+    ws = (st[:, 16] > 0).any()
     print(f"=== {label}: M={b * h * w} N={co} K={ci * k * k} tile {tile} split-K {sk}: {n} blocks", flush=True)
     ent = us(st[:, 0])
     print(f"   block entry: median {np.median(ent):6.2f} us, 90 % {np.percentile(ent, 90):6.2f}, last {ent.max():6.2f}")
@@ -83,9 +83,18 @@ def run(label, b, h, w, ci, co, k, tile, sk, with_res, with_bias=True, with_temb
         print(f"   -> {names[s_]:16s}: median {np.median(d):6.2f} us  max {d.max():6.2f}   (reached at: median {np.median(us(cur[ok])):6.2f}, last {us(cur[ok]).max():6.2f})")
         prev = np.where(ok, cur, prev)
     if ws:
-        p = st[:, 8:]
+        p = st[:, 16:]
         ok = p[:, 0] > 0
         print(f"   staging wave: prologue {np.median((p[ok, 1] - p[ok, 0]) / 100.0):5.2f} us, tile 0 landed after {np.median((p[ok, 2] - p[ok, 1]) / 100.0):5.2f} us (max {((p[ok, 2] - p[ok, 1]) / 100.0).max():5.2f})")
+    for ih in range(2):                         # warp-specialised epilogue rounds: slab written / barrier passed / stores issued
+        a, b_, c = st[:, 7 + 3 * ih], st[:, 8 + 3 * ih], st[:, 9 + 3 * ih]
+        if (a > 0).any():
+            ref_t = st[:, 4] if ih == 0 else st[:, 9]
+            print(f"   epilogue round {ih} (wave 0): slab written +{np.median((a - ref_t) / 100.0):5.2f} us, barrier +{np.median((b_ - a) / 100.0):5.2f}, "
+                  f"chunks read / finished / stores issued +{np.median((c - b_) / 100.0):5.2f}")
+            if ws:
+                pa, pb, pc = st[:, 16 + 7 + 3 * ih], st[:, 16 + 8 + 3 * ih], st[:, 16 + 9 + 3 * ih]
+                print(f"      staging wave 0: barrier reached at +{np.median((pb - (st[:, 4] if ih == 0 else st[:, 9])) / 100.0):5.2f} us of the round, stores issued +{np.median((pc - pb) / 100.0):5.2f}")
     print(f"   launch span (first entry -> last exit): {us(st[:, 6]).max():6.2f} us", flush=True)
 
 
