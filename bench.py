@@ -194,7 +194,7 @@ def train_main(a, D):
 
     # one process, no gradient sync: zero_grad + forward + backward + clip replayed from one hipGraph (training.GraphedTrainStep;
     # its first two calls are the eager step — run them inside the warm-up).  MF_TRAIN_GRAPH=0: the eager step throughout.
-    graphed = GraphedTrainStep(model, ns, opt, max_grad_norm=1.0) if (sync is None and os.environ.get("MF_TRAIN_GRAPH", "1") != "0") else None
+    graphed = GraphedTrainStep(model, ns, opt, max_grad_norm=1.0, grad_sync=sync) if os.environ.get("MF_TRAIN_GRAPH", "1") != "0" else None
 
     def one_step(i):
         ts = torch.randint(0, 1000, (b,), generator=g)

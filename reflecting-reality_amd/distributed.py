@@ -109,6 +109,9 @@ class GradBuckets:
         self.force = os.environ.get("MF_FORCE_GRAD_SYNC") == "1" and dist.is_initialized()
         self.bucket_floats = int(bucket_floats)
         self._stream = None
+        # training.GraphedTrainStep sets this while it captures: a bucket that becomes ready is reported to it (it cuts the graph
+        # there and issues the exchange between two graph segments at replay) instead of being all-reduced during the capture
+        self.capture_hook = None
         self._plan = []
         for m in self.models:
             n = m.num_arena_floats()
@@ -153,6 +156,14 @@ class GradBuckets:
     def _send(self, pi: int, b: int) -> None:
         p, st = self._plan[pi], self._state[pi]
         st["sent"][b] = True
+        if self.capture_hook is not None:
+            self.capture_hook(pi, b)
+            return
+        self.send_bucket(pi, b)
+
+    def send_bucket(self, pi: int, b: int) -> None:
+        """All-reduce bucket b of model pi asynchronously on the side stream, ordered after everything the current stream holds."""
+        p, st = self._plan[pi], self._state[pi]
         lo, hi = b * self.bucket_floats, min((b + 1) * self.bucket_floats, p["n"])
         buf = p["model"].flat_g[lo:hi]
         if buf.is_cuda and dist.get_backend() == "gloo":
@@ -175,17 +186,32 @@ class GradBuckets:
     def finish(self) -> None:
         if self.world == 1 and not self.force:
             return
+        self.flush()
+        self.wait()
+        self.scale()
+
+    def flush(self) -> None:
+        """Send every bucket the backward pass has not released (parameters that received no gradient this step)."""
         for pi, p in enumerate(self._plan):
             for b in range(p["nb"]):
                 if not self._state[pi]["sent"][b]:
                     self._send(pi, b)
+
+    def wait(self) -> None:
+        """Order the current stream after every exchange in flight."""
         for pi, p in enumerate(self._plan):
             for h in self._state[pi]["handles"]:
                 h.wait()
+            self._state[pi]["handles"] = []
+            g = p["model"].flat_g
+            if g.is_cuda and self._stream is not None:
+                torch.cuda.current_stream(g.device).wait_stream(self._stream)
+
+    def scale(self) -> None:
+        """Sum -> mean over the ranks (one streaming kernel per arena)."""
+        for p in self._plan:
             g = p["model"].flat_g[: p["n"]]
             if g.is_cuda:
-                if self._stream is not None:
-                    torch.cuda.current_stream(g.device).wait_stream(self._stream)
                 from . import hip
                 hip.axpby_n([g], [1.0 / self.world], out=g)
             else:

@@ -292,15 +292,21 @@ class GraphedTrainStep:
     the host, :1416), the SNR weights (:1437-1449), the range-guard read-back, and the optimizer (its bias corrections are
     host scalars).  Inputs are copied into static device buffers; shapes are fixed at the first call.  The first `warmup`
     calls run the eager train_step (they tune GEMM tiles, build the frozen network's derived weights and learn which
-    data-gradient layouts to prefetch); the next call captures.  Single-process only: with a GradBuckets gradient sync the
-    eager step is used (RCCL calls are not captured).  The arithmetic and its order are the eager step's: weights are
+    data-gradient layouts to prefetch); the next call captures.  With a GradBuckets gradient sync (several ranks) the step is
+    captured as a CHAIN of graphs cut at every point where the backward pass releases a gradient bucket; at replay the bucket's
+    RCCL all-reduce is issued eagerly on the side stream between two segments (RCCL calls are never captured), the last segment
+    (mean over ranks, clip) runs once every exchange has been awaited.  The arithmetic and its order are the eager step's: weights are
     bit-identical after the same number of steps (tests/test_training_gpu.py).  The returned (loss, grad_norm) tensors live
     in the graph's memory pool and are overwritten by the next call: read them (float(), .clone()) before stepping again.
     Memory: the graph keeps one step's activations resident between calls (they are reused, not reallocated)."""
 
     def __init__(self, model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, snr_gamma: Optional[float] = None,
-                 max_grad_norm: float = 1.0, check_overflow: bool = True, warmup: int = 2, lr_scheduler=None):
+                 max_grad_norm: float = 1.0, check_overflow: bool = True, warmup: int = 2, lr_scheduler=None, grad_sync=None):
         self.model, self.ns, self.opt = model, noise_scheduler, optimizer
+        # a distributed.GradBuckets: the step is then captured as a CHAIN of graphs cut wherever the backward pass releases a
+        # gradient bucket, and the bucket's all-reduce is issued eagerly between two replays (RCCL calls are never captured)
+        self.grad_sync = grad_sync
+        self.segments = None
         self.snr_gamma, self.max_grad_norm, self.check_overflow = snr_gamma, max_grad_norm, check_overflow
         self.warmup, self.calls, self.graph = max(int(warmup), 1), 0, None
         self.lr_scheduler = lr_scheduler
@@ -336,6 +342,8 @@ class GraphedTrainStep:
         mods = model.get_trainable_modules()
         self.opt.zero_grad()
         tape = autograd.Tape(prec.tape_code)
+        if self.grad_sync is not None:
+            self.grad_sync.begin(tape)
         dgrad_ready = None
         prefetch = getattr(model, "_dgrad_prefetch", None)
         cur = torch.cuda.current_stream(mods[0].device)
@@ -364,8 +372,58 @@ class GraphedTrainStep:
         if dgrad_ready is not None:
             cur.wait_event(dgrad_ready)
         tape.backward()
+        if self.grad_sync is not None and self.segments is not None:
+            gs = self.grad_sync
+            gs.flush()                      # (capturing: reported to _cut like the buckets released during the backward pass)
+            self._cut(None, None)           # everything issued so far ends a segment; the exchanges are awaited between replays
+            gs.scale()
         norm, coef = clip_grad_norm_(mods, self.max_grad_norm, loss_scale=scale)
         return loss, norm, coef
+
+    # -- a chain of graphs with the gradient exchange between them ----------------------------------------------------------
+    def _cut(self, pi, b):
+        """Capture hook of GradBuckets: end the graph segment being captured here, remember that bucket (pi, b) is sent after
+        it (pi None: wait for every exchange instead), and begin the next segment in the same memory pool."""
+        self._cur.capture_end()
+        self.segments.append((self._cur, (pi, b)))
+        self._cur = torch.cuda.CUDAGraph()
+        self._cur.capture_begin(pool=self._pool)
+
+    def _capture_chain(self):
+        dev = self.model.get_trainable_modules()[0].device
+        gs = self.grad_sync
+        self.segments, self._pool = [], torch.cuda.graph_pool_handle()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        gs.capture_hook = self._cut
+        try:
+            with torch.cuda.stream(side):
+                self._cur = torch.cuda.CUDAGraph()
+                self._cur.capture_begin(pool=self._pool)
+                try:
+                    out = self._body()
+                finally:
+                    self._cur.capture_end()
+                self.segments.append((self._cur, None))
+        finally:
+            gs.capture_hook = None
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return out
+
+    def _replay_chain(self):
+        gs = self.grad_sync
+        gs.begin(autograd.Tape(self.model.brushnet.prec.tape_code))       # fresh per-step exchange state (handles, sent flags)
+        for graph, after in self.segments:
+            graph.replay()
+            if after is None:
+                continue
+            pi, b = after
+            if pi is None:
+                gs.wait()
+            else:
+                gs._state[pi]["sent"][b] = True
+                gs.send_bucket(pi, b)
 
     def __call__(self, latents, noise, timesteps, encoder_hidden_states, conditioning_latents):
         model = self.model
@@ -376,12 +434,12 @@ class GraphedTrainStep:
             self.calls += 1
             return train_step(model, self.ns, self.opt, latents, noise, timesteps, encoder_hidden_states, conditioning_latents,
                               snr_gamma=self.snr_gamma, max_grad_norm=self.max_grad_norm, check_overflow=self.check_overflow,
-                              lr_scheduler=self.lr_scheduler)
+                              lr_scheduler=self.lr_scheduler, grad_sync=self.grad_sync)
         dev = mods[0].device
         prec = model.brushnet.prec
         if self.graph is not None and self._arenas() != self._arena_key:
             # prepare_training() rebuilt an arena since the capture: the graph's kernels point at freed memory
-            self.graph = None
+            self.graph, self.segments = None, None
         if self.graph is None:
             f32 = dict(dtype=torch.float32, device=dev)
             self.noisy, self.target = torch.empty(latents.shape, **f32), torch.empty(latents.shape, **f32)
@@ -397,8 +455,11 @@ class GraphedTrainStep:
             # updating the arena.  The token makes each of them rebuild once during this capture.
             ops.CAPTURE_TOKEN = object()
             try:
-                with torch.cuda.graph(self.graph):
-                    self.loss, self.norm, self.coef = self._body()
+                if self.grad_sync is not None and (self.grad_sync.world > 1 or self.grad_sync.force):
+                    self.loss, self.norm, self.coef = self._capture_chain()
+                else:
+                    with torch.cuda.graph(self.graph):
+                        self.loss, self.norm, self.coef = self._body()
             finally:
                 ops.CAPTURE_TOKEN = None
             self._arena_key = self._arenas()
@@ -410,9 +471,16 @@ class GraphedTrainStep:
         guard = prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and self.check_overflow
         if guard:
             hip.split_overflow(reset=True)
-        self.graph.replay()
+        if self.segments is not None:
+            self._replay_chain()
+        else:
+            self.graph.replay()
         self.calls += 1
-        if guard and hip.split_overflow(reset=True):
+        raised = hip.split_overflow(reset=True) if guard else 0
+        if guard and self.grad_sync is not None and getattr(self.grad_sync, "world", 1) > 1:
+            from . import distributed as D
+            raised = int(D.max_over_ranks(float(raised), device=dev))      # every rank skips together
+        if raised:
             import warnings
             model.overflow_steps = getattr(model, "overflow_steps", 0) + 1
             warnings.warn(f"GraphedTrainStep: a split-precision operand exceeded the fp16 range; optimizer step skipped "
@@ -421,7 +489,8 @@ class GraphedTrainStep:
             return self.loss, self.norm
         self.opt.step(grad_scale=self.coef)
         if self.lr_scheduler is not None:
-            self.lr_scheduler.step()
+            for _ in range(max(int(getattr(self.grad_sync, "world", 1) or 1), 1) if self.grad_sync is not None else 1):
+                self.lr_scheduler.step()
         return self.loss, self.norm
 
 

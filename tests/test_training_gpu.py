@@ -930,3 +930,45 @@ def test_baseline_config3_full_size_step_against_the_reference_backward(prec, ta
         assert abs(dw - ref_dw) < (2e-3 if env is None else 2e-2) * ref_dw, (name, dw, ref_dw)
     del model, opt, unet, bn
     torch.cuda.empty_cache()
+
+
+def test_graphed_step_with_gradient_sync_is_a_chain_of_graphs_and_equals_the_eager_step():
+    """GraphedTrainStep with a GradBuckets gradient exchange.  RCCL calls are never captured: the step is a
+    chain of graphs cut where the backward pass releases a gradient bucket, the bucket's all-reduce is issued between two
+    replays.  Run here with the exchange forced through RCCL on this one rank (MF_FORCE_GRAD_SYNC=1, small buckets so that the
+    tiny BrushNet has several): >= 3 segments, and loss, norm and weights bit-identical to the eager synchronised step over five
+    steps with changing inputs."""
+    import socket
+    import torch.distributed as dist
+    from reflecting_reality_amd import distributed as D
+    from reflecting_reality_amd.training import GraphedTrainStep
+    ns = DDPMScheduler(**SD_SCHED)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MF_FORCE_GRAD_SYNC"] = "1"
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        def run(graphed):
+            model = _model("f16x3").prepare_training()
+            opt = AdamW(model.get_trainable_modules())
+            sync = D.GradBuckets(model.get_trainable_modules(), bucket_floats=64 * 1024)
+            assert sync.force and sum(p["nb"] for p in sync._plan) >= 3
+            step = GraphedTrainStep(model, ns, opt, warmup=2, grad_sync=sync) if graphed else None
+            out = []
+            for i in range(5):
+                args = _skip_inputs(i)
+                loss, norm = step(*args) if graphed else train_step(model, ns, opt, *args, grad_sync=sync)
+                out.append((float(loss), float(norm)))
+            if graphed:
+                assert step.segments is not None and len(step.segments) >= 3, "the captured step must be cut at the bucket boundaries"
+                sends = [a for _, a in step.segments if a is not None and a[0] is not None]
+                assert len(sends) == sum(p["nb"] for p in sync._plan), "every bucket is exchanged exactly once per step"
+            return model.brushnet.flat_w.clone(), out
+
+        (wa, la), (wb, lb) = run(False), run(True)
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("MF_FORCE_GRAD_SYNC", None)
+    assert la == lb, (la, lb)
+    assert torch.equal(wa, wb), "the chained-graph step with gradient sync differs from the eager one"
