@@ -235,6 +235,17 @@ typedef struct mf_attn_bwd_desc {
 } mf_attn_bwd_desc;
 int mf_sizeof_attn_bwd_desc(void);
 int mf_attention_bwd_f16x3(const mf_attn_bwd_desc* d, void* stream);
+/* The same backward on ONE bf16 plane per operand (the *_hi pointers; *_lo are ignored) and one bf16 MFMA per product, P and dS
+ * rounded to bf16: the attention backward of the MF_BF16X1 training mode on pre-rounded operands (what the reference's bf16 autocast
+ * computes in F.scaled_dot_product_attention's backward, attention_processor.py:1266-1268).  head_dim 8 / 40. */
+int mf_attention_bwd_bf16(const mf_attn_bwd_desc* d, void* stream);
+/* mf_attention_bf16 that also writes lse[b][head][q] = log2 of the row's softmax denominator in the exp2 domain (m + log2 l), the row
+ * statistic the flash backward recomputes P from.  lse may be NULL. */
+int mf_attention_bf16_lse(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* out, int64_t ldo,
+                          float* lse, int32_t batch, int32_t heads, int32_t sq, int32_t skv, int32_t head_dim, float scale, void* stream);
+/* mf_rowdot_heads with a bf16 second operand (the bf16 forward's output O) */
+int mf_rowdot_heads_bf16(const float* a, const void* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
+                         void* stream);
 /* out[b][head][i] = sum_c a[b][i][head*d + c] * b[b][i][head*d + c]  (fp32 [B][S][ld] inputs) */
 int mf_rowdot_heads(const float* a, const float* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
                     void* stream);
@@ -267,6 +278,10 @@ int mf_unpack_nchw(const void* src, int32_t src_dtype, int64_t ld, float* dst, i
 /* out = a + b (elementwise over n elements, dtypes independent) (unet_2d_condition.py:1218) */
 int mf_add(const void* a, int32_t a_dtype, const void* b, int32_t b_dtype, void* out, int32_t out_dtype,
            int64_t n, void* stream);
+/* out[i] = bf16(x[i]), nearest-even, n elements (x and out 16-byte aligned): the operand copies of the MF_BF16X1 training mode —
+ * the reference's autocast rounds every conv / linear operand to bf16 (train_brushnet_mirror.py:567, 1127-1131); rounding them ONCE
+ * into a copy lets the step's forward and data-gradient GEMMs run on the LDS-DMA bf16 kernels of the inference path. */
+int mf_cast_bf16(const float* x, void* out, int64_t n, void* stream);
 /* GEGLU: out[r][j] = h[r][j] * gelu_erf(h[r][c + j]) for h = [rows][2c] (activations.py:100-103) */
 int mf_geglu(const void* h, int32_t in_dtype, void* out, int32_t out_dtype, int64_t rows, int32_t c,
              void* stream);
@@ -369,6 +384,9 @@ int mf_hwc_to_chw_affine(const float* x, float* y, int64_t hw, int32_t channels,
  * output pixels m of dy[m][n] * A[pixel(m, ky, kx)][c].  dtype MF_F32 (fp32 MFMA) or MF_F16X3 (split precision).
  * Replaces autograd's conv2d / linear weight gradients (torch/nn/grad.py conv2d_weight; linear: dy^T x). */
 typedef struct mf_wgrad_desc {
+    /* MF_F32 / MF_F16X3 / MF_BF16X1: fp32 a0 / a1 / dy (rounded or split while staged).  MF_BF16: a0 / a1 / dy are bf16 tensors
+     * (declared float* for the layout's sake; strides in elements; channel counts multiples of 8) — the pre-rounded operand copies of
+     * the bf16x1 training mode: half the operand bytes, no conversion in the staging loop, the same products as MF_BF16X1. */
     int32_t dtype;
     const float* a0; const float* a1;   /* the forward input, NHWC, one or two channel segments */
     int32_t c0, c1;
@@ -396,6 +414,10 @@ int mf_split_pack(const float* w, int64_t ldw, void* out, int64_t rows, int32_t 
  * a negative zsy with y pointing at the last matrix writes the batch in reverse — the tap flip of a dgrad weight) */
 int mf_transpose(const float* x, float* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,
                  int64_t zsy, void* stream);
+/* The same with a bf16 (nearest-even) result, strides in elements: the transposed, tap-flipped weight of the data-gradient GEMM in the
+ * bf16x1 training mode is rounded while it is laid out (one launch instead of mf_transpose + mf_cast_bf16). */
+int mf_transpose_bf16(const float* x, void* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,
+                      int64_t zsy, void* stream);
 
 /* out[s][j] (+)= sum over the rows of segment s (rows_per_seg consecutive rows) of x[row][j], j < n: bias gradients
  * (one segment), the time-embedding gradient of a resnet (one segment per image), dgamma / dbeta partials */

@@ -128,6 +128,17 @@ def _dgrad_weight(cw, tape) -> torch.Tensor:
     if gen != cw.generation() or getattr(cw, "_wd", None) is None or getattr(cw, "_wd_code", None) != code or recapture:
         cw._wd_tok = tok
         taps, n, ct = cw.kh * cw.kw, cw.n, cw.cin_pad
+        if code == hip.MF_BF16X1 and cw.fast16() and n % 8 == 0:
+            # MF_BF16X1 on pre-rounded copies (ops.ConvWeight.fast16): the data gradient only ever reads the bf16 layout
+            wd16 = getattr(cw, "_wd16", None)
+            if wd16 is None:
+                wd16 = cw._wd16 = torch.empty(ct, taps * n, dtype=torch.bfloat16, device=cw.w.device)
+            hip.transpose(cw.w, n, ct, nz=taps, ldx=taps * ct, ldy=taps * n, zsx=ct, zsy=-n, out=wd16, y_offset=(taps - 1) * n)
+            cw._wd, cw._wd_split, cw._wd_ld, cw._wd_gen, cw._wd_code = wd16, 0, taps * n, cw.generation(), code
+            if not isinstance(tape, int) and cw.p_w is not None and cw.p_w.grad is not None:
+                tape.dgrad_rebuilt.append(cw)
+            return cw._wd
+        cw._wd16 = None
         wd = getattr(cw, "_wd_f32", None)
         if wd is None:
             wd = cw._wd_f32 = torch.empty(ct, taps * n, dtype=torch.float32, device=cw.w.device)
@@ -146,7 +157,7 @@ def _dgrad_weight(cw, tape) -> torch.Tensor:
 
 
 def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, stride, pad_t, pad_l, upsample, temb, res0, res1,
-                alpha, act) -> None:
+                alpha, act, x16=None) -> None:
     """out = alpha * (conv(cat(x, x1)) + bias + temb[b]) + res0 + res1  (mf_gemm_conv; linear = 1x1 over batch rows)."""
     if act != hip.ACT_NONE:
         raise hip.MfhipError("training: fused activations are not differentiated; apply ops.silu / ops.geglu as their own op")
@@ -167,9 +178,16 @@ def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, 
         if cw.p_bias is not None and cw.p_bias.grad is not None:
             hip.colsum(gc, n, out=cw.p_bias.grad.view(1, n), accumulate=True)
             tape.param_grad_done(cw.p_bias)
+        # x16 = the bf16 copies the forward GEMM ran on (MF_BF16X1 on pre-rounded operands): the gradient is rounded to bf16 ONCE
+        # here, and both the weight gradient and the data gradient read 16-bit operands
+        gc16 = hip.cast_bf16(gc.contiguous()) if (x16 is not None and n % 8 == 0) else None
         if cw.p_w is not None and cw.p_w.grad is not None:
-            hip.conv_wgrad(x, gc, cw.p_w.grad, code=tape.code, c0=c0, x1=x1, c1=c1, batch=batch, h_in=h_in, w_in=w_in, h_out=h_out,
-                           w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n)
+            if gc16 is not None:
+                hip.conv_wgrad(x16[0], gc16, cw.p_w.grad, code=hip.MF_BF16, c0=c0, x1=x16[1], c1=c1, batch=batch, h_in=h_in, w_in=w_in,
+                               h_out=h_out, w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n)
+            else:
+                hip.conv_wgrad(x, gc, cw.p_w.grad, code=tape.code, c0=c0, x1=x1, c1=c1, batch=batch, h_in=h_in, w_in=w_in, h_out=h_out,
+                               w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n)
             tape.param_grad_done(cw.p_w)
         if not (tape.needs(x) or tape.needs(x1)):
             return
@@ -184,14 +202,23 @@ def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, 
         hu, wu = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
         outs = []
         off = 0
+        # MF_BF16X1 on pre-rounded copies: the gradient is rounded to bf16 once, the transposed weight once per step, and the data
+        # gradient runs on the bf16 LDS-DMA kernels (same arithmetic per product as the in-register rounding)
+        fast = n % 8 == 0 and (taps * n) % 8 == 0 and cw.fast16() and getattr(cw, "_wd16", None) is not None
+        a16 = (gc16 if (gc16 is not None and stride == 1) else hip.cast_bf16(a.contiguous())) if fast else None
         for seg, cs in ((x, c0), (x1, c1)):
             if seg is None:
                 continue
             if tape.needs(seg):
                 dx = torch.empty(batch, hu, wu, cs, dtype=torch.float32, device=x.device)
-                hip.gemm_conv(a, wd[off:off + cs], dx, dtype=tape.code, w_split=cw._wd_split, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
-                              h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
-                              ldw=cw._wd_ld, n=cs)
+                if fast:
+                    hip.gemm_conv(a16, cw._wd16[off:off + cs], dx, dtype=hip.MF_BF16, w_split=0, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
+                                  h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
+                                  ldw=taps * n, n=cs)
+                else:
+                    hip.gemm_conv(a, wd[off:off + cs], dx, dtype=tape.code, w_split=cw._wd_split, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
+                                  h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
+                                  ldw=cw._wd_ld, n=cs)
                 outs.append((seg, hip.sumpool2x2(dx) if upsample else dx))
             off += cs
         for seg, dx in outs:
@@ -301,6 +328,34 @@ def record_attention(tape: Tape, q, k, v, out, heads: int, skv: int, scale: floa
         dk = torch.empty(b, skv, c, dtype=torch.float32, device=dev)
         hip.gemm_conv(dst, qt, dk, dtype=code, c0=sq, lda0=sq, batch=skv, h_in=1, w_in=1, h_out=1, w_out=1, ldw=sq, n=d, ldc=c, nz=z,
                       zdiv=heads, a_zs=(heads * skv * sq, skv * sq), w_zs=(c * sq, d * sq), o_zs=(skv * c, d), splitk=1)
+        tape.add(q, dq)
+        tape.add(k, dk)
+        tape.add(v, dv)
+
+    tape.record(bwd)
+
+
+def record_attention_flash_bf16(tape: Tape, q, k, v, out16, lse, heads: int, scale: float, q16, k16, v16) -> None:
+    """Backward of the bf16 flash forward of the bf16x1 mode (ops.attention_train): mf_attention_bwd_bf16 on single bf16 planes.
+    q / k / v are the fp32 tensors the gradients are keyed on; q16 / k16 / v16 their rounded copies made for the forward; the
+    transposed operands are rounded by the transposes themselves."""
+    from . import ops
+    b, sq, c = q.shape
+    skv = k.shape[1]
+
+    def bwd():
+        g = tape.take(out16)
+        if g is None:
+            return
+        g = g.view(b, sq, c).contiguous()
+        dd = hip.rowdot_heads(g, out16, heads)
+        ldq, ldk = (sq + 7) // 8 * 8, (skv + 7) // 8 * 8
+        g16 = hip.cast_bf16(g)
+        qt = ops.transpose_tokens(q, ldq, torch.bfloat16)
+        kt = ops.transpose_tokens(k, ldk, torch.bfloat16)
+        gt = ops.transpose_tokens(g, ldq, torch.bfloat16)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        hip.attention_bwd_bf16(q16, k16, v16, g16, qt, kt, gt, lse, dd, dq, dk, dv, heads=heads, scale=scale)
         tape.add(q, dq)
         tape.add(k, dk)
         tape.add(v, dv)

@@ -423,9 +423,11 @@ struct AttnBwdArgs {
 // Eight waves per block (256 column items against one streamed tile): two waves per SIMD, so one wave's exp2 / split VALU work
 // runs under the other's MFMAs, and each staged tile feeds twice the products of the first version's four waves.
 constexpr int BWD_NW = 8;
-template <int HD, bool KV>
+// B16: the same kernel on ONE bf16 plane per operand and one bf16 MFMA per product (P and dS rounded to bf16): the attention
+// backward of the bf16x1 training mode on pre-rounded operands — a third of the matrix work of the split form.
+template <int HD, bool KV, bool B16 = false>
 __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdArgs p) {
-    constexpr int NP = 2, NW = BWD_NW;
+    constexpr int NP = B16 ? 1 : 2, NW = BWD_NW;
     constexpr int DK = (HD + 15) / 16 * 16, KS = DK / 16;
     constexpr int DV = (HD + 31) / 32 * 32, DT = DV / 32;
     constexpr int RBK = DK * 2 + 16, RBV = 144, RBO = DV * 4 + 16;
@@ -575,15 +577,20 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
             for (int tt = 0; tt < 2; ++tt) {
                 const int fo = (32 * tt + r) * RBK + (16 * ks + 8 * h) * 2;
                 const uint4 ah = *reinterpret_cast<const uint4*>(B0 + fo);
-                const uint4 al = *reinterpret_cast<const uint4*>(B0 + K_BYTES + fo);
-                T[tt] = mfma16(al, f1[0][ks], ks == 0 ? zero16 : T[tt], true);
-                T[tt] = mfma16(ah, f1[1][ks], T[tt], true);
-                T[tt] = mfma16(ah, f1[0][ks], T[tt], true);
                 const uint4 bh_ = *reinterpret_cast<const uint4*>(B0 + R2_OFF + fo);
-                const uint4 bl_ = *reinterpret_cast<const uint4*>(B0 + R2_OFF + K_BYTES + fo);
-                U[tt] = mfma16(bl_, f2[0][ks], ks == 0 ? zero16 : U[tt], true);
-                U[tt] = mfma16(bh_, f2[1][ks], U[tt], true);
-                U[tt] = mfma16(bh_, f2[0][ks], U[tt], true);
+                if constexpr (B16) {
+                    T[tt] = mfma16(ah, f1[0][ks], ks == 0 ? zero16 : T[tt], false);
+                    U[tt] = mfma16(bh_, f2[0][ks], ks == 0 ? zero16 : U[tt], false);
+                } else {
+                    const uint4 al = *reinterpret_cast<const uint4*>(B0 + K_BYTES + fo);
+                    T[tt] = mfma16(al, f1[0][ks], ks == 0 ? zero16 : T[tt], true);
+                    T[tt] = mfma16(ah, f1[NP - 1][ks], T[tt], true);
+                    T[tt] = mfma16(ah, f1[0][ks], T[tt], true);
+                    const uint4 bl_ = *reinterpret_cast<const uint4*>(B0 + R2_OFF + K_BYTES + fo);
+                    U[tt] = mfma16(bl_, f2[0][ks], ks == 0 ? zero16 : U[tt], true);
+                    U[tt] = mfma16(bh_, f2[NP - 1][ks], U[tt], true);
+                    U[tt] = mfma16(bh_, f2[0][ks], U[tt], true);
+                }
             }
         // ---- P = exp2(T c - lse), dS = scale P (U - D); accumulator register e of sub-tile tt is tile row
         //      32 tt + (e & 3) + 4 ((e >> 2) & 1) + 16 (e >> 3) + 8 h (natural order: the tile's rows are stored permuted) ----
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
                 float pv = __builtin_amdgcn_exp2f(fmaf(T[tt][e], p.c, -lv[e]));
                 if (n >= p.sr) pv = 0.0f;
                 const float ds = p.scale * pv * (U[tt][e] - dv[e]);
-                amax = mf_amax3(amax, ds, 0.0f);
+                if constexpr (!B16) amax = mf_amax3(amax, ds, 0.0f);
                 T[tt][e] = pv;
                 U[tt][e] = ds;
             }
@@ -619,9 +626,13 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float p0 = T[tt][8 * s2 + 2 * e], p1 = T[tt][8 * s2 + 2 * e + 1];
-                    mf_split_f16x2(p0, p1, a_h[e], a_l[e]);
                     const float d0 = U[tt][8 * s2 + 2 * e], d1 = U[tt][8 * s2 + 2 * e + 1];
-                    mf_split_f16x2(d0, d1, b_h[e], b_l[e]);
+                    if constexpr (B16) {
+                        a_h[e] = pack_bf16x2(p0, p1); b_h[e] = pack_bf16x2(d0, d1); a_l[e] = 0; b_l[e] = 0;
+                    } else {
+                        mf_split_f16x2(p0, p1, a_h[e], a_l[e]);
+                        mf_split_f16x2(d0, d1, b_h[e], b_l[e]);
+                    }
                 }
                 ph[2 * tt + s2] = uint4{a_h[0], a_h[1], a_h[2], a_h[3]};
                 plo[2 * tt + s2] = uint4{a_l[0], a_l[1], a_l[2], a_l[3]};
@@ -636,6 +647,13 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
             for (int d = 0; d < DT; ++d) {
                 const int fo = (32 * d + r) * RBV + (16 * kst + 8 * h) * 2;
                 const uint4 ah = *reinterpret_cast<const uint4*>(B0 + T1_OFF + fo);
+                if constexpr (B16) {
+                    acc1[d] = mfma16(ah, sh[kst], acc1[d], false);
+                    if (KV) {
+                        const uint4 bh_ = *reinterpret_cast<const uint4*>(B0 + T2_OFF + fo);
+                        acc2[d] = mfma16(bh_, ph[kst], acc2[d], false);
+                    }
+                } else {
                 const uint4 al = *reinterpret_cast<const uint4*>(B0 + T1_OFF + V_BYTES + fo);
                 acc1[d] = mfma16(al, sh[kst], acc1[d], true);
                 acc1[d] = mfma16(ah, slo[kst], acc1[d], true);
@@ -647,11 +665,12 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
                     acc2[d] = mfma16(bh_, plo[kst], acc2[d], true);
                     acc2[d] = mfma16(bh_, ph[kst], acc2[d], true);
                 }
+                }
             }
         wait_vmcnt<0>();
         __syncthreads();
     }
-    mf_raise_if_over(&g_split_ovf_attn, amax);
+    if constexpr (!B16) mf_raise_if_over(&g_split_ovf_attn, amax);
 
     // ---- epilogue: transpose through LDS, row-contiguous fp32 stores ----
     char* Os = smem + wave * 32 * RBO;
@@ -684,8 +703,10 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
 }
 
 // D[b][head][q] = sum_c dO[b][q][head*d + c] * O[b][q][head*d + c]
-__global__ __launch_bounds__(256) void rowdot_heads_kernel(const float* a, const float* bb, float* out, int batch, int sq, int heads, int hd,
+template <bool B16>      // B16: the second operand (the forward's output O) is bf16
+__global__ __launch_bounds__(256) void rowdot_heads_kernel(const float* a, const void* bv, float* out, int batch, int sq, int heads, int hd,
                                                            int64_t ld) {
+    const float* bb = reinterpret_cast<const float*>(bv);
     const int64_t total = (int64_t)batch * sq * heads;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int hh = (int)(i % heads);
@@ -693,11 +714,21 @@ __global__ __launch_bounds__(256) void rowdot_heads_kernel(const float* a, const
         const int q = (int)(t % sq);
         const int b = (int)(t / sq);
         const float* pa = a + ((int64_t)b * sq + q) * ld + hh * hd;
-        const float* pb = bb + ((int64_t)b * sq + q) * ld + hh * hd;
         float s0 = 0.0f;
+        if constexpr (B16) {
+            const unsigned short* pb = reinterpret_cast<const unsigned short*>(bv) + ((int64_t)b * sq + q) * ld + hh * hd;
+            for (int c = 0; c < hd; c += 4) {
+                const float4 x = *reinterpret_cast<const float4*>(pa + c);
+                const uint2 y = *reinterpret_cast<const uint2*>(pb + c);
+                s0 += (x.x * __uint_as_float(y.x << 16) + x.y * __uint_as_float(y.x & 0xffff0000u)) +
+                      (x.z * __uint_as_float(y.y << 16) + x.w * __uint_as_float(y.y & 0xffff0000u));
+            }
+        } else {
+        const float* pb = bb + ((int64_t)b * sq + q) * ld + hh * hd;
         for (int c = 0; c < hd; c += 4) {
             const float4 x = *reinterpret_cast<const float4*>(pa + c), y = *reinterpret_cast<const float4*>(pb + c);
             s0 += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        }
         }
         out[((int64_t)b * heads + hh) * sq + q] = s0;
     }
@@ -732,9 +763,18 @@ unsigned* mf_ovf_flag_attention() {
     return p;
 }
 
+extern "C" int mf_attention_bf16_lse(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                                     void* out, int64_t ldo, float* lse, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                                     int32_t head_dim, float scale, void* stream);
 extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                                  void* out, int64_t ldo, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
                                  int32_t head_dim, float scale, void* stream) {
+    return mf_attention_bf16_lse(q, ldq, k, ldk, vt, ldvt, out, ldo, nullptr, batch, heads, sq, skv, head_dim, scale, stream);
+}
+
+extern "C" int mf_attention_bf16_lse(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                                     void* out, int64_t ldo, float* lse, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                                     int32_t head_dim, float scale, void* stream) {
     MF_CHECK_ARG(q && k && vt && out, "mf_attention_bf16: null pointer");
     MF_CHECK_ARG(batch >= 1 && heads >= 1 && sq >= 1 && skv >= 1, "mf_attention_bf16: bad sizes");
     MF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0 && ldvt >= skv,
@@ -746,6 +786,7 @@ extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int6
     AttnArgs a{};
     a.q = (const char*)q; a.ldq = ldq; a.k = (const char*)k; a.ldk = ldk; a.vt = (const char*)vt; a.ldvt = ldvt;
     a.out = (char*)out; a.ldo = ldo; a.heads = heads; a.sq = sq; a.skv = skv; a.batch = batch;
+    a.lse = lse;
     a.c = scale * 1.44269504088896340736f;
     { static const bool off = getenv("MFHIP_ATTN_NOXCD") != nullptr; a.no_xcd_order = off; }
     hipStream_t s = (hipStream_t)stream;
@@ -822,11 +863,11 @@ extern "C" int mf_attention_f16x3_lse(const void* q_hi, const void* q_lo, int64_
     return MF_OK;
 }
 
-template <int HD>
+template <int HD, bool B16 = false>
 static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
     const float c = d->scale * 1.44269504088896340736f;
     int sh = 0;
-    while (sh < 8 && (2 << sh) <= d->skv) ++sh;                // 2^sh <= skv, at most 2^8: P * 2^sh <= 256, far inside fp16
+    while (!B16 && sh < 8 && (2 << sh) <= d->skv) ++sh;        // 2^sh <= skv, at most 2^8: P * 2^sh <= 256, far inside fp16 (bf16: none)
     const float pshift = (float)sh, inv_pscale = 1.0f / (float)(1 << sh);
     {   // dK, dV: a wave owns 32 keys and streams the query tiles
         AttnBwdArgs a{};
@@ -840,7 +881,7 @@ static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
         a.heads = d->heads; a.sc = d->skv; a.sr = d->sq; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
         a.pshift = pshift; a.inv_pscale = inv_pscale;
         dim3 grid((unsigned)(((d->skv + BWD_NW * 32 - 1) / (BWD_NW * 32)) * d->heads * d->batch));
-        hipLaunchKernelGGL((attn_bwd_kernel<HD, true>), grid, dim3(BWD_NW * 64), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, true, B16>), grid, dim3(BWD_NW * 64), 0, s, a);
     }
     {   // dQ: a wave owns 32 queries and streams the key tiles
         AttnBwdArgs a{};
@@ -854,7 +895,7 @@ static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
         a.heads = d->heads; a.sc = d->sq; a.sr = d->skv; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
         a.pshift = pshift; a.inv_pscale = inv_pscale;
         dim3 grid((unsigned)(((d->sq + BWD_NW * 32 - 1) / (BWD_NW * 32)) * d->heads * d->batch));
-        hipLaunchKernelGGL((attn_bwd_kernel<HD, false>), grid, dim3(BWD_NW * 64), 0, s, a);
+        hipLaunchKernelGGL((attn_bwd_kernel<HD, false, B16>), grid, dim3(BWD_NW * 64), 0, s, a);
     }
 }
 
@@ -887,6 +928,31 @@ extern "C" int mf_attention_bwd_f16x3(const mf_attn_bwd_desc* d, void* stream) {
     return MF_OK;
 }
 
+extern "C" int mf_attention_bwd_bf16(const mf_attn_bwd_desc* d, void* stream) {
+    MF_CHECK_ARG(d && d->q_hi && d->k_hi && d->v_hi && d->do_hi && d->qt_hi && d->kt_hi && d->dot_hi && d->lse && d->dd && d->dq && d->dk && d->dv,
+                 "mf_attention_bwd_bf16: null pointer");
+    MF_CHECK_ARG(d->batch >= 1 && d->heads >= 1 && d->sq >= 1 && d->skv >= 1, "mf_attention_bwd_bf16: bad sizes");
+    MF_CHECK_ARG(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->lddo % 8 == 0 && d->ldqt % 8 == 0 && d->ldkt % 8 == 0 &&
+                     d->lddot % 8 == 0 && d->ldo % 4 == 0 && d->ldqt >= d->sq && d->lddot >= d->sq && d->ldkt >= d->skv && d->sq % 4 == 0,
+                 "mf_attention_bwd_bf16: leading dims must be multiples of 8 (ldo: 4), transposed rows at least as long as the sequence, sq %% 4 == 0");
+    const void* ptrs[] = {d->q_hi, d->k_hi, d->v_hi, d->do_hi, d->qt_hi, d->kt_hi, d->dot_hi, d->dq, d->dk, d->dv, d->lse, d->dd};
+    for (const void* q : ptrs)
+        if (!mf_aligned16(q)) {
+            mf_set_error("mf_attention_bwd_bf16: pointers must be 16-byte aligned");
+            return MF_EALIGN;
+        }
+    hipStream_t s = (hipStream_t)stream;
+    switch (d->head_dim) {
+        case 8: launch_attn_bwd<8, true>(d, s); break;
+        case 40: launch_attn_bwd<40, true>(d, s); break;
+        default:
+            mf_set_error("mf_attention_bwd_bf16: unsupported head_dim %d (have 8, 40)", d->head_dim);
+            return MF_EINVAL;
+    }
+    MF_CHECK_LAUNCH("mf_attention_bwd_bf16");
+    return MF_OK;
+}
+
 extern "C" int mf_rowdot_heads(const float* a, const float* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
                                void* stream) {
     MF_CHECK_ARG(a && b && out && batch >= 1 && sq >= 1 && heads >= 1 && head_dim >= 4 && head_dim % 4 == 0 && ld % 4 == 0 && ld >= heads * head_dim,
@@ -898,7 +964,23 @@ extern "C" int mf_rowdot_heads(const float* a, const float* b, float* out, int32
     const int64_t total = (int64_t)batch * sq * heads;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(rowdot_heads_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, batch, sq, heads, head_dim, ld);
+    hipLaunchKernelGGL(rowdot_heads_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (const void*)b, out, batch, sq, heads, head_dim, ld);
     MF_CHECK_LAUNCH("mf_rowdot_heads");
+    return MF_OK;
+}
+
+extern "C" int mf_rowdot_heads_bf16(const float* a, const void* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
+                                    void* stream) {
+    MF_CHECK_ARG(a && b && out && batch >= 1 && sq >= 1 && heads >= 1 && head_dim >= 4 && head_dim % 4 == 0 && ld % 4 == 0 && ld >= heads * head_dim,
+                 "mf_rowdot_heads_bf16: bad arguments (head_dim and ld multiples of 4)");
+    if (!mf_aligned16(a) || (((uintptr_t)b) & 7) != 0) {
+        mf_set_error("mf_rowdot_heads_bf16: a must be 16-byte, b 8-byte aligned");
+        return MF_EALIGN;
+    }
+    const int64_t total = (int64_t)batch * sq * heads;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rowdot_heads_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, batch, sq, heads, head_dim, ld);
+    MF_CHECK_LAUNCH("mf_rowdot_heads_bf16");
     return MF_OK;
 }

@@ -283,6 +283,25 @@ extern "C" int mf_add(const void* a, int32_t a_dtype, const void* b, int32_t b_d
     return MF_OK;
 }
 
+// fp32 -> bf16 (nearest-even), 8 elements per thread; the scalar tail by the first threads
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, int64_t n8, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = *reinterpret_cast<const float4*>(x + i * 8);
+        const float4 b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+        *reinterpret_cast<uint4*>(out + i * 8) = uint4{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
+    }
+    const int64_t t = n8 * 8 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) out[t] = f32_to_bf16(x[t]);
+}
+
+extern "C" int mf_cast_bf16(const float* x, void* out, int64_t n, void* stream) {
+    MF_CHECK_ARG(x && out && n >= 0 && mf_aligned16(x) && mf_aligned16(out), "mf_cast_bf16: null or misaligned arguments");
+    if (n == 0) return MF_OK;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)out, n / 8, n);
+    MF_CHECK_LAUNCH("mf_cast_bf16");
+    return MF_OK;
+}
+
 extern "C" int mf_geglu(const void* h, int32_t in_dtype, void* out, int32_t out_dtype, int64_t rows, int32_t c,
                         void* stream) {
     MF_CHECK_ARG(h && out && rows >= 0 && c > 0, "mf_geglu: bad arguments");

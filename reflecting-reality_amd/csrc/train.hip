@@ -210,8 +210,12 @@ __device__ __forceinline__ f16x8_t wt_frag(const char* base, int a0, int a1) {
     return __builtin_bit_cast(f16x8_t, v);
 }
 
-template <int DT>
+// IN16 (DT == MF_BF16X1 only): x and dy are ALREADY bf16 in memory (mf_conv_wgrad with dtype MF_BF16: the pre-rounded operand
+// copies of the bf16x1 training mode) — a staged chunk of 8 columns is one 16-byte load written to LDS as it is: half the operand
+// bytes and no conversion in the staging loop.
+template <int DT, bool IN16 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p) {
+    static_assert(!IN16 || DT == MF_BF16X1, "16-bit inputs: the one-plane bf16 form");
     constexpr int NPL = DT == MF_F16X3 ? 2 : 1;              // planes per operand: (hi, lo) or the one bf16 plane
     constexpr int STAGE = 2 * NPL * WT_PLANE;                // Y planes, then A planes
     extern __shared__ __attribute__((aligned(16))) char wt_smem[];
@@ -259,6 +263,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
 #pragma unroll
         for (int k = 0; k < 4; ++k) { vy[k] = make_float4(0, 0, 0, 0); va[k] = make_float4(0, 0, 0, 0); }
         if (m < m_end) {
+            const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
+            const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
+            const bool inside = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+            const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+            if constexpr (IN16) {      // 8 bf16 = 16 bytes per chunk, carried in vy / va [0] and [2] (N, C0, Ctot multiples of 8: host check)
+                const unsigned short* yrow = reinterpret_cast<const unsigned short*>(p.dy) + (int64_t)m * p.lddy;
+                const unsigned short* r0 = reinterpret_cast<const unsigned short*>(p.a0) + pix * p.lda0;
+                const unsigned short* r1 = reinterpret_cast<const unsigned short*>(p.a1) + pix * p.lda1 - p.C0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int n = n0 + scol + 8 * k, c = c0 + scol + 8 * k;
+                    if (n < p.N) vy[2 * k] = *reinterpret_cast<const float4*>(yrow + n);
+                    if (inside && c < p.Ctot) va[2 * k] = *reinterpret_cast<const float4*>((c < p.C0 ? r0 : r1) + c);
+                }
+            } else {
             const float* yrow = p.dy + (int64_t)m * p.lddy;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -270,10 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
                     vy[k] = make_float4(t[0], t[1], t[2], t[3]);
                 }
             }
-            const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
-            const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
-            if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
-                const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+            if (inside) {
                 const float* r0 = p.a0 + pix * p.lda0;
                 const float* r1 = p.a1 + pix * p.lda1 - p.C0;
 #pragma unroll
@@ -281,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
                     const int c = c0 + scol + 4 * k;
                     if (c < p.Ctot) va[k] = *reinterpret_cast<const float4*>((c < p.C0 ? r0 : r1) + c);   // channel counts are multiples of 4
                 }
+            }
             }
         }
     };
@@ -294,6 +311,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
         }
     };
     auto put2 = [&](char* dst, const float4 u, const float4 v) {          // eight consecutive columns = one 16-byte chunk per plane
+        if constexpr (IN16) {
+            *reinterpret_cast<float4*>(dst) = u;                          // already 8 bf16
+            return;
+        }
         uint2 h0, l0, h1, l1;
         cvt(u, h0, l0); cvt(v, h1, l1);
         *reinterpret_cast<uint4*>(dst) = uint4{h0.x, h0.y, h1.x, h1.y};
@@ -430,8 +451,9 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
 // the reads are conflict-free without a swizzle.  80 KB of LDS (two stages) = two blocks per CU.
 constexpr int W160 = 160, W160_PITCH = 2 * W160, W160_PLANE = WG_BP * W160_PITCH;     // 10 KB per plane
 
-template <int DT, int NST>
+template <int DT, int NST, bool IN16 = false>
 __global__ __launch_bounds__(320, 2) void conv_wgrad_tr160_kernel(const WgradArgs p) {
+    static_assert(!IN16 || DT == MF_BF16X1, "16-bit inputs: the one-plane bf16 form");
     constexpr int NPL = DT == MF_F16X3 ? 2 : 1;
     constexpr int STAGE = 2 * NPL * W160_PLANE;
     extern __shared__ __attribute__((aligned(16))) char wt_smem[];
@@ -474,6 +496,19 @@ __global__ __launch_bounds__(320, 2) void conv_wgrad_tr160_kernel(const WgradArg
             const int m = m0 + srow + 16 * k;
             vy[k][0] = vy[k][1] = va[k][0] = va[k][1] = make_float4(0, 0, 0, 0);
             if (m < m_end) {
+                const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
+                const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
+                const bool inside = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+                const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+                if constexpr (IN16) {      // one 16-byte chunk of 8 bf16 per operand and row, carried in vy / va [k][0]
+                    const int n = n0 + 8 * sch, c = c0 + 8 * sch;
+                    if (n < p.N) vy[k][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.dy) + (int64_t)m * p.lddy + n);
+                    if (inside && c < p.Ctot) {
+                        const unsigned short* r0 = reinterpret_cast<const unsigned short*>(p.a0) + pix * p.lda0;
+                        const unsigned short* r1 = reinterpret_cast<const unsigned short*>(p.a1) + pix * p.lda1 - p.C0;
+                        va[k][0] = *reinterpret_cast<const float4*>((c < p.C0 ? r0 : r1) + c);
+                    }
+                } else {
                 const float* yrow = p.dy + (int64_t)m * p.lddy;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -485,10 +520,7 @@ __global__ __launch_bounds__(320, 2) void conv_wgrad_tr160_kernel(const WgradArg
                         vy[k][j] = make_float4(t[0], t[1], t[2], t[3]);
                     }
                 }
-                const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
-                const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
-                if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) {
-                    const int64_t pix = (int64_t)b * p.Hin * p.Win + (int64_t)(iy >> p.ups) * p.Win + (ix >> p.ups);
+                if (inside) {
                     const float* r0 = p.a0 + pix * p.lda0;
                     const float* r1 = p.a1 + pix * p.lda1 - p.C0;
 #pragma unroll
@@ -496,6 +528,7 @@ __global__ __launch_bounds__(320, 2) void conv_wgrad_tr160_kernel(const WgradArg
                         const int c = c0 + 8 * sch + 4 * j;
                         if (c < p.Ctot) va[k][j] = *reinterpret_cast<const float4*>((c < p.C0 ? r0 : r1) + c);
                     }
+                }
                 }
             }
         }
@@ -510,6 +543,10 @@ __global__ __launch_bounds__(320, 2) void conv_wgrad_tr160_kernel(const WgradArg
         }
     };
     auto put2 = [&](char* dst, const float4 u, const float4 v) {
+        if constexpr (IN16) {
+            *reinterpret_cast<float4*>(dst) = u;
+            return;
+        }
         uint2 h0, l0, h1, l1;
         cvt(u, h0, l0); cvt(v, h1, l1);
         *reinterpret_cast<uint4*>(dst) = uint4{h0.x, h0.y, h1.x, h1.y};
@@ -605,11 +642,30 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* ws, int nsl
 // ------------------------------------------------------------------------------------------------------------
 // strided batched transpose: y[z][c][r] = x[z][r][c]
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_kernel(const float* x, float* y, int rows, int cols, int64_t ldx, int64_t ldy,
+// OUT16: y is bf16 (nearest-even): the transposed data-gradient weight of the bf16x1 mode is rounded while it is laid out
+template <bool OUT16>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* x, void* yv, int rows, int cols, int64_t ldx, int64_t ldy,
                                                         int64_t zsx, int64_t zsy) {
     __shared__ float t[32][33];
     const float* xs = x + (int64_t)blockIdx.z * zsx;
-    float* ys = y + (int64_t)blockIdx.z * zsy;
+    if constexpr (OUT16) {
+        unsigned short* ys = reinterpret_cast<unsigned short*>(yv) + (int64_t)blockIdx.z * zsy;
+        const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = r0 + ty + 8 * i, cc = c0 + tx;
+            t[ty + 8 * i][tx] = (rr < rows && cc < cols) ? xs[(int64_t)rr * ldx + cc] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = c0 + ty + 8 * i, rr = r0 + tx;
+            if (cc < cols && rr < rows) ys[(int64_t)cc * ldy + rr] = f32_to_bf16(t[tx][ty + 8 * i]);
+        }
+        return;
+    }
+    float* ys = reinterpret_cast<float*>(yv) + (int64_t)blockIdx.z * zsy;
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -1193,7 +1249,11 @@ extern "C" int64_t mf_conv_wgrad_ws_floats(const mf_wgrad_desc* d) {
 
 extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     MF_CHECK_ARG(d != nullptr, "mf_conv_wgrad: null descriptor");
-    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X1, "mf_conv_wgrad: dtype must be MF_F32, MF_F16X3 or MF_BF16X1");
+    MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X1 || d->dtype == MF_BF16,
+                 "mf_conv_wgrad: dtype must be MF_F32, MF_F16X3, MF_BF16X1 or MF_BF16");
+    const bool in16 = d->dtype == MF_BF16;        // x and dy are bf16 tensors (the pre-rounded operand copies of the bf16x1 mode)
+    MF_CHECK_ARG(!in16 || (d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->n % 8 == 0 && d->lda0 % 8 == 0 && d->lda1 % 8 == 0 && d->lddy % 8 == 0),
+                 "mf_conv_wgrad: MF_BF16 operands need channel counts and strides that are multiples of 8");
     MF_CHECK_ARG(d->a0 && d->dy && d->dw, "mf_conv_wgrad: null a0/dy/dw");
     MF_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && (d->a1 != nullptr) == (d->c1 > 0) && d->c0 % 4 == 0 && d->c1 % 4 == 0 &&
                      d->lda0 % 4 == 0 && d->lda1 % 4 == 0,
@@ -1275,7 +1335,7 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     const dim3 grid1((unsigned)(tiles * a.splitm));
     static const bool old_form = getenv("MFHIP_WGRAD_V1") != nullptr;        // developer A/B: the first version of the 16-bit forms
     if (d->dtype == MF_F32) hipLaunchKernelGGL(conv_wgrad_kernel<MF_F32>, grid, dim3(256), 0, s, a);
-    else if (old_form) {
+    else if (old_form && !in16) {
         if (d->dtype == MF_BF16X1) hipLaunchKernelGGL(conv_wgrad_kernel<MF_BF16X1>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_wgrad_kernel<MF_F16X3>, grid, dim3(256), 0, s, a);
     } else if (t160) {
@@ -1286,8 +1346,11 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
         }();
         (void)attr160;
         // (one LDS stage + a second barrier per step measured the same as two stages: 383 vs 371 us on 8 x 64 x 64 320 -> 320 3x3)
-        if (d->dtype == MF_BF16X1) hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_BF16X1, 2>), grid1, dim3(320), 2 * 2 * W160_PLANE, s, a);
+        if (in16) hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_BF16X1, 2, true>), grid1, dim3(320), 2 * 2 * W160_PLANE, s, a);
+        else if (d->dtype == MF_BF16X1) hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_BF16X1, 2>), grid1, dim3(320), 2 * 2 * W160_PLANE, s, a);
         else hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_F16X3, 2>), grid1, dim3(320), 2 * 4 * W160_PLANE, s, a);
+    } else if (in16) {
+        hipLaunchKernelGGL((conv_wgrad_tr_kernel<MF_BF16X1, true>), grid1, dim3(256), 2 * 2 * WT_PLANE, s, a);
     } else if (d->dtype == MF_BF16X1) {
         hipLaunchKernelGGL(conv_wgrad_tr_kernel<MF_BF16X1>, grid1, dim3(256), 2 * 2 * WT_PLANE, s, a);
     } else {
@@ -1327,8 +1390,18 @@ extern "C" int mf_transpose(const float* x, float* y, int32_t nz, int32_t rows, 
     MF_CHECK_ARG(x && y && nz >= 1 && rows >= 1 && cols >= 1 && nz < 65536, "mf_transpose: bad arguments");
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, nz);
     MF_CHECK_ARG(grid.y < 65536, "mf_transpose: too many rows");
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ldx, ldy, zsx, zsy);
+    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (void*)y, rows, cols, ldx, ldy, zsx, zsy);
     MF_CHECK_LAUNCH("mf_transpose");
+    return MF_OK;
+}
+
+extern "C" int mf_transpose_bf16(const float* x, void* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,
+                                 int64_t zsy, void* stream) {
+    MF_CHECK_ARG(x && y && nz >= 1 && rows >= 1 && cols >= 1 && nz < 65536, "mf_transpose_bf16: bad arguments");
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, nz);
+    MF_CHECK_ARG(grid.y < 65536, "mf_transpose_bf16: too many rows");
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ldx, ldy, zsx, zsy);
+    MF_CHECK_LAUNCH("mf_transpose_bf16");
     return MF_OK;
 }
 

@@ -124,8 +124,9 @@ EXPORTS = [
     "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape", "mf_gemm_tile_table_version",
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
     "mf_attention_f16x3", "mf_attention_f16x3_lse", "mf_sizeof_attn_bwd_desc", "mf_attention_bwd_f16x3", "mf_rowdot_heads",
+    "mf_attention_bwd_bf16", "mf_attention_bf16_lse", "mf_rowdot_heads_bf16",
     "mf_split_halves", "mf_split_overflow", "mf_quantize_rows_fp8",
-    "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
+    "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_cast_bf16", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
     # image front-end (csrc/frontend.hip)
     "mf_minmax_ws_floats", "mf_minmax", "mf_image_normalize", "mf_mask_keep", "mf_concat_channels", "mf_postprocess",
@@ -133,7 +134,7 @@ EXPORTS = [
     "mf_bicubic_aa_resize_crop",
     "mf_hwc_to_chw_affine",
     # training (csrc/train.hip)
-    "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_split_pack", "mf_transpose", "mf_colsum_ws_floats", "mf_colsum",
+    "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_split_pack", "mf_transpose", "mf_transpose_bf16", "mf_colsum_ws_floats", "mf_colsum",
     "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_groupnorm_bwd_ws_floats", "mf_groupnorm_bwd_streams", "mf_layernorm_bwd", "mf_layernorm_bwd_parts", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
     "mf_zero_insert2x", "mf_sumpool2x2", "mf_mse_grad", "mf_sumsq_ws_doubles", "mf_sumsq", "mf_clip_coef", "mf_adamw",
 ]
@@ -611,13 +612,23 @@ def softmax_rows(scores: torch.Tensor, cols: int, out_dtype: torch.dtype) -> tor
 
 
 def attention_bf16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, ldq: int, ldk: int,
-                   ldvt: int, ldo: int, batch: int, heads: int, sq: int, skv: int, head_dim: int, scale: float
-                   ) -> torch.Tensor:
-    _req_cuda(q, k, vt, out)
-    _check(load().mf_attention_bf16(C.c_void_p(q.data_ptr()), C.c_int64(ldq), C.c_void_p(k.data_ptr()), C.c_int64(ldk),
-                                    C.c_void_p(vt.data_ptr()), C.c_int64(ldvt), C.c_void_p(out.data_ptr()),
-                                    C.c_int64(ldo), batch, heads, sq, skv, head_dim, C.c_float(scale), _stream()),
-           "mf_attention_bf16")
+                   ldvt: int, ldo: int, batch: int, heads: int, sq: int, skv: int, head_dim: int, scale: float,
+                   lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`lse` (fp32 [batch, heads, sq], written): the row statistic of the flash backward (mf_attention_bf16_lse)."""
+    _req_cuda(q, k, vt, out, lse)
+    if lse is None:
+        _check(load().mf_attention_bf16(C.c_void_p(q.data_ptr()), C.c_int64(ldq), C.c_void_p(k.data_ptr()), C.c_int64(ldk),
+                                        C.c_void_p(vt.data_ptr()), C.c_int64(ldvt), C.c_void_p(out.data_ptr()),
+                                        C.c_int64(ldo), batch, heads, sq, skv, head_dim, C.c_float(scale), _stream()),
+               "mf_attention_bf16")
+        return out
+    _f32(lse)
+    if lse.numel() != batch * heads * sq or not lse.is_contiguous():
+        raise MfhipError("attention_bf16: lse is a contiguous [batch, heads, sq] tensor")
+    _check(load().mf_attention_bf16_lse(C.c_void_p(q.data_ptr()), C.c_int64(ldq), C.c_void_p(k.data_ptr()), C.c_int64(ldk),
+                                        C.c_void_p(vt.data_ptr()), C.c_int64(ldvt), C.c_void_p(out.data_ptr()), C.c_int64(ldo),
+                                        C.c_void_p(lse.data_ptr()), batch, heads, sq, skv, head_dim, C.c_float(scale), _stream()),
+           "mf_attention_bf16_lse")
     return out
 
 
@@ -700,17 +711,26 @@ def attention_f16x3(q, k, vt, out: torch.Tensor, *, ldq: int, ldk: int, ldvt: in
 
 
 def rowdot_heads(a: torch.Tensor, b: torch.Tensor, heads: int) -> torch.Tensor:
-    """[B, S, C] x [B, S, C] -> [B, heads, S]: per-head dot products of the rows (the D term of the attention backward)."""
-    _f32(a, b)
+    """[B, S, C] x [B, S, C] -> [B, heads, S]: per-head dot products of the rows (the D term of the attention backward).
+    `b` may be bf16 (the bf16 forward's output)."""
+    _f32(a)
     bsz, s, c = a.shape
     out = torch.empty(bsz, heads, s, dtype=torch.float32, device=a.device)
+    if b.dtype == torch.bfloat16:
+        _req_cuda(b)
+        if b.shape != a.shape or not (a.is_contiguous() and b.is_contiguous()):
+            raise MfhipError("rowdot_heads: contiguous operands of one shape")
+        _check(load().mf_rowdot_heads_bf16(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), bsz, s, heads,
+                                           c // heads, C.c_int64(c), _stream()), "mf_rowdot_heads_bf16")
+        return out
+    _f32(b)
     _check(load().mf_rowdot_heads(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), bsz, s, heads, c // heads,
                                   C.c_int64(c), _stream()), "mf_rowdot_heads")
     return out
 
 
 def attention_bwd_f16x3(q, k, v, do, qt, kt, dot, lse: torch.Tensor, dd: torch.Tensor, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, *,
-                        heads: int, scale: float) -> None:
+                        heads: int, scale: float, _entry: str = "mf_attention_bwd_f16x3") -> None:
     """Flash attention backward (mf_attention_bwd_f16x3).  q / k / v / do: (hi, lo) planes [B, S, C]; qt / kt / dot: (hi, lo) planes of
     the transposed tensors [B, C, ld]; lse / dd fp32 [B, heads, Sq]; dq / dk / dv fp32 [B, S, C] (written)."""
     b, sq, c = q[0].shape
@@ -726,7 +746,18 @@ def attention_bwd_f16x3(q, k, v, do, qt, kt, dot, lse: torch.Tensor, dd: torch.T
     d.lse, d.dd = lse.data_ptr(), dd.data_ptr()
     d.dq, d.dk, d.dv, d.ldo = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), c
     d.batch, d.heads, d.sq, d.skv, d.head_dim, d.scale = b, heads, sq, skv, c // heads, scale
-    _check(load().mf_attention_bwd_f16x3(C.byref(d), _stream()), "mf_attention_bwd_f16x3")
+    _check(getattr(load(), _entry)(C.byref(d), _stream()), _entry)
+
+
+def attention_bwd_bf16(q, k, v, do, qt, kt, dot, lse: torch.Tensor, dd: torch.Tensor, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, *,
+                       heads: int, scale: float) -> None:
+    """mf_attention_bwd_bf16: the flash backward on single bf16 planes.  q / k / v / do bf16 [B, S, C]; qt / kt / dot bf16 [B, C, ld]."""
+    for t in (q, k, v, do, qt, kt, dot):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise MfhipError("attention_bwd_bf16: contiguous bf16 operands")
+    _f32(lse, dd, dq, dk, dv)
+    attention_bwd_f16x3((q, q), (k, k), (v, v), (do, do), (qt, qt), (kt, kt), (dot, dot), lse, dd, dq, dk, dv, heads=heads, scale=scale,
+                        _entry="mf_attention_bwd_bf16")
 
 
 def pack_nhwc(src0: torch.Tensor, src1: Optional[torch.Tensor], c_pad: int, out_dtype: torch.dtype) -> torch.Tensor:
@@ -764,6 +795,19 @@ def add(a: torch.Tensor, b: torch.Tensor, out_dtype: torch.dtype, out: Optional[
         raise MfhipError("mf_add: `out` must be a contiguous tensor of the operands' shape and the output dtype")
     _check(load().mf_add(C.c_void_p(a.data_ptr()), dt_code(a.dtype), C.c_void_p(b.data_ptr()), dt_code(b.dtype),
                          C.c_void_p(out.data_ptr()), dt_code(out_dtype), C.c_int64(a.numel()), _stream()), "mf_add")
+    return out
+
+
+def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 -> bf16 (nearest-even) copy of a contiguous tensor (mf_cast_bf16)."""
+    _req_cuda(x, out)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise MfhipError("cast_bf16: contiguous fp32 input")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    elif out.dtype != torch.bfloat16 or out.numel() != x.numel() or not out.is_contiguous():
+        raise MfhipError("cast_bf16: `out` must be a contiguous bf16 tensor of the same size")
+    _check(load().mf_cast_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int64(x.numel()), _stream()), "mf_cast_bf16")
     return out
 
 
@@ -894,10 +938,15 @@ def _f32(*ts):
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, code: int, c0: int, batch: int, h_in: int, w_in: int,
                h_out: int, w_out: int, kh: int = 1, kw: int = 1, stride: int = 1, pad_t: int = 0, pad_l: int = 0,
                upsample: bool = False, x1: Optional[torch.Tensor] = None, c1: int = 0, n: int, accumulate: bool = True) -> None:
-    """dw[n][kh*kw*(c0+c1)] (+)= sum_m dy[m][n] * im2col(x | x1)[m][:] (mf_conv_wgrad)."""
-    _f32(x, x1, dy, dw)
+    """dw[n][kh*kw*(c0+c1)] (+)= sum_m dy[m][n] * im2col(x | x1)[m][:] (mf_conv_wgrad).  code MF_BF16: x / x1 / dy are bf16 tensors."""
+    if code == MF_BF16:
+        _req_cuda(x, x1, dy, dw)
+        if any(t is not None and t.dtype != torch.bfloat16 for t in (x, x1, dy)) or dw.dtype != torch.float32:
+            raise MfhipError("conv_wgrad(MF_BF16): bf16 x / dy, fp32 dw")
+    else:
+        _f32(x, x1, dy, dw)
     d = WgradDesc()
-    d.dtype = code if code in (MF_F16X3, MF_BF16X1) else MF_F32
+    d.dtype = code if code in (MF_F16X3, MF_BF16X1, MF_BF16) else MF_F32
     d.a0, d.a1, d.c0, d.c1, d.lda0, d.lda1 = _ptr(x), _ptr(x1), c0, c1, c0, c1
     d.batch, d.h_in, d.w_in, d.h_out, d.w_out = batch, h_in, w_in, h_out, w_out
     d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.upsample = kh, kw, stride, pad_t, pad_l, int(upsample)
@@ -914,10 +963,16 @@ WGRAD_WS_FLOATS = 64 * 1024 * 1024      # 256 MiB of split-M slabs
 
 def transpose(x: torch.Tensor, rows: int, cols: int, *, nz: int = 1, ldx: Optional[int] = None, ldy: Optional[int] = None,
               zsx: int = 0, zsy: int = 0, out: Optional[torch.Tensor] = None, y_offset: int = 0) -> torch.Tensor:
-    """out[z][c][r] = x[z][r][c] (element strides; see mf_transpose)."""
-    _f32(x, out)
+    """out[z][c][r] = x[z][r][c] (element strides; see mf_transpose).  A bf16 `out` takes the rounding variant (mf_transpose_bf16)."""
     ldx = cols if ldx is None else ldx
     ldy = rows if ldy is None else ldy
+    if out is not None and out.dtype == torch.bfloat16:
+        _f32(x)
+        _req_cuda(out)
+        _check(load().mf_transpose_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr() + 2 * y_offset), nz, rows, cols, C.c_int64(ldx),
+                                        C.c_int64(ldy), C.c_int64(zsx), C.c_int64(zsy), _stream()), "mf_transpose_bf16")
+        return out
+    _f32(x, out)
     if out is None:
         out = torch.empty(nz, cols, ldy, dtype=torch.float32, device=x.device)
     _check(load().mf_transpose(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr() + 4 * y_offset), nz, rows, cols, C.c_int64(ldx),

@@ -168,7 +168,7 @@ class HipModel:
             raise RuntimeError("no parameters loaded")
         cap = 0
         for shp in self.param_shapes().values():
-            cap += (int(torch.Size(shp).numel()) // shp[1] * ((shp[1] + 7) // 8 * 8) if len(shp) == 4 else int(torch.Size(shp).numel())) + 16
+            cap += (int(torch.Size(shp).numel()) // shp[1] * ((shp[1] + 7) // 8 * 8) if len(shp) == 4 else int(torch.Size(shp).numel())) + 24
         self.flat_w = torch.zeros(cap, dtype=F32, device=self.device)
         self.flat_g = torch.zeros(cap, dtype=F32, device=self.device) if self._requires_grad else None
         self._arena_used = 0
@@ -181,7 +181,8 @@ class HipModel:
         return self
 
     def _alloc(self, name: str, t: torch.Tensor, meta: tuple) -> Param:
-        """Bump-allocate t (kernel layout, fp32) in the arena; 16-byte aligned."""
+        """Bump-allocate t (kernel layout, fp32) in the arena; 32-byte aligned, so that the same offsets are 16-byte aligned in the
+        bf16 twin arena (weights_bf16)."""
         n = t.numel()
         a = self._arena_used
         if a + n > self.flat_w.numel():
@@ -189,13 +190,29 @@ class HipModel:
         w = self.flat_w[a:a + n].view(t.shape)
         w.copy_(t.to(self.device, F32))
         g = self.flat_g[a:a + n].view(t.shape) if self.flat_g is not None else None
-        self._arena_used = a + (n + 3) // 4 * 4
+        self._arena_used = a + (n + 7) // 8 * 8
         p = Param(name, w, g)
         self._pmap[name] = (a, tuple(t.shape), meta)
         return p
 
     def num_arena_floats(self) -> int:
         return self._arena_used
+
+    def weights_bf16(self) -> torch.Tensor:
+        """The bf16 twin of the weight arena (same offsets), refreshed by ONE mf_cast_bf16 launch per weight generation — per
+        optimizer step for a network that trains, once for a frozen one: the forward GEMM operands of the bf16x1 mode on
+        pre-rounded copies (ops.ConvWeight.operand_bf16) are views of it."""
+        n = self._arena_used
+        tok = ops.CAPTURE_TOKEN            # capturing a training graph: the refresh must be IN the graph (training.GraphedTrainStep)
+        recapture = tok is not None and self._requires_grad and getattr(self, "_w16_tok", None) is not tok
+        w16 = getattr(self, "flat_w16", None)
+        if w16 is None or w16.numel() != self.flat_w.numel() or getattr(self, "_w16_src", None) != self.flat_w.data_ptr():
+            w16 = self.flat_w16 = torch.empty(self.flat_w.numel(), dtype=torch.bfloat16, device=self.device)
+            self._w16_gen, self._w16_src = None, self.flat_w.data_ptr()
+        if self._w16_gen != self._weights_gen or recapture:
+            hip.cast_bf16(self.flat_w[:n], out=w16[:n])
+            self._w16_gen, self._w16_tok = self._weights_gen, tok
+        return w16
 
     def _export(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
         out = {}
@@ -554,6 +571,14 @@ class _UNetCore(HipModel):
         a, b = self.temb_slices[p]
         return temb_all[:, a:b]
 
+    def _operand_dtype(self) -> torch.dtype:
+        """Storage dtype of a norm / activation output whose ONLY consumers are conv / linear operands (resnet norms, the transformer's
+        GroupNorm, LayerNorms and GEGLU).  bf16x1 training on pre-rounded operands (ops.ConvWeight.fast16): the producer writes bf16 — the
+        very rounding the GEMM would apply, done once, with half the bytes written, read and kept for the backward pass."""
+        if self.training and ops.BF16X1_FAST and self.prec.code == hip.MF_BF16X1:
+            return torch.bfloat16
+        return self.prec.act
+
     def _resnet(self, p: str, x: torch.Tensor, temb_all, x1: Optional[torch.Tensor] = None,
                 inj: Optional[torch.Tensor] = None, eps: Optional[float] = None) -> torch.Tensor:
         """ResnetBlock2D (resnet.py:329-405) on NHWC x (or the never-materialised cat([x, x1], C)), with the
@@ -567,9 +592,9 @@ class _UNetCore(HipModel):
             sc, join = self._on_aux(lambda: ops.conv2d(x, P[p + "conv_shortcut"], padding=0, x1=x1))
         else:
             sc = x
-        h = ops.groupnorm(x, P[p + "norm1"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act, x1=x1)
+        h = ops.groupnorm(x, P[p + "norm1"], groups=g, eps=eps, silu=True, out_dtype=self._operand_dtype(), x1=x1)
         h = ops.conv2d(h, P[p + "conv1"], temb=self._temb(temb_all, p))
-        h = ops.groupnorm(h, P[p + "norm2"], groups=g, eps=eps, silu=True, out_dtype=self.prec.act)
+        h = ops.groupnorm(h, P[p + "norm2"], groups=g, eps=eps, silu=True, out_dtype=self._operand_dtype())
         if join is not None:
             join()
         return ops.conv2d(h, P[p + "conv2"], res0=sc, res1=inj)
@@ -693,7 +718,7 @@ class _UNetCore(HipModel):
         P = self.P
         bsz, hh, ww, c = x.shape
         g = self.config["norm_num_groups"]
-        h = ops.groupnorm(x, P[p + "norm"], groups=g, eps=1e-6, silu=False, out_dtype=self.prec.act)
+        h = ops.groupnorm(x, P[p + "norm"], groups=g, eps=1e-6, silu=False, out_dtype=self._operand_dtype())
         if P[p + "proj_in"].fp8:           # use_linear_projection (SDXL): a Linear over tokens, on the fp8 path
             h = ops.linear(h.view(bsz, hh * ww, c), P[p + "proj_in"])
         else:
@@ -721,13 +746,13 @@ class _UNetCore(HipModel):
                 n = ops.layernorm(h, P[b + "norm3"], 1e-5, self.prec.act)
                 h = ops.linear(ops.linear_geglu(n, P[b + "ff.net.0.proj"]), P[b + "ff.net.2"], res0=h)
                 continue
-            n = ops.layernorm(h, P[b + "norm1"], 1e-5, self.prec.act, fp8=P[b + "attn1.to_out.0"].fp8)
+            n = ops.layernorm(h, P[b + "norm1"], 1e-5, self._operand_dtype(), fp8=P[b + "attn1.to_out.0"].fp8)
             h = self._attention(b + "attn1.", n, None, heads, h)
-            n = ops.layernorm(h, P[b + "norm2"], 1e-5, self.prec.act, fp8=P[b + "attn2.to_q"].fp8)
+            n = ops.layernorm(h, P[b + "norm2"], 1e-5, self._operand_dtype(), fp8=P[b + "attn2.to_q"].fp8)
             h = self._attention(b + "attn2.", n, ehs, heads, h)
-            n = ops.layernorm(h, P[b + "norm3"], 1e-5, self.prec.act, fp8=P[b + "ff.net.2"].fp8)
+            n = ops.layernorm(h, P[b + "norm3"], 1e-5, self._operand_dtype(), fp8=P[b + "ff.net.2"].fp8)
             if self.training:      # GEGLU as its own (differentiated) launch on the plain, un-interleaved weight
-                gg = ops.geglu(ops.linear(n, P[b + "ff.net.0.proj"]), self.prec.act)
+                gg = ops.geglu(ops.linear(n, P[b + "ff.net.0.proj"]), self._operand_dtype())
             else:
                 gg = ops.linear_geglu(n, P[b + "ff.net.0.proj"])
             h = ops.linear(gg, P[b + "ff.net.2"], res0=h)

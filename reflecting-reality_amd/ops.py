@@ -153,6 +153,29 @@ class ConvWeight:
             self._wp_gen, self._wp_tok = gen, CAPTURE_TOKEN
         return self._wp, 1, self._wp_ld
 
+    def fast16(self, *channels: int) -> bool:
+        """MF_BF16X1 (fp32 storage, every GEMM operand rounded to bf16, fp32 accumulate) on PRE-ROUNDED COPIES: the activation is
+        cast once (mf_cast_bf16), the weight once per generation, and the product runs on the LDS-DMA, warp-specialised bf16
+        kernels of the inference path instead of the register-staged forms that round in the main loop.  Same arithmetic per
+        product (nearest-even bf16 operands, fp32 accumulate and output).  Needs 16-byte rows: channel counts that are multiples
+        of 8 (everything but the 4- / 10-channel stems)."""
+        return (BF16X1_FAST and self.prec.code == hip.MF_BF16X1 and not self.fp8 and self.w.dtype == torch.float32 and self.ldw % 8 == 0
+                and all(c % 8 == 0 for c in channels))
+
+    def operand_bf16(self) -> torch.Tensor:
+        """The bf16 copy of the fp32 weight ([N][ldw]), rebuilt when the weights changed (per step for a network that trains)."""
+        src = self._gen_src
+        if self.p_w is not None and getattr(src, "flat_w", None) is not None and hasattr(src, "weights_bf16"):
+            # a weight of a model's training arena: a view of the arena's bf16 twin (one cast launch per generation for ALL weights)
+            off = (self.w.data_ptr() - src.flat_w.data_ptr()) // 4
+            return src.weights_bf16()[off: off + self.n * self.ldw].view(self.n, self.ldw)
+        gen = self.generation()
+        recapture = CAPTURE_TOKEN is not None and self.trains() and getattr(self, "_wb_tok", None) is not CAPTURE_TOKEN
+        if getattr(self, "_wb_gen", None) != gen or getattr(self, "_wb", None) is None or recapture:
+            self._wb = hip.cast_bf16(self.w.reshape(self.n, self.ldw), out=getattr(self, "_wb", None))
+            self._wb_gen, self._wb_tok = gen, CAPTURE_TOKEN
+        return self._wb
+
     def trains(self) -> bool:
         """The weight lives in an arena the optimizer updates (its derived layouts go stale every step)."""
         return self.p_w is not None and self.p_w.grad is not None
@@ -163,6 +186,7 @@ class ConvWeight:
 
 
 PRESPLIT_TRAINING = os.environ.get("MFHIP_NO_PRESPLIT", "0") != "1"      # developer A/B: split arena weights in registers
+BF16X1_FAST = os.environ.get("MFHIP_BF16X1_SLOW", "0") != "1"             # developer A/B: bf16x1 on pre-rounded operand copies
 # Set (to a fresh object) by training.GraphedTrainStep while it captures: every per-step re-layout of a weight that trains
 # (operand() here, autograd._dgrad_weight) is rebuilt once under the capture regardless of its generation stamp, so that the
 # rebuild is part of the graph.
@@ -219,7 +243,14 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
     wo = (wu + pl + pr - cw.kw) // stride + 1
     out = torch.empty(b, ho, wo, cw.n, dtype=out_dtype or cw.prec.act, device=x.device)
     wt, wsp, wld = cw.operand()
-    hip.gemm_conv(x, wt, out, dtype=cw.prec.code, w_split=wsp, ldw=wld, c0=c0, lda0=c0, a1=x1, c1=c1, lda1=c1,
+    code, xa, x1a = cw.prec.code, x, x1
+    fast = cw.fast16(c0, c1)
+    if fast:
+        b16 = lambda t: t if (t is None or t.dtype == torch.bfloat16) else hip.cast_bf16(t)
+        code, wt, wsp, wld, xa, x1a = hip.MF_BF16, cw.operand_bf16(), 0, cw.ldw, b16(x), b16(x1)
+    elif x.dtype == torch.bfloat16 and cw.prec.code == hip.MF_BF16X1:
+        raise hip.MfhipError("conv2d: a bf16 activation in the bf16x1 mode needs channel counts that are multiples of 8")
+    hip.gemm_conv(xa, wt, out, dtype=code, w_split=wsp, ldw=wld, c0=c0, lda0=c0, a1=x1a, c1=c1, lda1=c1,
                   batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, kh=cw.kh, kw=cw.kw, stride=stride,
                   pad_t=pt, pad_l=pl, upsample=upsample, n=cw.n, bias=cw.bias,
                   temb=temb, ld_temb=(temb.stride(0) if temb is not None else 0),
@@ -227,7 +258,7 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
                   tile=tile, sk_fused=sk_fused)
     if TAPE is not None:
         autograd.record_conv(TAPE, x, x1, cw, out, batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, pad_t=pt, pad_l=pl,
-                             upsample=upsample, temb=temb, res0=res0, res1=res1, alpha=alpha, act=act)
+                             upsample=upsample, temb=temb, res0=res0, res1=res1, alpha=alpha, act=act, x16=(xa, x1a) if fast else None)
     return out
 
 
@@ -246,14 +277,20 @@ def linear(x: torch.Tensor, lw: ConvWeight, *, res0: Optional[torch.Tensor] = No
     if out is None:
         out = torch.empty(*x.shape[:-1], lw.n, dtype=out_dtype or lw.prec.act, device=x.device)
     wt, wsp, wld = lw.operand()
-    hip.gemm_conv(x, wt, out, dtype=lw.prec.code, w_split=wsp, ldw=wld, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
+    code, xa = lw.prec.code, x
+    fast = x.is_contiguous() and lw.ln_colsum is None and lw.fast16(k)
+    if fast:
+        code, wt, wsp, wld, xa = hip.MF_BF16, lw.operand_bf16(), 0, lw.ldw, (x if x.dtype == torch.bfloat16 else hip.cast_bf16(x))
+    elif x.dtype == torch.bfloat16 and lw.prec.code == hip.MF_BF16X1:
+        raise hip.MfhipError("linear: a bf16 activation in the bf16x1 mode needs K % 8 == 0 and a contiguous input")
+    hip.gemm_conv(xa, wt, out, dtype=code, w_split=wsp, ldw=wld, c0=k, lda0=k, batch=m, h_in=1, w_in=1,
                   h_out=1, w_out=1, n=lw.n, bias=lw.bias, res0=res0, res1=res1, res1_rows=_shared_rows(res1, m, lw.n), alpha=alpha,
                   act=act, splitk=splitk, tile=tile, ln_colsum=lw.ln_colsum, ln_eps=lw.ln_eps, sk_fused=sk_fused)
     if TAPE is not None:
         if lw.ln_colsum is not None:
             raise hip.MfhipError("training: folded LayerNorms are inference only")
         autograd.record_conv(TAPE, x, None, lw, out, batch=m, h_in=1, w_in=1, h_out=1, w_out=1, stride=1, pad_t=0, pad_l=0,
-                             upsample=False, temb=None, res0=res0, res1=res1, alpha=alpha, act=act)
+                             upsample=False, temb=None, res0=res0, res1=res1, alpha=alpha, act=act, x16=(xa, None) if fast else None)
     return out
 
 
@@ -404,10 +441,10 @@ def geglu(h: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
     return out
 
 
-def transpose_tokens(v: torch.Tensor, ld: int) -> torch.Tensor:
-    """[B, S, C] -> V^T [B, C, ld] (columns past S zero): the training path's stand-in for linear_t."""
+def transpose_tokens(v: torch.Tensor, ld: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """[B, S, C] -> V^T [B, C, ld] (columns past S zero): the training path's stand-in for linear_t.  dtype bf16 rounds."""
     b, s, c = v.shape
-    vt = torch.zeros(b, c, ld, dtype=torch.float32, device=v.device) if ld != s else torch.empty(b, c, ld, dtype=torch.float32, device=v.device)
+    vt = torch.zeros(b, c, ld, dtype=dtype, device=v.device) if ld != s else torch.empty(b, c, ld, dtype=dtype, device=v.device)
     hip.transpose(v, s, c, nz=b, ldx=c, ldy=ld, zsx=s * c, zsy=c * ld, out=vt)
     return vt
 
@@ -427,6 +464,19 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
                       splitk=1)
         return hip.softmax_rows(scores, skv, torch.float32)
 
+    flash = d in FLASH_BWD_HEAD_DIMS and sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS and tape is not None and FLASH_BWD
+    if flash and prec.code == hip.MF_BF16X1 and BF16X1_FAST:
+        # the bf16x1 mode on pre-rounded operands: q / k / v rounded to bf16 once (what the reference's autocast hands to
+        # F.scaled_dot_product_attention, attention_processor.py:1266), the inference flash kernel with the row statistics,
+        # and the single-plane flash backward (autograd.record_attention_flash_bf16)
+        q16, k16, v16 = hip.cast_bf16(q.contiguous()), hip.cast_bf16(k.contiguous()), hip.cast_bf16(v.contiguous())
+        vt16 = transpose_tokens(v, ld, torch.bfloat16)
+        o16 = torch.empty(b, sq, c, dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty(b, heads, sq, dtype=torch.float32, device=q.device)
+        hip.attention_bf16(q16, k16, vt16, o16, ldq=c, ldk=c, ldvt=ld, ldo=c, batch=b, heads=heads, sq=sq, skv=skv, head_dim=d,
+                           scale=scale, lse=lse)
+        autograd.record_attention_flash_bf16(tape, q, k, v, o16, lse, heads, scale, q16, k16, v16)
+        return o16
     vt = transpose_tokens(v, ld)
     if (prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and d in FLASH_BWD_HEAD_DIMS and sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS
             and tape is not None and FLASH_BWD):

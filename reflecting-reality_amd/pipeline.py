@@ -720,7 +720,8 @@ class StableDiffusionBrushNetPipeline:
                     graph = torch.cuda.CUDAGraph()
                     self._overlap(True)                      # the side stream forks from / joins the capture stream
                     try:
-                        with torch.cuda.graph(graph):
+                        # (thread_local: with an initialised process group its watchdog thread may poll events while this thread captures)
+                        with torch.cuda.graph(graph, capture_error_mode="thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"):
                             one_step()
                     finally:
                         self._overlap(False)

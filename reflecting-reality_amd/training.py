@@ -387,7 +387,7 @@ class GraphedTrainStep:
         self._cur.capture_end()
         self.segments.append((self._cur, (pi, b)))
         self._cur = torch.cuda.CUDAGraph()
-        self._cur.capture_begin(pool=self._pool)
+        self._cur.capture_begin(pool=self._pool, capture_error_mode="thread_local")
 
     def _capture_chain(self):
         dev = self.model.get_trainable_modules()[0].device
@@ -400,7 +400,9 @@ class GraphedTrainStep:
         try:
             with torch.cuda.stream(side):
                 self._cur = torch.cuda.CUDAGraph()
-                self._cur.capture_begin(pool=self._pool)
+                # thread_local: an initialised process group's watchdog thread polls its events with hipEventQuery while this thread
+                # captures; in the default "global" mode that call invalidates the capture (SIGABRT from the watchdog)
+                self._cur.capture_begin(pool=self._pool, capture_error_mode="thread_local")
                 try:
                     out = self._body()
                 finally:
@@ -458,7 +460,8 @@ class GraphedTrainStep:
                 if self.grad_sync is not None and (self.grad_sync.world > 1 or self.grad_sync.force):
                     self.loss, self.norm, self.coef = self._capture_chain()
                 else:
-                    with torch.cuda.graph(self.graph):
+                    mode = "thread_local" if torch.distributed.is_available() and torch.distributed.is_initialized() else "global"
+                    with torch.cuda.graph(self.graph, capture_error_mode=mode):
                         self.loss, self.norm, self.coef = self._body()
             finally:
                 ops.CAPTURE_TOKEN = None

@@ -461,6 +461,42 @@ def test_attention_backward(code_name, heads, d, sq, skv):
     assert max(e) < 3e-5
 
 
+@pytest.mark.parametrize("heads,d,sq,skv", [(8, 40, 1024, 1024), (2, 40, 4096, 4096), (4, 40, 1024, 77), (3, 8, 260, 300), (2, 8, 256, 77)])
+def test_attention_backward_bf16_planes(heads, d, sq, skv):
+    """The bf16x1 mode's attention on pre-rounded operands (mf_attention_bf16_lse + mf_attention_bwd_bf16): against torch autograd
+    in float64 ON THE bf16-ROUNDED q / k / v / dO — what the reference's bf16 autocast feeds F.scaled_dot_product_attention —
+    so the difference is the kernel's own roundings: of q * scale * log2(e) in the forward (the inference kernel folds the scale into
+    its Q tile — one rounding the reference does not have, the size of the input rounding itself), of P / dS, and of the bf16
+    output.  Bound 1e-2 of the tensor's maximum (bf16 has 8 bits: 2^-9 = 2e-3 per rounding; measured 2e-3 .. 7e-3)."""
+    from reflecting_reality_amd import autograd as AG
+    prec = ops.Precision.get("bf16x1")
+    assert ops.BF16X1_FAST
+    g = torch.Generator().manual_seed(57)
+    c = heads * d
+    r16 = lambda t: t.float().bfloat16().double()
+    q, k, v = (r16(torch.randn(2, s_, c, generator=g, dtype=torch.float64)).requires_grad_(True) for s_ in (sq, skv, skv))
+    qh, kh, vh = (t.view(2, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    o = (torch.softmax(qh @ kh.transpose(-1, -2) / d ** 0.5, -1) @ vh).transpose(1, 2).reshape(2, sq, c)
+    go = r16(torch.randn(2, sq, c, generator=g, dtype=torch.float64))
+    o.backward(go)
+    qd, kd, vd = (t.detach().float().to(DEV) for t in (q, k, v))
+    tape = AG.Tape(prec.code)
+    ops.TAPE = tape
+    try:
+        out = ops.attention_train(qd, kd, vd, heads, 1.0 / d ** 0.5, prec)
+    finally:
+        ops.TAPE = None
+    assert out.dtype == torch.bfloat16                   # the flash path ran
+    assert _rel(out.float(), o.detach()) < 1e-2
+    tape.add(out, go.float().to(DEV))
+    got = {}
+    tape.add = lambda t, gg: got.__setitem__(t.data_ptr(), gg)
+    tape.backward()
+    e = [_rel(got[t.data_ptr()].view(t.shape), r.grad) for t, r in ((qd, q), (kd, k), (vd, v))]
+    print(f"attention backward[bf16 planes, h{heads} d{d} {sq}x{skv}]: dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
+    assert max(e) < 1e-2
+
+
 def test_adamw_and_clip_against_torch():
     g = torch.Generator().manual_seed(55)
     n = 100003
