@@ -237,7 +237,7 @@ int mf_sizeof_attn_bwd_desc(void);
 int mf_attention_bwd_f16x3(const mf_attn_bwd_desc* d, void* stream);
 /* The same backward on ONE bf16 plane per operand (the *_hi pointers; *_lo are ignored) and one bf16 MFMA per product, P and dS
  * rounded to bf16: the attention backward of the MF_BF16X1 training mode on pre-rounded operands (what the reference's bf16 autocast
- * computes in F.scaled_dot_product_attention's backward, attention_processor.py:1266-1268).  head_dim 8 / 40. */
+ * computes in F.scaled_dot_product_attention's backward, attention_processor.py:1266-1268).  head_dim 8 / 40 / 80. */
 int mf_attention_bwd_bf16(const mf_attn_bwd_desc* d, void* stream);
 /* mf_attention_bf16 that also writes lse[b][head][q] = log2 of the row's softmax denominator in the exp2 domain (m + log2 l), the row
  * statistic the flash backward recomputes P from.  lse may be NULL. */

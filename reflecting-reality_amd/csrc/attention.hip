@@ -945,8 +945,9 @@ extern "C" int mf_attention_bwd_bf16(const mf_attn_bwd_desc* d, void* stream) {
     switch (d->head_dim) {
         case 8: launch_attn_bwd<8, true>(d, s); break;
         case 40: launch_attn_bwd<40, true>(d, s); break;
+        case 80: launch_attn_bwd<80, true>(d, s); break;      // single planes only: the split form's tiles do not fit in LDS at 80
         default:
-            mf_set_error("mf_attention_bwd_bf16: unsupported head_dim %d (have 8, 40)", d->head_dim);
+            mf_set_error("mf_attention_bwd_bf16: unsupported head_dim %d (have 8, 40, 80)", d->head_dim);
             return MF_EINVAL;
     }
     MF_CHECK_LAUNCH("mf_attention_bwd_bf16");

@@ -464,8 +464,8 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
                       splitk=1)
         return hip.softmax_rows(scores, skv, torch.float32)
 
-    flash = d in FLASH_BWD_HEAD_DIMS and sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS and tape is not None and FLASH_BWD
-    if flash and prec.code == hip.MF_BF16X1 and BF16X1_FAST:
+    flash = sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS and tape is not None and FLASH_BWD
+    if flash and d in FLASH_BWD_BF16_HEAD_DIMS and prec.code == hip.MF_BF16X1 and BF16X1_FAST:
         # the bf16x1 mode on pre-rounded operands: q / k / v rounded to bf16 once (what the reference's autocast hands to
         # F.scaled_dot_product_attention, attention_processor.py:1266), the inference flash kernel with the row statistics,
         # and the single-plane flash backward (autograd.record_attention_flash_bf16)
@@ -478,8 +478,7 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
         autograd.record_attention_flash_bf16(tape, q, k, v, o16, lse, heads, scale, q16, k16, v16)
         return o16
     vt = transpose_tokens(v, ld)
-    if (prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and d in FLASH_BWD_HEAD_DIMS and sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS
-            and tape is not None and FLASH_BWD):
+    if flash and prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and d in FLASH_BWD_HEAD_DIMS:
         # flash forward WITH the row statistics, flash backward (autograd.record_attention_flash): nothing of size Sq x Skv is
         # ever written in either direction.  The bf16x1 mode (fp32 storage, bf16 products) takes the same split-precision kernels:
         # finer than its own arithmetic, and the S x S tensors of the unfused form are what bounds it at 64 x 64 latents.
@@ -526,6 +525,7 @@ def attention_unfused(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads:
 
 
 FLASH_BWD_HEAD_DIMS = (8, 40)                    # mf_attention_bwd_f16x3
+FLASH_BWD_BF16_HEAD_DIMS = (8, 40, 80)           # mf_attention_bwd_bf16 (single planes: 80 fits in LDS)
 FLASH_BWD_MIN_TOKENS = 256                       # shorter sequences keep the unfused backward (its S x S tensors are small there)
 import os as _os
 FLASH_BWD = _os.environ.get("MFHIP_NO_FLASH_BWD") != "1"       # A/B switch

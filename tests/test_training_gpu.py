@@ -461,7 +461,8 @@ def test_attention_backward(code_name, heads, d, sq, skv):
     assert max(e) < 3e-5
 
 
-@pytest.mark.parametrize("heads,d,sq,skv", [(8, 40, 1024, 1024), (2, 40, 4096, 4096), (4, 40, 1024, 77), (3, 8, 260, 300), (2, 8, 256, 77)])
+@pytest.mark.parametrize("heads,d,sq,skv", [(8, 40, 1024, 1024), (2, 40, 4096, 4096), (4, 40, 1024, 77), (3, 8, 260, 300), (2, 8, 256, 77),
+                                            (8, 80, 1024, 1024), (8, 80, 1024, 77), (2, 80, 300, 333)])
 def test_attention_backward_bf16_planes(heads, d, sq, skv):
     """The bf16x1 mode's attention on pre-rounded operands (mf_attention_bf16_lse + mf_attention_bwd_bf16): against torch autograd
     in float64 ON THE bf16-ROUNDED q / k / v / dO — what the reference's bf16 autocast feeds F.scaled_dot_product_attention —
