@@ -54,7 +54,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 14
+#define MF_ABI_VERSION 15
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -229,9 +229,11 @@ typedef struct mf_attn_bwd_desc {
     const void* kt_hi; const void* kt_lo; int64_t ldkt;
     const void* dot_hi; const void* dot_lo; int64_t lddot;
     const float* lse; const float* dd;
-    float* dq; float* dk; float* dv; int64_t ldo;      /* fp32 [B][S][ldo] */
+    void* dq; void* dk; void* dv; int64_t ldo;         /* [B][S][ldo], fp32 — or bf16 with out_dtype = MF_BF16 (mf_attention_bwd_bf16 only) */
     int32_t batch, heads, sq, skv, head_dim;
     float scale;
+    int32_t out_dtype;                                 /* 0 / MF_F32: fp32 gradients; MF_BF16: bf16 (the operands of the q / k / v projections'
+                                                          weight and data gradients in the MF_BF16X1 mode, which rounds them anyway) */
 } mf_attn_bwd_desc;
 int mf_sizeof_attn_bwd_desc(void);
 int mf_attention_bwd_f16x3(const mf_attn_bwd_desc* d, void* stream);
@@ -421,9 +423,21 @@ int mf_transpose_bf16(const float* x, void* y, int32_t nz, int32_t rows, int32_t
 
 /* out[s][j] (+)= sum over the rows of segment s (rows_per_seg consecutive rows) of x[row][j], j < n: bias gradients
  * (one segment), the time-embedding gradient of a resnet (one segment per image), dgamma / dbeta partials */
+/* mf_transpose on bf16 in and out (16-byte accesses both ways): cols, ldx, ldy, zsx, zsy multiples of 8, ldy >= rows rounded up to 8
+ * (pad columns are written as zeros).  Q^T / K^T / V^T of the MF_BF16X1 attention. */
+int mf_transpose_bf16_bf16(const void* x, void* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,
+                           int64_t zsy, void* stream);
+
 int64_t mf_colsum_ws_floats(int32_t segs, int64_t rows_per_seg, int32_t n);
 int mf_colsum(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t segs, int64_t rows_per_seg, int32_t n,
               int32_t accumulate, float* ws, void* stream);
+
+/* mf_cast_bf16 of a contiguous [segs * rows_per_seg][n] gradient (n % 8 == 0) AND its column sums from the same read: seg_out[s][j]
+ * (+)= the sum over segment s (nullable: the time-embedding gradient of a resnet, resnet.py:369-381), tot_out[j] (+)= the sum over all
+ * rows (nullable: the bias gradient).  Replaces mf_cast_bf16 + up to two mf_colsum passes in the bf16x1 training mode. */
+int64_t mf_cast_bf16_colsum_ws_floats(int32_t segs, int64_t rows_per_seg, int32_t n);
+int mf_cast_bf16_colsum(const float* x, void* out16, int32_t segs, int64_t rows_per_seg, int32_t n, float* seg_out, int64_t ldo,
+                        int32_t seg_accumulate, float* tot_out, int32_t tot_accumulate, float* ws, void* stream);
 
 /* Backward of mf_groupnorm (GroupNorm + optional SiLU over one or two NHWC segments; native_group_norm_backward +
  * silu_backward in the reference's autograd): dx per segment, per-image dgamma / dbeta partials [batch][c0+c1]
@@ -457,6 +471,11 @@ int mf_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int
 int mf_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
 /* h = [a | g] ([rows][2c]), out = a * gelu_erf(g): dh from dout ([rows][c]) */
 int mf_geglu_bwd(const float* h, const float* dout, float* dh, int64_t rows, int32_t c, void* stream);
+/* mf_geglu_bwd on a bf16 pre-activation h16 [rows][2c] (the MF_BF16X1 mode keeps FeedForward's hidden tensor in bf16, as the reference's
+ * autocast does: attention.py:617-675 under train_brushnet_mirror.py:902-907,1127-1131): dh16 bf16 [rows][2c]; bias_grad (nullable, fp32 [2c],
+ * ADDED to) receives the column sums of dh16 — ff.net.0.proj's bias gradient — from the same pass (ws: mf_geglu_bwd_bf16_ws_floats). */
+int64_t mf_geglu_bwd_bf16_ws_floats(int64_t rows, int32_t c);
+int mf_geglu_bwd_bf16(const void* h16, const float* dout, void* dh16, int64_t rows, int32_t c, float* bias_grad, float* ws, void* stream);
 /* y[b][2h][2w][c]: x at the even positions, zeros elsewhere (a stride-2 conv's data gradient as a stride-1 conv) */
 int mf_zero_insert2x(const float* x, float* y, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
 /* y[b][h][w][c] = sum of the 2x2 block of x[b][2h][2w][c]: backward of the nearest-2x upsample (upsampling.py:170-178) */

@@ -21,6 +21,7 @@ import torch
 from . import hip
 
 FUSE_GRAD_ADD = os.environ.get("MFHIP_NO_FUSED_GRAD_ADD", "0") != "1"   # developer A/B: norm backwards add the residual's gradient
+CAST_COLSUM = os.environ.get("MFHIP_NO_CAST_COLSUM", "0") != "1"  # developer A/B: mf_cast_bf16 + mf_colsum passes instead
 GN_GRAD_ACC = os.environ.get("MFHIP_NO_GN_ACC", "0") != "1"      # developer A/B: per-image partials + mf_colsum instead
 
 
@@ -45,6 +46,7 @@ class Tape:
         self.stop = set()                      # storages that need no gradient (the batch's inputs)
         self.on_param_grad: Optional[Callable[[Param], None]] = None   # gradient-bucket hook (distributed.GradBuckets)
         self.dgrad_rebuilt: list = []          # trainable weights whose data-gradient layout this backward had to rebuild
+        self.colsum_done = set()               # data_ptr of bf16 gradients whose producer already added their column sums (a bias gradient)
 
     # ---- bookkeeping ---------------------------------------------------------------------------------------
     def no_grad(self, *ts: Optional[torch.Tensor]) -> None:
@@ -87,16 +89,21 @@ class Tape:
     def add_cols(self, view: torch.Tensor, g_rows: torch.Tensor, n: int, segs: int) -> None:
         """view = parent[:, a:b] (a column slice of a 2-D fp32 tensor): add the per-segment column sums of g_rows
         ([segs * rows_per_seg][n]) into the matching columns of the parent's dense gradient."""
+        tgt = self.cols_target(view)
+        if tgt is not None:
+            hip.colsum(g_rows, n, segs=segs, out=tgt, ldo=view.stride(0), accumulate=True)
+
+    def cols_target(self, view: torch.Tensor) -> Optional[torch.Tensor]:
+        """The slice of the parent's dense gradient that matches `view` (created zeroed on first use); None when not needed."""
         if not self.needs(view):
-            return
+            return None
         k = _key(view)
         dense = self.grads.get(k)
         numel = view.untyped_storage().nbytes() // 4
         if dense is None:
             dense = torch.zeros(numel, dtype=torch.float32, device=view.device)
             self.grads[k] = dense
-        tgt = dense.as_strided(view.shape, view.stride(), view.storage_offset())
-        hip.colsum(g_rows, n, segs=segs, out=tgt, ldo=view.stride(0), accumulate=True)
+        return dense.as_strided(view.shape, view.stride(), view.storage_offset())
 
     def take(self, t: torch.Tensor) -> Optional[torch.Tensor]:
         g = self.grads.pop(_key(t), None)
@@ -110,6 +117,7 @@ class Tape:
         for fn in reversed(self.ops):
             fn()
         self.ops.clear()
+        self.colsum_done.clear()
         self.grads.clear()
 
 
@@ -170,17 +178,50 @@ def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, 
         if g is None:
             return
         g = g.view(-1, n)
+        if g.dtype == torch.bfloat16:
+            # a gradient its producer already rounded (the bf16 tensors of the MF_BF16X1 mode: q / k / v and FeedForward's hidden
+            # tensor): it IS the 16-bit operand; a bias gradient was added by the producer from the same pass
+            want_b = cw.p_bias is not None and cw.p_bias.grad is not None
+            if (res0 is not None or res1 is not None or temb is not None or alpha != 1.0 or x16 is None or n % 8 or stride != 1
+                    or (want_b and g.data_ptr() not in tape.colsum_done)):
+                raise hip.MfhipError("training: a bf16 output gradient needs a plain fast-path GEMM (no residual / temb / scale, n % 8 == 0)")
+            if want_b:
+                tape.param_grad_done(cw.p_bias)
+            return _conv_grads(tape, cw, x, x1, c0, c1, n, None, g, x16, batch, h_in, w_in, h_out, w_out, stride, pad_t, pad_l, upsample)
         tape.add(res0, g)
         tape.add(res1, g)
         gc = g if alpha == 1.0 else hip.axpby_n([g], [alpha])
-        if temb is not None:
-            tape.add_cols(temb, gc, n, batch)
-        if cw.p_bias is not None and cw.p_bias.grad is not None:
-            hip.colsum(gc, n, out=cw.p_bias.grad.view(1, n), accumulate=True)
-            tape.param_grad_done(cw.p_bias)
         # x16 = the bf16 copies the forward GEMM ran on (MF_BF16X1 on pre-rounded operands): the gradient is rounded to bf16 ONCE
-        # here, and both the weight gradient and the data gradient read 16-bit operands
-        gc16 = hip.cast_bf16(gc.contiguous()) if (x16 is not None and n % 8 == 0) else None
+        # here, and both the weight gradient and the data gradient read 16-bit operands; the bias / time-embedding gradients
+        # (column sums of the same tensor) come out of that one read (mf_cast_bf16_colsum)
+        want_b = cw.p_bias is not None and cw.p_bias.grad is not None
+        gc16, sums_done = None, False
+        if x16 is not None and n % 8 == 0:
+            t_tgt = tape.cols_target(temb) if temb is not None else None
+            if (want_b or t_tgt is not None) and CAST_COLSUM and (t_tgt is None or batch <= 32):
+                gc16 = hip.cast_bf16_colsum(gc.contiguous(), n, segs=batch if t_tgt is not None else 1, seg_out=t_tgt,
+                                            ldo=temb.stride(0) if t_tgt is not None else None,
+                                            tot_out=cw.p_bias.grad.view(n) if want_b else None)
+                sums_done = True
+                if want_b:
+                    tape.param_grad_done(cw.p_bias)
+            else:
+                gc16 = hip.cast_bf16(gc.contiguous())
+        if not sums_done:
+            if temb is not None:
+                tape.add_cols(temb, gc, n, batch)
+            if want_b:
+                hip.colsum(gc, n, out=cw.p_bias.grad.view(1, n), accumulate=True)
+                tape.param_grad_done(cw.p_bias)
+        _conv_grads(tape, cw, x, x1, c0, c1, n, gc, gc16, x16, batch, h_in, w_in, h_out, w_out, stride, pad_t, pad_l, upsample)
+
+    tape.record(bwd)
+
+
+def _conv_grads(tape: Tape, cw, x, x1, c0, c1, n, gc, gc16, x16, batch, h_in, w_in, h_out, w_out, stride, pad_t, pad_l, upsample) -> None:
+    """Weight and data gradients of one conv / linear from its output gradient gc (fp32 [M, n]; None when only the rounded copy
+    exists) and / or gc16 (its bf16 copy, MF_BF16X1 on pre-rounded operands)."""
+    if True:
         if cw.p_w is not None and cw.p_w.grad is not None:
             if gc16 is not None:
                 hip.conv_wgrad(x16[0], gc16, cw.p_w.grad, code=hip.MF_BF16, c0=c0, x1=x16[1], c1=c1, batch=batch, h_in=h_in, w_in=w_in,
@@ -193,6 +234,11 @@ def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, 
             return
         wd = _dgrad_weight(cw, tape)
         taps = cw.kh * cw.kw
+        # MF_BF16X1 on pre-rounded copies: the gradient is rounded to bf16 once, the transposed weight once per step, and the data
+        # gradient runs on the bf16 LDS-DMA kernels (same arithmetic per product as the in-register rounding)
+        fast = n % 8 == 0 and (taps * n) % 8 == 0 and cw.fast16() and getattr(cw, "_wd16", None) is not None
+        if gc is None and not (fast and stride == 1):
+            raise hip.MfhipError("training: a bf16 output gradient needs the bf16 data-gradient path (stride 1, channels % 8 == 0)")
         a, gh, gw = gc, h_out, w_out
         if stride == 2:
             a = hip.zero_insert2x(gc.view(batch, h_out, w_out, n))
@@ -202,29 +248,27 @@ def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, 
         hu, wu = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
         outs = []
         off = 0
-        # MF_BF16X1 on pre-rounded copies: the gradient is rounded to bf16 once, the transposed weight once per step, and the data
-        # gradient runs on the bf16 LDS-DMA kernels (same arithmetic per product as the in-register rounding)
-        fast = n % 8 == 0 and (taps * n) % 8 == 0 and cw.fast16() and getattr(cw, "_wd16", None) is not None
         a16 = (gc16 if (gc16 is not None and stride == 1) else hip.cast_bf16(a.contiguous())) if fast else None
         for seg, cs in ((x, c0), (x1, c1)):
             if seg is None:
                 continue
             if tape.needs(seg):
                 dx = torch.empty(batch, hu, wu, cs, dtype=torch.float32, device=x.device)
+                # what the tensor's other consumers left so far rides the GEMM epilogue as its fp32 residual (no accumulation pass)
+                acc = tape.peek(seg) if (not upsample and cs % 8 == 0) else None
+                ra = acc.view(-1, cs) if acc is not None else None
                 if fast:
                     hip.gemm_conv(a16, cw._wd16[off:off + cs], dx, dtype=hip.MF_BF16, w_split=0, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
                                   h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
-                                  ldw=taps * n, n=cs)
+                                  ldw=taps * n, n=cs, res0=ra)
                 else:
                     hip.gemm_conv(a, wd[off:off + cs], dx, dtype=tape.code, w_split=cw._wd_split, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
                                   h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
-                                  ldw=cw._wd_ld, n=cs)
-                outs.append((seg, hip.sumpool2x2(dx) if upsample else dx))
+                                  ldw=cw._wd_ld, n=cs, res0=ra)
+                outs.append((seg, hip.sumpool2x2(dx) if upsample else dx, acc is not None))
             off += cs
-        for seg, dx in outs:
-            tape.add(seg, dx)
-
-    tape.record(bwd)
+        for seg, dx, fused in outs:
+            tape.put(seg, dx, fused)
 
 
 def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, groups: int, eps: float, silu: bool) -> None:

@@ -411,7 +411,8 @@ struct AttnBwdArgs {
     const char* t1[2]; int64_t ldt1;      // streamed transposed tiles for out1: dQ pass K^T, dK/dV pass Q^T       [B][heads*d][ldt]
     const char* t2[2]; int64_t ldt2;      // dK/dV pass only: dO^T (for out2 = dV)
     const float* lse; const float* dd;    // [B][heads][Sq]
-    float* out1; float* out2; int64_t ldo;   // fp32 [B][Sc][ldo]: dQ, or dK and dV
+    float* out1; float* out2; int64_t ldo;   // fp32 (out16: bf16) [B][Sc][ldo]: dQ, or dK and dV
+    int out16;
     int heads, sc, sr, batch, sq;         // sc / sr: items on the column / row side; sq: queries (lse / dd row length)
     float c, scale;                       // scale * log2(e), scale
     // P and dS are split into fp16 halves whose low half is an fp16 SUBNORMAL for the small probabilities of a long row
@@ -694,7 +695,12 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
             const int cc = c0 + row;
             if (cc < p.sc) {
                 const uint4 val = *reinterpret_cast<const uint4*>(Os + row * RBO + cv * 16);
-                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(outp) + (((int64_t)b * p.sc + cc) * p.ldo + head * HD + cv * 4) * 4) = val;
+                const int64_t eo = ((int64_t)b * p.sc + cc) * p.ldo + head * HD + cv * 4;
+                if (B16 && p.out16)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(outp) + eo * 2) =
+                        uint2{pack_bf16x2(__uint_as_float(val.x), __uint_as_float(val.y)), pack_bf16x2(__uint_as_float(val.z), __uint_as_float(val.w))};
+                else
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(outp) + eo * 4) = val;
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -877,9 +883,9 @@ static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
         a.r2[0] = (const char*)d->do_hi; a.r2[1] = (const char*)d->do_lo; a.ldr2 = d->lddo;
         a.t1[0] = (const char*)d->qt_hi; a.t1[1] = (const char*)d->qt_lo; a.ldt1 = d->ldqt;
         a.t2[0] = (const char*)d->dot_hi; a.t2[1] = (const char*)d->dot_lo; a.ldt2 = d->lddot;
-        a.lse = d->lse; a.dd = d->dd; a.out1 = d->dk; a.out2 = d->dv; a.ldo = d->ldo;
+        a.lse = d->lse; a.dd = d->dd; a.out1 = (float*)d->dk; a.out2 = (float*)d->dv; a.ldo = d->ldo;
         a.heads = d->heads; a.sc = d->skv; a.sr = d->sq; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
-        a.pshift = pshift; a.inv_pscale = inv_pscale;
+        a.pshift = pshift; a.inv_pscale = inv_pscale; a.out16 = B16 && d->out_dtype == MF_BF16;
         dim3 grid((unsigned)(((d->skv + BWD_NW * 32 - 1) / (BWD_NW * 32)) * d->heads * d->batch));
         hipLaunchKernelGGL((attn_bwd_kernel<HD, true, B16>), grid, dim3(BWD_NW * 64), 0, s, a);
     }
@@ -891,9 +897,9 @@ static void launch_attn_bwd(const mf_attn_bwd_desc* d, hipStream_t s) {
         a.r2[0] = (const char*)d->v_hi; a.r2[1] = (const char*)d->v_lo; a.ldr2 = d->ldv;
         a.t1[0] = (const char*)d->kt_hi; a.t1[1] = (const char*)d->kt_lo; a.ldt1 = d->ldkt;
         a.t2[0] = a.t1[0]; a.t2[1] = a.t1[1]; a.ldt2 = d->ldkt;
-        a.lse = d->lse; a.dd = d->dd; a.out1 = d->dq; a.out2 = nullptr; a.ldo = d->ldo;
+        a.lse = d->lse; a.dd = d->dd; a.out1 = (float*)d->dq; a.out2 = nullptr; a.ldo = d->ldo;
         a.heads = d->heads; a.sc = d->sq; a.sr = d->skv; a.batch = d->batch; a.sq = d->sq; a.c = c; a.scale = d->scale;
-        a.pshift = pshift; a.inv_pscale = inv_pscale;
+        a.pshift = pshift; a.inv_pscale = inv_pscale; a.out16 = B16 && d->out_dtype == MF_BF16;
         dim3 grid((unsigned)(((d->sq + BWD_NW * 32 - 1) / (BWD_NW * 32)) * d->heads * d->batch));
         hipLaunchKernelGGL((attn_bwd_kernel<HD, false, B16>), grid, dim3(BWD_NW * 64), 0, s, a);
     }

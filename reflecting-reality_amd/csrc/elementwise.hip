@@ -106,6 +106,26 @@ __global__ void geglu_kernel(const char* h, int in_dt, char* out, int out_dt, in
     }
 }
 
+// bf16 [rows][2c] -> bf16 [rows][c], 8 channels per thread (16-byte loads and stores); c % 8 == 0
+__global__ __launch_bounds__(256) void geglu16_kernel(const unsigned short* __restrict__ h, unsigned short* __restrict__ out, int64_t rows, int c8) {
+    const int64_t total = rows * c8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c8;
+        const int j = (int)(i - r * c8);
+        const uint4 a = *reinterpret_cast<const uint4*>(h + (r * 2 * c8 + j) * 8);
+        const uint4 g = *reinterpret_cast<const uint4*>(h + (r * 2 * c8 + c8 + j) * 8);
+        const unsigned aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = __uint_as_float(aw[e] << 16), a1 = __uint_as_float(aw[e] & 0xffff0000u);
+            const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
+            o[e] = pack_bf16x2(a0 * gelu_erf(g0), a1 * gelu_erf(g1));
+        }
+        *reinterpret_cast<uint4*>(out + i * 8) = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+
 // embeddings.py:27-67 (scale = 1, max_period = 10000)
 __global__ void timestep_embedding_kernel(const float* t, float* out, int n, int dim, int flip, float shift) {
     const int half = dim / 2;
@@ -306,6 +326,12 @@ extern "C" int mf_geglu(const void* h, int32_t in_dtype, void* out, int32_t out_
                         void* stream) {
     MF_CHECK_ARG(h && out && rows >= 0 && c > 0, "mf_geglu: bad arguments");
     if (rows == 0) return MF_OK;
+    if (in_dtype == MF_BF16 && out_dtype == MF_BF16 && c % 8 == 0 && mf_aligned16(h) && mf_aligned16(out)) {
+        hipLaunchKernelGGL(geglu16_kernel, dim3(grid_for(rows * (c / 8))), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)h,
+                           (unsigned short*)out, rows, c / 8);
+        MF_CHECK_LAUNCH("mf_geglu");
+        return MF_OK;
+    }
     hipLaunchKernelGGL(geglu_kernel, dim3(grid_for(rows * c)), dim3(256), 0, (hipStream_t)stream, (const char*)h,
                        in_dtype, (char*)out, out_dtype, rows, c);
     MF_CHECK_LAUNCH("mf_geglu");

@@ -643,6 +643,35 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float* ws, int nsl
 // strided batched transpose: y[z][c][r] = x[z][r][c]
 // ------------------------------------------------------------------------------------------------------------
 // OUT16: y is bf16 (nearest-even): the transposed data-gradient weight of the bf16x1 mode is rounded while it is laid out
+// bf16 -> bf16, 64 x 64 tiles, 16-byte loads along the input rows and 16-byte stores along the output rows (8 consecutive input
+// rows of one channel).  cols, ldx, ldy multiples of 8; ldy >= rows rounded up to 8 (the pad columns are written as zeros).
+__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int rows, int cols,
+                                                          int64_t ldx, int64_t ldy, int64_t zsx, int64_t zsy) {
+    __shared__ unsigned short t[64][72];
+    const unsigned short* xs = x + (int64_t)blockIdx.z * zsx;
+    unsigned short* ys = y + (int64_t)blockIdx.z * zsy;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (threadIdx.x >> 3) + 32 * i, cg = (threadIdx.x & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + rr < rows && c0 + cg < cols) v = *reinterpret_cast<const uint4*>(xs + (int64_t)(r0 + rr) * ldx + c0 + cg);
+        *reinterpret_cast<uint4*>(&t[rr][cg]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cc = (threadIdx.x >> 3) + 32 * i, rg = (threadIdx.x & 7) * 8;
+        if (c0 + cc < cols && r0 + rg < rows) {
+            unsigned short e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = t[rg + j][cc];
+            *reinterpret_cast<uint4*>(ys + (int64_t)(c0 + cc) * ldy + r0 + rg) =
+                uint4{e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)};
+        }
+    }
+}
+
 template <bool OUT16>
 __global__ __launch_bounds__(256) void transpose_kernel(const float* x, void* yv, int rows, int cols, int64_t ldx, int64_t ldy,
                                                         int64_t zsx, int64_t zsy) {
@@ -710,6 +739,102 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* part, float* o
         for (int c = 0; c < chunks; ++c) s += part[((int64_t)seg * chunks + c) * n + col];
         float* o = out + (int64_t)seg * ldo + col;
         *o = accumulate ? *o + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 -> bf16 copy of a gradient WITH its column sums (per row segment) from the same read: the bf16x1 training mode rounds
+// every conv / linear output gradient once (the operand of its weight and data gradients), and the bias / time-embedding
+// gradients are column sums of the very same tensor.  Stage 1: a block owns `cpb` 8-column groups x one row chunk, a thread one
+// 8-column group of every rpp-th row; stage 2: 4 lanes per column over the chunk partials.  Fixed order, no atomics.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_colsum_stage1(const float* __restrict__ x, unsigned short* __restrict__ out, float* __restrict__ part,
+                                                          int n, int cpb, int rpp, int64_t rows_per_seg, int chunks, int64_t rows_per_chunk) {
+    __shared__ float red[256 * 8];
+    const int rl = threadIdx.x / cpb, cl = threadIdx.x - rl * cpb;
+    const int col = (blockIdx.x * cpb + cl) * 8;
+    const int seg = blockIdx.y / chunks, ch = blockIdx.y - seg * chunks;
+    const int64_t r0 = (int64_t)seg * rows_per_seg + (int64_t)ch * rows_per_chunk;
+    int64_t r1 = r0 + rows_per_chunk;
+    if (r1 > (int64_t)(seg + 1) * rows_per_seg) r1 = (int64_t)(seg + 1) * rows_per_seg;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (rl < rpp && col < n) {
+        const float* xp = x + col;
+        unsigned short* op = out + col;
+        int64_t rr = r0 + rl;
+        for (; rr + 3 * (int64_t)rpp < r1; rr += 4 * (int64_t)rpp) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = *reinterpret_cast<const float4*>(xp + (rr + (int64_t)u * rpp) * n);
+                b[u] = *reinterpret_cast<const float4*>(xp + (rr + (int64_t)u * rpp) * n + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                *reinterpret_cast<uint4*>(op + (rr + (int64_t)u * rpp) * n) =
+                    uint4{pack_bf16x2(a[u].x, a[u].y), pack_bf16x2(a[u].z, a[u].w), pack_bf16x2(b[u].x, b[u].y), pack_bf16x2(b[u].z, b[u].w)};
+                s[0] += a[u].x; s[1] += a[u].y; s[2] += a[u].z; s[3] += a[u].w;
+                s[4] += b[u].x; s[5] += b[u].y; s[6] += b[u].z; s[7] += b[u].w;
+            }
+        }
+        for (; rr < r1; rr += rpp) {
+            const float4 a = *reinterpret_cast<const float4*>(xp + rr * n), b = *reinterpret_cast<const float4*>(xp + rr * n + 4);
+            *reinterpret_cast<uint4*>(op + rr * n) = uint4{pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w)};
+            s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+            s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[j * 256 + threadIdx.x] = s[j];
+    __syncthreads();
+    // thread t < cpb * 8: column (t >> 3 group, t & 7) summed over the row lanes in order
+    for (int t = threadIdx.x; t < cpb * 8; t += 256) {
+        const int g = t >> 3, j = t & 7;
+        const int c = (blockIdx.x * cpb + g) * 8 + j;
+        if (c >= n) continue;
+        float acc = 0.0f;
+        for (int q = 0; q < rpp; ++q) acc += red[j * 256 + q * cpb + g];
+        part[((int64_t)seg * chunks + ch) * n + c] = acc;
+    }
+}
+
+// Stage 2: a block owns 16 columns, 16 lanes per column walk the chunk partials (four independent loads in flight per lane), then
+// the 16 lane sums of every (segment, column) are added in order.  segs <= CC2_MAX_SEGS.
+constexpr int CC2_MAX_SEGS = 32;
+__global__ __launch_bounds__(256) void cast_colsum_stage2(const float* __restrict__ part, float* seg_out, int64_t ldo, int seg_acc, float* tot_out,
+                                                          int tot_acc, int n, int segs, int chunks) {
+    __shared__ float red[CC2_MAX_SEGS][16][17];
+    __shared__ float segsum[CC2_MAX_SEGS][16];
+    const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
+    for (int seg = 0; seg < segs; ++seg) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        if (col < n) {
+            const float* pp = part + (int64_t)seg * chunks * n + col;
+            int c = j;
+            for (; c + 48 < chunks; c += 64) {
+                const float v0 = pp[(int64_t)c * n], v1 = pp[(int64_t)(c + 16) * n], v2 = pp[(int64_t)(c + 32) * n], v3 = pp[(int64_t)(c + 48) * n];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            }
+            for (; c < chunks; c += 16) a0 += pp[(int64_t)c * n];
+        }
+        red[seg][j][cl] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < segs * 16; t += 256) {
+        const int seg = t >> 4, c = t & 15;
+        float sv = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sv += red[seg][q][c];
+        segsum[seg][c] = sv;
+        const int cc = blockIdx.x * 16 + c;
+        if (seg_out && cc < n) { float* o = seg_out + (int64_t)seg * ldo + cc; *o = seg_acc ? *o + sv : sv; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && col < n && tot_out) {
+        float tot = 0.0f;
+        for (int seg = 0; seg < segs; ++seg) tot += segsum[seg][cl];
+        tot_out[col] = tot_acc ? tot_out[col] + tot : tot;
     }
 }
 
@@ -1136,6 +1261,67 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float* hin, const 
     }
 }
 
+// The same on a bf16 hidden tensor (the bf16x1 mode keeps FeedForward's [rows][2c] pre-activation — its largest activation — in
+// bf16, as the reference's autocast does): dh comes out in bf16, the operand of ff.net.0.proj's weight / data gradients, and its
+// column sums (that layer's bias gradient) leave the same pass as chunk partials (cast_colsum_stage2 finishes them).  A thread
+// owns 8 value + 8 gate columns of every rpp-th row of its chunk.  The sums are of the ROUNDED values: the gradient tensor the
+// bias gradient is defined on is the bf16 one.
+__global__ __launch_bounds__(256) void geglu_bwd16_kernel(const unsigned short* __restrict__ hin, const float* __restrict__ dout,
+                                                          unsigned short* __restrict__ dh, float* __restrict__ part, int c, int cpb, int rpp,
+                                                          int64_t rows, int chunks, int64_t rows_per_chunk) {
+    __shared__ float red[256 * 16];
+    const int rl = threadIdx.x / cpb, cl = threadIdx.x - rl * cpb;
+    const int col = (blockIdx.x * cpb + cl) * 8;
+    const int ch = blockIdx.y;
+    const int64_t r0 = (int64_t)ch * rows_per_chunk;
+    int64_t r1 = r0 + rows_per_chunk;
+    if (r1 > rows) r1 = rows;
+    float s[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s[j] = 0.0f;
+    if (rl < rpp && col < c) {
+        for (int64_t rr = r0 + rl; rr < r1; rr += rpp) {
+            const uint4 a = *reinterpret_cast<const uint4*>(hin + rr * 2 * c + col);
+            const uint4 g = *reinterpret_cast<const uint4*>(hin + rr * 2 * c + c + col);
+            const float4 d0 = *reinterpret_cast<const float4*>(dout + rr * c + col), d1 = *reinterpret_cast<const float4*>(dout + rr * c + col + 4);
+            const unsigned aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+            const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            unsigned oa[4], og[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float ra[2], rg[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float av = q ? __uint_as_float(aw[e] & 0xffff0000u) : __uint_as_float(aw[e] << 16);
+                    const float gv = q ? __uint_as_float(gw[e] & 0xffff0000u) : __uint_as_float(gw[e] << 16);
+                    const float Phi = 0.5f * (1.0f + erff(gv * 0.70710678118654752440f));
+                    const float phi = 0.39894228040143267794f * expf(-0.5f * gv * gv);
+                    ra[q] = dv[2 * e + q] * (gv * Phi);
+                    rg[q] = dv[2 * e + q] * av * (Phi + gv * phi);
+                }
+                oa[e] = pack_bf16x2(ra[0], ra[1]);
+                og[e] = pack_bf16x2(rg[0], rg[1]);
+                s[2 * e] += __uint_as_float(oa[e] << 16); s[2 * e + 1] += __uint_as_float(oa[e] & 0xffff0000u);
+                s[8 + 2 * e] += __uint_as_float(og[e] << 16); s[8 + 2 * e + 1] += __uint_as_float(og[e] & 0xffff0000u);
+            }
+            *reinterpret_cast<uint4*>(dh + rr * 2 * c + col) = uint4{oa[0], oa[1], oa[2], oa[3]};
+            *reinterpret_cast<uint4*>(dh + rr * 2 * c + c + col) = uint4{og[0], og[1], og[2], og[3]};
+        }
+    }
+    if (!part) return;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[j * 256 + threadIdx.x] = s[j];
+    __syncthreads();
+    for (int t = threadIdx.x; t < cpb * 16; t += 256) {
+        const int g = t >> 4, j = t & 15;
+        const int cc = (blockIdx.x * cpb + g) * 8 + (j & 7);
+        if (cc >= c) continue;
+        float acc = 0.0f;
+        for (int q = 0; q < rpp; ++q) acc += red[j * 256 + q * cpb + g];
+        part[(int64_t)ch * 2 * c + (j >> 3) * c + cc] = acc;
+    }
+}
+
 // y[b][2h][2w][c]: y[2i][2j] = x[i][j], zeros elsewhere (data gradient of a stride-2 conv as a stride-1 conv)
 __global__ __launch_bounds__(256) void zero_insert2x_kernel(const float* x, float* y, int b, int h, int w, int c4) {
     const int64_t total = (int64_t)b * 2 * h * 2 * w * c4;
@@ -1405,6 +1591,23 @@ extern "C" int mf_transpose_bf16(const float* x, void* y, int32_t nz, int32_t ro
     return MF_OK;
 }
 
+extern "C" int mf_transpose_bf16_bf16(const void* x, void* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,
+                                      int64_t zsy, void* stream) {
+    MF_CHECK_ARG(x && y && nz >= 1 && rows >= 1 && cols >= 8 && nz < 65536 && cols % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && zsx % 8 == 0 &&
+                     zsy % 8 == 0 && ldy >= (rows + 7) / 8 * 8,
+                 "mf_transpose_bf16_bf16: cols, the leading dimensions and the batch strides are multiples of 8; ldy covers rows rounded up to 8");
+    if (!mf_aligned16(x) || !mf_aligned16(y)) {
+        mf_set_error("mf_transpose_bf16_bf16: pointers must be 16-byte aligned");
+        return MF_EALIGN;
+    }
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64, nz);
+    MF_CHECK_ARG(grid.y < 65536, "mf_transpose_bf16_bf16: too many rows");
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)y, rows, cols, ldx,
+                       ldy, zsx, zsy);
+    MF_CHECK_LAUNCH("mf_transpose_bf16_bf16");
+    return MF_OK;
+}
+
 extern "C" int64_t mf_colsum_ws_floats(int32_t segs, int64_t rows_per_seg, int32_t n) {
     int64_t chunks = (rows_per_seg + 63) / 64;
     if (chunks > 64) chunks = 64;
@@ -1425,6 +1628,47 @@ extern "C" int mf_colsum(const float* x, int64_t ldx, float* out, int64_t ldo, i
     MF_CHECK_LAUNCH("mf_colsum");
     hipLaunchKernelGGL(colsum_stage2, dim3(grid_for((int64_t)segs * n, 1024)), dim3(256), 0, s, ws, out, ldo, n, segs, (int)chunks, accumulate);
     MF_CHECK_LAUNCH("mf_colsum(stage 2)");
+    return MF_OK;
+}
+
+static void cast_colsum_plan(int32_t segs, int64_t rows_per_seg, int32_t n, int& ncb, int& cpb, int& rpp, int64_t& chunks) {
+    const int n8 = n / 8;
+    ncb = (n8 + 255) / 256;
+    cpb = (n8 + ncb - 1) / ncb;                    // 8-column groups per block (<= 256)
+    rpp = 256 / cpb;
+    if (rpp > 32) rpp = 32;
+    chunks = (512 + segs - 1) / segs;              // ~512 blocks over the row dimension
+    const int64_t most = (rows_per_seg + rpp - 1) / rpp;
+    if (chunks > most) chunks = most;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+}
+
+extern "C" int64_t mf_cast_bf16_colsum_ws_floats(int32_t segs, int64_t rows_per_seg, int32_t n) {
+    int ncb, cpb, rpp; int64_t chunks;
+    cast_colsum_plan(segs, rows_per_seg, n, ncb, cpb, rpp, chunks);
+    return (int64_t)segs * chunks * n;
+}
+
+extern "C" int mf_cast_bf16_colsum(const float* x, void* out16, int32_t segs, int64_t rows_per_seg, int32_t n, float* seg_out, int64_t ldo,
+                                   int32_t seg_accumulate, float* tot_out, int32_t tot_accumulate, float* ws, void* stream) {
+    MF_CHECK_ARG(x && out16 && ws && segs >= 1 && segs <= CC2_MAX_SEGS && rows_per_seg >= 1 && n >= 8 && n % 8 == 0 && (seg_out || tot_out),
+                 "mf_cast_bf16_colsum: bad arguments (n a multiple of 8, at most 32 segments, at least one of seg_out / tot_out)");
+    if (!mf_aligned16(x) || !mf_aligned16(out16)) {
+        mf_set_error("mf_cast_bf16_colsum: x / out16 must be 16-byte aligned");
+        return MF_EALIGN;
+    }
+    int ncb, cpb, rpp; int64_t chunks;
+    cast_colsum_plan(segs, rows_per_seg, n, ncb, cpb, rpp, chunks);
+    MF_CHECK_ARG((int64_t)segs * chunks < 65536, "mf_cast_bf16_colsum: too many segments");
+    const int64_t rpc = (rows_per_seg + chunks - 1) / chunks;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cast_colsum_stage1, dim3(ncb, (unsigned)(segs * chunks)), dim3(256), 0, s, x, (unsigned short*)out16, ws, n, cpb, rpp,
+                       rows_per_seg, (int)chunks, rpc);
+    MF_CHECK_LAUNCH("mf_cast_bf16_colsum");
+    hipLaunchKernelGGL(cast_colsum_stage2, dim3((n + 15) / 16), dim3(256), 0, s, ws, seg_out, ldo, seg_accumulate, tot_out, tot_accumulate, n, segs,
+                       (int)chunks);
+    MF_CHECK_LAUNCH("mf_cast_bf16_colsum(stage 2)");
     return MF_OK;
 }
 
@@ -1524,6 +1768,48 @@ extern "C" int mf_geglu_bwd(const float* h, const float* dout, float* dh, int64_
     MF_CHECK_ARG(h && dout && dh && rows >= 1 && c >= 1, "mf_geglu_bwd: bad arguments");
     hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(rows * c)), dim3(256), 0, (hipStream_t)stream, h, dout, dh, rows, c);
     MF_CHECK_LAUNCH("mf_geglu_bwd");
+    return MF_OK;
+}
+
+static void geglu_bwd16_plan(int64_t rows, int32_t c, int& ncb, int& cpb, int& rpp, int64_t& chunks) {
+    const int c8 = c / 8;
+    ncb = (c8 + 127) / 128;                        // a thread keeps 16 sums: at most 128 column groups per block
+    cpb = (c8 + ncb - 1) / ncb;
+    rpp = 256 / cpb;
+    if (rpp > 32) rpp = 32;
+    chunks = (1024 + ncb - 1) / ncb;
+    const int64_t most = (rows + rpp - 1) / rpp;
+    if (chunks > most) chunks = most;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+}
+
+extern "C" int64_t mf_geglu_bwd_bf16_ws_floats(int64_t rows, int32_t c) {
+    int ncb, cpb, rpp; int64_t chunks;
+    geglu_bwd16_plan(rows, c, ncb, cpb, rpp, chunks);
+    return chunks * 2 * c;
+}
+
+extern "C" int mf_geglu_bwd_bf16(const void* h16, const float* dout, void* dh16, int64_t rows, int32_t c, float* bias_grad, float* ws,
+                                 void* stream) {
+    MF_CHECK_ARG(h16 && dout && dh16 && rows >= 1 && c >= 8 && c % 8 == 0 && (!bias_grad || ws),
+                 "mf_geglu_bwd_bf16: bad arguments (c a multiple of 8; the bias gradient needs the workspace)");
+    if (!mf_aligned16(h16) || !mf_aligned16(dout) || !mf_aligned16(dh16)) {
+        mf_set_error("mf_geglu_bwd_bf16: pointers must be 16-byte aligned");
+        return MF_EALIGN;
+    }
+    int ncb, cpb, rpp; int64_t chunks;
+    geglu_bwd16_plan(rows, c, ncb, cpb, rpp, chunks);
+    const int64_t rpc = (rows + chunks - 1) / chunks;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(geglu_bwd16_kernel, dim3(ncb, (unsigned)chunks), dim3(256), 0, s, (const unsigned short*)h16, dout, (unsigned short*)dh16,
+                       bias_grad ? ws : nullptr, c, cpb, rpp, rows, (int)chunks, rpc);
+    MF_CHECK_LAUNCH("mf_geglu_bwd_bf16");
+    if (bias_grad) {
+        hipLaunchKernelGGL(cast_colsum_stage2, dim3((2 * c + 15) / 16), dim3(256), 0, s, ws, (float*)nullptr, (int64_t)0, 0, bias_grad, 1, 2 * c, 1,
+                           (int)chunks);
+        MF_CHECK_LAUNCH("mf_geglu_bwd_bf16(bias gradient)");
+    }
     return MF_OK;
 }
 

@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1 = 0, 1, 2, 3, 4, 5
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class MfhipError(RuntimeError):
@@ -99,7 +99,7 @@ class AttnBwdDesc(C.Structure):
         ("lse", C.c_void_p), ("dd", C.c_void_p),
         ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("ldo", C.c_int64),
         ("batch", C.c_int32), ("heads", C.c_int32), ("sq", C.c_int32), ("skv", C.c_int32), ("head_dim", C.c_int32),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("out_dtype", C.c_int32),
     ]
 
 
@@ -124,7 +124,8 @@ EXPORTS = [
     "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape", "mf_gemm_tile_table_version",
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
     "mf_attention_f16x3", "mf_attention_f16x3_lse", "mf_sizeof_attn_bwd_desc", "mf_attention_bwd_f16x3", "mf_rowdot_heads",
-    "mf_attention_bwd_bf16", "mf_attention_bf16_lse", "mf_rowdot_heads_bf16",
+    "mf_attention_bwd_bf16", "mf_attention_bf16_lse", "mf_rowdot_heads_bf16", "mf_cast_bf16_colsum", "mf_cast_bf16_colsum_ws_floats",
+    "mf_transpose_bf16_bf16", "mf_geglu_bwd_bf16", "mf_geglu_bwd_bf16_ws_floats",
     "mf_split_halves", "mf_split_overflow", "mf_quantize_rows_fp8",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_cast_bf16", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
@@ -746,6 +747,7 @@ def attention_bwd_f16x3(q, k, v, do, qt, kt, dot, lse: torch.Tensor, dd: torch.T
     d.lse, d.dd = lse.data_ptr(), dd.data_ptr()
     d.dq, d.dk, d.dv, d.ldo = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), c
     d.batch, d.heads, d.sq, d.skv, d.head_dim, d.scale = b, heads, sq, skv, c // heads, scale
+    d.out_dtype = dt_code(dq.dtype)
     _check(getattr(load(), _entry)(C.byref(d), _stream()), _entry)
 
 
@@ -755,7 +757,9 @@ def attention_bwd_bf16(q, k, v, do, qt, kt, dot, lse: torch.Tensor, dd: torch.Te
     for t in (q, k, v, do, qt, kt, dot):
         if t.dtype != torch.bfloat16 or not t.is_contiguous():
             raise MfhipError("attention_bwd_bf16: contiguous bf16 operands")
-    _f32(lse, dd, dq, dk, dv)
+    _f32(lse, dd)
+    if not (dq.dtype == dk.dtype == dv.dtype and dq.dtype in (torch.float32, torch.bfloat16)):
+        raise MfhipError("attention_bwd_bf16: dq / dk / dv are all fp32 or all bf16")
     attention_bwd_f16x3((q, q), (k, k), (v, v), (do, do), (qt, qt), (kt, kt), (dot, dot), lse, dd, dq, dk, dv, heads=heads, scale=scale,
                         _entry="mf_attention_bwd_bf16")
 
@@ -808,6 +812,23 @@ def cast_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tens
     elif out.dtype != torch.bfloat16 or out.numel() != x.numel() or not out.is_contiguous():
         raise MfhipError("cast_bf16: `out` must be a contiguous bf16 tensor of the same size")
     _check(load().mf_cast_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_int64(x.numel()), _stream()), "mf_cast_bf16")
+    return out
+
+
+def cast_bf16_colsum(x: torch.Tensor, n: int, *, segs: int = 1, seg_out: Optional[torch.Tensor] = None, ldo: Optional[int] = None,
+                     tot_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 copy of the contiguous fp32 [rows, n] gradient `x` plus, from the same read, its column sums ADDED into
+    seg_out[s][:n] (row stride ldo; one row per segment of rows / segs rows) and / or tot_out[:n] (mf_cast_bf16_colsum)."""
+    _f32(x, seg_out, tot_out)
+    if not x.is_contiguous() or x.numel() % n or (x.numel() // n) % segs:
+        raise MfhipError("cast_bf16_colsum: contiguous [segs * rows_per_seg, n] input")
+    rps = x.numel() // n // segs
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lib = load()
+    ws = scratch("cast_colsum", int(lib.mf_cast_bf16_colsum_ws_floats(segs, C.c_int64(rps), n)), x.device)
+    _check(lib.mf_cast_bf16_colsum(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), segs, C.c_int64(rps), n, C.c_void_p(_ptr(seg_out)),
+                                   C.c_int64(n if ldo is None else ldo), 1, C.c_void_p(_ptr(tot_out)), 1, C.c_void_p(ws.data_ptr()), _stream()),
+           "mf_cast_bf16_colsum")
     return out
 
 
@@ -966,6 +987,13 @@ def transpose(x: torch.Tensor, rows: int, cols: int, *, nz: int = 1, ldx: Option
     """out[z][c][r] = x[z][r][c] (element strides; see mf_transpose).  A bf16 `out` takes the rounding variant (mf_transpose_bf16)."""
     ldx = cols if ldx is None else ldx
     ldy = rows if ldy is None else ldy
+    if x.dtype == torch.bfloat16:
+        _req_cuda(x, out)
+        if out is None or out.dtype != torch.bfloat16 or y_offset:
+            raise MfhipError("transpose: a bf16 input takes a bf16 `out`")
+        _check(load().mf_transpose_bf16_bf16(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), nz, rows, cols, C.c_int64(ldx), C.c_int64(ldy),
+                                             C.c_int64(zsx), C.c_int64(zsy), _stream()), "mf_transpose_bf16_bf16")
+        return out
     if out is not None and out.dtype == torch.bfloat16:
         _f32(x)
         _req_cuda(out)
@@ -1070,6 +1098,22 @@ def geglu_bwd(h: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
     dh = torch.empty_like(h)
     _check(load().mf_geglu_bwd(C.c_void_p(h.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(dh.data_ptr()),
                                C.c_int64(h.numel() // (2 * c)), c, _stream()), "mf_geglu_bwd")
+    return dh
+
+
+def geglu_bwd_bf16(h16: torch.Tensor, dout: torch.Tensor, bias_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mf_geglu_bwd_bf16: h16 bf16 [..., 2c], dout fp32 [..., c] -> dh bf16 [..., 2c]; the column sums of dh are ADDED into bias_grad."""
+    _req_cuda(h16)
+    _f32(dout, bias_grad)
+    c = h16.shape[-1] // 2
+    rows = h16.numel() // (2 * c)
+    if h16.dtype != torch.bfloat16 or not h16.is_contiguous() or not dout.is_contiguous() or dout.numel() != rows * c:
+        raise MfhipError("geglu_bwd_bf16: contiguous bf16 [rows, 2c] pre-activation and fp32 [rows, c] gradient")
+    dh = torch.empty_like(h16)
+    lib = load()
+    ws = scratch("geglu_bwd", int(lib.mf_geglu_bwd_bf16_ws_floats(C.c_int64(rows), c)), h16.device) if bias_grad is not None else None
+    _check(lib.mf_geglu_bwd_bf16(C.c_void_p(h16.data_ptr()), C.c_void_p(dout.data_ptr()), C.c_void_p(dh.data_ptr()), C.c_int64(rows), c,
+                                 C.c_void_p(_ptr(bias_grad)), C.c_void_p(_ptr(ws)), _stream()), "mf_geglu_bwd_bf16")
     return dh
 
 

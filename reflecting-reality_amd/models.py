@@ -636,9 +636,12 @@ class _UNetCore(HipModel):
             # training layout: separate q / k / v projections and the unfused, differentiated attention; the prompt's
             # K / V are recomputed every step (their weights may be training)
             src = x if ctx is None else ctx
-            q = ops.linear(x, P[b + "to_q"])
-            k = ops.linear(src, P[b + "to_k"])
-            v = ops.linear(src, P[b + "to_v"])
+            # bf16x1 on the bf16 flash kernels: q / k / v leave their projections in bf16 (as under the reference's autocast)
+            qdt = torch.bfloat16 if (ops.flash_bf16_train(self.prec, xt.shape[1], d) and c % 8 == 0 and P[b + "to_q"].fast16(xt.shape[-1])
+                                     and P[b + "to_k"].fast16(src.shape[-1]) and P[b + "to_v"].fast16(src.shape[-1])) else None
+            q = ops.linear(x, P[b + "to_q"], out_dtype=qdt)
+            k = ops.linear(src, P[b + "to_k"], out_dtype=qdt)
+            v = ops.linear(src, P[b + "to_v"], out_dtype=qdt)
             o = ops.attention_train(q, k, v, heads, 1.0 / (d ** 0.5), self.prec)
             return ops.linear(o, P[b + "to_out.0"], res0=residual)
         if fold and ctx is None:
@@ -752,7 +755,12 @@ class _UNetCore(HipModel):
             h = self._attention(b + "attn2.", n, ehs, heads, h)
             n = ops.layernorm(h, P[b + "norm3"], 1e-5, self._operand_dtype(), fp8=P[b + "ff.net.2"].fp8)
             if self.training:      # GEGLU as its own (differentiated) launch on the plain, un-interleaved weight
-                gg = ops.geglu(ops.linear(n, P[b + "ff.net.0.proj"]), self._operand_dtype())
+                ff0 = P[b + "ff.net.0.proj"]
+                if ops.bf16x1_operands(self.prec) and ff0.n % 16 == 0 and ff0.fast16(n.shape[-1]):
+                    # the [rows, 2 inner] pre-activation — the largest activation of the network — in bf16, its gradient too
+                    gg = ops.geglu(ops.linear(n, ff0, out_dtype=torch.bfloat16), torch.bfloat16, bias=ff0.p_bias)
+                else:
+                    gg = ops.geglu(ops.linear(n, ff0), self._operand_dtype())
             else:
                 gg = ops.linear_geglu(n, P[b + "ff.net.0.proj"])
             h = ops.linear(gg, P[b + "ff.net.2"], res0=h)

@@ -434,11 +434,35 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def geglu(h: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+def geglu(h: torch.Tensor, out_dtype: torch.dtype, bias: Optional["autograd.Param"] = None) -> torch.Tensor:
+    """a * gelu(g) of h = [a | g].  A bf16 `h` (the MF_BF16X1 mode's FeedForward pre-activation) is differentiated into a bf16
+    gradient; `bias` = the bias parameter of the Linear that produced h: its gradient (the column sums of dh) leaves the same pass."""
     out = hip.geglu(h, out_dtype)
-    if TAPE is not None:
-        autograd.record_pointwise(TAPE, (h,), out, lambda g: (hip.geglu_bwd(h, g.view(out.shape)),))
+    tape = TAPE
+    if tape is not None and h.dtype == torch.bfloat16:
+        def bwd():
+            g = tape.take(out)
+            if g is None:
+                return
+            bg = bias.grad if (bias is not None and bias.grad is not None) else None
+            dh = hip.geglu_bwd_bf16(h, g.view(-1, out.shape[-1]).contiguous(), bg)
+            if bg is not None:
+                tape.colsum_done.add(dh.data_ptr())
+            tape.add(h, dh)
+        tape.record(bwd)
+    elif tape is not None:
+        autograd.record_pointwise(tape, (h,), out, lambda g: (hip.geglu_bwd(h, g.view(out.shape)),))
     return out
+
+
+def bf16x1_operands(prec: Precision) -> bool:
+    """The MF_BF16X1 mode on pre-rounded bf16 operand copies (training)."""
+    return TAPE is not None and BF16X1_FAST and prec.code == hip.MF_BF16X1
+
+
+def flash_bf16_train(prec: Precision, sq: int, d: int) -> bool:
+    """Whether ops.attention_train takes the bf16 flash route for these sizes (its q / k / v may then be produced in bf16)."""
+    return (bf16x1_operands(prec) and FLASH_BWD and d in FLASH_BWD_BF16_HEAD_DIMS and sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS)
 
 
 def transpose_tokens(v: torch.Tensor, ld: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
@@ -465,11 +489,14 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
         return hip.softmax_rows(scores, skv, torch.float32)
 
     flash = sq % 4 == 0 and sq >= FLASH_BWD_MIN_TOKENS and tape is not None and FLASH_BWD
-    if flash and d in FLASH_BWD_BF16_HEAD_DIMS and prec.code == hip.MF_BF16X1 and BF16X1_FAST:
-        # the bf16x1 mode on pre-rounded operands: q / k / v rounded to bf16 once (what the reference's autocast hands to
-        # F.scaled_dot_product_attention, attention_processor.py:1266), the inference flash kernel with the row statistics,
-        # and the single-plane flash backward (autograd.record_attention_flash_bf16)
-        q16, k16, v16 = hip.cast_bf16(q.contiguous()), hip.cast_bf16(k.contiguous()), hip.cast_bf16(v.contiguous())
+    if flash_bf16_train(prec, sq, d):
+        # the bf16x1 mode on pre-rounded operands: q / k / v in bf16 (produced so by their projections, or rounded here: what
+        # the reference's autocast hands to F.scaled_dot_product_attention, attention_processor.py:1266), the inference flash
+        # kernel with the row statistics, and the single-plane flash backward (autograd.record_attention_flash_bf16)
+        if not (q.dtype == k.dtype == v.dtype):
+            raise hip.MfhipError("attention_train: q / k / v of one dtype")
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        q16, k16, v16 = (q, k, v) if q.dtype == torch.bfloat16 else (hip.cast_bf16(q), hip.cast_bf16(k), hip.cast_bf16(v))
         vt16 = transpose_tokens(v, ld, torch.bfloat16)
         o16 = torch.empty(b, sq, c, dtype=torch.bfloat16, device=q.device)
         lse = torch.empty(b, heads, sq, dtype=torch.float32, device=q.device)
@@ -477,6 +504,8 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
                            scale=scale, lse=lse)
         autograd.record_attention_flash_bf16(tape, q, k, v, o16, lse, heads, scale, q16, k16, v16)
         return o16
+    if q.dtype != torch.float32:
+        raise hip.MfhipError("attention_train: bf16 q / k / v only on the bf16 flash route (ops.flash_bf16_train)")
     vt = transpose_tokens(v, ld)
     if flash and prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and d in FLASH_BWD_HEAD_DIMS:
         # flash forward WITH the row statistics, flash backward (autograd.record_attention_flash): nothing of size Sq x Skv is

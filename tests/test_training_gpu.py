@@ -498,6 +498,81 @@ def test_attention_backward_bf16_planes(heads, d, sq, skv):
     assert max(e) < 1e-2
 
 
+def test_bf16_tensors_of_the_bf16x1_mode_geglu_transpose_attention_outputs():
+    """The tensors the bf16x1 mode keeps in bf16 (q / k / v, FeedForward's pre-activation) and their gradients:
+    mf_geglu (bf16 -> bf16, vectorised) and mf_geglu_bwd_bf16 (+ the bias gradient from the same pass) against float64 on the rounded
+    inputs; mf_transpose_bf16_bf16 exact; the attention backward's bf16 outputs = its fp32 outputs rounded (same kernel)."""
+    from reflecting_reality_amd import autograd as AG
+    g = torch.Generator().manual_seed(59)
+    for rows, c in ((4096, 1280), (77, 2560), (1000, 5120), (5, 16), (300, 648)):
+        h = torch.randn(rows, 2 * c, generator=g).bfloat16()
+        do = torch.randn(rows, c, generator=g)
+        hd = h.double().requires_grad_(True)
+        a, gt = hd.chunk(2, -1)
+        out = a * torch.nn.functional.gelu(gt)
+        out.backward(do.double())
+        got = hip.geglu(h.to(DEV), torch.bfloat16)
+        assert _rel(got.float(), out.detach()) < 4e-3                      # one bf16 rounding of the output
+        bias0 = torch.randn(2 * c, generator=g)
+        bias = bias0.clone().to(DEV)
+        dh = hip.geglu_bwd_bf16(h.to(DEV), do.to(DEV), bias)
+        assert dh.dtype == torch.bfloat16 and _rel(dh.float(), hd.grad) < 4e-3
+        # the bias gradient is the column sum of the ROUNDED gradient tensor
+        ref_b = dh.double().sum(0).cpu()
+        assert float((bias.cpu().double() - bias0.double() - ref_b).abs().max()) < 2e-5 * float(dh.double().abs().sum(0).max()) + 1e-6
+        assert torch.equal(hip.geglu_bwd_bf16(h.to(DEV), do.to(DEV)), dh)
+    for nz, rows, cols in ((2, 4096, 320), (3, 77, 640), (1, 1024, 1280), (2, 260, 24), (1, 8, 8)):
+        x = torch.randn(nz, rows, cols, generator=g).bfloat16().to(DEV)
+        ld = (rows + 7) // 8 * 8
+        y = torch.full((nz, cols, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+        hip.transpose(x, rows, cols, nz=nz, ldx=cols, ldy=ld, zsx=rows * cols, zsy=cols * ld, out=y)
+        assert torch.equal(y[:, :, :rows], x.transpose(1, 2)) and float(y[:, :, rows:].abs().max() if ld > rows else 0.0) == 0.0
+    prec = ops.Precision.get("bf16x1")
+    for heads, d, sq, skv in ((8, 40, 1024, 1024), (4, 80, 512, 77), (2, 8, 256, 300)):
+        c = heads * d
+        q, k, v = (torch.randn(2, s_, c, generator=g).bfloat16().to(DEV) for s_ in (sq, skv, skv))
+        go = torch.randn(2, sq, c, generator=g).to(DEV)
+        res = []
+        for cast in (lambda t: t, lambda t: t.float()):
+            tape = AG.Tape(prec.code)
+            ops.TAPE = tape
+            try:
+                qq, kk, vv = cast(q), cast(k), cast(v)
+                out = ops.attention_train(qq, kk, vv, heads, 1.0 / d ** 0.5, prec)
+            finally:
+                ops.TAPE = None
+            tape.add(out, go)
+            got = {}
+            tape.add = lambda t, gg: got.__setitem__(t.data_ptr(), gg)
+            tape.backward()
+            res.append((out, [got[t.data_ptr()] for t in (qq, kk, vv)]))
+        assert torch.equal(res[0][0], res[1][0])
+        for a16, a32 in zip(res[0][1], res[1][1]):
+            assert a16.dtype == torch.bfloat16 and a32.dtype == torch.float32 and torch.equal(a16.view(-1), a32.view(-1).bfloat16())
+
+
+def test_cast_bf16_with_column_sums_in_one_read():
+    """mf_cast_bf16_colsum: the bf16 copy is bit-identical to mf_cast_bf16 / torch's rounding; the per-segment and total column sums
+    match float64 sums to fp32 accumulation error and are ADDED to what the targets held."""
+    g = torch.Generator().manual_seed(58)
+    for segs, rps, n, ldo in ((8, 4096, 320, 1280), (1, 32768, 320, 320), (8, 64, 1280, 1280), (2, 77, 8, 16), (3, 5, 2560, 2560),
+                              (8, 1024, 640, 640), (1, 1, 24, 24), (4, 300, 1928, 2000)):
+        x = torch.randn(segs * rps, n, generator=g) * 3.0 + 0.25
+        xd = x.to(DEV)
+        seg0, tot0 = torch.randn(segs, ldo, generator=g), torch.randn(n, generator=g)
+        seg, tot = seg0.clone().to(DEV), tot0.clone().to(DEV)
+        out = hip.cast_bf16_colsum(xd, n, segs=segs, seg_out=seg, ldo=ldo, tot_out=tot)
+        assert torch.equal(out.cpu(), x.bfloat16()) and torch.equal(out, hip.cast_bf16(xd))
+        ref_seg = x.double().view(segs, rps, n).sum(1)
+        scale = float(x.abs().double().view(segs, rps, n).sum(1).max())
+        assert float((seg.cpu()[:, :n].double() - seg0[:, :n].double() - ref_seg).abs().max()) < 4e-6 * scale
+        assert torch.equal(seg.cpu()[:, n:], seg0[:, n:])
+        assert float((tot.cpu().double() - tot0.double() - ref_seg.sum(0)).abs().max()) < 4e-6 * scale * segs
+        only_tot = torch.zeros(n, device=DEV)
+        out2 = hip.cast_bf16_colsum(xd, n, tot_out=only_tot)
+        assert torch.equal(out2, out) and float((only_tot.cpu().double() - ref_seg.sum(0)).abs().max()) < 4e-6 * scale * segs
+
+
 def test_adamw_and_clip_against_torch():
     g = torch.Generator().manual_seed(55)
     n = 100003
