@@ -248,6 +248,10 @@ int mf_attention_bf16_lse(const void* q, int64_t ldq, const void* k, int64_t ldk
 /* mf_rowdot_heads with a bf16 second operand (the bf16 forward's output O) */
 int mf_rowdot_heads_bf16(const float* a, const void* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
                          void* stream);
+/* mf_rowdot_heads_bf16 on contiguous [batch * sq][heads * head_dim] rows that ALSO writes a16 = bf16(a): the flash backward of the
+ * MF_BF16X1 mode needs D = rowdot(dO, O) and the rounded dO, both from one read of dO.  head_dim % 8 == 0, heads * head_dim <= 2048. */
+int mf_rowdot_heads_cast(const float* a, const void* b16, void* a16, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim,
+                         void* stream);
 /* out[b][head][i] = sum_c a[b][i][head*d + c] * b[b][i][head*d + c]  (fp32 [B][S][ld] inputs) */
 int mf_rowdot_heads(const float* a, const float* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
                     void* stream);

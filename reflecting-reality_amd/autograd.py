@@ -392,12 +392,14 @@ def record_attention_flash_bf16(tape: Tape, q, k, v, out16, lse, heads: int, sca
         if g is None:
             return
         g = g.view(b, sq, c).contiguous()
-        dd = hip.rowdot_heads(g, out16, heads)
         ldq, ldk = (sq + 7) // 8 * 8, (skv + 7) // 8 * 8
-        g16 = hip.cast_bf16(g)
+        if (c // heads) % 8 == 0 and c <= 2048:
+            dd, g16 = hip.rowdot_heads_cast(g, out16, heads)            # D and the rounded dO from one read of dO
+        else:
+            dd, g16 = hip.rowdot_heads(g, out16, heads), hip.cast_bf16(g)
         qt = ops.transpose_tokens(q, ldq, torch.bfloat16)
         kt = ops.transpose_tokens(k, ldk, torch.bfloat16)
-        gt = ops.transpose_tokens(g, ldq, torch.bfloat16)
+        gt = ops.transpose_tokens(g16, ldq, torch.bfloat16)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         hip.attention_bwd_bf16(q16, k16, v16, g16, qt, kt, gt, lse, dd, dq, dk, dv, heads=heads, scale=scale)
         tape.add(q, dq)

@@ -976,6 +976,58 @@ extern "C" int mf_rowdot_heads(const float* a, const float* b, float* out, int32
     return MF_OK;
 }
 
+// D = rowdot(dO, O16) AND dO16 = bf16(dO) from one read of dO (the backward needs both).  A thread owns 8 channels of one row: two
+// 16-byte loads of dO, one of O16, one 16-byte store of dO16; the head_dim / 8 partial products of a head are added in lane order.
+__global__ __launch_bounds__(256) void rowdot_cast_kernel(const float* __restrict__ a, const unsigned short* __restrict__ b16,
+                                                          unsigned short* __restrict__ a16, float* __restrict__ out, int batch, int sq, int heads,
+                                                          int tph, int c8, int rpp) {
+    __shared__ float part[256];
+    const int rl = threadIdx.x / c8, cl = threadIdx.x - rl * c8;
+    const int64_t rows = (int64_t)batch * sq;
+    for (int64_t r0 = (int64_t)blockIdx.x * rpp; r0 < rows; r0 += (int64_t)gridDim.x * rpp) {
+        const int64_t row = r0 + rl;
+        float pv = 0.0f;
+        if (rl < rpp && row < rows) {
+            const int64_t e = (row * c8 + cl) * 8;
+            const float4 x0 = *reinterpret_cast<const float4*>(a + e), x1 = *reinterpret_cast<const float4*>(a + e + 4);
+            const uint4 y = *reinterpret_cast<const uint4*>(b16 + e);
+            *reinterpret_cast<uint4*>(a16 + e) = uint4{pack_bf16x2(x0.x, x0.y), pack_bf16x2(x0.z, x0.w), pack_bf16x2(x1.x, x1.y), pack_bf16x2(x1.z, x1.w)};
+            pv = ((x0.x * __uint_as_float(y.x << 16) + x0.y * __uint_as_float(y.x & 0xffff0000u)) +
+                  (x0.z * __uint_as_float(y.y << 16) + x0.w * __uint_as_float(y.y & 0xffff0000u))) +
+                 ((x1.x * __uint_as_float(y.z << 16) + x1.y * __uint_as_float(y.z & 0xffff0000u)) +
+                  (x1.z * __uint_as_float(y.w << 16) + x1.w * __uint_as_float(y.w & 0xffff0000u)));
+        }
+        part[threadIdx.x] = pv;
+        __syncthreads();
+        if (rl < rpp && row < rows && cl < heads) {
+            float sv = 0.0f;
+            for (int j = 0; j < tph; ++j) sv += part[rl * c8 + cl * tph + j];
+            const int64_t b = row / sq, q = row - b * sq;
+            out[(b * heads + cl) * sq + q] = sv;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int mf_rowdot_heads_cast(const float* a, const void* b16, void* a16, float* out, int32_t batch, int32_t sq, int32_t heads,
+                                    int32_t head_dim, void* stream) {
+    MF_CHECK_ARG(a && b16 && a16 && out && batch >= 1 && sq >= 1 && heads >= 1 && head_dim >= 8 && head_dim % 8 == 0 && heads * head_dim <= 2048,
+                 "mf_rowdot_heads_cast: bad arguments (head_dim a multiple of 8, heads * head_dim <= 2048, contiguous rows)");
+    if (!mf_aligned16(a) || !mf_aligned16(b16) || !mf_aligned16(a16)) {
+        mf_set_error("mf_rowdot_heads_cast: pointers must be 16-byte aligned");
+        return MF_EALIGN;
+    }
+    const int c8 = heads * head_dim / 8;
+    const int rpp = 256 / c8;
+    const int64_t rows = (int64_t)batch * sq;
+    int64_t blocks = (rows + rpp - 1) / rpp;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(rowdot_cast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (const unsigned short*)b16,
+                       (unsigned short*)a16, out, batch, sq, heads, head_dim / 8, c8, rpp);
+    MF_CHECK_LAUNCH("mf_rowdot_heads_cast");
+    return MF_OK;
+}
+
 extern "C" int mf_rowdot_heads_bf16(const float* a, const void* b, float* out, int32_t batch, int32_t sq, int32_t heads, int32_t head_dim, int64_t ld,
                                     void* stream) {
     MF_CHECK_ARG(a && b && out && batch >= 1 && sq >= 1 && heads >= 1 && head_dim >= 4 && head_dim % 4 == 0 && ld % 4 == 0 && ld >= heads * head_dim,

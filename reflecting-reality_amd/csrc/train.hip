@@ -672,6 +672,35 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* 
     }
 }
 
+// fp32 -> bf16 (nearest-even), 64 x 64 tiles: 16-byte loads along the input rows, 16-byte stores of 8 consecutive input rows of one
+// column.  cols / ldx / zsx multiples of 4, ldy / zsy multiples of 8, 16-byte aligned bases (mf_transpose_bf16 checks).
+__global__ __launch_bounds__(256) void transpose_f2b_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int rows, int cols,
+                                                            int64_t ldx, int64_t ldy, int64_t zsx, int64_t zsy) {
+    __shared__ float t[64][65];
+    const float* xs = x + (int64_t)blockIdx.z * zsx;
+    unsigned short* ys = y + (int64_t)blockIdx.z * zsy;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (threadIdx.x >> 4) + 16 * i, cg = (threadIdx.x & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + rr < rows && c0 + cg < cols) v = *reinterpret_cast<const float4*>(xs + (int64_t)(r0 + rr) * ldx + c0 + cg);
+        t[rr][cg] = v.x; t[rr][cg + 1] = v.y; t[rr][cg + 2] = v.z; t[rr][cg + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cc = (threadIdx.x >> 3) + 32 * i, rg = (threadIdx.x & 7) * 8;
+        if (c0 + cc >= cols || r0 + rg >= rows) continue;
+        unsigned short* o = ys + (int64_t)(c0 + cc) * ldy + r0 + rg;
+        if (r0 + rg + 8 <= rows)
+            *reinterpret_cast<uint4*>(o) = uint4{pack_bf16x2(t[rg][cc], t[rg + 1][cc]), pack_bf16x2(t[rg + 2][cc], t[rg + 3][cc]),
+                                                 pack_bf16x2(t[rg + 4][cc], t[rg + 5][cc]), pack_bf16x2(t[rg + 6][cc], t[rg + 7][cc])};
+        else
+            for (int j = 0; r0 + rg + j < rows; ++j) o[j] = f32_to_bf16(t[rg + j][cc]);
+    }
+}
+
 template <bool OUT16>
 __global__ __launch_bounds__(256) void transpose_kernel(const float* x, void* yv, int rows, int cols, int64_t ldx, int64_t ldy,
                                                         int64_t zsx, int64_t zsy) {
@@ -1098,16 +1127,28 @@ __global__ __launch_bounds__(256) void gn_bwd2_reduce_acc_kernel(const GnBwd2Arg
         const int c = g * cpg + cc;
         const double gm = (double)p.gamma[c];
         double da = 0.0, db = 0.0;
-        for (int b = 0; b < p.batch; ++b) {
-            double a = 0.0, bb = 0.0;
-            for (int ch = lane; ch < q2.chunks; ch += 64) {
-                const float* src = q2.part + (((int64_t)b * q2.chunks + ch) * 2) * C + c;
-                a += (double)src[0]; bb += (double)src[C];
+        // eight images per round: their partial loads are all in flight before the first reduction (one memory round trip per
+        // round instead of one per image — this kernel runs on `groups` blocks only and was latency-bound at ~50 us)
+        for (int b0 = 0; b0 < p.batch; b0 += 8) {
+            double a[8], bb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = 0.0; bb[u] = 0.0;
+                if (b0 + u < p.batch)
+                    for (int ch = lane; ch < q2.chunks; ch += 64) {
+                        const float* src = q2.part + (((int64_t)(b0 + u) * q2.chunks + ch) * 2) * C + c;
+                        a[u] += (double)src[0]; bb[u] += (double)src[C];
+                    }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); }
-            da += a; db += bb;
-            if (lane == 0) { red[0][wave][b] += a * gm; red[1][wave][b] += bb * gm; }     // this wave's share of image b's group sums
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { a[u] += __shfl_xor(a[u], o, 64); bb[u] += __shfl_xor(bb[u], o, 64); }
+                if (b0 + u < p.batch) {
+                    da += a[u]; db += bb[u];
+                    if (lane == 0) { red[0][wave][b0 + u] += a[u] * gm; red[1][wave][b0 + u] += bb[u] * gm; }   // this wave's share of the image's group sums
+                }
+            }
         }
         if (lane == 0) {
             dbeta_acc[c] += (float)da;
@@ -1369,9 +1410,22 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* pred, const 
 constexpr int SUMSQ_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void sumsq_stage1(const float* x, int64_t n, double* part) {
     __shared__ double red[4];
-    double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)x[i] * (double)x[i];
-    const double t = block_sum(s, red);
+    // 16-byte loads, two of them in flight per thread, four double accumulators (fixed order: deterministic)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(x)[i + stride];
+        s0 += (double)a.x * (double)a.x + (double)b.x * (double)b.x; s1 += (double)a.y * (double)a.y + (double)b.y * (double)b.y;
+        s2 += (double)a.z * (double)a.z + (double)b.z * (double)b.z; s3 += (double)a.w * (double)a.w + (double)b.w * (double)b.w;
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        s0 += (double)a.x * (double)a.x; s1 += (double)a.y * (double)a.y; s2 += (double)a.z * (double)a.z; s3 += (double)a.w * (double)a.w;
+    }
+    for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) s0 += (double)x[j] * (double)x[j];
+    const double t = block_sum((s0 + s1) + (s2 + s3), red);
     if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 __global__ __launch_bounds__(256) void sumsq_stage2(const double* part, int nparts, double* out, int accumulate) {
@@ -1584,6 +1638,13 @@ extern "C" int mf_transpose(const float* x, float* y, int32_t nz, int32_t rows, 
 extern "C" int mf_transpose_bf16(const float* x, void* y, int32_t nz, int32_t rows, int32_t cols, int64_t ldx, int64_t ldy, int64_t zsx,
                                  int64_t zsy, void* stream) {
     MF_CHECK_ARG(x && y && nz >= 1 && rows >= 1 && cols >= 1 && nz < 65536, "mf_transpose_bf16: bad arguments");
+    if (cols % 4 == 0 && ldx % 4 == 0 && zsx % 4 == 0 && ldy % 8 == 0 && zsy % 8 == 0 && mf_aligned16(x) && mf_aligned16(y) && rows >= 32 &&
+        (rows + 63) / 64 < 65536) {
+        hipLaunchKernelGGL(transpose_f2b_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, nz), dim3(256), 0, (hipStream_t)stream, x,
+                           (unsigned short*)y, rows, cols, ldx, ldy, zsx, zsy);
+        MF_CHECK_LAUNCH("mf_transpose_bf16");
+        return MF_OK;
+    }
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, nz);
     MF_CHECK_ARG(grid.y < 65536, "mf_transpose_bf16: too many rows");
     hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, y, rows, cols, ldx, ldy, zsx, zsy);

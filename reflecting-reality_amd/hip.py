@@ -125,7 +125,7 @@ EXPORTS = [
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
     "mf_attention_f16x3", "mf_attention_f16x3_lse", "mf_sizeof_attn_bwd_desc", "mf_attention_bwd_f16x3", "mf_rowdot_heads",
     "mf_attention_bwd_bf16", "mf_attention_bf16_lse", "mf_rowdot_heads_bf16", "mf_cast_bf16_colsum", "mf_cast_bf16_colsum_ws_floats",
-    "mf_transpose_bf16_bf16", "mf_geglu_bwd_bf16", "mf_geglu_bwd_bf16_ws_floats",
+    "mf_transpose_bf16_bf16", "mf_geglu_bwd_bf16", "mf_geglu_bwd_bf16_ws_floats", "mf_rowdot_heads_cast",
     "mf_split_halves", "mf_split_overflow", "mf_quantize_rows_fp8",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_cast_bf16", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
@@ -728,6 +728,20 @@ def rowdot_heads(a: torch.Tensor, b: torch.Tensor, heads: int) -> torch.Tensor:
     _check(load().mf_rowdot_heads(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), bsz, s, heads, c // heads,
                                   C.c_int64(c), _stream()), "mf_rowdot_heads")
     return out
+
+
+def rowdot_heads_cast(a: torch.Tensor, b16: torch.Tensor, heads: int):
+    """(D [B, heads, S] = per-head row dots of a (fp32) with b16 (bf16), a16 = bf16(a)) from one read of a (mf_rowdot_heads_cast)."""
+    _f32(a)
+    _req_cuda(b16)
+    bsz, s, c = a.shape
+    if b16.dtype != torch.bfloat16 or b16.shape != a.shape or not (a.is_contiguous() and b16.is_contiguous()):
+        raise MfhipError("rowdot_heads_cast: contiguous fp32 / bf16 operands of one shape")
+    out = torch.empty(bsz, heads, s, dtype=torch.float32, device=a.device)
+    a16 = torch.empty_like(b16)
+    _check(load().mf_rowdot_heads_cast(C.c_void_p(a.data_ptr()), C.c_void_p(b16.data_ptr()), C.c_void_p(a16.data_ptr()), C.c_void_p(out.data_ptr()),
+                                       bsz, s, heads, c // heads, _stream()), "mf_rowdot_heads_cast")
+    return out, a16
 
 
 def attention_bwd_f16x3(q, k, v, do, qt, kt, dot, lse: torch.Tensor, dd: torch.Tensor, dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, *,

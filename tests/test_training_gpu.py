@@ -527,6 +527,20 @@ def test_bf16_tensors_of_the_bf16x1_mode_geglu_transpose_attention_outputs():
         y = torch.full((nz, cols, ld), 7.0, dtype=torch.bfloat16, device=DEV)
         hip.transpose(x, rows, cols, nz=nz, ldx=cols, ldy=ld, zsx=rows * cols, zsy=cols * ld, out=y)
         assert torch.equal(y[:, :, :rows], x.transpose(1, 2)) and float(y[:, :, rows:].abs().max() if ld > rows else 0.0) == 0.0
+    # fp32 -> bf16 transposes: the vectorised form (and the scalar fallback at odd sizes) against torch; the data-gradient weight
+    # layout (taps flipped by a negative batch stride, as autograd._dgrad_weight calls it)
+    for nz, rows, cols in ((2, 4096, 320), (3, 77, 640), (1, 1000, 1284), (2, 33, 24), (1, 36, 7)):
+        x = torch.randn(nz, rows, cols, generator=g).to(DEV)
+        ld = (rows + 7) // 8 * 8
+        y = torch.zeros(nz, cols, ld, dtype=torch.bfloat16, device=DEV)
+        hip.transpose(x, rows, cols, nz=nz, ldx=cols, ldy=ld, zsx=rows * cols, zsy=cols * ld, out=y)
+        assert torch.equal(y[:, :, :rows], x.transpose(1, 2).bfloat16()) and float(y[:, :, rows:].float().abs().max() if ld > rows else 0.0) == 0.0
+    n, ct, taps = 320, 640, 9
+    w = torch.randn(n, taps * ct, generator=g).to(DEV)
+    wd = torch.zeros(ct, taps * n, dtype=torch.bfloat16, device=DEV)
+    hip.transpose(w, n, ct, nz=taps, ldx=taps * ct, ldy=taps * n, zsx=ct, zsy=-n, out=wd, y_offset=(taps - 1) * n)
+    ref = w.view(n, taps, ct).flip(1).permute(2, 1, 0).reshape(ct, taps * n).bfloat16()
+    assert torch.equal(wd, ref)
     prec = ops.Precision.get("bf16x1")
     for heads, d, sq, skv in ((8, 40, 1024, 1024), (4, 80, 512, 77), (2, 8, 256, 300)):
         c = heads * d
