@@ -180,6 +180,7 @@ typedef struct mf_groupnorm_desc {
     int32_t silu;                     /* 1: y = silu(gn(x)) */
     void* out; int32_t out_dtype;     /* [batch][hw][c0+c1] */
     float* ws;
+    float* stats_out;                 /* nullable [batch][groups][2]: (mean, rstd) of every group, for mf_groupnorm_bwd's stats_in */
 } mf_groupnorm_desc;
 int mf_groupnorm(const mf_groupnorm_desc* d, void* stream);
 int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups, int32_t channels);
@@ -459,6 +460,8 @@ typedef struct mf_groupnorm_bwd_desc {
                                             * are ADDED here (needs mf_groupnorm_bwd_streams(...) != 0 and ws) */
     const float* add0; const float* add1;  /* nullable, laid out like dx0 / dx1: dx = gradient + add (the gradient a residual
                                             * connection already left for the same tensor: no separate accumulation pass) */
+    const float* stats_in;                 /* nullable [batch][groups][2]: the (mean, rstd) mf_groupnorm wrote to stats_out for the same
+                                            * input — the streaming form then skips its statistics pass (one read of x less) */
 } mf_groupnorm_bwd_desc;
 int mf_sizeof_groupnorm_bwd_desc(void);
 int mf_groupnorm_bwd_streams(int32_t batch, int32_t hw, int32_t c0, int32_t c1);   /* 1: this shape runs the streaming form */

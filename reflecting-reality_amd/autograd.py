@@ -271,7 +271,7 @@ def _conv_grads(tape: Tape, cw, x, x1, c0, c1, n, gc, gc16, x16, batch, h_in, w_
             tape.put(seg, dx, fused)
 
 
-def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, groups: int, eps: float, silu: bool) -> None:
+def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, groups: int, eps: float, silu: bool, stats=None) -> None:
     def bwd():
         g = tape.take(out)
         if g is None:
@@ -280,7 +280,7 @@ def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, gro
         a0, a1 = tape.peek(x0), (tape.peek(x1) if x1 is not None else None)
         dx0, dx1, dg, db = hip.groupnorm_bwd(x0, g.view(out.shape), p_gamma.data, p_beta.data, groups=groups, eps=eps, silu=silu,
                                              x1=x1, want_param_grads=want, grad_acc=(p_gamma.grad, p_beta.grad) if (want and GN_GRAD_ACC) else None,
-                                             add0=a0, add1=a1)
+                                             add0=a0, add1=a1, stats=stats)
         if want:
             if dg is not None:                     # small maps: per-image partials (the streaming form adds into the arena itself)
                 c = dg.shape[1]

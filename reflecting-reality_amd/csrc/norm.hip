@@ -20,6 +20,7 @@ struct GnArgs {
     float* ws;   // [batch][G][nchunks][2] = (mean, M2) of each chunk
     float* ws_ab;   // [batch][2][C] per-channel scale / shift (separate-finalize path)
     int fuse_finalize;
+    float* stats_out;   // nullable [batch][G][2]: (mean, rstd) of every group, kept for mf_groupnorm_bwd (training)
 };
 
 __device__ __forceinline__ float4 load4(const char* p, int dt, int64_t idx) {
@@ -212,6 +213,11 @@ __global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
     const int b = blockIdx.x, t = threadIdx.x;
     gn_group_mean_rstd(p, b, gm, gr);
     __syncthreads();
+    if (p.stats_out)
+        for (int g = t; g < p.G; g += blockDim.x) {
+            p.stats_out[((int64_t)b * p.G + g) * 2] = gm[g];
+            p.stats_out[((int64_t)b * p.G + g) * 2 + 1] = gr[g];
+        }
     float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
     for (int c = t; c < p.C; c += blockDim.x) {
         const int g = c / p.cpg;
@@ -230,6 +236,11 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
     if (p.fuse_finalize) {       // every block combines the chunk statistics itself: one launch (and its gap) less
         gn_group_mean_rstd(p, b, gm, gr);
         __syncthreads();
+        if (p.stats_out && blockIdx.x == 0)
+            for (int g = t; g < p.G; g += blockDim.x) {
+                p.stats_out[((int64_t)b * p.G + g) * 2] = gm[g];
+                p.stats_out[((int64_t)b * p.G + g) * 2 + 1] = gr[g];
+            }
     }
     if (trow >= p.rif) return;
     const int r0 = blockIdx.x * rows_per_block;
@@ -362,6 +373,10 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, i
                 if (m2 < 0.0) m2 = 0.0;
                 gm[g] = (float)mean;
                 gr[g] = (float)(1.0 / sqrt(m2 / n + (double)p.eps));
+                if (p.stats_out) {
+                    p.stats_out[((int64_t)b * p.G + slab * gps + g) * 2] = gm[g];
+                    p.stats_out[((int64_t)b * p.G + slab * gps + g) * 2 + 1] = gr[g];
+                }
             }
         }
     }
@@ -546,7 +561,7 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     if (a.rows_per_chunk < 16) a.rows_per_chunk = 16;
     a.nchunks = (d->hw + a.rows_per_chunk - 1) / a.rows_per_chunk;
     a.eps = d->eps; a.gamma = d->gamma; a.beta = d->beta; a.silu = d->silu;
-    a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ws = d->ws;
+    a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ws = d->ws; a.stats_out = d->stats_out;
     a.ws_ab = d->ws + (int64_t)d->batch * d->groups * GN_MAX_CHUNKS * 2;
     MF_CHECK_ARG(d->groups <= 64, "mf_groupnorm: at most 64 groups");
     static const bool gn3 = getenv("MFHIP_GN3") != nullptr;     // A/B switch: separate finalize launch

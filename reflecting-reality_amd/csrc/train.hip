@@ -971,6 +971,7 @@ struct GnBwd2Args {
     float* part;        // [batch][chunks][2][C]
     float* stats;       // [batch][groups][4]: mean, rstd, m1, m2
     int chunks, rpc;    // pixel rows per chunk
+    const float* mr;    // nullable [batch][groups][2]: (mean, rstd) kept by the forward pass (mf_groupnorm stats_out): phase 0 is skipped
 };
 
 __device__ __forceinline__ float4 gn_ld4(const GnBwdArgs& p, int b, int px, int q) {
@@ -997,7 +998,8 @@ __global__ __launch_bounds__(256) void gn_bwd2_kernel(const GnBwd2Args q2) {
             for (int j = 0; j < 4; ++j) {
                 const int c = 4 * q + j, g = c / cpg;
                 const float* st = q2.stats + ((int64_t)b * p.groups + g) * 4;
-                mean[j] = st[0]; rstd[j] = st[1];
+                if (q2.mr) { mean[j] = q2.mr[((int64_t)b * p.groups + g) * 2]; rstd[j] = q2.mr[((int64_t)b * p.groups + g) * 2 + 1]; }
+                else { mean[j] = st[0]; rstd[j] = st[1]; }
                 if (PHASE == 2) { m1[j] = st[2]; m2[j] = st[3]; }
                 gam[j] = p.gamma[c]; bet[j] = p.beta[c];
             }
@@ -1762,9 +1764,12 @@ extern "C" int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream) {
         q.chunks = (d->hw + q.rpc - 1) / q.rpc;
         q.stats = d->ws;
         q.part = d->ws + (((int64_t)d->batch * d->groups * 4 + 3) & ~3ll);
+        q.mr = d->stats_in;
         const dim3 grid((unsigned)(d->batch * q.chunks));
-        hipLaunchKernelGGL(gn_bwd2_kernel<0>, grid, dim3(256), 0, s, q);
-        hipLaunchKernelGGL(gn_bwd2_reduce_kernel<0>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
+        if (!q.mr) {       // no statistics from the forward pass: recompute them (one more read of x)
+            hipLaunchKernelGGL(gn_bwd2_kernel<0>, grid, dim3(256), 0, s, q);
+            hipLaunchKernelGGL(gn_bwd2_reduce_kernel<0>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
+        }
         hipLaunchKernelGGL(gn_bwd2_kernel<1>, grid, dim3(256), 0, s, q);
         if (d->dgamma_acc) hipLaunchKernelGGL(gn_bwd2_reduce_acc_kernel, dim3((unsigned)d->groups), dim3(256), 0, s, q, d->dgamma_acc, d->dbeta_acc);
         else hipLaunchKernelGGL(gn_bwd2_reduce_kernel<1>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);

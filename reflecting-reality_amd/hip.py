@@ -84,6 +84,7 @@ class GroupNormBwdDesc(C.Structure):
         ("ws", C.c_void_p),
         ("dgamma_acc", C.c_void_p), ("dbeta_acc", C.c_void_p),
         ("add0", C.c_void_p), ("add1", C.c_void_p),
+        ("stats_in", C.c_void_p),
     ]
 
 
@@ -114,7 +115,7 @@ class GroupNormDesc(C.Structure):
         ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("silu", C.c_int32),
         ("out", C.c_void_p), ("out_dtype", C.c_int32),
-        ("ws", C.c_void_p),
+        ("ws", C.c_void_p), ("stats_out", C.c_void_p),
     ]
 
 
@@ -564,9 +565,10 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
 
 
 def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int, eps: float, silu: bool,
-              out_dtype: torch.dtype, x1: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None
-              ) -> torch.Tensor:
-    """x0/x1: NHWC [B, H, W, C] (or [B, HW, C]); returns the normalised tensor over cat([x0, x1], -1)."""
+              out_dtype: torch.dtype, x1: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              stats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x0/x1: NHWC [B, H, W, C] (or [B, HW, C]); returns the normalised tensor over cat([x0, x1], -1).  stats_out (fp32
+    [B, groups, 2], written): every group's (mean, rstd), which groupnorm_bwd takes as `stats`."""
     _req_cuda(x0, x1, gamma, beta)
     b = x0.shape[0]
     c0 = x0.shape[-1]
@@ -585,6 +587,11 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, grou
     lib = load()
     ws = scratch("gn", int(lib.mf_groupnorm_ws_floats(b, groups, c0 + c1)), x0.device)
     d.ws = ws.data_ptr()
+    if stats_out is not None:
+        _f32(stats_out)
+        if stats_out.numel() != b * groups * 2 or not stats_out.is_contiguous():
+            raise MfhipError("groupnorm: stats_out is a contiguous [batch, groups, 2] tensor")
+        d.stats_out = stats_out.data_ptr()
     _check(lib.mf_groupnorm(C.byref(d), _stream()), "mf_groupnorm")
     return out
 
@@ -1039,8 +1046,9 @@ def colsum(x: torch.Tensor, n: int, *, segs: int = 1, rows_per_seg: Optional[int
 def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, groups: int, eps: float, silu: bool,
                   x1: Optional[torch.Tensor] = None, want_param_grads: bool = True, streaming: bool = True,
                   grad_acc: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, add0: Optional[torch.Tensor] = None,
-                  add1: Optional[torch.Tensor] = None):
-    """Returns (dx0, dx1 or None, dgamma_part [B, C] or None, dbeta_part).  streaming=False withholds the workspace, which keeps
+                  add1: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
+    """`stats`: the [B, groups, 2] (mean, rstd) hip.groupnorm(..., stats_out=) kept for this input (the streaming form skips its
+    statistics pass).  Returns (dx0, dx1 or None, dgamma_part [B, C] or None, dbeta_part).  streaming=False withholds the workspace, which keeps
     the one-block-per-(image, group) kernel at every size (tests compare the two).  grad_acc = (dgamma, dbeta) fp32 [C]: where
     the shape runs the streaming form the parameter gradients are ADDED there by the kernel itself and the partials come back
     None; elsewhere it is ignored (sum the partials with colsum)."""
@@ -1065,6 +1073,11 @@ def groupnorm_bwd(x0: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta:
     d.x0, d.x1, d.c0, d.c1, d.dy = _ptr(x0), _ptr(x1), c0, c1, _ptr(dy)
     d.gamma, d.beta, d.dx0, d.dx1, d.dgamma_part, d.dbeta_part = _ptr(gamma), _ptr(beta), _ptr(dx0), _ptr(dx1), _ptr(dg), _ptr(db)
     d.batch, d.hw, d.groups, d.silu, d.eps = b, hw, groups, int(silu), eps
+    if stats is not None:
+        _f32(stats)
+        if stats.numel() != b * groups * 2 or not stats.is_contiguous():
+            raise MfhipError("groupnorm_bwd: stats is a contiguous [batch, groups, 2] tensor")
+        d.stats_in = stats.data_ptr()
     if streaming:
         d.ws = _ptr(scratch("gn_bwd", int(load().mf_groupnorm_bwd_ws_floats(b, hw, c0 + c1, groups)), x0.device))
     _check(load().mf_groupnorm_bwd(C.byref(d), _stream()), "mf_groupnorm_bwd")

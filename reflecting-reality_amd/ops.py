@@ -186,6 +186,7 @@ class ConvWeight:
 
 
 PRESPLIT_TRAINING = os.environ.get("MFHIP_NO_PRESPLIT", "0") != "1"      # developer A/B: split arena weights in registers
+GN_KEEP_STATS = os.environ.get("MFHIP_GN_RECOMPUTE_STATS", "0") != "1"    # developer A/B: the backward pass recomputes the statistics
 BF16X1_FAST = os.environ.get("MFHIP_BF16X1_SLOW", "0") != "1"             # developer A/B: bf16x1 on pre-rounded operand copies
 # Set (to a fresh object) by training.GraphedTrainStep while it captures: every per-step re-layout of a weight that trains
 # (operand() here, autograd._dgrad_weight) is rebuilt once under the capture regardless of its generation stamp, so that the
@@ -389,11 +390,14 @@ def groupnorm(x0: torch.Tensor, norm, *, groups: int, eps: float, silu: bool, ou
     """hip.groupnorm over `norm` = (gamma, beta) tensors or autograd.Params."""
     g, b = norm
     pg = g if isinstance(g, autograd.Param) else None
-    out = hip.groupnorm(x0, g.data if pg else g, b.data if pg else b, groups=groups, eps=eps, silu=silu, out_dtype=out_dtype, x1=x1)
+    # training: the forward pass keeps every group's (mean, rstd) for the backward pass (one read of x less there)
+    stats = torch.empty(x0.shape[0], groups, 2, dtype=torch.float32, device=x0.device) if (TAPE is not None and GN_KEEP_STATS) else None
+    out = hip.groupnorm(x0, g.data if pg else g, b.data if pg else b, groups=groups, eps=eps, silu=silu, out_dtype=out_dtype, x1=x1,
+                        stats_out=stats)
     if TAPE is not None:
         if pg is None:
             raise hip.MfhipError("training: GroupNorm parameters must be autograd.Params (model built with train=True)")
-        autograd.record_groupnorm(TAPE, x0, x1, g, b, out, groups, eps, silu)
+        autograd.record_groupnorm(TAPE, x0, x1, g, b, out, groups, eps, silu, stats)
     return out
 
 

@@ -381,6 +381,18 @@ def test_groupnorm_backward(shape, silu):
                                                  beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu, x1=x1, grad_acc=acc)
         assert dg2 is None and db2 is None and torch.equal(dx0b, dx0)
         assert _rel(acc[0] - 0.5, gamma.grad) < 2e-5 and _rel(acc[1] + 0.25, beta.grad) < 2e-5
+    # the (mean, rstd) the FORWARD kernel keeps (every forward path: slab / fused finalize / separate finalize) fed to the backward
+    # pass, which then skips its statistics pass: the same gradients to fp32 rounding, and the statistics themselves against float64
+    stats = torch.empty(b, groups, 2, device=DEV)
+    hip.groupnorm(x0, gamma.detach().float().to(DEV), beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu,
+                  out_dtype=torch.float32, x1=x1, stats_out=stats)
+    xg = x.detach().view(b, groups, -1)
+    assert _rel(stats[..., 0], xg.mean(-1)) < 2e-6 and _rel(stats[..., 1], 1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5)) < 2e-6
+    sx0, sx1, sdg, sdb = hip.groupnorm_bwd(x0, gy.float().permute(0, 2, 3, 1).contiguous().to(DEV), gamma.detach().float().to(DEV),
+                                           beta.detach().float().to(DEV), groups=groups, eps=1e-5, silu=silu, x1=x1, streaming=streaming,
+                                           stats=stats)
+    sdx = torch.cat([sx0, sx1], -1) if c1 else sx0
+    assert max(_rel(sdx.permute(0, 3, 1, 2), x.grad), _rel(hip.colsum(sdg, c0 + c1)[0], gamma.grad), _rel(hip.colsum(sdb, c0 + c1)[0], beta.grad)) < 2e-5
     # dx = gradient + add (the gradient a residual connection already left): both kernel forms
     add0 = torch.randn_like(x0)
     add1 = torch.randn_like(x1) if c1 else None
