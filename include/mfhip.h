@@ -409,6 +409,9 @@ typedef struct mf_wgrad_desc {
 int mf_sizeof_wgrad_desc(void);
 int64_t mf_conv_wgrad_ws_floats(const mf_wgrad_desc* d);
 int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream);
+/* Developer / test switch: 0 routes bf16-input weight gradients to the register-staged kernel instead of the LDS-DMA one (the two are
+ * bit-identical; tests compare them).  Process-wide, not thread-safe against concurrent mf_conv_wgrad calls. */
+void mf_debug_set_wgrad_dma(int on);
 
 /* fp32 weight [rows][k] (row stride ldw) -> mf_gemm_desc's w_split layout for MF_F16X3 / MF_BF16X3: out = 16-bit
  * [rows][2 * kp], kp = round_up(k, 32), per 32 k the 32 high halves then the 32 low halves (hi = RNE(w), lo = RNE(w - hi)),

@@ -408,6 +408,153 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_kernel(const WgradArgs p
         }
 }
 
+// ---- bf16 inputs, staged by LDS-DMA ----------------------------------------------------------------------------------------
+// conv_wgrad_tr_kernel<MF_BF16X1, IN16> with the register staging replaced by `buffer_load ... lds`: the operands are already bf16 in
+// memory, so a tile's 16-byte chunks go from HBM / L2 straight to their (swizzled) LDS places — no staging registers, no ds_write, no
+// conversion — and three stages are in flight (two tiles ahead of the MFMAs) at three blocks per CU (the register-staged form holds
+// 206 VGPRs: two).  A DMA instruction writes 64 lanes x 16 B = four consecutive 256-byte pixel rows; lane L lands on row L >> 4, chunk
+// position L & 15, so it FETCHES chunk (L & 15) ^ swizzle(row): the XOR swizzle of the transposing reads is applied on the global side.
+// Out-of-range rows / columns / padding taps use an offset past the descriptor's range and arrive as zeros.  Same tiles, same MFMA
+// order, same epilogue as conv_wgrad_tr_kernel: bit-identical results.  One input segment per tile (host check: no x1, or C0 % 128 == 0).
+constexpr int WD_NST = 3;
+__global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(const WgradArgs p) {
+    constexpr int STAGE = 2 * WT_PLANE;                      // Y plane, then A plane
+    extern __shared__ __attribute__((aligned(16))) char wt_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int tiles_all = p.tiles_n * p.tiles_k_per_tap * p.taps;
+    int bid, slab_id;
+    if ((int)blockIdx.x < p.slabs_xcd * tiles_all) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        slab_id = xcd + 8 * (idx / tiles_all);
+        bid = idx % tiles_all;
+    } else {
+        slab_id = blockIdx.x / tiles_all;
+        bid = blockIdx.x - slab_id * tiles_all;
+    }
+    const int tile_n = bid % p.tiles_n;
+    bid /= p.tiles_n;
+    const int tile_k = bid % p.tiles_k_per_tap;
+    const int tap = bid / p.tiles_k_per_tap;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int n0 = tile_n * WG_BN, c0 = tile_k * WG_BC;
+    const int m_begin = slab_id * p.m_per_split;
+    int m_end = m_begin + p.m_per_split;
+    if (m_end > p.M) m_end = p.M;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // ---- staging by DMA: wave w owns pixel rows [8w, 8w + 8) of every tile, two 4-row instructions per plane
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)wt_smem);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int Hlim = p.Hin << p.ups, Wlim = p.Win << p.ups;
+    const bool seg1 = c0 >= p.C0;                              // the tile's columns lie in x1
+    const int64_t ldx = seg1 ? p.lda1 : p.lda0;
+    const int cseg = seg1 ? c0 - p.C0 : c0, climit = seg1 ? p.Ctot - p.C0 : p.C0;
+    const int batch = p.M / p.HoWo;
+    const srd_t srdX = make_srd(reinterpret_cast<const char*>(seg1 ? p.a1 : p.a0), (unsigned)((int64_t)batch * p.Hin * p.Win * ldx * 2));
+    const srd_t srdY = make_srd(reinterpret_cast<const char*>(p.dy) + ((int64_t)m_begin * p.lddy + n0) * 2,
+                                (unsigned)(((int64_t)(m_end - m_begin - 1) * p.lddy + (p.N - n0)) * 2));
+    int rowi[2];
+    unsigned yoff[2], xcol[2];
+    bool yok[2], xok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = 8 * wv + 4 * i + (lane >> 4);
+        const int ch = (lane & 15) ^ (((R & 3) << 2) | ((R >> 2) & 3));
+        rowi[i] = R;
+        yok[i] = n0 + 8 * ch < p.N;
+        yoff[i] = (unsigned)(((int64_t)R * p.lddy + 8 * ch) * 2);
+        xok[i] = cseg + 8 * ch < climit;
+        xcol[i] = (unsigned)((cseg + 8 * ch) * 2);
+    }
+    const unsigned ystep = (unsigned)(WG_BP * p.lddy * 2);
+    auto issue_tile = [&](int stage, int t) {
+        const int m0 = m_begin + t * WG_BP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned ly = lds0 + stage * STAGE + (8 * wv + 4 * i) * 256;
+            const int m = m0 + rowi[i];
+            const bool row_ok = m < m_end;
+            dma16_buf((row_ok && yok[i]) ? yoff[i] + (unsigned)t * ystep : 0x80000000u, srdY, ly);
+            unsigned xo = 0x80000000u;
+            if (row_ok && xok[i]) {
+                const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
+                const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
+                if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim)
+                    xo = (unsigned)((((int64_t)b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) * ldx * 2) + xcol[i];
+            }
+            dma16_buf(xo, srdX, ly + WT_PLANE);
+        }
+    };
+
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int ay[2][2], aa[2][2];                                   // [32-column block][pixels 0..3 / 4..7] (conv_wgrad_tr_kernel's addresses)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * (g >> 1) + 4 * j + q;
+            ay[i][j] = wt_off(row, ((wn * 64 + 32 * i + 16 * (g & 1)) >> 3) + (pp >> 1)) + 8 * (pp & 1);
+            aa[i][j] = wt_off(row, ((wk * 64 + 32 * i + 16 * (g & 1)) >> 3) + (pp >> 1)) + 8 * (pp & 1) + WT_PLANE;
+        }
+    auto compute = [&](const char* st) {
+#pragma unroll
+        for (int s = 0; s < WG_BP / 16; ++s) {
+            const char* sb = st + s * 16 * 256;
+            f16x8_t Y[2], A[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                Y[i] = wt_frag(sb, ay[i][0], ay[i][1]);
+                A[i] = wt_frag(sb, aa[i][0], aa[i][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, Y[i]), __builtin_bit_cast(bf16x8_t, A[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int tiles = (m_end - m_begin + WG_BP - 1) / WG_BP;
+    for (int s = 0; s < WD_NST - 1 && s < tiles; ++s) issue_tile(s, s);
+    int st_c = 0, st_i = WD_NST - 1;                         // stage computed this iteration / stage the next issue goes to
+    for (int t = 0; t < tiles; ++t) {
+        // tiles newer than t that may stay in flight: WD_NST - 2 (4 DMA instructions each), fewer at the tail
+        if (tiles - t - 1 >= WD_NST - 2) wait_vmcnt<4 * (WD_NST - 2)>();
+        else wait_vmcnt<0>();
+        __syncthreads();                                       // tile t is in LDS for everybody; everybody is done with tile t - 1's stage
+        if (t + WD_NST - 1 < tiles) issue_tile(st_i, t + WD_NST - 1);
+        compute(wt_smem + st_c * STAGE);
+        st_c = st_c + 1 == WD_NST ? 0 : st_c + 1;
+        st_i = st_i + 1 == WD_NST ? 0 : st_i + 1;
+    }
+    float* out = p.out + (int64_t)slab_id * p.slab;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wk * 64 + 32 * j + r;
+            if (c >= p.Ctot) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wn * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (n < p.N) {
+                    float* o = out + (int64_t)n * p.ldo + (int64_t)tap * p.Ctot + c;
+                    *o = p.acc_out ? *o + acc[i][j][e] : acc[i][j][e];
+                }
+            }
+        }
+}
+
 // fp32 [rows][k] (row stride ldw) -> mf_gemm_desc's w_split layout: per 32 k, [32 high halves | 32 low halves], rows zero-padded
 // to kp = round_up(k, 32); hi = RNE(w), lo = RNE(w - hi) (bit-identical to the host's torch split).  The trainable weights
 // change every optimizer step: one pass over them buys the pre-split GEMM forms for the step's forward and data gradients.
@@ -1168,6 +1315,19 @@ __global__ __launch_bounds__(256) void gn_bwd2_reduce_acc_kernel(const GnBwd2Arg
     }
 }
 
+// The fused parameter-gradient form, second version: the per-image partials of gn_bwd2_reduce_kernel<1> (batch x groups blocks)
+// summed over the batch in image order and ADDED to the arena — two short launches on many blocks instead of one block per group
+// walking every image and channel (51 us on 2560-channel inputs; now ~8 + 3).
+__global__ __launch_bounds__(256) void gn_bwd2_batchsum_acc_kernel(const float* __restrict__ dg_part, const float* __restrict__ db_part,
+                                                                   float* dgamma_acc, float* dbeta_acc, int batch, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double g = 0.0, b = 0.0;
+    for (int i = 0; i < batch; ++i) { g += (double)dg_part[(int64_t)i * C + c]; b += (double)db_part[(int64_t)i * C + c]; }
+    dgamma_acc[c] += (float)g;
+    dbeta_acc[c] += (float)b;
+}
+
 static inline int gn_bwd2_rpc(int batch, int hw) {
     int64_t r = ((int64_t)hw * batch + 1023) / 1024;
     return (int)(r < 8 ? 8 : (r > 64 ? 64 : r));
@@ -1489,6 +1649,9 @@ extern "C" int64_t mf_conv_wgrad_ws_floats(const mf_wgrad_desc* d) {
     return sm * d->n * K;
 }
 
+static int g_wgrad_dma = getenv("MFHIP_WGRAD_NO_DMA") ? 0 : 1;      // the LDS-DMA form of the bf16-input weight gradient
+extern "C" void mf_debug_set_wgrad_dma(int on) { g_wgrad_dma = on; }  // developer / test switch (the two forms are bit-identical)
+
 extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
     MF_CHECK_ARG(d != nullptr, "mf_conv_wgrad: null descriptor");
     MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X1 || d->dtype == MF_BF16,
@@ -1591,6 +1754,9 @@ extern "C" int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream) {
         if (in16) hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_BF16X1, 2, true>), grid1, dim3(320), 2 * 2 * W160_PLANE, s, a);
         else if (d->dtype == MF_BF16X1) hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_BF16X1, 2>), grid1, dim3(320), 2 * 2 * W160_PLANE, s, a);
         else hipLaunchKernelGGL((conv_wgrad_tr160_kernel<MF_F16X3, 2>), grid1, dim3(320), 2 * 4 * W160_PLANE, s, a);
+    } else if (in16 && g_wgrad_dma && (!a.a1 || a.C0 % WG_BC == 0) && (int64_t)a.M * a.lddy * 2 < 0x7fffffffll &&
+               (int64_t)(a.M / a.HoWo) * a.Hin * a.Win * (a.lda0 > a.lda1 ? a.lda0 : a.lda1) * 2 < 0x7fffffffll) {
+        hipLaunchKernelGGL(conv_wgrad_dma_kernel, grid1, dim3(256), WD_NST * 2 * WT_PLANE, s, a);
     } else if (in16) {
         hipLaunchKernelGGL((conv_wgrad_tr_kernel<MF_BF16X1, true>), grid1, dim3(256), 2 * 2 * WT_PLANE, s, a);
     } else if (d->dtype == MF_BF16X1) {
@@ -1771,8 +1937,17 @@ extern "C" int mf_groupnorm_bwd(const mf_groupnorm_bwd_desc* d, void* stream) {
             hipLaunchKernelGGL(gn_bwd2_reduce_kernel<0>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
         }
         hipLaunchKernelGGL(gn_bwd2_kernel<1>, grid, dim3(256), 0, s, q);
-        if (d->dgamma_acc) hipLaunchKernelGGL(gn_bwd2_reduce_acc_kernel, dim3((unsigned)d->groups), dim3(256), 0, s, q, d->dgamma_acc, d->dbeta_acc);
-        else hipLaunchKernelGGL(gn_bwd2_reduce_kernel<1>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
+        static const bool acc_v1 = getenv("MFHIP_GN_ACC_V1") != nullptr;       // developer A/B: one block per group over all images
+        if (d->dgamma_acc && acc_v1)
+            hipLaunchKernelGGL(gn_bwd2_reduce_acc_kernel, dim3((unsigned)d->groups), dim3(256), 0, s, q, d->dgamma_acc, d->dbeta_acc);
+        else if (d->dgamma_acc) {
+            float* pg = q.part + (int64_t)d->batch * q.chunks * 2 * C;                 // [2][batch][C] per-image partials (workspace tail)
+            q.a.dgamma_part = pg; q.a.dbeta_part = pg + (int64_t)d->batch * C;
+            hipLaunchKernelGGL(gn_bwd2_reduce_kernel<1>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
+            hipLaunchKernelGGL(gn_bwd2_batchsum_acc_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, q.a.dgamma_part, q.a.dbeta_part,
+                               d->dgamma_acc, d->dbeta_acc, d->batch, C);
+            q.a.dgamma_part = nullptr; q.a.dbeta_part = nullptr;
+        } else hipLaunchKernelGGL(gn_bwd2_reduce_kernel<1>, dim3((unsigned)(d->batch * d->groups)), dim3(256), 0, s, q);
         hipLaunchKernelGGL(gn_bwd2_kernel<2>, grid, dim3(256), 0, s, q);
         MF_CHECK_LAUNCH("mf_groupnorm_bwd(streaming)");
         return MF_OK;
@@ -1786,7 +1961,7 @@ extern "C" int64_t mf_groupnorm_bwd_ws_floats(int32_t batch, int32_t hw, int32_t
     if (batch < 1 || hw < 1 || channels < 1 || groups < 1) return 0;
     const int rpc = gn_bwd2_rpc(batch, hw);
     const int64_t chunks = (hw + rpc - 1) / rpc;
-    return (((int64_t)batch * groups * 4 + 3) & ~3ll) + (int64_t)batch * chunks * 2 * channels;
+    return (((int64_t)batch * groups * 4 + 3) & ~3ll) + (int64_t)batch * chunks * 2 * channels + (int64_t)2 * batch * channels;
 }
 
 extern "C" int64_t mf_layernorm_bwd_parts(int64_t rows) {

@@ -126,7 +126,7 @@ EXPORTS = [
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
     "mf_attention_f16x3", "mf_attention_f16x3_lse", "mf_sizeof_attn_bwd_desc", "mf_attention_bwd_f16x3", "mf_rowdot_heads",
     "mf_attention_bwd_bf16", "mf_attention_bf16_lse", "mf_rowdot_heads_bf16", "mf_cast_bf16_colsum", "mf_cast_bf16_colsum_ws_floats",
-    "mf_transpose_bf16_bf16", "mf_geglu_bwd_bf16", "mf_geglu_bwd_bf16_ws_floats", "mf_rowdot_heads_cast",
+    "mf_transpose_bf16_bf16", "mf_geglu_bwd_bf16", "mf_geglu_bwd_bf16_ws_floats", "mf_rowdot_heads_cast", "mf_debug_set_wgrad_dma",
     "mf_split_halves", "mf_split_overflow", "mf_quantize_rows_fp8",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_cast_bf16", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
@@ -165,7 +165,8 @@ def load() -> C.CDLL:
     lib.mf_groupnorm_bwd_ws_floats.restype = C.c_int64
     lib.mf_layernorm_bwd_parts.restype = C.c_int64
     lib.mf_layernorm_bwd_parts.argtypes = [C.c_int64]
-    for fn in ("mf_conv_wgrad_ws_floats", "mf_colsum_ws_floats", "mf_sumsq_ws_doubles", "mf_minmax_ws_floats", "mf_select_ws_bytes"):
+    for fn in ("mf_conv_wgrad_ws_floats", "mf_colsum_ws_floats", "mf_sumsq_ws_doubles", "mf_minmax_ws_floats", "mf_select_ws_bytes",
+               "mf_cast_bf16_colsum_ws_floats", "mf_geglu_bwd_bf16_ws_floats"):
         getattr(lib, fn).restype = C.c_int64
     if lib.mf_abi_version() != ABI_VERSION:
         raise MfhipError(f"libmfhip ABI {lib.mf_abi_version()} != binding ABI {ABI_VERSION}: rebuild the library")
@@ -998,6 +999,12 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, code: int
     ws = scratch("wgrad", WGRAD_WS_FLOATS, x.device)
     d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
     _check(load().mf_conv_wgrad(C.byref(d), _stream()), "mf_conv_wgrad")
+
+
+def set_wgrad_dma(on: bool) -> None:
+    """Developer / test switch (mf_debug_set_wgrad_dma): bf16-input weight gradients on the LDS-DMA kernel (default) or the
+    register-staged one; bit-identical."""
+    load().mf_debug_set_wgrad_dma(int(bool(on)))
 
 
 WGRAD_WS_FLOATS = 64 * 1024 * 1024      # 256 MiB of split-M slabs

@@ -328,6 +328,50 @@ def test_conv_wgrad_and_dgrad(code_name, case):
         assert _rel(got[x1a.data_ptr()].view(x1a.shape).permute(0, 3, 1, 2), xs[1].grad) < tol
 
 
+def test_weight_gradient_on_bf16_inputs_lds_dma_equals_register_staged():
+    """mf_conv_wgrad with bf16 x / dy (the bf16x1 mode's pre-rounded operands): the LDS-DMA kernel (three stages, chunks swizzled on
+    the global side, zeros from the descriptor's range check) is bit-identical to the register-staged kernel it replaces, and both
+    match float64 on the same bf16 values.  Shapes: 3x3 / 1x1 / stride 2 / asymmetric padding / fused upsample / two input segments
+    (C0 % 128 == 0) / ragged N, C and pixel counts / a pixel split into several slabs."""
+    g = torch.Generator().manual_seed(62)
+    cases = [  # (b, h, w, c0, c1, n, k, stride, pad_t, pad_l, upsample)
+        (2, 32, 32, 320, 0, 320, 3, 1, 1, 1, False), (8, 64, 64, 320, 0, 320, 3, 1, 1, 1, False), (2, 16, 16, 1280, 0, 640, 1, 1, 0, 0, False),
+        (2, 33, 31, 136, 0, 72, 3, 1, 1, 1, False), (2, 32, 32, 320, 0, 640, 3, 2, 1, 1, False), (1, 17, 19, 64, 0, 200, 3, 2, 0, 0, False),
+        (2, 8, 8, 256, 128, 384, 3, 1, 1, 1, False), (2, 16, 16, 128, 64, 96, 3, 1, 1, 1, True), (3, 5, 7, 8, 0, 8, 3, 1, 1, 1, False),
+    ]
+    for b, h, w_, c0, c1, n, k, stride, pt, pl, up in cases:
+        hu, wu = (2 * h, 2 * w_) if up else (h, w_)
+        ho = (hu + 2 * pt - k) // stride + 1 if (pt, pl) != (0, 0) or k == 1 else (hu + 1 - k) // stride + 1
+        wo = (wu + 2 * pl - k) // stride + 1 if (pt, pl) != (0, 0) or k == 1 else (wu + 1 - k) // stride + 1
+        x = torch.randn(b, h, w_, c0, generator=g).bfloat16().to(DEV)
+        x1 = torch.randn(b, h, w_, c1, generator=g).bfloat16().to(DEV) if c1 else None
+        dy = torch.randn(b * ho * wo, n, generator=g).bfloat16().to(DEV)
+        res = []
+        for dma in (True, False):
+            hip.set_wgrad_dma(dma)
+            try:
+                dw = torch.full((n, k * k * (c0 + c1)), 0.5, device=DEV)
+                hip.conv_wgrad(x, dy, dw, code=hip.MF_BF16, c0=c0, x1=x1, c1=c1, batch=b, h_in=h, w_in=w_, h_out=ho, w_out=wo, kh=k, kw=k,
+                               stride=stride, pad_t=pt, pad_l=pl, upsample=up, n=n)
+            finally:
+                hip.set_wgrad_dma(True)
+            res.append(dw)
+        assert torch.equal(res[0], res[1]), (b, h, w_, c0, c1, n, k, stride, up)
+        xin = torch.cat([x, x1], -1) if c1 else x
+        xin = xin.double().permute(0, 3, 1, 2).cpu()
+        if up:
+            xin = torch.nn.functional.interpolate(xin, scale_factor=2.0, mode="nearest")
+        wt = torch.zeros(n, c0 + c1, k, k, dtype=torch.float64, requires_grad=True)
+        if (pt, pl) == (0, 0) and k == 3:
+            ref = torch.nn.functional.conv2d(torch.nn.functional.pad(xin, (0, 1, 0, 1)), wt, stride=stride)
+        else:
+            ref = torch.nn.functional.conv2d(xin, wt, stride=stride, padding=(pt, pl))
+        assert ref.shape[2:] == (ho, wo)
+        ref.backward(dy.double().cpu().view(b, ho, wo, n).permute(0, 3, 1, 2))
+        got = (res[0] - 0.5).view(n, k, k, c0 + c1).permute(0, 3, 1, 2)
+        assert _rel(got, wt.grad) < 2e-5, (b, h, w_, c0, c1, n, k, stride, up)
+
+
 @pytest.mark.parametrize("code_name", ["f16x3", "bf16x3"])
 def test_device_split_pack_matches_the_host_split(code_name):
     """mf_split_pack (the per-step split of the weights the optimizer just changed) is bit-identical to ops.split_pack (the split the
