@@ -41,4 +41,4 @@ for name, b, hw, cin, cout, k in SHAPES:
                                 pad_l=pad, n=cout)
     gf = 2.0 * m * cout * k * k * cin / 1e9
     tf, tw = timeit(fwd), timeit(wg)
-    print(f"{name:24s} {gf:7.1f} GFLOP  forward {tf:7.1f} us ({gf / tf * 1e-3:6.1f} TF/s)   wgrad {tw:7.1f} us ({gf / tw * 1e-3:6.1f} TF/s)   ratio {tw / tf:4.2f}")
+    print(f"{name:24s} {gf:7.1f} GFLOP  forward {tf:7.1f} us ({gf / tf * 1e3:6.0f} TF/s)   wgrad {tw:7.1f} us ({gf / tw * 1e3:6.0f} TF/s)   ratio {tw / tf:4.2f}")
