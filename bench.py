@@ -393,12 +393,13 @@ def main():
             a_px = m * stride * stride / (4.0 if ups else 1.0)
             alg_bytes += nz * 2.0 * (a_px * k / (kh * kh) + n * k + m * n)
         traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_gemm_family.json")
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        pmc = next((q for q in (os.path.join(pdir, f"r0{r}_pmc_gemm_family.json") for r in (4, 3)) if os.path.exists(q)), "")
         if os.path.exists(pmc) and a.batch == 4 and a.size == 512 and a.precision == "bf16" and not xl:
             with open(pmc) as f:
                 pj = json.load(f)
             traffic = pj["traffic_bytes_per_launch"]          # separate rocprofv3 --pmc passes (tools/pmc_step.sh)
-            traffic_src = "profiles/r03_pmc_gemm_family.json: " + pj["method"]
+            traffic_src = "profiles/" + os.path.basename(pmc) + ": " + pj["method"]
         roofline = {"bound": "mfma", "kernel": "gemm_conv_kernel (all tile instantiations)",
                     "achieved": round(flops / secs / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(flops / secs / 1e12 / peak, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch",
