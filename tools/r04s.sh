@@ -1,7 +1,13 @@
 #!/bin/bash
-O=$MF_SESSION_OUT; R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_infer -o b -- python3 $R/bench.py --no-cpu-baseline --no-parity-mode 2>&1 | grep -a '"metric"' > $O/bench_under_rocprof.json; cut -c1-300 $O/bench_under_rocprof.json
-find $O -name "*kernel_trace.csv" -delete
-cd $R
-timeout 900 python bench.py --no-cpu-baseline --no-parity-mode 2>&1 | grep -a '"metric"' > $O/bench_same_box.json; cut -c1-300 $O/bench_same_box.json
+timeout 900 python -m pytest tests/test_ops_gpu.py -q -x -k "tiles or warp_specialised" 2>&1 | grep -a "passed\|failed\|Error\|error\|assert" | tail -6
+export MFHIP_RETUNE=1
+timeout 2400 python bench.py --no-cpu-baseline --no-parity-mode 2>&1 | grep -a '"metric"' | cut -c1-250
+unset MFHIP_RETUNE
+python - <<'PY'
+import json, collections
+j=json.load(open("gpurun_out/tune_cache_new.json"))
+c=collections.Counter(v[0] for v in j["entries"].values())
+print("tiles picked:", sorted(c.items()))
+print({k:v for k,v in j["entries"].items() if v[0] in (49,50)})
+PY
+cp gpurun_out/tune_cache_new.json $MF_SESSION_OUT/
