@@ -19,6 +19,7 @@
 // The softmax rescale factor is per query = per lane, so rescaling O^T is a plain register multiply.
 // O^T is transposed once through LDS at the end so the global stores are row-contiguous.
 #include <stdlib.h>
+#include <type_traits>
 #include "mf_common.h"
 
 namespace {
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
         // ---- P = exp2(T c - lse), dS = scale P (U - D); accumulator register e of sub-tile tt is tile row
         //      32 tt + (e & 3) + 4 ((e >> 2) & 1) + 16 (e >> 3) + 8 h (natural order: the tile's rows are stored permuted) ----
         uint4 ph[4], plo[4], sh[4], slo[4];
+        if constexpr (!B16) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             float lv[16], dv[16];
@@ -640,6 +642,72 @@ __global__ __launch_bounds__(BWD_NW * 64, 1) void attn_bwd_kernel(const AttnBwdA
                 sh[2 * tt + s2] = uint4{b_h[0], b_h[1], b_h[2], b_h[3]};
                 slo[2 * tt + s2] = uint4{b_l[0], b_l[1], b_l[2], b_l[3]};
             }
+        }
+        } else {
+        // MASK: only the LAST row tile can reach past the sequence (its DMA rows are zeros, exp2(0 - lse) is not): every other tile
+        // runs the form without the per-element row test — a third of this section's VALU instructions, and the section, not the
+        // MFMAs, bounds the single-plane (B16) kernel.  Pairs of elements are written as 2-vectors: v_pk_fma / v_pk_add / v_pk_mul.
+        auto elementwise = [&](auto mask_tag) {
+            constexpr bool MASK = decltype(mask_tag)::value;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float lv[16], dv[16];
+                if (KV) {
+                    const float* stl = reinterpret_cast<const float*>(B0 + ST_OFF);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int n = 32 * tt + (e & 7) + 16 * (e >> 3) + 8 * h;
+                        lv[e] = stl[n] - p.pshift;
+                        dv[e] = stl[256 + n];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { lv[e] = lse_l; dv[e] = dd_l; }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const mf_f32x2_t tv = {T[tt][e], T[tt][e + 1]}, l2 = {lv[e], lv[e + 1]}, uv = {U[tt][e], U[tt][e + 1]}, d2 = {dv[e], dv[e + 1]};
+                    const mf_f32x2_t c2 = {p.c, p.c}, s2v = {p.scale, p.scale};
+                    const mf_f32x2_t arg = __builtin_elementwise_fma(tv, c2, -l2);
+                    mf_f32x2_t pv = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                    if constexpr (MASK) {
+                        const int n = row0 + 32 * tt + (e & 7) + 16 * (e >> 3) + 8 * h;
+                        if (n >= p.sr) pv.x = 0.0f;
+                        if (n + 1 >= p.sr) pv.y = 0.0f;
+                    }
+                    const mf_f32x2_t ds = (s2v * pv) * (uv - d2);
+                    T[tt][e] = pv.x; T[tt][e + 1] = pv.y;
+                    U[tt][e] = ds.x; U[tt][e + 1] = ds.y;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    unsigned a_h[4], a_l[4], b_h[4], b_l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p0 = T[tt][8 * s2 + 2 * e], p1 = T[tt][8 * s2 + 2 * e + 1];
+                        const float d0 = U[tt][8 * s2 + 2 * e], d1 = U[tt][8 * s2 + 2 * e + 1];
+                        if constexpr (B16) {
+                            a_h[e] = pack_bf16x2(p0, p1); b_h[e] = pack_bf16x2(d0, d1); a_l[e] = 0; b_l[e] = 0;
+                        } else {
+                            mf_split_f16x2(p0, p1, a_h[e], a_l[e]);
+                            mf_split_f16x2(d0, d1, b_h[e], b_l[e]);
+                        }
+                    }
+                    ph[2 * tt + s2] = uint4{a_h[0], a_h[1], a_h[2], a_h[3]};
+                    plo[2 * tt + s2] = uint4{a_l[0], a_l[1], a_l[2], a_l[3]};
+                    sh[2 * tt + s2] = uint4{b_h[0], b_h[1], b_h[2], b_h[3]};
+                    slo[2 * tt + s2] = uint4{b_l[0], b_l[1], b_l[2], b_l[3]};
+                }
+            }
+        };
+        // (two copies of the section cost registers: the split-precision forms and head dim 80 sit at their budget and keep the one
+        // masked copy — they are matrix-bound anyway)
+        if constexpr (HD <= 40) {
+            if (row0 + 64 > p.sr) elementwise(std::true_type{});
+            else elementwise(std::false_type{});
+        } else {
+            elementwise(std::true_type{});
+        }
         }
         // ---- out1^T += T1 . dS   (and out2^T += T2 . P): [channels (registers)] x [32 column items (lanes)] ----
 #pragma unroll

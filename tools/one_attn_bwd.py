@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reflecting_reality_amd import autograd, hip, ops  # noqa: E402
 
-prec = ops.Precision.get("f16x3")
+prec = ops.Precision.get(sys.argv[1] if len(sys.argv) > 1 else "f16x3")      # "bf16x1": the single-plane bf16 kernels
 b, s, heads, d = 8, 4096, 8, 40
 c = heads * d
 q, k, v = (torch.randn(b, s, c, device="cuda") for _ in range(3))

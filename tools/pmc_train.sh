@@ -16,5 +16,8 @@ run() {   # name, program, args...
 run wg160 tools/one_wgrad.py 8 64 320 320 3
 run wg128 tools/one_wgrad.py 8 32 640 640 3
 run attnbwd tools/one_attn_bwd.py
+run wg160b tools/one_wgrad.py 8 64 320 320 3 bf16
+run wg128b tools/one_wgrad.py 8 32 640 640 3 bf16
+run attnbwdb tools/one_attn_bwd.py bf16x1
 python3 tools/pmc_train_summary.py gpurun_out > gpurun_out/pmc_train.txt
 cat gpurun_out/pmc_train.txt

@@ -5,10 +5,14 @@ root = sys.argv[1]
 info = collections.OrderedDict([
     ("wg160", ("weight gradient f16x3, conv3x3 320->320 @64x64 batch 8 (160 x 160 tiles, five waves)", 2.0 * 32768 * 320 * 2880, "conv_wgrad_tr160_kernel")),
     ("wg128", ("weight gradient f16x3, conv3x3 640->640 @32x32 batch 8 (128 x 128 tiles)", 2.0 * 8192 * 640 * 5760, "conv_wgrad_tr_kernel")),
-    ("attnbwd_kv", ("flash attention backward, dK / dV pass, d = 40, 4096 x 4096 tokens, 64 (batch, head) pairs (4 products)", 8.0 * 64 * 4096 * 4096 * 40, "attn_bwd_kernel<40, true>")),
-    ("attnbwd_q", ("flash attention backward, dQ pass (3 products)", 6.0 * 64 * 4096 * 4096 * 40, "attn_bwd_kernel<40, false>")),
+    ("attnbwd_kv", ("flash attention backward, dK / dV pass, d = 40, 4096 x 4096 tokens, 64 (batch, head) pairs (4 products)", 8.0 * 64 * 4096 * 4096 * 40, "attn_bwd_kernel<40, true, false>")),
+    ("attnbwd_q", ("flash attention backward, dQ pass (3 products)", 6.0 * 64 * 4096 * 4096 * 40, "attn_bwd_kernel<40, false, false>")),
+    ("wg160b", ("weight gradient on bf16 operands (bf16x1 mode), conv3x3 320->320 @64x64 batch 8 (160 x 160 tiles, register-staged)", 2.0 * 32768 * 320 * 2880, "conv_wgrad_tr160_kernel")),
+    ("wg128b", ("weight gradient on bf16 operands, conv3x3 640->640 @32x32 batch 8 (128 x 128 tiles, LDS-DMA)", 2.0 * 8192 * 640 * 5760, "conv_wgrad_dma_kernel")),
+    ("attnbwdb_kv", ("bf16 flash attention backward, dK / dV pass, d = 40, 4096 x 4096 tokens, 64 (batch, head) pairs (4 products)", 8.0 * 64 * 4096 * 4096 * 40, "attn_bwd_kernel<40, true, true>")),
+    ("attnbwdb_q", ("bf16 flash attention backward, dQ pass (3 products)", 6.0 * 64 * 4096 * 4096 * 40, "attn_bwd_kernel<40, false, true>")),
 ])
-DIRS = {"attnbwd_kv": "attnbwd", "attnbwd_q": "attnbwd"}
+DIRS = {"attnbwd_kv": "attnbwd", "attnbwd_q": "attnbwd", "attnbwdb_kv": "attnbwdb", "attnbwdb_q": "attnbwdb"}
 for name, (desc, flop, kname) in info.items():
     vals = collections.OrderedDict()
     dur = None
