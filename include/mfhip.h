@@ -413,6 +413,11 @@ int mf_conv_wgrad(const mf_wgrad_desc* d, void* stream);
  * bit-identical; tests compare them).  Process-wide, not thread-safe against concurrent mf_conv_wgrad calls. */
 void mf_debug_set_wgrad_dma(int on);
 
+/* base[offs[i] .. offs[i] + lens[i]) = 0 for i < count, one launch (offs / lens: DEVICE arrays of int64, element units).  The training
+ * step clears only the small accumulated parameters of the gradient arena this way; conv / linear weight gradients are written by their
+ * first mf_conv_wgrad of the step (accumulate = 0) — optimizer.zero_grad() of train_brushnet_mirror.py:1466 without the 2.5 GB memset. */
+int mf_zero_ranges(float* base, const int64_t* offs, const int64_t* lens, int32_t count, void* stream);
+
 /* fp32 weight [rows][k] (row stride ldw) -> mf_gemm_desc's w_split layout for MF_F16X3 / MF_BF16X3: out = 16-bit
  * [rows][2 * kp], kp = round_up(k, 32), per 32 k the 32 high halves then the 32 low halves (hi = RNE(w), lo = RNE(w - hi)),
  * zero padded.  The device form of what the inference weights get once on the host: training re-splits the weights the

@@ -28,10 +28,11 @@ GN_GRAD_ACC = os.environ.get("MFHIP_NO_GN_ACC", "0") != "1"      # developer A/B
 class Param:
     """A tensor of a model's flat arenas: `data` (fp32 master weight, in the kernels' layout) and `grad` (same shape; None
     when the parameter is frozen)."""
-    __slots__ = ("name", "data", "grad")
+    __slots__ = ("name", "data", "grad", "fresh")
 
     def __init__(self, name: str, data: torch.Tensor, grad: Optional[torch.Tensor]):
         self.name, self.data, self.grad = name, data, grad
+        self.fresh = False       # a conv / linear weight whose gradient was NOT cleared this step: its first weight gradient writes
 
 
 def _key(t: torch.Tensor):
@@ -223,12 +224,16 @@ def _conv_grads(tape: Tape, cw, x, x1, c0, c1, n, gc, gc16, x16, batch, h_in, w_
     exists) and / or gc16 (its bf16 copy, MF_BF16X1 on pre-rounded operands)."""
     if True:
         if cw.p_w is not None and cw.p_w.grad is not None:
+            acc = not cw.p_w.fresh           # fresh: the arena still holds the previous step's values here — write, do not add
+            cw.p_w.fresh = False
             if gc16 is not None:
                 hip.conv_wgrad(x16[0], gc16, cw.p_w.grad, code=hip.MF_BF16, c0=c0, x1=x16[1], c1=c1, batch=batch, h_in=h_in, w_in=w_in,
-                               h_out=h_out, w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n)
+                               h_out=h_out, w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n,
+                               accumulate=acc)
             else:
                 hip.conv_wgrad(x, gc, cw.p_w.grad, code=tape.code, c0=c0, x1=x1, c1=c1, batch=batch, h_in=h_in, w_in=w_in, h_out=h_out,
-                               w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n)
+                               w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n,
+                               accumulate=acc)
             tape.param_grad_done(cw.p_w)
         if not (tape.needs(x) or tape.needs(x1)):
             return

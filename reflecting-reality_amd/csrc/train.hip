@@ -1649,6 +1649,29 @@ extern "C" int64_t mf_conv_wgrad_ws_floats(const mf_wgrad_desc* d) {
     return sm * d->n * K;
 }
 
+// Zero a list of float ranges of one arena in ONE launch (a block per range, float4 where aligned): the gradient arena's small
+// parameters (biases, norm scales / shifts), whose gradients are accumulated, while the conv / linear weights — 99.9 % of the arena —
+// are WRITTEN by their first weight gradient of the step (mf_conv_wgrad with accumulate = 0) and need no clearing.
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* base, const int64_t* __restrict__ offs, const int64_t* __restrict__ lens) {
+    float* q = base + offs[blockIdx.x];
+    const int64_t n = lens[blockIdx.x];
+    if ((reinterpret_cast<uintptr_t>(q) & 15) == 0) {
+        const int64_t n4 = n / 4;
+        for (int64_t i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(q)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) q[i] = 0.0f;
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += 256) q[i] = 0.0f;
+    }
+}
+
+extern "C" int mf_zero_ranges(float* base, const int64_t* offs, const int64_t* lens, int32_t count, void* stream) {
+    MF_CHECK_ARG(base && offs && lens && count >= 0 && count < (1 << 30), "mf_zero_ranges: bad arguments");
+    if (count == 0) return MF_OK;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)count), dim3(256), 0, (hipStream_t)stream, base, offs, lens);
+    MF_CHECK_LAUNCH("mf_zero_ranges");
+    return MF_OK;
+}
+
 static int g_wgrad_dma = getenv("MFHIP_WGRAD_NO_DMA") ? 0 : 1;      // the LDS-DMA form of the bf16-input weight gradient
 extern "C" void mf_debug_set_wgrad_dma(int on) { g_wgrad_dma = on; }  // developer / test switch (the two forms are bit-identical)
 

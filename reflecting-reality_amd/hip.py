@@ -126,7 +126,7 @@ EXPORTS = [
     "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
     "mf_attention_f16x3", "mf_attention_f16x3_lse", "mf_sizeof_attn_bwd_desc", "mf_attention_bwd_f16x3", "mf_rowdot_heads",
     "mf_attention_bwd_bf16", "mf_attention_bf16_lse", "mf_rowdot_heads_bf16", "mf_cast_bf16_colsum", "mf_cast_bf16_colsum_ws_floats",
-    "mf_transpose_bf16_bf16", "mf_geglu_bwd_bf16", "mf_geglu_bwd_bf16_ws_floats", "mf_rowdot_heads_cast", "mf_debug_set_wgrad_dma",
+    "mf_transpose_bf16_bf16", "mf_geglu_bwd_bf16", "mf_geglu_bwd_bf16_ws_floats", "mf_rowdot_heads_cast", "mf_debug_set_wgrad_dma", "mf_zero_ranges",
     "mf_split_halves", "mf_split_overflow", "mf_quantize_rows_fp8",
     "mf_pack_nhwc", "mf_unpack_nchw", "mf_add", "mf_cast_bf16", "mf_geglu", "mf_timestep_embedding", "mf_silu_f32",
     "mf_cfg_ddim_step", "mf_cfg_ddim_step_dev", "mf_cfg_combine", "mf_axpby_n", "mf_mse_loss", "mf_vae_sample", "mf_nearest_resize",
@@ -999,6 +999,16 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, code: int
     ws = scratch("wgrad", WGRAD_WS_FLOATS, x.device)
     d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
     _check(load().mf_conv_wgrad(C.byref(d), _stream()), "mf_conv_wgrad")
+
+
+def zero_ranges(base: torch.Tensor, offs: torch.Tensor, lens: torch.Tensor) -> None:
+    """base[offs[i] : offs[i] + lens[i]] = 0 in one launch (mf_zero_ranges; offs / lens: int64 device tensors)."""
+    _f32(base)
+    _req_cuda(offs, lens)
+    if offs.dtype != torch.int64 or lens.dtype != torch.int64 or offs.numel() != lens.numel() or not (offs.is_contiguous() and lens.is_contiguous()):
+        raise MfhipError("zero_ranges: two contiguous int64 device tensors of one length")
+    _check(load().mf_zero_ranges(C.c_void_p(base.data_ptr()), C.c_void_p(offs.data_ptr()), C.c_void_p(lens.data_ptr()), offs.numel(), _stream()),
+           "mf_zero_ranges")
 
 
 def set_wgrad_dma(on: bool) -> None:

@@ -173,11 +173,16 @@ class HipModel:
         self.flat_g = torch.zeros(cap, dtype=F32, device=self.device) if self._requires_grad else None
         self._arena_used = 0
         self._pmap = OrderedDict()
+        self._plist = []               # (Param, arena offset) in allocation order
+        self._fw_params = []           # conv / linear weights of _conv_param: one ConvWeight each, whole [N][K] written by its wgrad
+        self._zero_tbl = None
         self.training = True
         self._src = None
         self._prepare({k: v.to("cpu", F32) for k, v in src.items()})
         self._weights_gen += 1
         self._ready = True
+        if self.flat_g is not None:
+            self._zero_table()                 # built here (host -> device copies): never inside a graph capture
         return self
 
     def _alloc(self, name: str, t: torch.Tensor, meta: tuple) -> Param:
@@ -193,7 +198,49 @@ class HipModel:
         self._arena_used = a + (n + 7) // 8 * 8
         p = Param(name, w, g)
         self._pmap[name] = (a, tuple(t.shape), meta)
+        self._plist.append((p, a))
         return p
+
+    def zero_grad_for_step(self) -> None:
+        """optimizer.zero_grad() (train_brushnet_mirror.py:1466) without clearing the whole arena: the conv / linear weights — all
+        but a few thousand of its floats — are marked `fresh`, so that their first mf_conv_wgrad of the step WRITES the gradient
+        (autograd._conv_grads), and only the small accumulated parameters (biases, norm scales / shifts) are zeroed, in one launch
+        (mf_zero_ranges).  finish_fresh() clears whatever weight no backward pass reached."""
+        if self.flat_g is None:
+            return
+        if not hasattr(self, "_fw_params"):          # a model with its own arena set-up: clear everything
+            self.flat_g.zero_()
+            return
+        tbl = self._zero_table()
+        if tbl[1].numel():
+            hip.zero_ranges(self.flat_g, tbl[1], tbl[2])
+        for prm in tbl[3]:
+            prm.fresh = True
+
+    def _zero_table(self):
+        """(arena address, offsets, lengths of the parameters zero_grad_for_step clears, the weights it marks fresh instead)."""
+        tbl = self._zero_tbl
+        if tbl is None or tbl[0] != self.flat_g.data_ptr():
+            conv = {id(prm): prm for prm in self._fw_params}
+            offs, lens = [], []
+            for prm, a in self._plist:
+                if prm.grad is not None and id(prm) not in conv:
+                    offs.append(a)
+                    lens.append(prm.grad.numel())
+            dev = self.flat_g.device
+            tbl = self._zero_tbl = (self.flat_g.data_ptr(), torch.tensor(offs, dtype=torch.int64, device=dev),
+                                    torch.tensor(lens, dtype=torch.int64, device=dev), list(conv.values()))
+        return tbl
+
+    def finish_fresh(self) -> None:
+        """After the backward pass: a weight still marked fresh received no gradient this step — clear it (it holds stale values)."""
+        tbl = getattr(self, "_zero_tbl", None)
+        if tbl is None:
+            return
+        for prm in tbl[3]:
+            if prm.fresh:
+                prm.grad.zero_()
+                prm.fresh = False
 
     def num_arena_floats(self) -> int:
         return self._arena_used
@@ -330,6 +377,8 @@ class HipModel:
             meta = ("pad_rows", name + ".weight", n, meta)
             rows = n_pad
         p_w = self._alloc(name + ".weight", wk, meta)
+        if rows == n and p_w.grad is not None:
+            self._fw_params.append(p_w)        # eligible for zero_grad_for_step's write-first (never the row-padded / fused matrices)
         p_b = None
         if bias is not None:
             bk = torch.nn.functional.pad(bias.float(), (0, rows - n))

@@ -116,9 +116,20 @@ class AdamW:
         self.exp_avg = [torch.zeros(m.num_arena_floats(), dtype=torch.float32, device=m.device) for m in self.models]
         self.exp_avg_sq = [torch.zeros_like(t) for t in self.exp_avg]
 
-    def zero_grad(self, set_to_none: bool = False) -> None:
+    def zero_grad(self, set_to_none: bool = False, for_step: bool = False) -> None:
+        """for_step (train_step / GraphedTrainStep): only the small accumulated parameters are cleared, the weights' first
+        gradient of the step overwrites (models.zero_grad_for_step); otherwise the whole arena is."""
         for m in self.models:
-            m.flat_g.zero_()
+            if for_step and FIRST_WRITE:
+                m.zero_grad_for_step()
+            else:
+                m.flat_g.zero_()
+                for prm, _ in getattr(m, "_plist", ()):
+                    prm.fresh = False
+
+    def finish_fresh(self) -> None:
+        for m in self.models:
+            m.finish_fresh()
 
     def step(self, grad_scale: Optional[torch.Tensor] = None) -> None:
         self.step_count += 1
@@ -159,6 +170,7 @@ class _ClipState:
 
 
 _clip_states: dict = {}
+FIRST_WRITE = os.environ.get("MFHIP_ZERO_WHOLE_ARENA", "0") != "1"         # developer A/B: memset the whole gradient arena every step
 DGRAD_PREFETCH = os.environ.get("MFHIP_NO_DGRAD_PREFETCH", "0") != "1"     # developer A/B
 
 
@@ -201,7 +213,7 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     prec = model.brushnet.prec
     guard = prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and check_overflow      # bf16x1 runs the fp16 split flash attention
     if micro == 0:
-        optimizer.zero_grad()
+        optimizer.zero_grad(for_step=True)
         if guard:
             hip.split_overflow(reset=True)     # flags raised by earlier, unrelated work do not count against this step; the
                                                # forward pass that follows DOES (the flags are sticky until the read below)
@@ -251,6 +263,7 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     if dgrad_ready is not None:
         torch.cuda.current_stream(mods[0].device).wait_event(dgrad_ready)
     tape.backward()
+    optimizer.finish_fresh()
     if tape.dgrad_rebuilt:
         known = {id(c) for c in (prefetch or [])}
         model._dgrad_prefetch = list(prefetch or []) + [c for c in tape.dgrad_rebuilt if id(c) not in known]
@@ -340,7 +353,7 @@ class GraphedTrainStep:
     def _body(self):
         model, prec = self.model, self.model.brushnet.prec
         mods = model.get_trainable_modules()
-        self.opt.zero_grad()
+        self.opt.zero_grad(for_step=True)
         tape = autograd.Tape(prec.tape_code)
         if self.grad_sync is not None:
             self.grad_sync.begin(tape)
@@ -372,6 +385,7 @@ class GraphedTrainStep:
         if dgrad_ready is not None:
             cur.wait_event(dgrad_ready)
         tape.backward()
+        self.opt.finish_fresh()
         if self.grad_sync is not None and self.segments is not None:
             gs = self.grad_sync
             gs.flush()                      # (capturing: reported to _cut like the buckets released during the backward pass)

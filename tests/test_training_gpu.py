@@ -176,6 +176,51 @@ def test_bf16x1_training_step_inside_the_reference_mixed_precision_envelope():
     print(f"   worst ratio to the reference's own bf16 deviation: {worst:.2f}")
 
 
+@pytest.mark.parametrize("prec_name", ["fp32", "bf16x1"])
+def test_step_without_the_arena_memset_equals_the_cleared_arena(prec_name):
+    """train_step clears only the small accumulated parameters and lets each conv / linear weight's first weight gradient of the
+    step WRITE (models.zero_grad_for_step): with the gradient arena poisoned with NaN beforehand, the step's gradients, norm and
+    updated weights are bit-identical to the step that memsets the whole arena; with gradient accumulation the second micro-step
+    adds; a weight no backward pass reaches is cleared."""
+    from reflecting_reality_amd import training as T
+    ns = DDPMScheduler(**SD_SCHED)
+    lat, noi, ts, ehs, cond = _batches()[0]
+
+    def run(first_write, accum):
+        T.FIRST_WRITE = first_write
+        try:
+            model = _model(prec_name).prepare_training()
+            opt = AdamW(model.get_trainable_modules())
+            if first_write:
+                for m in model.get_trainable_modules():          # (the parameters only: the alignment slack between them stays 0)
+                    for prm, _ in m._plist:
+                        if prm.grad is not None:
+                            prm.grad.fill_(float("nan"))
+            for _ in range(accum):
+                loss, norm = train_step(model, ns, opt, lat.to(DEV), noi.to(DEV), ts, ehs.to(DEV), cond.to(DEV), gradient_accumulation_steps=accum)
+            return float(loss), float(norm), [m.flat_g.clone() for m in model.get_trainable_modules()], [m.flat_w.clone() for m in model.get_trainable_modules()], model
+        finally:
+            T.FIRST_WRITE = True
+
+    for accum in (1, 2):
+        a, b = run(True, accum), run(False, accum)
+        assert a[0] == b[0] and a[1] == b[1] and np.isfinite(a[1])
+        for ga, gb in zip(a[2], b[2]):
+            assert torch.equal(ga, gb)
+        for wa, wb in zip(a[3], b[3]):
+            assert torch.equal(wa, wb)
+    # a weight nothing reaches: marked fresh by zero_grad_for_step, cleared by finish_fresh
+    model = a[4]
+    bn = model.brushnet
+    bn.flat_g.fill_(7.0)
+    bn.zero_grad_for_step()
+    assert all(p.fresh for p in bn._fw_params) and float(bn._fw_params[0].grad.abs().max()) == 7.0
+    small = [p for p, _ in bn._plist if p.grad is not None and all(p is not q for q in bn._fw_params)]
+    assert small and all(float(p.grad.abs().max()) == 0.0 for p in small)
+    bn.finish_fresh()
+    assert not any(p.fresh for p in bn._fw_params) and float(bn.flat_g[: bn.num_arena_floats()].abs().max()) == 0.0
+
+
 def test_training_step_is_deterministic_and_checkpoints_resume(tmp_path):
     """Two identical runs give bit-identical weights (fixed-order reductions, no atomics); save_state writes
     checkpoint-N/{brushnet} in the reference's layout, rotates old checkpoints, and load_state resumes: step 2 after a
