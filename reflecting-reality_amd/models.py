@@ -223,10 +223,13 @@ class HipModel:
         if tbl is None or tbl[0] != self.flat_g.data_ptr():
             conv = {id(prm): prm for prm in self._fw_params}
             offs, lens = [], []
+            chunk = 16384                     # floats per block of mf_zero_ranges: a fused matrix (temb_proj: 13 M floats) spreads over the chip
             for prm, a in self._plist:
                 if prm.grad is not None and id(prm) not in conv:
-                    offs.append(a)
-                    lens.append(prm.grad.numel())
+                    n = prm.grad.numel()
+                    for o in range(0, n, chunk):
+                        offs.append(a + o)
+                        lens.append(min(chunk, n - o))
             dev = self.flat_g.device
             tbl = self._zero_tbl = (self.flat_g.data_ptr(), torch.tensor(offs, dtype=torch.int64, device=dev),
                                     torch.tensor(lens, dtype=torch.int64, device=dev), list(conv.values()))
@@ -497,6 +500,8 @@ class _UNetCore(HipModel):
                               ("rows", [n + ".time_emb_proj.bias" for n in names], rows))
             k = ws[0].shape[1]
             self.temb_proj = ConvWeight.from_params(p_w, p_b, f32, sum(rows), k, k, 1, 1, self)
+            if p_w.grad is not None:
+                self._fw_params.append(p_w)        # one Linear, one weight gradient over all its rows: write-first like _conv_param's
         else:
             self.temb_proj = ConvWeight(torch.cat(ws, 0), torch.cat(bs, 0), f32, self.device)
 
