@@ -222,58 +222,57 @@ def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, 
 def _conv_grads(tape: Tape, cw, x, x1, c0, c1, n, gc, gc16, x16, batch, h_in, w_in, h_out, w_out, stride, pad_t, pad_l, upsample) -> None:
     """Weight and data gradients of one conv / linear from its output gradient gc (fp32 [M, n]; None when only the rounded copy
     exists) and / or gc16 (its bf16 copy, MF_BF16X1 on pre-rounded operands)."""
-    if True:
-        if cw.p_w is not None and cw.p_w.grad is not None:
-            acc = not cw.p_w.fresh           # fresh: the arena still holds the previous step's values here — write, do not add
-            cw.p_w.fresh = False
-            if gc16 is not None:
-                hip.conv_wgrad(x16[0], gc16, cw.p_w.grad, code=hip.MF_BF16, c0=c0, x1=x16[1], c1=c1, batch=batch, h_in=h_in, w_in=w_in,
-                               h_out=h_out, w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n,
-                               accumulate=acc)
+    if cw.p_w is not None and cw.p_w.grad is not None:
+        acc = not cw.p_w.fresh           # fresh: the arena still holds the previous step's values here — write, do not add
+        cw.p_w.fresh = False
+        if gc16 is not None:
+            hip.conv_wgrad(x16[0], gc16, cw.p_w.grad, code=hip.MF_BF16, c0=c0, x1=x16[1], c1=c1, batch=batch, h_in=h_in, w_in=w_in,
+                           h_out=h_out, w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n,
+                           accumulate=acc)
+        else:
+            hip.conv_wgrad(x, gc, cw.p_w.grad, code=tape.code, c0=c0, x1=x1, c1=c1, batch=batch, h_in=h_in, w_in=w_in, h_out=h_out,
+                           w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n,
+                           accumulate=acc)
+        tape.param_grad_done(cw.p_w)
+    if not (tape.needs(x) or tape.needs(x1)):
+        return
+    wd = _dgrad_weight(cw, tape)
+    taps = cw.kh * cw.kw
+    # MF_BF16X1 on pre-rounded copies: the gradient is rounded to bf16 once, the transposed weight once per step, and the data
+    # gradient runs on the bf16 LDS-DMA kernels (same arithmetic per product as the in-register rounding)
+    fast = n % 8 == 0 and (taps * n) % 8 == 0 and cw.fast16() and getattr(cw, "_wd16", None) is not None
+    if gc is None and not (fast and stride == 1):
+        raise hip.MfhipError("training: a bf16 output gradient needs the bf16 data-gradient path (stride 1, channels % 8 == 0)")
+    a, gh, gw = gc, h_out, w_out
+    if stride == 2:
+        a = hip.zero_insert2x(gc.view(batch, h_out, w_out, n))
+        gh, gw = 2 * h_out, 2 * w_out
+    elif stride != 1:
+        raise hip.MfhipError("training: only stride 1 / 2 convolutions are differentiated")
+    hu, wu = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
+    outs = []
+    off = 0
+    a16 = (gc16 if (gc16 is not None and stride == 1) else hip.cast_bf16(a.contiguous())) if fast else None
+    for seg, cs in ((x, c0), (x1, c1)):
+        if seg is None:
+            continue
+        if tape.needs(seg):
+            dx = torch.empty(batch, hu, wu, cs, dtype=torch.float32, device=x.device)
+            # what the tensor's other consumers left so far rides the GEMM epilogue as its fp32 residual (no accumulation pass)
+            acc = tape.peek(seg) if (not upsample and cs % 8 == 0) else None
+            ra = acc.view(-1, cs) if acc is not None else None
+            if fast:
+                hip.gemm_conv(a16, cw._wd16[off:off + cs], dx, dtype=hip.MF_BF16, w_split=0, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
+                              h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
+                              ldw=taps * n, n=cs, res0=ra)
             else:
-                hip.conv_wgrad(x, gc, cw.p_w.grad, code=tape.code, c0=c0, x1=x1, c1=c1, batch=batch, h_in=h_in, w_in=w_in, h_out=h_out,
-                               w_out=w_out, kh=cw.kh, kw=cw.kw, stride=stride, pad_t=pad_t, pad_l=pad_l, upsample=upsample, n=n,
-                               accumulate=acc)
-            tape.param_grad_done(cw.p_w)
-        if not (tape.needs(x) or tape.needs(x1)):
-            return
-        wd = _dgrad_weight(cw, tape)
-        taps = cw.kh * cw.kw
-        # MF_BF16X1 on pre-rounded copies: the gradient is rounded to bf16 once, the transposed weight once per step, and the data
-        # gradient runs on the bf16 LDS-DMA kernels (same arithmetic per product as the in-register rounding)
-        fast = n % 8 == 0 and (taps * n) % 8 == 0 and cw.fast16() and getattr(cw, "_wd16", None) is not None
-        if gc is None and not (fast and stride == 1):
-            raise hip.MfhipError("training: a bf16 output gradient needs the bf16 data-gradient path (stride 1, channels % 8 == 0)")
-        a, gh, gw = gc, h_out, w_out
-        if stride == 2:
-            a = hip.zero_insert2x(gc.view(batch, h_out, w_out, n))
-            gh, gw = 2 * h_out, 2 * w_out
-        elif stride != 1:
-            raise hip.MfhipError("training: only stride 1 / 2 convolutions are differentiated")
-        hu, wu = (2 * h_in, 2 * w_in) if upsample else (h_in, w_in)
-        outs = []
-        off = 0
-        a16 = (gc16 if (gc16 is not None and stride == 1) else hip.cast_bf16(a.contiguous())) if fast else None
-        for seg, cs in ((x, c0), (x1, c1)):
-            if seg is None:
-                continue
-            if tape.needs(seg):
-                dx = torch.empty(batch, hu, wu, cs, dtype=torch.float32, device=x.device)
-                # what the tensor's other consumers left so far rides the GEMM epilogue as its fp32 residual (no accumulation pass)
-                acc = tape.peek(seg) if (not upsample and cs % 8 == 0) else None
-                ra = acc.view(-1, cs) if acc is not None else None
-                if fast:
-                    hip.gemm_conv(a16, cw._wd16[off:off + cs], dx, dtype=hip.MF_BF16, w_split=0, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
-                                  h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
-                                  ldw=taps * n, n=cs, res0=ra)
-                else:
-                    hip.gemm_conv(a, wd[off:off + cs], dx, dtype=tape.code, w_split=cw._wd_split, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
-                                  h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
-                                  ldw=cw._wd_ld, n=cs, res0=ra)
-                outs.append((seg, hip.sumpool2x2(dx) if upsample else dx, acc is not None))
-            off += cs
-        for seg, dx, fused in outs:
-            tape.put(seg, dx, fused)
+                hip.gemm_conv(a, wd[off:off + cs], dx, dtype=tape.code, w_split=cw._wd_split, c0=n, lda0=n, batch=batch, h_in=gh, w_in=gw,
+                              h_out=hu, w_out=wu, kh=cw.kh, kw=cw.kw, stride=1, pad_t=cw.kh - 1 - pad_t, pad_l=cw.kw - 1 - pad_l,
+                              ldw=cw._wd_ld, n=cs, res0=ra)
+            outs.append((seg, hip.sumpool2x2(dx) if upsample else dx, acc is not None))
+        off += cs
+    for seg, dx, fused in outs:
+        tape.put(seg, dx, fused)
 
 
 def record_groupnorm(tape: Tape, x0, x1, p_gamma: Param, p_beta: Param, out, groups: int, eps: float, silu: bool, stats=None) -> None:

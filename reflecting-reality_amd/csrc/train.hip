@@ -476,6 +476,7 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(const WgradArgs 
         xcol[i] = (unsigned)((cseg + 8 * ch) * 2);
     }
     const unsigned ystep = (unsigned)(WG_BP * p.lddy * 2);
+    const unsigned ldx2 = (unsigned)(ldx * 2);
     auto issue_tile = [&](int stage, int t) {
         const int m0 = m_begin + t * WG_BP;
 #pragma unroll
@@ -484,12 +485,14 @@ __global__ __launch_bounds__(256, 3) void conv_wgrad_dma_kernel(const WgradArgs 
             const int m = m0 + rowi[i];
             const bool row_ok = m < m_end;
             dma16_buf((row_ok && yok[i]) ? yoff[i] + (unsigned)t * ystep : 0x80000000u, srdY, ly);
+            // 32-bit arithmetic throughout (the host guarantees every byte offset < 2^31): this address computation runs once per
+            // row and tile, and as 64-bit code it cost more VALU issue than the tile's eight MFMAs (10 VALU per MFMA under the counters)
             unsigned xo = 0x80000000u;
-            if (row_ok && xok[i]) {
+            {
                 const int b = wg_fastdiv(m, p.mul_howo, p.sh_howo), rr = m - b * p.HoWo, oy = wg_fastdiv(rr, p.mul_wo, p.sh_wo), ox = rr - oy * p.Wo;
                 const int iy = oy * p.stride - p.pad_t + ky, ix = ox * p.stride - p.pad_l + kx;
-                if ((unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim)
-                    xo = (unsigned)((((int64_t)b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups)) * ldx * 2) + xcol[i];
+                const unsigned pix = (unsigned)((b * p.Hin + (iy >> p.ups)) * p.Win + (ix >> p.ups));
+                if (row_ok && xok[i] && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim) xo = pix * ldx2 + xcol[i];
             }
             dma16_buf(xo, srdX, ly + WT_PLANE);
         }
