@@ -175,7 +175,11 @@ def train_main(a, D):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     hip.load()
-    prec = a.precision if a.precision in ("fp32", "f16x3", "bf16x1") else "f16x3"
+    # --precision bf16 (the default) = the arithmetic of the reference's --mixed_precision=bf16: bf16 products on pre-rounded operands,
+    # fp32 master weights / residual stream / summed gradients ("bf16x1", pinned to the reference's own bf16 deviation); f16x3 is the
+    # mode that meets the fp32-class bounds (2e-4 of every gradient) and fp32 the plain one
+    prec = {"bf16": "bf16x1"}.get(a.precision, a.precision)
+    prec = prec if prec in ("fp32", "f16x3", "bf16x1") else "f16x3"
     t0 = time.time()
     unet = UNet2DConditionModel(dict(SD15_UNET), precision=prec, device=device)
     unet.load_state_dict(synth.state_dict_for(unet.param_shapes(), 0))
