@@ -47,7 +47,10 @@ class Tape:
         self.stop = set()                      # storages that need no gradient (the batch's inputs)
         self.on_param_grad: Optional[Callable[[Param], None]] = None   # gradient-bucket hook (distributed.GradBuckets)
         self.dgrad_rebuilt: list = []          # trainable weights whose data-gradient layout this backward had to rebuild
-        self.colsum_done = set()               # data_ptr of bf16 gradients whose producer already added their column sums (a bias gradient)
+        # bf16 gradients whose producer already added their column sums (a bias gradient), by address; the tensor itself is kept
+        # as the value, so the caching allocator cannot hand that address to a later gradient while the entry exists, and the
+        # consumer removes the entry when it takes the gradient (a stale address must never read as 'done')
+        self.colsum_done: Dict[int, torch.Tensor] = {}
 
     # ---- bookkeeping ---------------------------------------------------------------------------------------
     def no_grad(self, *ts: Optional[torch.Tensor]) -> None:
@@ -183,8 +186,9 @@ def record_conv(tape: Tape, x, x1, cw, out, *, batch, h_in, w_in, h_out, w_out, 
             # a gradient its producer already rounded (the bf16 tensors of the MF_BF16X1 mode: q / k / v and FeedForward's hidden
             # tensor): it IS the 16-bit operand; a bias gradient was added by the producer from the same pass
             want_b = cw.p_bias is not None and cw.p_bias.grad is not None
+            bias_done = tape.colsum_done.pop(g.data_ptr(), None) is not None
             if (res0 is not None or res1 is not None or temb is not None or alpha != 1.0 or x16 is None or n % 8 or stride != 1
-                    or (want_b and g.data_ptr() not in tape.colsum_done)):
+                    or (want_b and not bias_done)):
                 raise hip.MfhipError("training: a bf16 output gradient needs a plain fast-path GEMM (no residual / temb / scale, n % 8 == 0)")
             if want_b:
                 tape.param_grad_done(cw.p_bias)

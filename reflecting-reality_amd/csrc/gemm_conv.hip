@@ -104,6 +104,12 @@ const TileCfg kTiles[] = {
     {256, 128, 256, 3},        // 46  = 45 on 16x16x32 MFMAs
     {128, 160, 256, 2, 0, 1},  // 47  = 38 / 40 with EIGHT compute waves (4x2 of 32x80, 16x16x32 MFMAs only) + 4 staging
     {128, 160, 256, 3},        // 48  = 41 / 43 with eight compute waves of 32x80 + 4 staging
+    // 49-52 (round 5): 64x80 wave tiles on 16x16x32 MFMAs — 9 fragment reads per 20 MFMAs instead of 12 (32x160) or 14 (32x80) —
+    // with the cross-tile fragment pipeline (gemm_conv_kernel.h, XT)
+    {256, 160, 256, 2, 0, 1},  // 49  dx-reuse conv, 4x2 compute waves of 64x80 + 4 staging (the successor of 37 / 39)
+    {256, 160, 256, 3},        // 50  plain ring, 4x2 compute waves of 64x80 + 4 staging (the successor of 42)
+    {128, 160, 256, 2, 0, 1},  // 51  dx-reuse conv, 2x2 compute waves of 64x80 + 4 staging
+    {128, 160, 256, 3},        // 52  plain ring, 2x2 compute waves of 64x80 + 4 staging
     // (round 3: FOUR-deep rings of 48 / 41 — 147 KB, three K tiles in flight — were built, parity-tested and offered to the tuner
     // over the whole step: picked for none of 100 shapes, gpurun_out/r03e/tune_user.json; removed again)
 };
@@ -242,7 +248,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         MF_CHECK_ARG(d->dtype == MF_BF16 && d->a_dtype == MF_BF16 && d->kh == 1 && d->kw == 1 && d->c1 == 0 && d->nz == 1 &&
                          (d->splitk == 0 || d->splitk == 1) && d->a_scale == nullptr && d->w_scale == nullptr,
                      "mf_gemm_conv: ln_colsum / vt_out need a plain bf16 1x1 GEMM (one A segment, no batching, no split-K, no scales)");
-        MF_CHECK_ARG(d->tile == 0 || (d->tile >= 41 && d->tile <= 48 && d->tile != 47), "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (tiles 41-46, 48 do)", d->tile);
+        MF_CHECK_ARG(d->tile == 0 || (d->tile >= 41 && d->tile <= 48 && d->tile != 47) || d->tile == 50 || d->tile == 52,
+                     "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (the warp-specialised ring tiles 41-46, 48, 50, 52 do)", d->tile);
         MF_CHECK_ARG(!d->ln_colsum || (mf_aligned16(d->ln_colsum) && d->n % 8 == 0 && d->ln_eps > 0.0f), "mf_gemm_conv: ln_colsum must be 16-byte aligned, n %% 8 == 0, ln_eps > 0");
         if (d->vt_out) {
             MF_CHECK_ARG(d->out_dtype == MF_BF16 && mf_aligned16(d->vt_out) && d->vt_tokens > 0 && d->vt_tokens % 8 == 0 && a.M % d->vt_tokens == 0 &&
@@ -375,6 +382,22 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
                   d->w_out == d->w_in;
     a.tiles_n = cdiv(a.N, tc.bn);
     a.tiles_m = cdiv(a.M, tc.bm);
+    {   // staged epilogue rows (GemmArgs::epb): warp-specialised tiles, the vector epilogue, per-column bias, no split-K slabs;
+        // a time embedding needs Ho * Wo a power of two and the tile's images inside the rows the tile reserves
+        static const bool off = getenv("MFHIP_NO_EPB") != nullptr;          // A/B switch
+        const int nimg_max = tile >= 37 ? epb_nimg(tc.bm, tc.bn, 3, tc.dxr != 0, true) : 0;
+        bool ok = !off && nimg_max > 0 && a.vec_ok && a.bias_mode == 0 && a.splitk == 1 && (a.bias || a.temb || a.ln_cs);
+        a.epb_sh = 31;
+        if (ok && a.temb) {
+            const int hw = a.HoWo;
+            int sh = 0;
+            while ((1 << sh) < hw) ++sh;
+            const int nimg = hw >= tc.bm ? (hw % tc.bm == 0 ? 1 : 0) : (tc.bm % hw == 0 ? tc.bm / hw : 0);
+            ok = (1 << sh) == hw && nimg >= 1 && nimg <= nimg_max;
+            a.epb_sh = sh;
+        }
+        a.epb = ok ? 1 : 0;
+    }
     const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * a.splitk;
     MF_CHECK_ARG(nblk < (1ll << 31) && a.nz < 65536, "mf_gemm_conv: grid too large");
     a.nblk = (int)nblk;
@@ -409,7 +432,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         launched = (a_f32 || tile <= 6) ? launch_bf16_a(tile, a, grid, s, a_f32)
                    : tile <= 24         ? launch_bf16_b(tile, a, grid, s)
                    : tile <= 36         ? launch_bf16_c(tile, a, grid, s)
-                   : (tile <= 40 || tile == 47) ? launch_bf16_ws_dx(tile, a, grid, s)
+                   : (tile <= 40 || tile == 47 || tile == 49 || tile == 51) ? launch_bf16_ws_dx(tile, a, grid, s)
                                                 : launch_bf16_ws_ring(tile, a, grid, s);
     } else {
         launched = tile <= 12 ? launch_f32_a(tile, a, grid, s) : launch_f32_b(tile, a, grid, s);

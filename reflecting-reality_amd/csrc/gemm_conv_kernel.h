@@ -33,6 +33,11 @@
 
 #include <type_traits>
 
+// developer switch (A/B builds): 0 restores the one-barrier-per-tile consumer loop without the cross-tile fragment pipeline
+#ifndef MF_XTAP
+#define MF_XTAP 1
+#endif
+
 namespace mfgemm {
 
 static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];   // zero-initialised module global (one per translation unit)
@@ -45,9 +50,18 @@ static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];   /
     if (t_ == 0) p.stamps[(size_t)blockIdx.x * 32 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
     else if (t_ == (int)blockDim.x - 256) p.stamps[(size_t)blockIdx.x * 32 + 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #define MF_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")     // slot 5 = "the epilogue's stores have left"
+// who waits for whom in the warp-specialised main loops: shader-clock sums per wave (slots 13-15 of wave 0 / the first staging wave)
+#define MF_CLK(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define MF_SUM(acc, a, b) acc += (b) - (a)
+#define MF_PUT(slot, v) do { if (p.stamps) { const int t_ = (int)threadIdx.x; \
+    if (t_ == 0) p.stamps[(size_t)blockIdx.x * 32 + (slot)] = (v); \
+    else if (t_ == (int)blockDim.x - 256) p.stamps[(size_t)blockIdx.x * 32 + 16 + (slot)] = (v); } } while (0)
 #else
 #define MF_STAMP(slot) do { } while (0)
 #define MF_STAMP_DRAIN() do { } while (0)
+#define MF_CLK(v) do { } while (0)
+#define MF_SUM(acc, a, b) do { } while (0)
+#define MF_PUT(slot, v) do { } while (0)
 #endif
 
 struct GemmArgs {
@@ -72,6 +86,12 @@ struct GemmArgs {
     int tiles_n, tiles_m, ord_mfast, ord_pw, nblk, vec_ok, fast, dbg_no_res_pre;
     int dbg_epi;             // developer switch (MFHIP_DBG_EPI, stamped builds): bit 0 skip the epilogue's global stores, bit 1 skip its slab reads
     int pointwise;           // kh = kw = 1, stride 1, no padding, no upsample, same extent: input pixel index == output row
+    // Warp-specialised tiles: the per-column epilogue operands of the block's BN columns (bias, the folded LayerNorm's column sums,
+    // the time-embedding row of each image the tile touches) are fetched into LDS by the staging waves' FIRST DMAs, so the
+    // epilogue's item loops contain no global load: loads and stores share vmcnt and return in order, and a bias load issued after
+    // the previous item's store used to wait for that store's round trip (~1.5 us per 64-item chunk, stamped).
+    int epb;                 // 1: the rows are staged (the host checked the geometry: epb_layout below)
+    int epb_sh;              // log2(Ho * Wo) (a power of two whenever temb is staged): image of output row m = m >> epb_sh
     unsigned* ovf;           // device flag raised when an MF_F16X3 operand exceeded the fp16 range (mf_common.h)
     unsigned long long* stamps;   // developer build (-DMF_STAMPS) only: [blocks][32] phase time stamps, or nullptr
     // LayerNorm folded into this GEMM (warp-specialised ring tiles): ln_cs[n] = sum_k W'[n][k] of the gamma-scaled weight;
@@ -125,8 +145,11 @@ __device__ __forceinline__ void unpack8_bf16(const uint4& u, float* o) {
 }
 
 // `pre`: the bf16 residual vectors of this item were fetched ahead of the LDS transposition (q0 / q1).
+// `eb` (warp-specialised tiles with staged epilogue rows): LDS address of this item's 8 columns in the bias row; `et`: in the
+// time-embedding row of the item's image (rows are `pitch` floats apart: see epb_off).
 __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, int m, int n, float* v, bool pre = false,
-                                                const uint4& q0 = uint4{0, 0, 0, 0}, const uint4& q1 = uint4{0, 0, 0, 0}, int zq = 0) {
+                                                const uint4& q0 = uint4{0, 0, 0, 0}, const uint4& q1 = uint4{0, 0, 0, 0}, int zq = 0,
+                                                const char* eb = nullptr, const char* et = nullptr) {
     if (p.rs || p.cs) {
         const float r = p.rs ? p.rs[zq * p.rs_zs + m] : 1.0f;
         float c8[8] = {1, 1, 1, 1, 1, 1, 1, 1};
@@ -141,14 +164,16 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
             for (int j = 0; j < 8; ++j) v[j] += b;
         } else {
             float b[8];
-            load8_as_f32((const char*)p.bias, MF_F32, n, b);
+            if (eb) load8_as_f32(eb, MF_F32, 0, b);
+            else load8_as_f32((const char*)p.bias, MF_F32, n, b);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += b[j];
         }
     }
     if (p.temb) {
         float t[8];
-        load8_as_f32((const char*)p.temb, MF_F32, (int64_t)(m / p.HoWo) * p.ld_temb + n, t);
+        if (et) load8_as_f32(et, MF_F32, 0, t);
+        else load8_as_f32((const char*)p.temb, MF_F32, (int64_t)(m / p.HoWo) * p.ld_temb + n, t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += t[j];
     }
@@ -240,6 +265,18 @@ __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_off) : "memory");
+}
+
+// LDS layout of the staged epilogue rows of a warp-specialised tile: [bias][ln_colsum][temb of image 0 .. nimg-1], fp32, each row
+// padded to whole 64-float DMA pieces; placed behind the ring (and the LayerNorm statistics).  nimg = 0: the tile has no room.
+constexpr int epb_pitch(int bn) { return (bn + 63) / 64 * 64; }
+constexpr int epb_off(int bm, int bn, int stages, bool dx, bool ws) {
+    return dx ? 2 * (bm + 32) * 128 + (ws ? stages : 2) * bn * 128 : stages * (bm + bn) * 128 + (ws ? bm * 8 : 0);
+}
+constexpr int epb_nimg(int bm, int bn, int stages, bool dx, bool ws) {
+    if (!ws) return 0;
+    const int room = 160 * 1024 - epb_off(bm, bn, stages, dx, ws), row = epb_pitch(bn) * 4;
+    return room >= 6 * row ? 4 : (room >= 3 * row ? 1 : 0);
 }
 
 // waves per SIMD the LDS footprint allows (register budget follows from it: 512 / waves per lane)
@@ -341,7 +378,9 @@ void gemm_conv_kernel(const GemmArgs p) {
     // P16 (warp-specialised dx-reuse convs, bf16): the wave tile is made of 16x16 MFMA tiles only (v_mfma_f32_16x16x32_bf16), so
     // WN needs to be a multiple of 16, not 32: 4x2 compute waves of 32x80 put TWO compute waves on every SIMD for a
     // 128x160 block (a CU's whole share of the 32x32-level convs)
-    static_assert(!P16 || (WS && DT == MF_BF16 && !M16 && WM == 32 && WN % 16 == 0), "P16: warp-specialised forms, 32-row wave tiles");
+    // (round 5: 64-row wave tiles too — 4x2 waves of 64x80 on a 256x160 block read 9 fragments per 20 MFMAs where 8x1 waves of
+    // 32x160 read 12, and their two register sets of the cross-tile pipeline fit the 168 registers of three waves per SIMD)
+    static_assert(!P16 || (WS && DT == MF_BF16 && !M16 && (WM == 32 || WM == 64) && WN % 16 == 0), "P16: warp-specialised forms, 32- or 64-row wave tiles");
     constexpr int MT = WM / 32, NT = P16 ? 1 : WN / 32;
     constexpr int MT16 = WM / 16, NT16 = WN / 16;
     constexpr int RPP = NSTG / 8;                // rows staged per pass (8 lanes per 128-B row)
@@ -392,6 +431,30 @@ void gemm_conv_kernel(const GemmArgs p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
     const int zq = z / p.zdiv, zr = z - zq * p.zdiv;
+
+    // ---- staged epilogue rows (see GemmArgs::epb): the staging waves' first DMAs ----------------------------------------
+    constexpr int EPB_NIMG = epb_nimg(BM, BN, STAGES, DXR, WS), EPB_PITCH = epb_pitch(BN), EPB_OFF = epb_off(BM, BN, STAGES, DXR, WS);
+    const bool epb = EPB_NIMG > 0 && p.epb != 0;
+    if constexpr (EPB_NIMG > 0) {
+        if (producer && epb) {
+            constexpr int PIECES = EPB_PITCH / 64;
+            const int img0 = m0 >> p.epb_sh;
+            const unsigned lds_e = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem) + EPB_OFF;
+            const int nb = p.M >> p.epb_sh;                           // images (only read when temb is staged)
+            for (int row = 0; row < 2 + EPB_NIMG; ++row) {
+                const float* base = row == 0 ? p.bias : row == 1 ? p.ln_cs
+                                    : (p.temb && img0 + row - 2 < nb) ? p.temb + (int64_t)(img0 + row - 2) * p.ld_temb : nullptr;
+                if (base == nullptr) continue;
+                const srd_t srd = make_srd(reinterpret_cast<const char*>(base), (unsigned)p.N * 4u);
+#pragma unroll
+                for (int q = 0; q < PIECES; ++q) {
+                    if (((row * PIECES + q) & 3) != wave) continue;   // dealt over the four staging waves
+                    const int col = q * 64 + lane;
+                    dma4_buf(col < BN ? (unsigned)(n0 + col) * 4u : 0x80000000u, srd, lds_e + (row * EPB_PITCH + q * 64) * 4);
+                }
+            }
+        }
+    }
 
     const char* a0 = p.a0 + (zq * p.a_zs_o + zr * p.a_zs_i) * AES;
     const char* a1 = p.a1 ? p.a1 + (zq * p.a_zs_o + zr * p.a_zs_i) * AES : a0;
@@ -813,6 +876,81 @@ void gemm_conv_kernel(const GemmArgs p) {
         mma(fa1, fb1);
     };
 
+    // ---- cross-tap software pipeline of the warp-specialised bf16 forms (XT) -------------------------------------------
+    // The compute waves of a block meet at one barrier per K tile, so without it they all read their fragments at the same
+    // time and then all multiply: the LDS pipe and the matrix pipe take turns (measured: 128x160 / 8 + 4 waves, 1200 clocks per
+    // K tile = 580 of LDS traffic + 640 of MFMA).  Here a K tile is two halves with a register set each (xa / xb [0], [1]):
+    //     load half 1 of tile t | MFMAs of half 0 | lgkmcnt(0), barrier #(t + 1) | load half 0 of tile t + 1 | MFMAs of half 1
+    // i.e. the barrier sits in the MIDDLE of a tile's arithmetic and every fragment read flies under the other half's MFMAs.
+    // The producer protocol is unchanged: barrier #k still means "tile k has landed" and "tile k - 1 is no longer read" — the
+    // consumers now arrive when tile k - 1's READS are complete instead of its MFMAs.  Same accumulation order: bit-identical.
+    // Not for 8 x 1 compute waves of 32x160 (tiles 37 / 39 / 42): two sets of 12 fragments beside 80 accumulators exceed the 168
+    // registers of three waves per SIMD and spill INSIDE the loop; tiles 49 / 50 are their 4 x 2 (64x80) successors.
+    constexpr bool XT = WS && DT == MF_BF16 && !A_F32 && (MF_XTAP != 0) && !(WAVES_M == 8 && WAVES_N == 1);
+    constexpr int XNA = !XT ? 1 : (P16 ? MT16 : 2 * MT), XNB = !XT ? 1 : (P16 ? NT16 : 2 * NT);
+    uint4 xa[2][XNA], xb[2][XNB];
+    // fragments of half H (compile-time) of one K tile.  arow(t): LDS row of this lane's row of A fragment t (P16 / M16: 16-row
+    // fragments, r16; else 32-row fragments, frow); Ab: the A buffer; Bb: the W tile's first row of this wave (lane row included).
+    auto xt_load = [&](auto H, const char* Ab, auto arow, const char* Bb) {
+        constexpr int hh = decltype(H)::value;
+        if constexpr (P16 || M16) {
+            const int key16 = (r16 >> 1) & 7;
+#pragma unroll
+            for (int t = 0; t < XNA; ++t) {
+                const int r = arow(t);
+                xa[hh][t] = *reinterpret_cast<const uint4*>(Ab + r * 128 + (((4 * hh + kg) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int t = 0; t < XNB; ++t) xb[hh][t] = *reinterpret_cast<const uint4*>(Bb + t * 16 * 128 + (((4 * hh + kg) ^ key16) << 4));
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int ch = 2 * (2 * hh + kk) + fh;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int r = arow(i);
+                    xa[hh][kk * MT + i] = *reinterpret_cast<const uint4*>(Ab + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) xb[hh][kk * NT + j] = *reinterpret_cast<const uint4*>(Bb + j * 32 * 128 + ((ch ^ fkey) << 4));
+            }
+        }
+    };
+    auto xt_mma = [&](auto H) {
+        constexpr int hh = decltype(H)::value;
+        if constexpr (P16) {
+#pragma unroll
+            for (int a = 0; a < MT16; ++a)
+#pragma unroll
+                for (int b = 0; b < NT16; ++b)
+                    acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xa[hh][a]),
+                                                                          __builtin_bit_cast(bf16x8_t, xb[hh][b]), acc16[a][b], 0, 0, 0);
+        } else if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4_t c = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xa[hh][2 * i + (q >> 1)]),
+                                                                    __builtin_bit_cast(bf16x8_t, xb[hh][2 * j + (q & 1)]), c, 0, 0, 0);
+                        acc[i][j][4 * q] = c[0]; acc[i][j][4 * q + 1] = c[1]; acc[i][j][4 * q + 2] = c[2]; acc[i][j][4 * q + 3] = c[3];
+                    }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, xa[hh][kk * MT + i]),
+                                                                            __builtin_bit_cast(bf16x8_t, xb[hh][kk * NT + j]), acc[i][j], 0, 0, 0);
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+
     // ---- main loop ------------------------------------------------------------------------
     MF_STAMP(1);
     if (nt > 0) {
@@ -1013,15 +1151,60 @@ void gemm_conv_kernel(const GemmArgs p) {
                     wait_for(0);
                     __builtin_amdgcn_s_barrier();                  // #0
                     MF_STAMP(2);
+                    [[maybe_unused]] unsigned long long w_iss = 0, w_vm = 0, w_bar = 0;
                     for (int t = 0; t + 1 < nt; ++t) {
+                        MF_CLK(c0);
                         if (t + PFD < nt) issue_next();            // tap t + PFD
+                        MF_CLK(c1);
                         wait_for(t + 1);
+                        MF_CLK(c2);
                         __builtin_amdgcn_s_barrier();              // #(t + 1)
+                        MF_CLK(c3);
+                        MF_SUM(w_iss, c0, c1); MF_SUM(w_vm, c1, c2); MF_SUM(w_bar, c2, c3);
                     }
+                    MF_PUT(13, w_vm); MF_PUT(14, w_bar); MF_PUT(15, w_iss);
                 } else {
                     int c_kx = 0, c_grp = 0, c_st = 0;
                     __builtin_amdgcn_s_barrier();                  // #0
                     MF_STAMP(2);
+                    if constexpr (XT) {
+                        // tap (c_grp, c_st, c_kx): A window buffer, W stage and the window's row shift
+                        auto ld = [&](auto H) {
+                            const int kx = c_kx;
+                            const char* Ab = smem + (c_grp & 1) * AB;
+                            const char* Bb = smem + 2 * AB + c_st * WB + (wn * WN + ((P16 || M16) ? r16 : frow)) * 128;
+                            if constexpr (P16 || M16) xt_load(H, Ab, [&](int t) { return arow16[t] + kx; }, Bb);
+                            else xt_load(H, Ab, [&](int i) { return arow0[i] + kx; }, Bb);
+                        };
+                        // (the last tap is peeled: a straight-line loop body lets hipcc's waitcnt pass count the reads in flight
+                        // across the back edge instead of draining lgkmcnt(0) in front of the first MFMA)
+                        ld(H0{});
+                        [[maybe_unused]] unsigned long long w_bar = 0;
+                        MF_CLK(tl0);
+                        for (int t = 0; t + 1 < nt; ++t) {
+                            ld(H1{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            xt_mma(H0{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            c_st = c_st == WST - 1 ? 0 : c_st + 1;
+                            if (++c_kx == 3) { c_kx = 0; ++c_grp; }
+                            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): every read of tap t has returned
+                            MF_CLK(tb0);
+                            __builtin_amdgcn_s_barrier();               // #(t + 1): tap t + 1 has landed
+                            MF_CLK(tb1);
+                            MF_SUM(w_bar, tb0, tb1);
+                            ld(H0{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            xt_mma(H1{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ld(H1{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        xt_mma(H0{});
+                        xt_mma(H1{});
+                        MF_CLK(tl1);
+                        MF_PUT(13, w_bar); MF_PUT(14, tl1 - tl0); MF_PUT(15, (unsigned long long)nt);
+                    } else
                     for (int t = 0; t < nt; ++t) {
                         compute3(c_grp & 1, c_st, c_kx);
                         c_st = c_st == WST - 1 ? 0 : c_st + 1;
@@ -1113,12 +1296,19 @@ void gemm_conv_kernel(const GemmArgs p) {
                     wait_for(0);
                     __builtin_amdgcn_s_barrier();                  // #0
                     MF_STAMP(2);
+                    [[maybe_unused]] unsigned long long w_iss = 0, w_vm = 0, w_bar = 0;
                     for (int t = 0; t + 1 < nt; ++t) {
+                        MF_CLK(c0);
                         if (t + PF < nt) issue_next();             // into the stage of tile t - 1: the DMA goes out FIRST ...
                         if (lnf) ln_tile();                        // ... and tile t is summed while it flies
+                        MF_CLK(c1);
                         wait_for(t + 1);
+                        MF_CLK(c2);
                         __builtin_amdgcn_s_barrier();              // #(t + 1)
+                        MF_CLK(c3);
+                        MF_SUM(w_iss, c0, c1); MF_SUM(w_vm, c1, c2); MF_SUM(w_bar, c2, c3);
                     }
+                    MF_PUT(13, w_vm); MF_PUT(14, w_bar); MF_PUT(15, w_iss);
                     if (lnf) {
                         ln_tile();                                 // tile nt - 1
                         float2* lnst = reinterpret_cast<float2*>(smem + STAGES * STAGE_BYTES);   // [BM] (mean, rstd): past the ring
@@ -1141,6 +1331,40 @@ void gemm_conv_kernel(const GemmArgs p) {
                     int st_c = 0;
                     __builtin_amdgcn_s_barrier();                  // #0
                     MF_STAMP(2);
+                    if constexpr (XT) {
+                        const int arb = wm * WM + ((P16 || M16) ? r16 : frow);      // this lane's row of A fragment 0
+                        auto ld = [&](auto H) {
+                            const char* Ab = smem + st_c * STAGE_BYTES;
+                            const char* Bb = Ab + BM * 128 + (wn * WN + ((P16 || M16) ? r16 : frow)) * 128;
+                            if constexpr (P16 || M16) xt_load(H, Ab, [&](int t) { return arb + t * 16; }, Bb);
+                            else xt_load(H, Ab, [&](int i) { return arb + i * 32; }, Bb);
+                        };
+                        ld(H0{});
+                        [[maybe_unused]] unsigned long long w_bar = 0;
+                        MF_CLK(tl0);
+                        for (int t = 0; t + 1 < nt; ++t) {             // (last tile peeled: see the dx-reuse loop)
+                            ld(H1{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            xt_mma(H0{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
+                            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): every read of tile t has returned
+                            MF_CLK(tb0);
+                            __builtin_amdgcn_s_barrier();               // #(t + 1): tile t + 1 has landed
+                            MF_CLK(tb1);
+                            MF_SUM(w_bar, tb0, tb1);
+                            ld(H0{});
+                            __builtin_amdgcn_sched_barrier(0);
+                            xt_mma(H1{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        ld(H1{});
+                        __builtin_amdgcn_sched_barrier(0);
+                        xt_mma(H0{});
+                        xt_mma(H1{});
+                        MF_CLK(tl1);
+                        MF_PUT(13, w_bar); MF_PUT(14, tl1 - tl0); MF_PUT(15, (unsigned long long)nt);
+                    } else
                     for (int t = 0; t < nt; ++t) {
                         compute(st_c);
                         st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
@@ -1177,6 +1401,9 @@ void gemm_conv_kernel(const GemmArgs p) {
         }
     }
     MF_STAMP(3);
+    if constexpr (EPB_NIMG > 0) {
+        if (producer && epb) wait_vmcnt<0>();     // (the loop's own waits cover these oldest DMAs; this is for nt == 0)
+    }
     __syncthreads();   // every wave is done reading the staging LDS: reuse it for the epilogue slabs
     MF_STAMP(4);
     if constexpr (DT == MF_F16X3) mf_raise_if_over(p.ovf, split_amax);
@@ -1226,16 +1453,16 @@ void gemm_conv_kernel(const GemmArgs p) {
                 }
             }
             if (!producer) {
-                if constexpr (P16) {
+                if constexpr (P16) {      // acc16[2i + a][b] element r: row 32i + 16a + 4 kg + r, column 16b + r16 of the wave tile
 #pragma unroll
-                    for (int a = 0; a < MT16; ++a)
+                    for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int b = 0; b < NT16; ++b)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int row = 16 * a + 4 * kg + r - half * SR;
                                 if (SR == 32 || a == half)
-                                    *reinterpret_cast<float*>(slab + row * EP_RS + (16 * b + r16) * 4) = acc16[a][b][r];
+                                    *reinterpret_cast<float*>(slab + row * EP_RS + (16 * b + r16) * 4) = acc16[2 * i + a][b][r];
                             }
                 } else {
 #pragma unroll
@@ -1276,15 +1503,16 @@ void gemm_conv_kernel(const GemmArgs p) {
                         float tv[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) tv[j] = *reinterpret_cast<const float*>(sl + (rg * 8 + j) * EP_RS + col * 4);
+                        const char* erow = smem + EPB_OFF + (nt_ - n0) * 4;           // this column in the staged bias row
                         if (p.ln_cs) {
-                            const float cs = p.ln_cs[nt_];
+                            const float cs = epb ? *reinterpret_cast<const float*>(erow + EPB_PITCH * 4) : p.ln_cs[nt_];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const float2 st = lnst[mt - m0 + j];
                                 tv[j] = st.y * (tv[j] - st.x * cs);
                             }
                         }
-                        const float b = p.bias ? p.bias[nt_] : 0.0f;
+                        const float b = p.bias ? (epb ? *reinterpret_cast<const float*>(erow) : p.bias[nt_]) : 0.0f;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) tv[j] = (tv[j] + b) * p.alpha;
                         const int img = mt / p.vt_tokens, tok = mt - img * p.vt_tokens;
@@ -1309,8 +1537,9 @@ void gemm_conv_kernel(const GemmArgs p) {
 #endif
                 if (p.ln_cs && m < p.M && n + 8 <= p.N) {            // LayerNorm fold: rstd * (acc - mean * colsum)
                     const float2 st = lnst[m - m0];
-                    const float4 c0 = *reinterpret_cast<const float4*>(p.ln_cs + n);
-                    const float4 c1 = *reinterpret_cast<const float4*>(p.ln_cs + n + 4);
+                    const float* lc = epb ? reinterpret_cast<const float*>(smem + EPB_OFF + (EPB_PITCH + n - n0) * 4) : p.ln_cs + n;
+                    const float4 c0 = *reinterpret_cast<const float4*>(lc);
+                    const float4 c1 = *reinterpret_cast<const float4*>(lc + 4);
                     lo.x = st.y * (lo.x - st.x * c0.x); lo.y = st.y * (lo.y - st.x * c0.y);
                     lo.z = st.y * (lo.z - st.x * c0.z); lo.w = st.y * (lo.w - st.x * c0.w);
                     hi.x = st.y * (hi.x - st.x * c1.x); hi.y = st.y * (hi.y - st.x * c1.y);
@@ -1326,7 +1555,12 @@ void gemm_conv_kernel(const GemmArgs p) {
                             for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
                         }
                     } else if (p.vec_ok && n + 8 <= p.N) {
-                        epilogue_store8(p, zo, m, n, v, res_pre, q0[u], q1[u], zq);
+                        if (epb) {
+                            const char* eb = smem + EPB_OFF + (n - n0) * 4;
+                            epilogue_store8(p, zo, m, n, v, res_pre, q0[u], q1[u], zq, eb, eb + (2 + (m >> p.epb_sh) - (m0 >> p.epb_sh)) * (EPB_PITCH * 4));
+                        } else {
+                            epilogue_store8(p, zo, m, n, v, res_pre, q0[u], q1[u], zq);
+                        }
                     } else {
                         for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj], zq);
                     }
@@ -1364,16 +1598,16 @@ void gemm_conv_kernel(const GemmArgs p) {
                 }
             }
         }
-        if constexpr (P16) {      // acc16[a][b] element r: row 16a + 4 kg + r, column 16b + r16 of the wave tile
+        if constexpr (P16) {      // acc16[2i + a][b] element r: row 32i + 16a + 4 kg + r, column 16b + r16 of the wave tile
 #pragma unroll
-            for (int a = 0; a < MT16; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < NT16; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * a + 4 * kg + r - half * SR;
                         if (SR == 32 || a == half)
-                            *reinterpret_cast<float*>(slab + row * EP_RS + (16 * b + r16) * 4) = acc16[a][b][r];
+                            *reinterpret_cast<float*>(slab + row * EP_RS + (16 * b + r16) * 4) = acc16[2 * i + a][b][r];
                     }
         } else
 #pragma unroll
@@ -1432,10 +1666,12 @@ template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = f
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     // warp-specialised ring tiles keep BM (mean, rstd) pairs of a folded LayerNorm past the ring
     constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? ST : 2) * BN * 128 : ST * (BM + BN) * 128 + (WS ? BM * 8 : 0);
-    static_assert(smem_k <= 160 * 1024, "LDS");
+    constexpr int smem_e = epb_nimg(BM, BN, ST, DX, WS) > 0 ? (2 + epb_nimg(BM, BN, ST, DX, WS)) * epb_pitch(BN) * 4 : 0;   // staged epilogue rows
+    static_assert(smem_k == epb_off(BM, BN, ST, DX, WS) || !WS, "epb_off must equal the ring's footprint");
+    static_assert(smem_k + smem_e <= 160 * 1024, "LDS");
     // experiment switch: MFHIP_SMEM_MIN=<bytes> raises the LDS request (occupancy control for ring-depth A/B runs)
     static const int smem_min = getenv("MFHIP_SMEM_MIN") ? atoi(getenv("MFHIP_SMEM_MIN")) : 0;
-    const int smem = smem_k > smem_min ? smem_k : smem_min;
+    const int smem = smem_k + smem_e > smem_min ? smem_k + smem_e : smem_min;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, SKF>),
@@ -1457,8 +1693,8 @@ void launch_skf(const GemmArgs& a, dim3 grid, hipStream_t s) {
 bool launch_bf16_a(int tile, const GemmArgs& a, dim3 grid, hipStream_t s, bool a_f32);   // tiles 1-6 (+ fp32 activations, + in-launch split-K twins)
 bool launch_bf16_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);               // 7-15, 20-24
 bool launch_bf16_c(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);               // 25-36
-bool launch_bf16_ws_dx(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);           // 37-40, 47: warp-specialised dx-reuse convs
-bool launch_bf16_ws_ring(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);         // 41-46, 48: warp-specialised plain ring
+bool launch_bf16_ws_dx(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);           // 37-40, 47, 49, 51: warp-specialised dx-reuse convs
+bool launch_bf16_ws_ring(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);         // 41-46, 48, 50, 52: warp-specialised plain ring
 bool launch_f32_a(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);                // fp32 MFMA, tiles 1-12
 bool launch_f32_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);                // fp32 MFMA, tiles 13-15, 20-24, 31-36
 bool launch_f16x3(int tile, const GemmArgs& a, dim3 grid, hipStream_t s, bool wpk);

@@ -81,6 +81,12 @@ __device__ __forceinline__ void dma16_buf(unsigned voff, srd_t srd, unsigned lds
                  ::"v"(voff), "s"(srd), "s"(lds_off) : "memory", "m0");
 }
 
+// the same with 4 bytes per lane: 64 consecutive dwords into LDS [lds_off, +256 B)
+__device__ __forceinline__ void dma4_buf(unsigned voff, srd_t srd, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen lds"
+                 ::"v"(voff), "s"(srd), "s"(lds_off) : "memory", "m0");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

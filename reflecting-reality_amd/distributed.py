@@ -58,17 +58,31 @@ def tuned_once(warm: Callable[[], None], save: Optional[Callable[[], None]] = No
     (shape -> tile, split-K) once and persists the winners: hip.tune_save), the other ranks wait at a barrier, re-read the cache
     (hip.tune_reload) and only then run `warm` themselves — one tuning pass per node instead of one per rank (an 8-rank start used
     to time every candidate tile eight times, on eight GPUs contending for the host).  Ranks whose shapes differ from rank 0's (a
-    ragged last batch shard) still tune their own misses.  A single process just runs `warm`."""
+    ragged last batch shard) still tune their own misses.  A single process just runs `warm`.
+
+    `warm` MUST BE COLLECTIVE-FREE (no gradient exchange, no max_over_ranks): rank 0 runs it while the other ranks sit in a
+    collective (the barrier), so a collective inside it would pair up with that barrier and hang or corrupt the job.  If rank 0
+    fails, the barrier is still reached and EVERY rank raises (the others would otherwise wait for the watchdog)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         warm()
         return
     if save is None or reload is None:
         from . import hip
         save, reload = save or hip.tune_save, reload or hip.tune_reload
+    err: Optional[BaseException] = None
     if dist.get_rank() == 0:
-        warm()
-        save()
-    dist.barrier()
+        try:
+            warm()
+            save()
+        except BaseException as e:          # noqa: BLE001 — re-raised below, after the other ranks have been told
+            err = e
+    flag = torch.tensor([1.0 if err is not None else 0.0], dtype=torch.float64,
+                        device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # doubles as the barrier the waiting ranks sit in
+    if err is not None:
+        raise err
+    if float(flag.item()) > 0.0:
+        raise RuntimeError("tuned_once: rank 0 failed during its warm-up / autotune pass (see its traceback)")
     if dist.get_rank() != 0:
         reload()
         warm()

@@ -342,9 +342,17 @@ class HipModel:
         return self
 
     def enable_gradient_checkpointing(self):
-        """brushnet.py:674-676 / train_brushnet_mirror.py:1153-1155.  Accepted and recorded; the tape keeps every
-        activation (a per-GPU batch of 8 at 512 x 512 holds ~60 GB of fp32 activations in 288 GB of HBM), so nothing is
-        recomputed except the attention probabilities, which are never stored."""
+        """brushnet.py:674-676 / train_brushnet_mirror.py:1153-1155 (`--gradient_checkpointing`).  NOT built: the backward tape
+        keeps every activation (a per-GPU batch of 8 at 512 x 512 holds ~60 GB of fp32 activations, 288 GB of HBM are there),
+        and nothing is recomputed except the attention probabilities, which are never stored.  A memory switch that silently
+        does nothing would let a user raise the batch size until the run dies elsewhere, so this raises like every other
+        unbuilt switch; a caller that knows its batch fits sets `model.allow_noop_gradient_checkpointing = True` first and
+        gets the recorded flag with no recomputation."""
+        if not getattr(self, "allow_noop_gradient_checkpointing", False):
+            raise NotImplementedError(
+                "enable_gradient_checkpointing (brushnet.py:674-676): activation recomputation is not built — the tape keeps "
+                "every activation (~7.5 GB per sample at 512 x 512 in fp32; batch 8 uses ~60 of 288 GB).  Drop "
+                "--gradient_checkpointing, or set model.allow_noop_gradient_checkpointing = True to accept the flag as a no-op.")
         self.gradient_checkpointing = True
 
     def save_pretrained(self, path: str, **unused):

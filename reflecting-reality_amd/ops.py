@@ -451,7 +451,7 @@ def geglu(h: torch.Tensor, out_dtype: torch.dtype, bias: Optional["autograd.Para
             bg = bias.grad if (bias is not None and bias.grad is not None) else None
             dh = hip.geglu_bwd_bf16(h, g.view(-1, out.shape[-1]).contiguous(), bg)
             if bg is not None:
-                tape.colsum_done.add(dh.data_ptr())
+                tape.colsum_done[dh.data_ptr()] = dh
             tape.add(h, dh)
         tape.record(bwd)
     elif tape is not None:

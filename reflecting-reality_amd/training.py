@@ -140,7 +140,9 @@ class AdamW:
             m._weights_gen += 1            # derived layouts (dgrad weights, captured graphs) are stale now
 
     def state_dict(self) -> dict:
-        return dict(step=self.step_count, lr=self.lr, betas=self.betas, weight_decay=self.weight_decay, eps=self.eps,
+        # initial_lr (set by optimization.LambdaLR): the base a resumed LR schedule multiplies — `lr` alone is the DECAYED value
+        return dict(step=self.step_count, lr=self.lr, initial_lr=getattr(self, "initial_lr", self.lr), betas=self.betas,
+                    weight_decay=self.weight_decay, eps=self.eps,
                     exp_avg=[t.cpu() for t in self.exp_avg], exp_avg_sq=[t.cpu() for t in self.exp_avg_sq])
 
     def load_state_dict(self, sd: dict) -> None:
@@ -153,6 +155,8 @@ class AdamW:
                              "loaded: the moments are stored as flat arenas in the kernels' layout)")
         self.step_count = int(sd["step"])
         self.lr = float(sd.get("lr", self.lr))
+        if "initial_lr" in sd:
+            self.initial_lr = float(sd["initial_lr"])
         self.betas = tuple(sd.get("betas", self.betas))
         self.weight_decay = float(sd.get("weight_decay", self.weight_decay))
         self.eps = float(sd.get("eps", self.eps))
@@ -256,6 +260,13 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
         # round 4: every gradient behind the 64 x 64 attention layers came out 0.3-0.5 % short.  bf16 rounding is invariant under
         # a power-of-two scale, so the mode's own arithmetic does not change.)
         scale = float(2 ** int(pred.numel() - 1).bit_length())
+        # one scale per accumulation window: the arena SUMS the micro-batches' scaled gradients and only the last
+        # call's scale is undone in the clip coefficient, so a ragged micro-batch whose element count crosses a power of two
+        # must not change it — the window keeps the scale of its first micro-batch
+        if micro == 0:
+            optimizer._window_scale = scale
+        else:
+            scale = float(getattr(optimizer, "_window_scale", scale))
     if scale != 1.0 or accum > 1:
         d_pred = hip.axpby_n([d_pred], [scale / accum], out=d_pred)      # 1 / G: accelerator.backward under accumulate()
     model.loss_scale = scale
@@ -515,10 +526,11 @@ class GraphedTrainStep:
 # checkpoints: accelerator.save_state with the script's hooks (:997-1069) and its rotation (:1474-1498)
 # ---------------------------------------------------------------------------------------------------------------------
 def save_state(output_dir: str, global_step: int, model: MirrorFusionModel, optimizer: Optional[AdamW] = None,
-               checkpoints_total_limit: Optional[int] = None, is_main_process: bool = True) -> Optional[str]:
+               checkpoints_total_limit: Optional[int] = None, is_main_process: bool = True, lr_scheduler=None) -> Optional[str]:
     """Writes `output_dir/checkpoint-<global_step>/{brushnet,unet}` (config.json + diffusion_pytorch_model.safetensors in
-    the reference's layout; `unet` only when it trains) and `optimizer.bin`; before that, removes the oldest checkpoints so
-    that at most `checkpoints_total_limit` remain — the script's order of operations."""
+    the reference's layout; `unet` only when it trains), `optimizer.bin` and — when a schedule is passed — `scheduler.bin`
+    (accelerate saves the prepared lr_scheduler with the state, train_brushnet_mirror.py:1267-1269, 1496); before that, removes
+    the oldest checkpoints so that at most `checkpoints_total_limit` remain — the script's order of operations."""
     if not is_main_process:
         return None
     os.makedirs(output_dir, exist_ok=True)
@@ -528,17 +540,22 @@ def save_state(output_dir: str, global_step: int, model: MirrorFusionModel, opti
             for d in cps[: len(cps) - checkpoints_total_limit + 1]:
                 shutil.rmtree(os.path.join(output_dir, d))
     path = os.path.join(output_dir, f"checkpoint-{global_step}")
+    os.makedirs(path, exist_ok=True)
     for m in model.get_trainable_modules():
         m.save_pretrained(os.path.join(path, "brushnet" if m is model.brushnet else "unet"))
     if optimizer is not None:
         torch.save(optimizer.state_dict(), os.path.join(path, "optimizer.bin"))
+    if lr_scheduler is not None:
+        torch.save(lr_scheduler.state_dict(), os.path.join(path, "scheduler.bin"))
     with open(os.path.join(path, "trainer_state.json"), "w") as f:
         json.dump(dict(global_step=global_step), f)
     return path
 
 
-def load_state(path: str, model: MirrorFusionModel, optimizer: Optional[AdamW] = None) -> int:
-    """load_model_hook (:1035-1066): each trainable module reloads its weights from its sub-folder; returns the step."""
+def load_state(path: str, model: MirrorFusionModel, optimizer: Optional[AdamW] = None, lr_scheduler=None) -> int:
+    """load_model_hook (:1035-1066): each trainable module reloads its weights from its sub-folder; returns the step.
+    `lr_scheduler` (built BEFORE this call, like the script builds and prepares it before accelerator.load_state, :1232-1300)
+    continues from the saved epoch: without it a non-constant schedule would replay its warm-up after a resume."""
     from safetensors.torch import load_file
     for m in model.get_trainable_modules():
         sub = "brushnet" if m is model.brushnet else "unet"
@@ -552,6 +569,14 @@ def load_state(path: str, model: MirrorFusionModel, optimizer: Optional[AdamW] =
             if [m for m in model.get_trainable_modules()] != optimizer.models:
                 optimizer.models = model.get_trainable_modules()
             optimizer.load_state_dict(torch.load(os.path.join(path, "optimizer.bin")))
+    if lr_scheduler is not None:
+        sp = os.path.join(path, "scheduler.bin")
+        if os.path.exists(sp):
+            lr_scheduler.load_state_dict(torch.load(sp))
+        else:
+            import warnings
+            warnings.warn(f"load_state: {path} has no scheduler.bin — the LR schedule restarts from its first step "
+                          "(checkpoints written before round 5, or without lr_scheduler=, do not carry it)")
     with open(os.path.join(path, "trainer_state.json")) as f:
         return int(json.load(f)["global_step"])
 

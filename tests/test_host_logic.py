@@ -450,3 +450,57 @@ def test_lr_schedules_match_the_reference_get_scheduler():
     b.load_state_dict(a.state_dict())
     a.step(); b.step()
     assert o.lr == o2.lr
+
+
+def test_checkpoints_carry_the_lr_schedule(tmp_path):
+    """accelerator.save_state / load_state persist the prepared lr_scheduler (scheduler.bin); without it a resumed
+    run replays its warm-up.  The schedule-side of training.save_state / load_state on a stub model (no GPU): a run interrupted
+    after 5 of 12 steps and resumed from its checkpoint follows the uninterrupted run's learning rates exactly, and AdamW's
+    state carries `initial_lr` (its `lr` alone is the decayed value)."""
+    from reflecting_reality_amd import optimization as O, training as T
+
+    class StubModel:
+        def get_trainable_modules(self):
+            return []
+
+    class StubOpt:            # AdamW's scheduler-facing surface (lr / initial_lr / state_dict), no arenas
+        def __init__(self, lr):
+            self.lr = lr
+        state_dict = T.AdamW.state_dict
+        step_count, betas, weight_decay, eps, exp_avg, exp_avg_sq, models = 0, (0.9, 0.999), 1e-2, 1e-8, [], [], []
+        def load_state_dict(self, sd):
+            self.lr, self.initial_lr = sd["lr"], sd["initial_lr"]
+
+    def make():
+        o = StubOpt(3e-4)
+        return o, O.get_scheduler("cosine", o, num_warmup_steps=3, num_training_steps=12)
+
+    o_ref, s_ref = make()
+    ref = []
+    for _ in range(12):
+        s_ref.step()
+        ref.append(o_ref.lr)
+    o1, s1 = make()
+    for _ in range(5):
+        s1.step()
+    sd = o1.state_dict()
+    assert sd["initial_lr"] == 3e-4 and sd["lr"] == o1.lr != 3e-4
+    path = T.save_state(str(tmp_path), 5, StubModel(), o1, lr_scheduler=s1)
+    assert os.path.exists(os.path.join(path, "scheduler.bin"))
+    o2, s2 = make()                                    # the resumed process builds its schedule first, then loads (script order)
+    assert T.load_state(path, StubModel(), o2, lr_scheduler=s2) == 5
+    got = []
+    for _ in range(7):
+        s2.step()
+        got.append(o2.lr)
+    assert got == ref[5:]
+    # a schedule built AFTER the load with last_epoch continues too: initial_lr survived in the optimizer state
+    o3 = StubOpt(1.0)
+    o3.load_state_dict(sd)
+    s3 = O.get_scheduler("cosine", o3, num_warmup_steps=3, num_training_steps=12, last_epoch=4)
+    s3.step()
+    assert o3.lr == ref[5]
+    # a checkpoint without scheduler.bin warns instead of silently restarting the schedule
+    p2 = T.save_state(str(tmp_path), 6, StubModel(), o1)
+    with pytest.warns(UserWarning, match="no scheduler.bin"):
+        T.load_state(p2, StubModel(), None, lr_scheduler=make()[1])

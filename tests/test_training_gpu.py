@@ -299,6 +299,11 @@ def test_training_needs_fp32_class_precision_and_the_training_layout():
         train_step(m32, DDPMScheduler(**SD_SCHED), None, lat, noi, torch.tensor([1, 2, 3]), ehs, cond)
     with pytest.raises(NotImplementedError):
         DDPMScheduler(**SD_SCHED).step(None, 0, None)
+    # a memory switch that would silently do nothing raises (brushnet.py:674-676 is not built) unless the caller opts in
+    with pytest.raises(NotImplementedError, match="recomputation is not built"):
+        m32.brushnet.enable_gradient_checkpointing()
+    assert not m32.brushnet.gradient_checkpointing
+    m32.brushnet.allow_noop_gradient_checkpointing = True
     m32.brushnet.enable_gradient_checkpointing()
     assert m32.brushnet.gradient_checkpointing
 

@@ -35,6 +35,12 @@ CASES = [  # (label, batch, h, w, cin, cout, k, tile, splitk, with residual[, wi
     ("conv 64^2 no bias no res", 8, 64, 64, 320, 320, 3, 39, 1, False, False), ("conv 64^2 bias+temb", 8, 64, 64, 320, 320, 3, 39, 1, False, True, True),
     ("conv 64^2 bias+temb+res", 8, 64, 64, 320, 320, 3, 39, 1, True, True, True),
     ("to_out 64^2 no bias no res", 8, 64, 64, 320, 320, 1, 26, 1, False, False),
+    # 19-: round 5, the cross-tile fragment pipeline and the 64x80 wave tiles
+    ("conv 64^2 t49", 8, 64, 64, 320, 320, 3, 49, 1, True), ("conv 64^2 960 t49", 8, 64, 64, 960, 320, 3, 49, 1, True),
+    ("conv 32^2 t48", 8, 32, 32, 640, 640, 3, 48, 1, True), ("conv 32^2 t52", 8, 32, 32, 640, 640, 3, 52, 1, True),
+    ("conv 32^2 t47", 8, 32, 32, 640, 640, 3, 47, 1, True), ("conv 32^2 1280 t48", 8, 32, 32, 1280, 640, 3, 48, 1, True),
+    ("conv 16^2 t48 sk2", 8, 16, 16, 1280, 1280, 3, 48, 2, True), ("proj 32^2 t48", 8, 32, 32, 640, 640, 1, 48, 1, True),
+    ("ff-out 64^2 1280->320 t48", 8, 64, 64, 1280, 320, 1, 48, 1, True),
 ]
 
 
@@ -95,6 +101,13 @@ def run(label, b, h, w, ci, co, k, tile, sk, with_res, with_bias=True, with_temb
             if ws:
                 pa, pb, pc = st[:, 16 + 7 + 3 * ih], st[:, 16 + 8 + 3 * ih], st[:, 16 + 9 + 3 * ih]
                 print(f"      staging wave 0: barrier reached at +{np.median((pb - (st[:, 4] if ih == 0 else st[:, 9])) / 100.0):5.2f} us of the round, stores issued +{np.median((pc - pb) / 100.0):5.2f}")
+    if ws and (st[:, 14] > 0).any():             # main-loop wait shares (shader clocks): who waits for whom
+        ok = st[:, 14] > 0
+        loop, wbar, ntap = st[ok, 14].astype(float), st[ok, 13].astype(float), st[ok, 15].astype(float)
+        p_vm, p_bar, p_iss = st[ok, 16 + 13].astype(float), st[ok, 16 + 14].astype(float), st[ok, 16 + 15].astype(float)
+        print(f"   main loop: {np.median(loop / ntap):6.0f} clocks per K tile over {int(np.median(ntap))} tiles; compute wave 0 waits at the barrier "
+              f"{np.median(wbar / loop) * 100:4.1f} % of it; staging wave 0: issuing {np.median(p_iss / loop) * 100:4.1f} %, waiting for its DMAs "
+              f"{np.median(p_vm / loop) * 100:4.1f} %, at the barrier {np.median(p_bar / loop) * 100:4.1f} %")
     print(f"   launch span (first entry -> last exit): {us(st[:, 6]).max():6.2f} us", flush=True)
 
 
