@@ -279,6 +279,8 @@ def main():
                     help="test hook: a sleeping stand-in for the pipeline on the CPU (gloo), to exercise the rank logic — "
                          "launch, rendezvous, barrier, max-over-ranks timing, the JSON line — where there is no GPU")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the secondary legs of the default line: fp16 mode, the training step (configs[3]) and SDXL fp8 (configs[4])")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(sys.argv[1:], a.gpus))          # before anything touches the GPU
@@ -491,6 +493,63 @@ def main():
         del ppipe, pipe
         torch.cuda.empty_cache()
 
+    # ---- secondary legs of the driver's line: never `value` ---------------------------------------------
+    fp16_mode = train_leg = sdxl_leg = None
+    extra = (rank == 0 and world == 1 and not a.no_extra_legs and not a.no_parity_mode and not a.no_profile and not xl
+             and a.precision == "bf16" and a.batch == 4 and a.size == 512)
+    if extra:
+        # (1) the SAME workload in the reference scripts' default precision, torch_dtype=torch.float16 (test_brushnet.py:122-126):
+        # fp16 storage, one f16 MFMA per product — the bf16 kernels' byte layout
+        try:
+            pipe = None
+            torch.cuda.empty_cache()
+            inp = inp_timed
+            hpipe, _ = build_pipeline("fp16", device, model=a.model)
+            pipe = hpipe
+            one_pass()
+            torch.cuda.synchronize()
+            th_ = time.perf_counter()
+            hd_ms = 0.0
+            for _ in range(a.steps):
+                himg = one_pass()
+                torch.cuda.synchronize()
+                hd_ms += timing["denoise_start"].elapsed_time(timing["denoise_end"])
+            th_ = time.perf_counter() - th_
+            hstep = hd_ms * 1e-3 / (a.steps * a.denoise_steps)
+            assert torch.isfinite(himg).all(), "non-finite fp16 image"
+            fp16_mode = {"precision": "fp16", "value": round(a.batch * a.steps / th_, 4), "unit": "images/sec",
+                         "ms_per_step": round(th_ / a.steps * 1e3, 2), "denoise_step_ms": round(hstep * 1e3, 3),
+                         "denoise_step_tflops": round(a.batch * gflop * 1e9 / hstep / 1e12, 2) if gflop else None,
+                         "tolerance": "inside 1.25 x (L-inf) / 1.1 x (mean) of the REFERENCE's own fp16 deviation from its fp32 results on the "
+                                      "same cases (tests/golden/fp16_envelope.json: ~1/9 of its bf16 deviation), tests/test_*_gpu.py [fp16]",
+                         "note": "the default precision of the reference's inference script; same workload and inputs as `value`"}
+            del hpipe, pipe
+            torch.cuda.empty_cache()
+        except Exception as e:          # a secondary leg must never take the headline line down
+            fp16_mode = {"error": f"{type(e).__name__}: {e}"[:300]}
+        pipe = None
+        torch.cuda.empty_cache()
+        # (2), (3) the other two workloads BASELINE.json names, each as its own child process of this one (this process only
+        # keeps its HIP context; nothing is exec'ed): configs[3] per-GPU training step, configs[4] SDXL + BrushNet-XL in fp8
+        import subprocess
+
+        def child(args, keys):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), *args, "--no-cpu-baseline", "--no-parity-mode", "--no-profile",
+                                    "--no-extra-legs"], capture_output=True, text=True, timeout=900)
+                line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{") and '"metric"' in l), None)
+                if line is None:
+                    return {"error": (r.stderr or r.stdout)[-300:]}
+                rec = json.loads(line)
+                return {k: rec.get(k) for k in keys}
+            except Exception as e:
+                return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+        train_leg = child(["--mode", "train", "--precision", "bf16", "--steps", "8", "--warmup", "3"],
+                          ("metric", "value", "unit", "ms_per_step", "dtype", "achieved_tflops", "algorithmic_gflop_per_sample", "config"))
+        sdxl_leg = child(["--model", "sdxl", "--precision", "fp8", "--steps", "2", "--warmup", "1"],
+                         ("metric", "value", "unit", "ms_per_step", "dtype", "config"))
+
     cpu = None
     if want_cpu:
         # cores this process may actually use (cgroup / affinity aware), capped: PyTorch's CPU conv/GEMM kernels
@@ -520,7 +579,7 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "height": a.size, "width": a.size,
                        "denoise_steps": a.denoise_steps, "parallelism": f"batch-shard x{world} (no collective)"},
             "roofline": roofline, "parity_mode": parity, "shared_conditioning_sample": shared, "cpu_baseline": cpu,
-            "host_inputs": host_inputs,
+            "host_inputs": host_inputs, "fp16_mode": fp16_mode, "train_step": train_leg, "sdxl": sdxl_leg,
         }
         print(json.dumps(out), flush=True)
         hip.tune_save()                      # per-shape (tile, split-K) winners found during warmup, for later processes

@@ -42,6 +42,11 @@ extern "C" {
  * MFMA, fp32 accumulate: the arithmetic of the reference's --mixed_precision=bf16 autocast (train_brushnet_mirror.py:567,
  * 1127-1131) with the activations still stored in fp32.  Training compute code (mf_gemm_conv, mf_conv_wgrad). */
 #define MF_BF16X1 5
+/* fp16 operands and activation storage (torch.float16: the default of the reference's inference script,
+ * examples/brushnet/test_brushnet.py:122-126), one v_mfma_f32_*_f16 per product at the bf16 rate, fp32 accumulate / statistics.
+ * Storage AND compute code: the byte layout of every tensor equals the MF_BF16 one.  11 significant bits against bf16's 8, range
+ * |x| < 65504 (a value beyond it becomes inf, as in the reference's fp16 run). */
+#define MF_F16 6
 
 #define MF_OK 0
 #define MF_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -54,7 +59,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 15
+#define MF_ABI_VERSION 16
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -199,6 +204,12 @@ int mf_softmax_rows(const float* scores, void* out, int32_t out_dtype, int64_t r
  * q: [B][Sq][ldq], k: [B][Skv][ldk], vt: V^T as [B][heads*d][ldvt] (keys contiguous),
  * replaces F.scaled_dot_product_attention (attention_processor.py:1266-1268). */
 int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                      void* out, int64_t ldo, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                      int32_t head_dim, float scale, void* stream);
+/* mf_attention_bf16 on fp16 operands (MF_F16 storage: q, k, vt and out are fp16; the f16 MFMA forms, fp32 softmax and accumulation):
+ * F.scaled_dot_product_attention of the reference's default torch_dtype=torch.float16 run (examples/brushnet/test_brushnet.py:122-126,
+ * models/attention_processor.py:1259-1268).  Same layouts, head dims and constraints. */
+int mf_attention_f16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                       void* out, int64_t ldo, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
                       int32_t head_dim, float scale, void* stream);
 

@@ -26,9 +26,10 @@ LIB_PATH = os.path.join(LIB_DIR, "libmfhip.so")
 INCLUDE = os.path.join(os.path.dirname(_PKG_DIR), "include")
 
 # longest compiles first (the pool takes them in this order)
-SOURCES = ["train.hip", "gemm_f32_b.hip", "gemm_f32_a.hip", "gemm_f16x3.hip", "gemm_bf16x3.hip", "gemm_bf16_ws_ring.hip",
-           "gemm_bf16_b.hip", "gemm_bf16_a.hip", "gemm_bf16_c.hip", "gemm_bf16_ws_dx.hip", "gemm_f16x3_ws.hip", "attention.hip",
-           "gemm_fp8.hip", "conv_halo.hip", "gemm_conv.hip", "norm.hip", "elementwise.hip", "frontend.hip", "fp8.hip"]
+SOURCES = ["train.hip", "gemm_f32_b.hip", "gemm_f32_a.hip", "gemm_f16x3.hip", "gemm_bf16x3.hip", "gemm_bf16_ws_ring.hip", "gemm_f16_ws_ring.hip",
+           "gemm_bf16_b.hip", "gemm_f16_b.hip", "gemm_bf16_a.hip", "gemm_bf16_c.hip", "gemm_f16_c.hip", "gemm_bf16_ws_dx.hip", "gemm_f16_ws_dx.hip",
+           "gemm_f16_a.hip", "gemm_f16x3_ws.hip", "attention.hip", "gemm_fp8.hip", "conv_halo.hip", "gemm_conv.hip", "norm.hip", "elementwise.hip",
+           "frontend.hip", "fp8.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
                f"-I{INCLUDE}"]
 

@@ -46,7 +46,7 @@ class MfhipAttnProcessor:
         inner = k.shape[-1]
         d = inner // heads
         skv = k.shape[1]
-        prec = Precision.get("bf16" if q.dtype == torch.bfloat16 else "fp32")
+        prec = Precision.get("bf16" if q.dtype == torch.bfloat16 else "fp16" if q.dtype == torch.float16 else "fp32")
         ld = (skv + 7) // 8 * 8
         vt = torch.zeros(v.shape[0], inner, ld, dtype=prec.act, device=v.device)      # V^T, keys contiguous
         vt[:, :, :skv] = v.to(prec.act).transpose(1, 2)

@@ -45,8 +45,13 @@ __device__ __forceinline__ f32x16_t mfma16(const uint4& a, const uint4& b, const
                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-template <int HD, bool DB, bool SP = false>
+// F16 (!SP): fp16 operands and output (MF_F16 storage) on the f16 MFMA forms — the byte layout of every tile equals the bf16 one; the
+// packs / unpacks (Q~ scaling, P, the three pieces of the exponent offset, the ones) use fp16 instead of bf16.
+template <int HD, bool DB, bool SP = false, bool F16 = false>
 __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2)) void attn_fwd_kernel(const AttnArgs p) {
+    static_assert(!(SP && F16), "F16 is the single-plane form");
+    constexpr int HDT = F16 ? MF_F16 : MF_BF16;       // 16-bit type of the operands / P / the output
+    constexpr unsigned ONE2 = F16 ? 0x3C003C00u : 0x3F803F80u;   // (1.0, 1.0)
     constexpr int NP = SP ? 2 : 1;            // operand planes (hi, lo)
     constexpr int OES = SP ? 4 : 2;           // output element size
     constexpr int DK = (HD + 15) / 16 * 16;   // QK^T reduction length, padded to the MFMA k-step
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
     if (ONES) {
         __syncthreads();
         for (int i = tid; i < NBUF * 32; i += 256)           // 64 keys = 128 B = 32 dwords per buffer
-            *reinterpret_cast<uint32_t*>(smem + (i >> 5) * BUF_BYTES + V0 + ONES_ROW * RBV + (i & 31) * 4) = SP ? 0x3C003C00u : 0x3F803F80u;   // 1.0 (hi plane only)
+            *reinterpret_cast<uint32_t*>(smem + (i >> 5) * BUF_BYTES + V0 + ONES_ROW * RBV + (i & 31) * 4) = SP ? 0x3C003C00u : ONE2;   // 1.0 (hi plane only)
     }
 
     // Q fragments (B operand of S^T = K.Q^T): lane (query r, half h) holds Q[q][16ks + 8h + j]
@@ -126,8 +131,11 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
             if constexpr (MJ) {          // Q~ = bf16(q * scale * log2 e): scores leave the MFMA in exp2 units
                 unsigned* w = reinterpret_cast<unsigned*>(&v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    w[e] = pack_bf16x2(__uint_as_float(w[e] << 16) * p.c, __uint_as_float(w[e] & 0xffff0000u) * p.c);
+                for (int e = 0; e < 4; ++e) {
+                    float x0, x1;
+                    unpack_h2(w[e], HDT, x0, x1);
+                    w[e] = pack_h2(x0 * p.c, x1 * p.c, HDT);
+                }
             }
             qf[pl][ks] = v;
         }
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
         for (int e = 0; e < 16; ++e) o[d][e] = 0.0f;
     float m = MJ ? 0.0f : -INFINITY, l = 0.0f;
     // MJ: bf16 ones in k slots HD, HD+1, HD+2 of the last K fragment, for the half-wave that reads the pad chunk
-    const unsigned ones_x = (MJ && h) ? 0x3F803F80u : 0u, ones_y = (MJ && h) ? 0x00003F80u : 0u;
+    const unsigned ones_x = (MJ && h) ? ONE2 : 0u, ones_y = (MJ && h) ? (ONE2 & 0xffffu) : 0u;
     (void)ones_x; (void)ones_y;
 
     const int ntiles = (p.skv + 63) / 64;
@@ -225,9 +233,9 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
                 } else if constexpr (MJ) {
                     uint4 am = a;
                     if (ks == KS - 1) { am.x |= ones_x; am.y |= ones_y; }     // K~[key][HD .. HD+2] = 1 (the DMA left zeros there)
-                    st[tt] = mfma16(am, qf[0][ks], ks == 0 ? zero16 : st[tt], false);
+                    st[tt] = mfma16(am, qf[0][ks], ks == 0 ? zero16 : st[tt], F16);
                 } else {
-                    st[tt] = mfma16(a, qf[0][ks], ks == 0 ? zero16 : st[tt], false);
+                    st[tt] = mfma16(a, qf[0][ks], ks == 0 ? zero16 : st[tt], F16);
                 }
             }
         }
@@ -251,13 +259,18 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
             // the first tile, where the offset is still 0): wave-uniform, rare after the first few tiles
             if (t == 0 || __builtin_amdgcn_ballot_w64(mx > MJ_T) != 0) {
                 const float want = m + (t == 0 ? mx : fmaxf(mx, 0.0f));
-                // the offset the matrix pipe can subtract exactly: three bf16 pieces
-                const unsigned b0 = pack_bf16x2(want, 0.0f) & 0xffffu;
-                const float r1 = want - __uint_as_float(b0 << 16);
-                const unsigned b1 = pack_bf16x2(r1, 0.0f) & 0xffffu;
-                const float r2 = r1 - __uint_as_float(b1 << 16);
-                const unsigned b2 = pack_bf16x2(r2, 0.0f) & 0xffffu;
-                const float m_rep = __uint_as_float(b0 << 16) + __uint_as_float(b1 << 16) + __uint_as_float(b2 << 16);
+                // the offset the matrix pipe can subtract exactly: three 16-bit pieces (bf16: 24 bits; fp16: 33, the last piece
+                // may be an fp16 subnormal — the matrix pipe keeps those)
+                float f0, f1, f2, dummy;
+                const unsigned b0 = pack_h2(want, 0.0f, HDT) & 0xffffu;
+                unpack_h2(b0, HDT, f0, dummy);
+                const float r1 = want - f0;
+                const unsigned b1 = pack_h2(r1, 0.0f, HDT) & 0xffffu;
+                unpack_h2(b1, HDT, f1, dummy);
+                const float r2 = r1 - f1;
+                const unsigned b2 = pack_h2(r2, 0.0f, HDT) & 0xffffu;
+                unpack_h2(b2, HDT, f2, dummy);
+                const float m_rep = f0 + f1 + f2;
                 const float dlt = m_rep - m;
                 m = m_rep;
                 if (h) {               // Q~[q][HD .. HD+2] = -(b0, b1, b2): the half-wave whose last fragment is the pad slots
@@ -329,10 +342,10 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
                     pf[1][2 * tt + s] = uint4{lw[0], lw[1], lw[2], lw[3]};
                 } else {
                     uint4 u;
-                    u.x = pack_bf16x2(st[tt][8 * s + 0], st[tt][8 * s + 1]);
-                    u.y = pack_bf16x2(st[tt][8 * s + 2], st[tt][8 * s + 3]);
-                    u.z = pack_bf16x2(st[tt][8 * s + 4], st[tt][8 * s + 5]);
-                    u.w = pack_bf16x2(st[tt][8 * s + 6], st[tt][8 * s + 7]);
+                    u.x = pack_h2(st[tt][8 * s + 0], st[tt][8 * s + 1], HDT);
+                    u.y = pack_h2(st[tt][8 * s + 2], st[tt][8 * s + 3], HDT);
+                    u.z = pack_h2(st[tt][8 * s + 4], st[tt][8 * s + 5], HDT);
+                    u.w = pack_h2(st[tt][8 * s + 6], st[tt][8 * s + 7], HDT);
                     pf[0][2 * tt + s] = u;
                 }
             }
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
                     o[d] = mfma16(a, pf[1][kst], o[d], true);
                     o[d] = mfma16(a, pf[0][kst], o[d], true);
                 } else {
-                    o[d] = mfma16(a, pf[0][kst], o[d], false);
+                    o[d] = mfma16(a, pf[0][kst], o[d], F16);
                 }
             }
         wait_vmcnt<0>();      // this wave's share of tile t+1 has landed ...
@@ -370,8 +383,8 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
                     make_float4(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
             } else {
                 uint2 u;
-                u.x = pack_bf16x2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
-                u.y = pack_bf16x2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
+                u.x = pack_h2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, HDT);
+                u.y = pack_h2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv, HDT);
                 *reinterpret_cast<uint2*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 2) = u;
             }
         }
@@ -808,10 +821,10 @@ __global__ __launch_bounds__(256) void rowdot_heads_kernel(const float* a, const
     }
 }
 
-template <int HD, bool SP = false>
+template <int HD, bool SP = false, bool F16 = false>
 void launch_attn(const AttnArgs& a, int batch, hipStream_t s) {
     dim3 grid((unsigned)(((a.sq + 127) / 128) * a.heads * batch));
-    hipLaunchKernelGGL((attn_fwd_kernel<HD, true, SP>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, true, SP, F16>), grid, dim3(256), 0, s, a);
 }
 
 // fp32 [rows][ld] (first `cols` columns) -> two fp16 planes of the same layout: hi toward zero, lo = x - hi
@@ -846,9 +859,25 @@ extern "C" int mf_attention_bf16(const void* q, int64_t ldq, const void* k, int6
     return mf_attention_bf16_lse(q, ldq, k, ldk, vt, ldvt, out, ldo, nullptr, batch, heads, sq, skv, head_dim, scale, stream);
 }
 
+static int attention_16(bool f16, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                        void* out, int64_t ldo, float* lse, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                        int32_t head_dim, float scale, void* stream);
+
 extern "C" int mf_attention_bf16_lse(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                                      void* out, int64_t ldo, float* lse, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
                                      int32_t head_dim, float scale, void* stream) {
+    return attention_16(false, q, ldq, k, ldk, vt, ldvt, out, ldo, lse, batch, heads, sq, skv, head_dim, scale, stream);
+}
+
+extern "C" int mf_attention_f16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                                void* out, int64_t ldo, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                                int32_t head_dim, float scale, void* stream) {
+    return attention_16(true, q, ldq, k, ldk, vt, ldvt, out, ldo, nullptr, batch, heads, sq, skv, head_dim, scale, stream);
+}
+
+static int attention_16(bool f16, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                        void* out, int64_t ldo, float* lse, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                        int32_t head_dim, float scale, void* stream) {
     MF_CHECK_ARG(q && k && vt && out, "mf_attention_bf16: null pointer");
     MF_CHECK_ARG(batch >= 1 && heads >= 1 && sq >= 1 && skv >= 1, "mf_attention_bf16: bad sizes");
     MF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0 && ldvt >= skv,
@@ -864,12 +893,17 @@ extern "C" int mf_attention_bf16_lse(const void* q, int64_t ldq, const void* k, 
     a.c = scale * 1.44269504088896340736f;
     { static const bool off = getenv("MFHIP_ATTN_NOXCD") != nullptr; a.no_xcd_order = off; }
     hipStream_t s = (hipStream_t)stream;
-    switch (head_dim) {
+    switch (f16 ? -head_dim : head_dim) {
         case 8: launch_attn<8>(a, batch, s); break;
         case 40: launch_attn<40>(a, batch, s); break;
         case 64: launch_attn<64>(a, batch, s); break;
         case 80: launch_attn<80>(a, batch, s); break;
         case 160: launch_attn<160>(a, batch, s); break;
+        case -8: launch_attn<8, false, true>(a, batch, s); break;
+        case -40: launch_attn<40, false, true>(a, batch, s); break;
+        case -64: launch_attn<64, false, true>(a, batch, s); break;
+        case -80: launch_attn<80, false, true>(a, batch, s); break;
+        case -160: launch_attn<160, false, true>(a, batch, s); break;
         default:
             mf_set_error("mf_attention_bf16: unsupported head_dim %d (have 8, 40, 64, 80, 160)", head_dim);
             return MF_EINVAL;

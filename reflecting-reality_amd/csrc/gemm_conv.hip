@@ -178,7 +178,7 @@ extern "C" int mf_gemm_tile_shape(int tile, int* bm, int* bn) {
 extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(d != nullptr, "mf_gemm_conv: null descriptor");
     MF_CHECK_ARG(d->dtype == MF_F32 || d->dtype == MF_BF16 || d->dtype == MF_F16X3 || d->dtype == MF_BF16X3 || d->dtype == MF_FP8 ||
-                     d->dtype == MF_BF16X1,
+                     d->dtype == MF_BF16X1 || d->dtype == MF_F16,
                  "mf_gemm_conv: bad dtype %d", d->dtype);
     const bool split = d->dtype == MF_F16X3 || d->dtype == MF_BF16X3 || d->dtype == MF_BF16X1;
     MF_CHECK_ARG(d->dtype != MF_BF16X1 || d->w_split == 0, "mf_gemm_conv: MF_BF16X1 takes the raw fp32 weight");
@@ -245,14 +245,14 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.vt_out = (char*)d->vt_out; a.vt_n0 = d->vt_n0; a.vt_tokens = d->vt_tokens; a.vt_ld = d->vt_ld;
     if (d->ln_colsum || d->vt_out) {
         // served by the warp-specialised ring tiles only (41-46, 48): the staging waves gather the row statistics
-        MF_CHECK_ARG(d->dtype == MF_BF16 && d->a_dtype == MF_BF16 && d->kh == 1 && d->kw == 1 && d->c1 == 0 && d->nz == 1 &&
+        MF_CHECK_ARG(mf_is16(d->dtype) && d->a_dtype == d->dtype && d->kh == 1 && d->kw == 1 && d->c1 == 0 && d->nz == 1 &&
                          (d->splitk == 0 || d->splitk == 1) && d->a_scale == nullptr && d->w_scale == nullptr,
-                     "mf_gemm_conv: ln_colsum / vt_out need a plain bf16 1x1 GEMM (one A segment, no batching, no split-K, no scales)");
+                     "mf_gemm_conv: ln_colsum / vt_out need a plain bf16 / fp16 1x1 GEMM (one A segment, no batching, no split-K, no scales)");
         MF_CHECK_ARG(d->tile == 0 || (d->tile >= 41 && d->tile <= 48 && d->tile != 47) || d->tile == 50 || d->tile == 52,
                      "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (the warp-specialised ring tiles 41-46, 48, 50, 52 do)", d->tile);
         MF_CHECK_ARG(!d->ln_colsum || (mf_aligned16(d->ln_colsum) && d->n % 8 == 0 && d->ln_eps > 0.0f), "mf_gemm_conv: ln_colsum must be 16-byte aligned, n %% 8 == 0, ln_eps > 0");
         if (d->vt_out) {
-            MF_CHECK_ARG(d->out_dtype == MF_BF16 && mf_aligned16(d->vt_out) && d->vt_tokens > 0 && d->vt_tokens % 8 == 0 && a.M % d->vt_tokens == 0 &&
+            MF_CHECK_ARG(mf_is16(d->out_dtype) && mf_aligned16(d->vt_out) && d->vt_tokens > 0 && d->vt_tokens % 8 == 0 && a.M % d->vt_tokens == 0 &&
                              d->vt_ld % 8 == 0 && d->vt_ld >= d->vt_tokens && d->vt_n0 > 0 && d->vt_n0 < d->n && d->vt_n0 % 160 == 0 &&
                              d->vt_n0 % 128 == 0 && d->res0 == nullptr && d->res1 == nullptr && d->temb == nullptr && d->act == MF_ACT_NONE &&
                              d->bias_mode == 0,
@@ -282,10 +282,10 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         if (tile >= 7 && tile <= 12) tile -= 6;
         MF_CHECK_ARG(tile <= 6, "mf_gemm_conv: tile %d does not apply to fp32 activations with bf16 compute (tiles 1-12 do)", tile);
     }
-    MF_CHECK_ARG(tile < 25 || tile > 30 || (d->dtype == MF_BF16 && !a_f32), "mf_gemm_conv: tile %d (16x16x32 MFMA form) does not apply: bf16 only", tile);
+    MF_CHECK_ARG(tile < 25 || tile > 30 || (mf_is16(d->dtype) && !a_f32), "mf_gemm_conv: tile %d (16x16x32 MFMA form) does not apply: bf16 / fp16 only", tile);
     const bool split_ws = d->dtype == MF_F16X3 && d->w_split == 1 && (tile == 37 || tile == 38 || tile == 41 || tile == 44);
     MF_CHECK_ARG(tile < 31 || split_ws || (!a_f32 && !split && d->dtype != MF_FP8), "mf_gemm_conv: tile %d (deep ring) does not apply to this precision", tile);
-    MF_CHECK_ARG(tile < 37 || d->dtype == MF_BF16 || split_ws,
+    MF_CHECK_ARG(tile < 37 || mf_is16(d->dtype) || split_ws,
                  "mf_gemm_conv: tile %d (warp-specialised) does not apply: bf16, or f16x3 with a pre-split weight on tiles 37 / 38 / 41 / 44", tile);
     const TileCfg& tc = kTiles[tile - 1];
     if (tc.halo) {
@@ -428,7 +428,13 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     else if (d->dtype == MF_BF16X1) launched = launch_bf16x1(tile, a, grid, s);
     else if (d->dtype == MF_F16X3) launched = (d->w_split && tile >= 37) ? launch_f16x3_ws(tile, a, grid, s) : launch_f16x3(tile, a, grid, s, d->w_split != 0);
     else if (d->dtype == MF_BF16X3) launched = launch_bf16x3(tile, a, grid, s, d->w_split != 0);
-    else if (d->dtype == MF_BF16) {
+    else if (d->dtype == MF_F16) {
+        launched = tile <= 6    ? launch_f16_a(tile, a, grid, s, false)
+                   : tile <= 24 ? launch_f16_b(tile, a, grid, s)
+                   : tile <= 36 ? launch_f16_c(tile, a, grid, s)
+                   : (tile <= 40 || tile == 47 || tile == 49 || tile == 51) ? launch_f16_ws_dx(tile, a, grid, s)
+                                                                            : launch_f16_ws_ring(tile, a, grid, s);
+    } else if (d->dtype == MF_BF16) {
         launched = (a_f32 || tile <= 6) ? launch_bf16_a(tile, a, grid, s, a_f32)
                    : tile <= 24         ? launch_bf16_b(tile, a, grid, s)
                    : tile <= 36         ? launch_bf16_c(tile, a, grid, s)

@@ -128,11 +128,7 @@ __device__ __forceinline__ void load8_as_f32(const char* p, int dt, int64_t idx,
         const float4 b = *reinterpret_cast<const float4*>(p + idx * 4 + 16);
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     } else {
-        const uint4 u = *reinterpret_cast<const uint4*>(p + idx * 2);
-        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
-        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
-        o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
-        o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+        unpack_h8(*reinterpret_cast<const uint4*>(p + idx * 2), dt, o);
     }
 }
 
@@ -181,14 +177,14 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
     if (p.res0) {
         float r[8];
-        if (pre) unpack8_bf16(q0, r);
+        if (pre) unpack_h8(q0, p.res0_dt, r);
         else load8_as_f32(p.res0, p.res0_dt, (int64_t)m * p.ld_res0 + n, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
     if (p.res1) {
         float r[8];
-        if (pre) unpack8_bf16(q1, r);
+        if (pre) unpack_h8(q1, p.res1_dt, r);
         else load8_as_f32(p.res1, p.res1_dt, (int64_t)res1_row(p, m) * p.ld_res1 + n, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
@@ -200,8 +196,8 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
     if (p.act == MF_ACT_GEGLU4) {
         // weight rows are interleaved [4 values | 4 gates]: out[n/2 + j] = v[j] * gelu_erf(v[4 + j])  (activations.py:100-103)
         float g[4];
-        if (p.out_dt == MF_BF16) {
-            // bf16 output: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside the bf16 rounding) on
+        if (p.out_dt != MF_F32) {
+            // 16-bit output: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside the bf16 rounding) on
             // v_rcp_f32 / v_exp_f32 -- about half the VALU work of erff, and this epilogue runs once per 5 K-tiles
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -221,8 +217,8 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
             *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(g[0], g[1], g[2], g[3]);
         } else {
             uint2 u;
-            u.x = pack_bf16x2(g[0], g[1]);
-            u.y = pack_bf16x2(g[2], g[3]);
+            u.x = pack_h2(g[0], g[1], p.out_dt);
+            u.y = pack_h2(g[2], g[3], p.out_dt);
             *reinterpret_cast<uint2*>(p.out + o * 2) = u;
         }
         return;
@@ -232,12 +228,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
         *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p.out + o * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        uint4 u;
-        u.x = pack_bf16x2(v[0], v[1]);
-        u.y = pack_bf16x2(v[2], v[3]);
-        u.z = pack_bf16x2(v[4], v[5]);
-        u.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(p.out + o * 2) = u;
+        *reinterpret_cast<uint4*>(p.out + o * 2) = pack_h8(v, p.out_dt);
     }
 }
 
@@ -265,6 +256,18 @@ __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_off) : "memory");
+}
+
+// one 16-bit MFMA by compute code (MF_BF16 / MF_F16): fragments are passed as bf16x8_t bit patterns
+template <int DT>
+__device__ __forceinline__ f32x4_t mfma16x32(bf16x8_t a, bf16x8_t b, f32x4_t c, int, int, int) {
+    if constexpr (DT == MF_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <int DT>
+__device__ __forceinline__ f32x16_t mfma32x16(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    if constexpr (DT == MF_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // LDS layout of the staged epilogue rows of a warp-specialised tile: [bias][ln_colsum][temb of image 0 .. nimg-1], fp32, each row
@@ -363,14 +366,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 + (WS ? 256 : 0),
 void gemm_conv_kernel(const GemmArgs p) {
     constexpr int NTHR = WAVES_M * WAVES_N * 64;      // compute threads (also the staging threads unless WS)
     constexpr int NSTG = WS ? 256 : NTHR;             // staging threads: WS adds four producer waves, one per SIMD
-    static_assert(!WS || ((DT == MF_BF16 || (DT == MF_F16X3 && WPK && !M16 && !P16)) && !A_F32 && STAGES == 3),
-                  "warp specialisation: bf16 (or the parity mode with a pre-split W), LDS-DMA staging, 3-deep ring");
-    static_assert(!M16 || (DT == MF_BF16 && !A_F32), "the 16x16x32 form is instantiated for bf16 only");
+    constexpr bool H16 = DT == MF_BF16 || DT == MF_F16;      // 16-bit operands in memory: one MFMA per product (MF_F16: the f16 forms)
+    static_assert(!WS || ((H16 || (DT == MF_F16X3 && WPK && !M16 && !P16)) && !A_F32 && STAGES == 3),
+                  "warp specialisation: bf16 / fp16 (or the parity mode with a pre-split W), LDS-DMA staging, 3-deep ring");
+    static_assert(!M16 || (H16 && !A_F32), "the 16x16x32 form is instantiated for bf16 / fp16 only");
     constexpr bool X1 = DT == MF_BF16X1;      // fp32 operands rounded to bf16 (RNE) in registers, ONE MFMA per product
     constexpr bool SPLIT = (DT == MF_F16X3 || DT == MF_BF16X3 || X1);
     static_assert(!WPK || (SPLIT && !X1), "a pre-split W operand only exists for the three-MFMA split codes");
     constexpr bool FP8 = (DT == MF_FP8);
-    constexpr int ES = (DT == MF_BF16) ? 2 : (FP8 ? 1 : 4);   // element size of the operands in memory / LDS
+    constexpr int ES = H16 ? 2 : (FP8 ? 1 : 4);   // element size of the operands in memory / LDS
     constexpr int AES = A_F32 ? 4 : ES;          // element size of the A storage dtype
     constexpr int VEC = 16 / ES;                 // elements per 16-byte LDS chunk
     constexpr int BK = 128 / ES;                 // K elements per tile (128 bytes per row)
@@ -380,7 +384,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     // 128x160 block (a CU's whole share of the 32x32-level convs)
     // (round 5: 64-row wave tiles too — 4x2 waves of 64x80 on a 256x160 block read 9 fragments per 20 MFMAs where 8x1 waves of
     // 32x160 read 12, and their two register sets of the cross-tile pipeline fit the 168 registers of three waves per SIMD)
-    static_assert(!P16 || (WS && DT == MF_BF16 && !M16 && (WM == 32 || WM == 64) && WN % 16 == 0), "P16: warp-specialised forms, 32- or 64-row wave tiles");
+    static_assert(!P16 || (WS && H16 && !M16 && (WM == 32 || WM == 64) && WN % 16 == 0), "P16: warp-specialised forms, 32- or 64-row wave tiles");
     constexpr int MT = WM / 32, NT = P16 ? 1 : WN / 32;
     constexpr int MT16 = WM / 16, NT16 = WN / 16;
     constexpr int RPP = NSTG / 8;                // rows staged per pass (8 lanes per 128-B row)
@@ -785,7 +789,7 @@ void gemm_conv_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4_t c = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][2 * i + (q >> 1)]),
+                        c = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, fa[ks][2 * i + (q >> 1)]),
                                                                     __builtin_bit_cast(bf16x8_t, fb[ks][2 * j + (q & 1)]), c, 0, 0, 0);
                         acc[i][j][4 * q] = c[0]; acc[i][j][4 * q + 1] = c[1]; acc[i][j][4 * q + 2] = c[2]; acc[i][j][4 * q + 3] = c[3];
                     }
@@ -799,6 +803,9 @@ void gemm_conv_kernel(const GemmArgs p) {
                 if constexpr (DT == MF_BF16) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8_t, fa[i]), __builtin_bit_cast(bf16x8_t, fb[j]), acc[i][j], 0, 0, 0);
+                } else if constexpr (DT == MF_F16) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                        __builtin_bit_cast(f16x8_t, fa[i]), __builtin_bit_cast(f16x8_t, fb[j]), acc[i][j], 0, 0, 0);
                 } else {
                     const f32x4_t av = __builtin_bit_cast(f32x4_t, fa[i]);
                     const f32x4_t bv = __builtin_bit_cast(f32x4_t, fb[j]);
@@ -829,7 +836,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                 for (int a = 0; a < MT16; ++a)
 #pragma unroll
                     for (int b = 0; b < NT16; ++b)
-                        acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][a]),
+                        acc16[a][b] = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, fa[ks][a]),
                                                                               __builtin_bit_cast(bf16x8_t, fb[ks][b]), acc16[a][b], 0, 0, 0);
             return;
         }
@@ -886,7 +893,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     // consumers now arrive when tile k - 1's READS are complete instead of its MFMAs.  Same accumulation order: bit-identical.
     // Not for 8 x 1 compute waves of 32x160 (tiles 37 / 39 / 42): two sets of 12 fragments beside 80 accumulators exceed the 168
     // registers of three waves per SIMD and spill INSIDE the loop; tiles 49 / 50 are their 4 x 2 (64x80) successors.
-    constexpr bool XT = WS && DT == MF_BF16 && !A_F32 && (MF_XTAP != 0) && !(WAVES_M == 8 && WAVES_N == 1);
+    constexpr bool XT = WS && H16 && !A_F32 && (MF_XTAP != 0) && !(WAVES_M == 8 && WAVES_N == 1);
     constexpr int XNA = !XT ? 1 : (P16 ? MT16 : 2 * MT), XNB = !XT ? 1 : (P16 ? NT16 : 2 * NT);
     uint4 xa[2][XNA], xb[2][XNB];
     // fragments of half H (compile-time) of one K tile.  arow(t): LDS row of this lane's row of A fragment t (P16 / M16: 16-row
@@ -923,7 +930,7 @@ void gemm_conv_kernel(const GemmArgs p) {
             for (int a = 0; a < MT16; ++a)
 #pragma unroll
                 for (int b = 0; b < NT16; ++b)
-                    acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xa[hh][a]),
+                    acc16[a][b] = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, xa[hh][a]),
                                                                           __builtin_bit_cast(bf16x8_t, xb[hh][b]), acc16[a][b], 0, 0, 0);
         } else if constexpr (M16) {
 #pragma unroll
@@ -933,7 +940,7 @@ void gemm_conv_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4_t c = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, xa[hh][2 * i + (q >> 1)]),
+                        c = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, xa[hh][2 * i + (q >> 1)]),
                                                                     __builtin_bit_cast(bf16x8_t, xb[hh][2 * j + (q & 1)]), c, 0, 0, 0);
                         acc[i][j][4 * q] = c[0]; acc[i][j][4 * q + 1] = c[1]; acc[i][j][4 * q + 2] = c[2]; acc[i][j][4 * q + 3] = c[3];
                     }
@@ -944,8 +951,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, xa[hh][kk * MT + i]),
-                                                                            __builtin_bit_cast(bf16x8_t, xb[hh][kk * NT + j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma32x16<DT>(__builtin_bit_cast(bf16x8_t, xa[hh][kk * MT + i]), __builtin_bit_cast(bf16x8_t, xb[hh][kk * NT + j]), acc[i][j]);
         }
     };
     using H0 = std::integral_constant<int, 0>;
@@ -1068,7 +1074,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                         for (int a = 0; a < MT16; ++a)
 #pragma unroll
                             for (int b = 0; b < NT16; ++b)
-                                acc16[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[ks][a]),
+                                acc16[a][b] = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, fa[ks][a]),
                                                                                       __builtin_bit_cast(bf16x8_t, fb[ks][b]), acc16[a][b], 0, 0, 0);
                     return;
                 }
@@ -1289,6 +1295,20 @@ void gemm_conv_kernel(const GemmArgs p) {
                                     ln_q[i] = __builtin_amdgcn_fdot2_f32_bf16(v, v, ln_q[i], false);
                                 }
                             }
+                        } else if constexpr (DT == MF_F16) {
+                            const char* As = smem + st_s * STAGE_BYTES + tid * 16;
+#pragma unroll
+                            for (int i = 0; i < A_IT; ++i) {
+                                const uint4 u = *reinterpret_cast<const uint4*>(As + i * RPP * 128);
+                                const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const mf_f16x2_t v = __builtin_bit_cast(mf_f16x2_t, w4[e]);
+                                    const float a0 = (float)v[0], a1 = (float)v[1];
+                                    ln_s[i] += a0 + a1;
+                                    ln_q[i] = fmaf(a0, a0, fmaf(a1, a1, ln_q[i]));
+                                }
+                            }
                         }
                         st_s = st_s == STAGES - 1 ? 0 : st_s + 1;
                     };
@@ -1416,8 +1436,8 @@ void gemm_conv_kernel(const GemmArgs p) {
     const int64_t zo = zq * p.o_zs_o + zr * p.o_zs_i;
     // bf16 residuals of a slab's items are fetched BEFORE its LDS transposition: loads and stores share vmcnt and
     // return in order, so a load issued after the previous item's store waits for that store's round trip
-    const bool res_pre = !ws && p.vec_ok && (p.res0 || p.res1) && (!p.res0 || p.res0_dt == MF_BF16) &&
-                         (!p.res1 || p.res1_dt == MF_BF16) && !p.dbg_no_res_pre;
+    const bool res_pre = !ws && p.vec_ok && (p.res0 || p.res1) && (!p.res0 || p.res0_dt != MF_F32) &&
+                         (!p.res1 || p.res1_dt != MF_F32) && !p.dbg_no_res_pre;
     constexpr int NIT = (ITEMS + 63) / 64;
     if constexpr (WS) {
         // Warp-specialised blocks: the four staging waves have nothing left to stage, so they take their share of the
@@ -1516,9 +1536,7 @@ void gemm_conv_kernel(const GemmArgs p) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) tv[j] = (tv[j] + b) * p.alpha;
                         const int img = mt / p.vt_tokens, tok = mt - img * p.vt_tokens;
-                        uint4 o;
-                        o.x = pack_bf16x2(tv[0], tv[1]); o.y = pack_bf16x2(tv[2], tv[3]);
-                        o.z = pack_bf16x2(tv[4], tv[5]); o.w = pack_bf16x2(tv[6], tv[7]);
+                        const uint4 o = pack_h8(tv, p.out_dt);
                         *reinterpret_cast<uint4*>(p.vt_out + (((int64_t)img * (p.N - p.vt_n0) + (nt_ - p.vt_n0)) * p.vt_ld + tok) * 2) = o;
                     }
                     continue;
@@ -1695,6 +1713,11 @@ bool launch_bf16_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);      
 bool launch_bf16_c(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);               // 25-36
 bool launch_bf16_ws_dx(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);           // 37-40, 47, 49, 51: warp-specialised dx-reuse convs
 bool launch_bf16_ws_ring(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);         // 41-46, 48, 50, 52: warp-specialised plain ring
+bool launch_f16_a(int tile, const GemmArgs& a, dim3 grid, hipStream_t s, bool a_f32);    // fp16: the bf16 groups' tiles on the f16 MFMA forms
+bool launch_f16_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);
+bool launch_f16_c(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);
+bool launch_f16_ws_dx(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);
+bool launch_f16_ws_ring(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);
 bool launch_f32_a(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);                // fp32 MFMA, tiles 1-12
 bool launch_f32_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);                // fp32 MFMA, tiles 13-15, 20-24, 31-36
 bool launch_f16x3(int tile, const GemmArgs& a, dim3 grid, hipStream_t s, bool wpk);

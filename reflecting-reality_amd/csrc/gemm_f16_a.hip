@@ -1,7 +1,7 @@
-// bf16 tiles 7-15, 20-24
+// f16 tiles 1-6
 // (one tile group of mf_gemm_conv; tile tables: gemm_16bit_tiles.h, kernel template: gemm_conv_kernel.h)
 #include "gemm_16bit_tiles.h"
 
 namespace mfgemm {
-bool launch_bf16_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) { return launch16_b<MF_BF16>(tile, a, grid, s); }
+bool launch_f16_a(int tile, const GemmArgs& a, dim3 grid, hipStream_t s, bool a_f32) { return launch16_a<MF_F16>(tile, a, grid, s, a_f32); }
 }  // namespace mfgemm

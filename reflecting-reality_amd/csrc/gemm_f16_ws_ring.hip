@@ -1,0 +1,7 @@
+// f16 tiles 41-46, 48, 50, 52: warp-specialised plain ring
+// (one tile group of mf_gemm_conv; tile tables: gemm_16bit_tiles.h, kernel template: gemm_conv_kernel.h)
+#include "gemm_16bit_tiles.h"
+
+namespace mfgemm {
+bool launch_f16_ws_ring(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) { return launch16_ws_ring<MF_F16>(tile, a, grid, s); }
+}  // namespace mfgemm

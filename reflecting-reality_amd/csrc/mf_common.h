@@ -47,12 +47,37 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mf_bf16x2_t));
 }
 
+// ---- the two 16-bit storage types (MF_BF16, MF_F16): a packed pair <-> two fp32, by dtype code (wave-uniform at every call site)
+typedef __attribute__((ext_vector_type(2))) _Float16 mf_f16x2_t;
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {          // nearest-even (v_cvt_f16_f32 x 2 + pack); NOT pkrtz
+    const mf_f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mf_f16x2_t));
+}
+__device__ __forceinline__ uint32_t pack_h2(float a, float b, int dt) { return dt == MF_F16 ? pack_f16x2(a, b) : pack_bf16x2(a, b); }
+__device__ __forceinline__ void unpack_h2(uint32_t u, int dt, float& a, float& b) {
+    if (dt == MF_F16) {
+        const mf_f16x2_t h = __builtin_bit_cast(mf_f16x2_t, u);
+        a = (float)h[0]; b = (float)h[1];
+    } else {
+        a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ void unpack_h8(const uint4& u, int dt, float* o) {
+    unpack_h2(u.x, dt, o[0], o[1]); unpack_h2(u.y, dt, o[2], o[3]); unpack_h2(u.z, dt, o[4], o[5]); unpack_h2(u.w, dt, o[6], o[7]);
+}
+__device__ __forceinline__ uint4 pack_h8(const float* v, int dt) {
+    return uint4{pack_h2(v[0], v[1], dt), pack_h2(v[2], v[3], dt), pack_h2(v[4], v[5], dt), pack_h2(v[6], v[7], dt)};
+}
+
 // dtype-generic scalar load/store (dt is wave-uniform at every call site)
 __device__ __forceinline__ float load_as_f32(const void* p, int dt, int64_t i) {
-    return dt == MF_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_raw*)p)[i]);
+    if (dt == MF_F32) return ((const float*)p)[i];
+    if (dt == MF_F16) return (float)((const _Float16*)p)[i];
+    return bf16_to_f32(((const bf16_raw*)p)[i]);
 }
 __device__ __forceinline__ void store_from_f32(void* p, int dt, int64_t i, float v) {
     if (dt == MF_F32) ((float*)p)[i] = v;
+    else if (dt == MF_F16) ((_Float16*)p)[i] = (_Float16)v;
     else ((bf16_raw*)p)[i] = f32_to_bf16(v);
 }
 
@@ -117,5 +142,6 @@ unsigned* mf_ovf_flag_attention();
 unsigned* mf_ovf_flag_train();
 
 // bytes per element in memory; the split compute codes keep fp32 operands
-static inline int mf_dtype_size(int dt) { return dt == MF_BF16 ? 2 : (dt == MF_FP8 ? 1 : 4); }
+static inline int mf_dtype_size(int dt) { return (dt == MF_BF16 || dt == MF_F16) ? 2 : (dt == MF_FP8 ? 1 : 4); }
+static inline bool mf_is16(int dt) { return dt == MF_BF16 || dt == MF_F16; }
 static inline bool mf_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

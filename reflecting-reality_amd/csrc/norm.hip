@@ -27,10 +27,8 @@ __device__ __forceinline__ float4 load4(const char* p, int dt, int64_t idx) {
     if (dt == MF_F32) return *reinterpret_cast<const float4*>(p + idx * 4);
     const uint2 u = *reinterpret_cast<const uint2*>(p + idx * 2);
     float4 r;
-    r.x = __uint_as_float(u.x << 16);
-    r.y = __uint_as_float(u.x & 0xffff0000u);
-    r.z = __uint_as_float(u.y << 16);
-    r.w = __uint_as_float(u.y & 0xffff0000u);
+    unpack_h2(u.x, dt, r.x, r.y);
+    unpack_h2(u.y, dt, r.z, r.w);
     return r;
 }
 __device__ __forceinline__ void store4(char* p, int dt, int64_t idx, float4 v) {
@@ -38,8 +36,8 @@ __device__ __forceinline__ void store4(char* p, int dt, int64_t idx, float4 v) {
         *reinterpret_cast<float4*>(p + idx * 4) = v;
     } else {
         uint2 u;
-        u.x = pack_bf16x2(v.x, v.y);
-        u.y = pack_bf16x2(v.z, v.w);
+        u.x = pack_h2(v.x, v.y, dt);
+        u.y = pack_h2(v.z, v.w, dt);
         *reinterpret_cast<uint2*>(p + idx * 2) = u;
     }
 }
@@ -50,11 +48,7 @@ __device__ __forceinline__ void load8(const char* p, int dt, int64_t idx, float*
         const float4 b = *reinterpret_cast<const float4*>(p + idx * 4 + 16);
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     } else {
-        const uint4 u = *reinterpret_cast<const uint4*>(p + idx * 2);
-        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
-        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
-        o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
-        o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+        unpack_h8(*reinterpret_cast<const uint4*>(p + idx * 2), dt, o);
     }
 }
 __device__ __forceinline__ void store8(char* p, int dt, int64_t idx, const float* v) {
@@ -62,12 +56,7 @@ __device__ __forceinline__ void store8(char* p, int dt, int64_t idx, const float
         *reinterpret_cast<float4*>(p + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p + idx * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        uint4 u;
-        u.x = pack_bf16x2(v[0], v[1]);
-        u.y = pack_bf16x2(v[2], v[3]);
-        u.z = pack_bf16x2(v[4], v[5]);
-        u.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(p + idx * 2) = u;
+        *reinterpret_cast<uint4*>(p + idx * 2) = pack_h8(v, dt);
     }
 }
 
@@ -248,7 +237,7 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
     if (r1 > p.HW) r1 = p.HW;
     const int esz = p.in_dt == MF_F32 ? 4 : 2, osz = p.out_dt == MF_F32 ? 4 : 2;
     const float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
-    const bool fast_silu = p.out_dt == MF_BF16;         // bf16 output: __expf is far inside the rounding
+    const bool fast_silu = p.out_dt != MF_F32;          // 16-bit output: __expf is far inside the rounding
     for (int col = lcol; col < p.cvn; col += p.tpr) {
         const int c = col * VW;
         const char* base; int64_t ld; int cc;
@@ -391,7 +380,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, i
         sa[e] = gr[g] * sa[e];
         sb[e] = sb[e] - gm[g] * sa[e];
     }
-    const bool fast_silu = p.out_dt == MF_BF16;
+    const bool fast_silu = p.out_dt != MF_F32;
     const int64_t ostep = (int64_t)P * p.C * osz;
     char* optr = p.out + (((int64_t)b * p.HW + lane) * p.C + c) * osz;
 #pragma unroll

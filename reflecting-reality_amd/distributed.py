@@ -146,7 +146,10 @@ class GradBuckets:
         self._by_grad = {}
         for pi, p in enumerate(self._plan):
             self._by_grad[p["model"].flat_g.untyped_storage().data_ptr()] = pi
-        tape.on_param_grad = self._on_param if (self.world > 1 or self.force) else None
+        # MF_GRAD_SYNC_SERIAL=1 (tools/run_8gpu.sh): no exchange under the backward pass — finish() sends every bucket afterwards; the
+        # step-time difference against the default is what the overlap hides
+        serial = os.environ.get("MF_GRAD_SYNC_SERIAL") == "1"
+        tape.on_param_grad = self._on_param if ((self.world > 1 or self.force) and not serial) else None
 
     def _on_param(self, param) -> None:
         pi = self._by_grad.get(param.grad.untyped_storage().data_ptr())

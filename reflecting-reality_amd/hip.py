@@ -14,10 +14,10 @@ import torch
 
 from . import _build
 
-MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1 = 0, 1, 2, 3, 4, 5
+MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1, MF_F16 = 0, 1, 2, 3, 4, 5, 6
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class MfhipError(RuntimeError):
@@ -123,7 +123,7 @@ class GroupNormDesc(C.Structure):
 EXPORTS = [
     "mf_abi_version", "mf_last_error", "mf_sizeof_gemm_desc", "mf_sizeof_groupnorm_desc",
     "mf_gemm_conv", "mf_gemm_num_tiles", "mf_gemm_tile_shape", "mf_gemm_tile_table_version",
-    "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16",
+    "mf_groupnorm", "mf_groupnorm_ws_floats", "mf_layernorm", "mf_softmax_rows", "mf_attention_bf16", "mf_attention_f16",
     "mf_attention_f16x3", "mf_attention_f16x3_lse", "mf_sizeof_attn_bwd_desc", "mf_attention_bwd_f16x3", "mf_rowdot_heads",
     "mf_attention_bwd_bf16", "mf_attention_bf16_lse", "mf_rowdot_heads_bf16", "mf_cast_bf16_colsum", "mf_cast_bf16_colsum_ws_floats",
     "mf_transpose_bf16_bf16", "mf_geglu_bwd_bf16", "mf_geglu_bwd_bf16_ws_floats", "mf_rowdot_heads_cast", "mf_debug_set_wgrad_dma", "mf_zero_ranges",
@@ -190,6 +190,8 @@ def dt_code(dtype: torch.dtype) -> int:
         return MF_F32
     if dtype == torch.bfloat16:
         return MF_BF16
+    if dtype == torch.float16:
+        return MF_F16
     if dtype == FP8:
         return MF_FP8
     raise MfhipError(f"unsupported dtype {dtype}")
@@ -313,6 +315,13 @@ AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
 SK_FUSED = os.environ.get("MFHIP_SK_FUSED", "0") == "1"
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
 TUNE_GRAPH = os.environ.get("MFHIP_TUNE_GRAPH", "0") == "1"   # developer switch: time candidates from a hipGraph (see _tuned_config)
+TUNE_LOG: Optional[dict] = None     # developer hook (tools/tune_step.py): every candidate's time of every key tuned while it is a dict
+KEY_LOG: Optional[list] = None      # developer hook: the tune key of every autotuned mf_gemm_conv call while it is a list
+# Where in the denoise step a call sits ("b": BrushNet, on the side stream under the UNet's encoder; "e": UNet encoder + mid block;
+# "d": UNet decoder, alone on the chip once BrushNet has finished).  The best tile for one shape differs between them — a tile that
+# leaves room for the other stream's blocks wins under overlap, a whole-CU ring tile wins alone (tools/tune_step.py) — so the tune
+# cache may hold "<key>@<ctx>" entries beside the plain one; a missing tagged entry falls back to the plain key.
+TUNE_CTX: Optional[str] = None
 # The package ships a cache tuned on MI355X (read-only); new winners go to a per-user file (MFHIP_TUNE_CACHE, default
 # ~/.cache/mfhip/tune_cache.json) that is overlaid on it.  Both carry the library's tile-table version: when tiles are
 # renumbered (mf_gemm_tile_table_version changes) stale indices are dropped instead of being trusted.
@@ -402,7 +411,7 @@ def _tuned_config(d: "GemmDesc", key: tuple):
         print(f"[mfhip] rank {os.environ['RANK']}: GEMM shape {ks} is not in the tune cache; autotuning on this rank "
               f"(further misses are tuned silently; winners go to {tune_user_path()})", file=sys.stderr, flush=True)
     m, n, k = key[2], key[3], key[4]
-    es = 2 if key[0] == MF_BF16 else 1 if key[0] == MF_FP8 else 4
+    es = 2 if key[0] in (MF_BF16, MF_F16) else 1 if key[0] == MF_FP8 else 4
     nkt = (k * es + 127) // 128
     cands = []
     ntiles = lib.mf_gemm_num_tiles()
@@ -454,6 +463,8 @@ def _tuned_config(d: "GemmDesc", key: tuple):
                 e1.record()
                 e1.synchronize()
                 dt = min(dt, e0.elapsed_time(e1))
+        if TUNE_LOG is not None:
+            TUNE_LOG.setdefault(ks, []).append((dt, t, s, mode))
         if dt < best_t:
             best, best_t = (t, s, mode), dt
     cache[ks] = best
@@ -488,7 +499,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     d.batch, d.h_in, d.w_in, d.h_out, d.w_out = batch, h_in, w_in, h_out, w_out
     d.kh, d.kw, d.stride, d.pad_t, d.pad_l, d.upsample = kh, kw, stride, pad_t, pad_l, int(upsample)
     want_w = ({MF_F16X3: torch.float16, MF_BF16X3: torch.bfloat16}[code] if w_split else
-              torch.bfloat16 if code == MF_BF16 else FP8 if code == MF_FP8 else torch.float32)
+              torch.bfloat16 if code == MF_BF16 else torch.float16 if code == MF_F16 else FP8 if code == MF_FP8 else torch.float32)
     if w.dtype != want_w:
         raise MfhipError(f"weight dtype {w.dtype} != {want_w} expected by compute code {code} (w_split={w_split})")
     d.w = _ptr(w)
@@ -528,8 +539,8 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         fused |= 1
     if vt_out is not None:
         _req_cuda(vt_out)
-        if vt_out.dtype != torch.bfloat16 or vt_out.dim() != 3 or not vt_out.is_contiguous():
-            raise MfhipError("vt_out must be a contiguous bf16 [images][n - vt_n0][ld] tensor")
+        if vt_out.dtype not in (torch.bfloat16, torch.float16) or vt_out.dim() != 3 or not vt_out.is_contiguous():
+            raise MfhipError("vt_out must be a contiguous bf16 / fp16 [images][n - vt_n0][ld] tensor")
         d.vt_out, d.vt_n0, d.vt_tokens, d.vt_ld = _ptr(vt_out), vt_n0, vt_tokens, vt_out.shape[-1]
         fused |= 2
     tkey = None
@@ -537,7 +548,16 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         tkey = (code, d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), int(c1 > 0),
                 nz, int(splitk == 1) if not fused else 1, act, h_out, w_out) + ((w_split,) if code in (MF_F16X3, MF_BF16X3) else ()) \
             + ((("ln", "vt", "lnvt")[fused - 1],) if fused else ())
-        cfg = _tuned_config(d, tkey)
+        cfg = None
+        if TUNE_CTX is not None:
+            ks_ctx = _tune_key(tkey) + "@" + TUNE_CTX
+            cfg = _tune_load().get(ks_ctx)
+            if KEY_LOG is not None:
+                KEY_LOG.append(ks_ctx)
+        elif KEY_LOG is not None:
+            KEY_LOG.append(_tune_key(tkey))
+        if cfg is None:
+            cfg = _tuned_config(d, tkey)
         d.tile, d.splitk = cfg[0], cfg[1]
         if len(cfg) > 2 and cfg[2]:
             tk = sk_tickets(out.device)
@@ -625,6 +645,14 @@ def attention_bf16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torc
                    lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`lse` (fp32 [batch, heads, sq], written): the row statistic of the flash backward (mf_attention_bf16_lse)."""
     _req_cuda(q, k, vt, out, lse)
+    if q.dtype == torch.float16:          # the fp16 storage mode: the same kernel on the f16 MFMA forms (inference: no row statistics)
+        if lse is not None or not (k.dtype == vt.dtype == out.dtype == torch.float16):
+            raise MfhipError("attention_bf16: fp16 operands take fp16 k / vt / out and no lse")
+        _check(load().mf_attention_f16(C.c_void_p(q.data_ptr()), C.c_int64(ldq), C.c_void_p(k.data_ptr()), C.c_int64(ldk),
+                                       C.c_void_p(vt.data_ptr()), C.c_int64(ldvt), C.c_void_p(out.data_ptr()),
+                                       C.c_int64(ldo), batch, heads, sq, skv, head_dim, C.c_float(scale), _stream()),
+               "mf_attention_f16")
+        return out
     if lse is None:
         _check(load().mf_attention_bf16(C.c_void_p(q.data_ptr()), C.c_int64(ldq), C.c_void_p(k.data_ptr()), C.c_int64(ldk),
                                         C.c_void_p(vt.data_ptr()), C.c_int64(ldvt), C.c_void_p(out.data_ptr()),

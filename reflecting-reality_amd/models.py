@@ -549,7 +549,7 @@ class _UNetCore(HipModel):
                                                                self.prec, self.device, fp8=ok8(b + "ff.net.0.proj"))
             self.P[b + "ff.net.2"] = self._conv(sd, b + "ff.net.2", fp8=ok8(b + "ff.net.2"))
             c = sd[b + "norm1.weight"].shape[0]
-            if self.prec.name == "bf16" and not self.training and c % 320 == 0:
+            if self.prec.name in ("bf16", "fp16") and not self.training and c % 320 == 0:
                 # bf16 inference: the three LayerNorms of the block are FOLDED into the Linears that consume them (W diag(gamma),
                 # bias + W beta; the GEMM gathers the row statistics itself and normalises in its epilogue), and q | k | v of the
                 # self-attention are one GEMM whose V third is stored transposed: 3 LayerNorm launches and the V^T launch less
@@ -1092,6 +1092,7 @@ class BrushNetModel(_UNetCore):
             with torch.cuda.stream(side):
                 d, m, u = self._forward_impl(sample, timestep, brushnet_cond, conditioning_scale, publish, added_cond_kwargs,
                                              guess_mode, _temb, _lazy)
+        hip.TUNE_CTX = None
         if not return_dict:
             return d, m, u
         return BrushNetOutput(down_block_res_samples=d, mid_block_res_sample=m, up_block_res_samples=u)
@@ -1109,6 +1110,7 @@ class BrushNetModel(_UNetCore):
         n = len(c["block_out_channels"])
         lpb = c["layers_per_block"]
         n_down, n_up = 1 + n * lpb + (n - 1), n * (lpb + 1) + (n - 1)
+        hip.TUNE_CTX = "b" if ops.TAPE is None else None      # inference: position-dependent tile choices (hip.TUNE_CTX)
         if guess_mode:
             sc = (torch.logspace(-1, 0, n_down + 1 + n_up) * conditioning_scale).tolist()
         else:
@@ -1301,6 +1303,7 @@ class UNet2DConditionModel(_UNetCore):
         x = from_nchw(sample.to(self.device), self.prec, self.cin_pad)
         if ops.TAPE is not None:
             ops.TAPE.no_grad(x, ehs)
+        hip.TUNE_CTX = "e" if ops.TAPE is None else None
         x = ops.conv2d(x, self.P["conv_in"])
         skips = [x]                                                                                 # :1215 pre-add
         if is_brushnet:
@@ -1327,6 +1330,8 @@ class UNet2DConditionModel(_UNetCore):
         x = self._transformer("mid_block.attentions.0.", x, ehs, self._heads(n - 1))
         x = self._resnet("mid_block.resnets.1.", x, temb,
                          inj=self._inj(mid_block_add_sample) if is_brushnet else None)              # :1288-1289
+        if hip.TUNE_CTX is not None:
+            hip.TUNE_CTX = "d"
         for i, bt in enumerate(c["up_block_types"]):
             has_attn = bt == "CrossAttnUpBlock2D"
             for j in range(lpb + 1):
@@ -1343,6 +1348,7 @@ class UNet2DConditionModel(_UNetCore):
         x = ops.groupnorm(x, self.P["conv_norm_out"], groups=c["norm_num_groups"], eps=c["norm_eps"], silu=True,
                           out_dtype=self.prec.act)
         y = ops.conv2d(x, self.P["conv_out"], out_dtype=F32)
+        hip.TUNE_CTX = None
         out = hip.unpack_nchw(y, c["out_channels"])
         if ops.TAPE is not None:           # d eps (NCHW) -> d y (NHWC, the conv's own channel count)
             autograd.record_pointwise(ops.TAPE, (y,), out,

@@ -50,16 +50,20 @@ class Precision:
             return Precision("bf16x1", torch.float32, torch.float32, hip.MF_BF16X1)
         if name == "fp8":
             return Precision("fp8", torch.bfloat16, torch.bfloat16, hip.MF_BF16, True)
-        if name == torch.float16:
-            # the reference's scripts default to fp16 (examples/brushnet/test_brushnet.py:124); the HIP path has no fp16
-            # storage mode and will not silently substitute another one
-            raise ValueError("torch_dtype=torch.float16 is not built: use torch.bfloat16 (the fast mode), torch.float32 "
-                             "or precision='f16x3' (fp32 storage, fp16 matrix pipe)")
-        raise ValueError(f"unsupported precision {name!r} (use 'bf16', 'fp8', 'fp32', 'f16x3', 'bf16x3' or 'bf16x1')")
+        if name in ("fp16", "f16", torch.float16):
+            # the reference's scripts default to fp16 (examples/brushnet/test_brushnet.py:122-126, --mixed_precision fp16 of the
+            # training script's validation): fp16 storage, one f16 MFMA per product — the bf16 kernels' byte layout and speed
+            # at 11 significant bits instead of 8 (range |x| < 65504, like the reference's own fp16 run)
+            return Precision("fp16", torch.float16, torch.float16, hip.MF_F16)
+        raise ValueError(f"unsupported precision {name!r} (use 'bf16', 'fp16', 'fp8', 'fp32', 'f16x3', 'bf16x3' or 'bf16x1')")
 
     @property
     def vec(self) -> int:         # elements per 16-byte vector: channel counts must be multiples of this
-        return 8 if self.compute == torch.bfloat16 else 4
+        return 8 if self.compute in (torch.bfloat16, torch.float16) else 4
+
+    @property
+    def half(self) -> bool:       # 16-bit storage and operands, one MFMA per product ("bf16", "fp16", "fp8"'s non-Linear layers)
+        return self.code in (hip.MF_BF16, hip.MF_F16)
 
     @property
     def split(self) -> bool:      # three MFMAs per product on (hi, lo) halves: weights are pre-split, gradients loss-scaled
@@ -87,8 +91,8 @@ class ConvWeight:
         if weight.dim() == 2:
             weight = weight[:, :, None, None]
         if ln is not None:
-            if fp8 or raw or prec.name != "bf16" or weight.shape[2:] != (1, 1):
-                raise hip.MfhipError("a folded LayerNorm needs a plain bf16 Linear")
+            if fp8 or raw or prec.name not in ("bf16", "fp16") or weight.shape[2:] != (1, 1):
+                raise hip.MfhipError("a folded LayerNorm needs a plain bf16 / fp16 Linear")
             g, b, eps = ln
             w2 = weight.detach().float().reshape(weight.shape[0], -1)
             bias = (bias.detach().float() if bias is not None else 0.0) + w2 @ b.detach().float().to(w2.device)
@@ -572,8 +576,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sk
     b, sq, ldq = q.shape
     c = c or ldq
     d = c // heads
-    if prec.compute == torch.bfloat16 and d in FLASH_HEAD_DIMS:
-        out = torch.empty(b, sq, c, dtype=torch.bfloat16, device=q.device)
+    if prec.half and d in FLASH_HEAD_DIMS:           # bf16, or fp16 on the f16 MFMA forms (hip.attention_bf16 dispatches on q.dtype)
+        out = torch.empty(b, sq, c, dtype=prec.compute, device=q.device)
         return hip.attention_bf16(q, k, vt, out, ldq=q.stride(1), ldk=k.stride(1), ldvt=vt.shape[-1], ldo=c, batch=b,
                                   heads=heads, sq=sq, skv=skv, head_dim=d, scale=scale)
     if prec.code == hip.MF_F16X3 and d in FLASH_SPLIT_HEAD_DIMS and vt.shape[-1] % 8 == 0:

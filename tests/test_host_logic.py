@@ -275,18 +275,20 @@ def test_split_pack_layout_and_precision():
     assert raw.w_split == 0 and raw.w.dtype == torch.float32
 
 
-def test_precision_names_and_fp16_is_refused():
-    """torch_dtype=torch.float16 (the default of examples/brushnet/test_brushnet.py:124) must not silently run as another
-    precision."""
+def test_precision_names_and_the_reference_default_fp16():
+    """torch_dtype=torch.float16 (the default of examples/brushnet/test_brushnet.py:122-126) selects the fp16 storage mode (round 5:
+    MF_F16, the f16 MFMA forms) — never another precision silently; unknown names still raise."""
     from reflecting_reality_amd import hip, ops
     assert ops.Precision.get(torch.bfloat16).code == hip.MF_BF16 and ops.Precision.get("fp32").code == hip.MF_F32
     for alias in ("f16x3", "split", "parity"):
         p = ops.Precision.get(alias)
         assert p.split and p.code == hip.MF_F16X3 and p.act == torch.float32 and p.vec == 4
-    with pytest.raises(ValueError, match="float16"):
-        ops.Precision.get(torch.float16)
-    with pytest.raises(ValueError, match="float16"):
-        UNet2DConditionModel(dict(configs.TINY_UNET), precision=torch.float16, device="cpu")
+    for alias in ("fp16", "f16", torch.float16):
+        p = ops.Precision.get(alias)
+        assert p.name == "fp16" and p.code == hip.MF_F16 and p.act == p.compute == torch.float16 and p.vec == 8 and p.half and not p.split
+    assert UNet2DConditionModel(dict(configs.TINY_UNET), precision=torch.float16, device="cpu").prec.name == "fp16"
+    with pytest.raises(ValueError, match="unsupported precision"):
+        ops.Precision.get(torch.float64)
 
 
 def test_randn_tensor_follows_the_generator_device():

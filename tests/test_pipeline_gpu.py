@@ -107,7 +107,7 @@ def test_scheduler_traces(name, cls, extra, n):
 # absolute error on each eps branch, guidance 7.5 multiplies the (cond - uncond) error and the 4-step schedule divides
 # by sqrt(alpha_t) ~ 0.2 — the REFERENCE run in bf16 moves its own latents by 0.5 ... 2.6 on these cases
 # (tests/golden/bf16_envelope.json); the HIP bf16 path is asserted to stay inside util.ENV_K_* times that, per step.
-PREC_TOL = [("fp32", 1e-3), ("f16x3", 1e-3), ("bf16", None)]
+PREC_TOL = [("fp32", 1e-3), ("f16x3", 1e-3), ("bf16", None), ("fp16", None)]
 
 
 @pytest.mark.parametrize("prec,tol", PREC_TOL)
@@ -457,7 +457,7 @@ def test_bench_two_ranks_on_one_device():
     assert abs(rec["value"] - 2 / (rec["ms_per_step"] * 1e-3)) < 0.02 * rec["value"]
 
 
-@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-3), ("bf16", None)])
+@pytest.mark.parametrize("prec,tol", [("f16x3", 1e-3), ("bf16", None), ("fp16", None)])
 def test_baseline_config1_batch4_512_against_reference(prec, tol):
     """BASELINE.json configs[1] sizes — batch 4 x 512 x 512, the tile choices the autotuner makes at M = 32768 — through
     the whole pipeline incl. the VAE decode at 64 x 64 latents (4096-token single-head d = 512 attention), against what

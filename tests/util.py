@@ -34,7 +34,7 @@ def strided_sample(t, stride, n=256):
     return t.float().cpu().double().flatten()[::int(stride)][:n].float()
 
 
-_ENV = None
+_ENV = {}
 # The HIP bf16 path must stay inside this multiple of the REFERENCE's own bf16 deviation from its fp32 results
 # (tests/golden/bf16_envelope.json, tools/make_bf16_envelope.py).  Two independent bf16 evaluations of the same net draw
 # their rounding errors independently: the means agree closely, the maxima (an extreme-value statistic) less so.
@@ -48,34 +48,35 @@ ENV_K_LINF, ENV_K_MEAN = 1.25, 1.1
 ENV_K_LINF_SMALL, ENV_SMALL_NUMEL = 1.75, 8192
 
 
-def envelope(key):
-    global _ENV
-    if _ENV is None:
-        with open(os.path.join(GOLD, "bf16_envelope.json")) as f:
-            _ENV = json.load(f)
-    return _ENV[key]
+def envelope(key, prec="bf16"):
+    """The reference's own deviation from its fp32 results when run in `prec` (bf16: tools/make_bf16_envelope.py; fp16, the
+    reference scripts' default torch_dtype: the same tool with --dtype fp16 -> tests/golden/fp16_envelope.json)."""
+    if prec not in _ENV:
+        with open(os.path.join(GOLD, f"{prec}_envelope.json")) as f:
+            _ENV[prec] = json.load(f)
+    return _ENV[prec][key]
 
 
-def report_env(name, got, ref, key, k_linf=None, k_mean=ENV_K_MEAN):
-    """bf16 mode: |got - ref| (ref = the reference's fp32 result) against the reference's own bf16 envelope for this case."""
+def report_env(name, got, ref, key, k_linf=None, k_mean=ENV_K_MEAN, prec="bf16"):
+    """bf16 / fp16 mode: |got - ref| (ref = the reference's fp32 result) against the reference's own envelope in that dtype for this case."""
     got = torch.as_tensor(np.asarray(got) if not torch.is_tensor(got) else got).float().cpu()
     ref = torch.as_tensor(ref).float()
     err = (got - ref).abs()
-    env = envelope(key)
+    env = envelope(key, prec)
     if k_linf is None:
         k_linf = ENV_K_LINF if ref.numel() >= ENV_SMALL_NUMEL else ENV_K_LINF_SMALL
     linf, mean = err.max().item(), err.mean().item()
-    print(f"{name}: max_abs_err={linf:.3e} (reference bf16: {env['linf']:.3e}) mean_abs_err={mean:.3e} "
-          f"(reference bf16: {env['mean']:.3e}) ref_absmax={ref.abs().max().item():.3e} "
+    print(f"{name}: max_abs_err={linf:.3e} (reference {prec}: {env['linf']:.3e}) mean_abs_err={mean:.3e} "
+          f"(reference {prec}: {env['mean']:.3e}) ref_absmax={ref.abs().max().item():.3e} "
           f"ENVRATIO linf {linf / max(env['linf'], 1e-30):.3f} mean {mean / max(env['mean'], 1e-30):.3f}")
     assert linf == linf, f"{name}: NaN"
-    assert linf <= k_linf * env["linf"], f"{name}: L-inf {linf:.3e} > {k_linf} x the reference's bf16 envelope {env['linf']:.3e}"
-    assert mean <= k_mean * env["mean"], f"{name}: mean error {mean:.3e} > {k_mean} x the reference's bf16 envelope {env['mean']:.3e}"
+    assert linf <= k_linf * env["linf"], f"{name}: L-inf {linf:.3e} > {k_linf} x the reference's {prec} envelope {env['linf']:.3e}"
+    assert mean <= k_mean * env["mean"], f"{name}: mean error {mean:.3e} > {k_mean} x the reference's {prec} envelope {env['mean']:.3e}"
     return linf
 
 
 def check(name, got, ref, prec, tol, key):
     """fp32-class precisions: atol/rtol `tol`; bf16: the reference-derived envelope `key`."""
-    if prec == "bf16":
-        return report_env(name, got, ref, key)
+    if prec in ("bf16", "fp16"):
+        return report_env(name, got, ref, key, prec=prec)
     return report(name, got, ref, **tol)

@@ -15,7 +15,6 @@ from reflecting_reality_amd import hip, ops  # noqa: E402
 from bench_k import timed  # noqa: E402
 
 hip.AUTOTUNE = False
-prec = ops.Precision.get("bf16")
 
 # (label, B, H, W, Cin, Cout, k, upsample, with residual)
 SETS = {
@@ -41,21 +40,23 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--set", default="conv,up,lin")
 ap.add_argument("--tiles", default="", help="comma list of tile[:splitk] candidates (besides the tuned one of the shipped cache)")
 ap.add_argument("--only", default="", help="substring filter on the case label")
+ap.add_argument("--prec", default="bf16", help="precision mode: bf16, fp16, f16x3, fp32")
 a = ap.parse_args()
+prec = ops.Precision.get(a.prec)
 extra = []
 for t in filter(None, a.tiles.split(",")):
     tt, _, sk = t.partition(":")
     extra.append((int(tt), int(sk) if sk else 0))
 
-print(f"library: {os.environ.get('MFHIP_LIB') or 'product build'}", flush=True)
+print(f"library: {os.environ.get('MFHIP_LIB') or 'product build'}; precision {a.prec}", flush=True)
 for name in a.set.split(","):
     for (label, b, h, w, ci, co, k, ups, with_res) in SETS[name]:
         if a.only and a.only not in label:
             continue
-        x = torch.randn(b, h, w, ci, device="cuda").bfloat16()
+        x = torch.randn(b, h, w, ci, device="cuda").to(prec.act)
         cw = ops.ConvWeight(torch.randn(co, ci, k, k) * 0.02, torch.randn(co), prec, "cuda")
         ho, wo = (2 * h, 2 * w) if ups else (h, w)
-        res = torch.randn(b, ho, wo, co, device="cuda").bfloat16() if with_res else None
+        res = torch.randn(b, ho, wo, co, device="cuda").to(prec.act) if with_res else None
         fl = 2.0 * b * ho * wo * ci * co * k * k
         # the tuned (tile, split-K) of the shipped cache for this call
         hip.AUTOTUNE = True

@@ -24,7 +24,8 @@ from make_golden import (DDIMScheduler, PNDMScheduler, UniPCMultistepScheduler, 
                          BrushNetModel, R, synth, GOLD)
 import diffusers.models.autoencoders.vae as ref_vae  # noqa: E402
 
-BF = torch.bfloat16
+BF = torch.bfloat16          # --dtype fp16 switches every cast below to torch.float16 (the reference scripts' default precision)
+DT_NAME = "bf16"
 torch.set_grad_enabled(False)
 
 
@@ -323,13 +324,17 @@ if __name__ == "__main__":
     ap.add_argument("--only-sdxl-full", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only-full", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="fp16: the reference's default torch_dtype (test_brushnet.py:122-126) -> tests/golden/fp16_envelope.json")
     a = ap.parse_args()
-    path = os.path.join(GOLD, "bf16_envelope.json")
+    if a.dtype == "fp16":
+        BF, DT_NAME = torch.float16, "fp16"
+    path = os.path.join(GOLD, f"{DT_NAME}_envelope.json")
     out = {}
     if os.path.exists(path):
         with open(path) as f:
             out = json.load(f)
-    out["_about"] = ("|reference(bf16) - reference(fp32)| of the imported reference on the golden cases "
+    out["_about"] = (f"|reference({DT_NAME}) - reference(fp32)| of the imported reference on the golden cases "
                      "(tools/make_bf16_envelope.py): linf / mean abs error, and the fp32 result's abs max / mean")
     if a.only_sdxl_full:
         sdxl_full(out)

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reflecting_reality_amd import hip, ops  # noqa: E402
 
 hip.AUTOTUNE = False
-prec = ops.Precision.get("bf16")
+prec = ops.Precision.get(os.environ.get("MF_STAMPS_PREC", "bf16"))      # MF_STAMPS_PREC=f16x3: the parity mode's kernels
 lib = hip.load()
 if not hasattr(lib, "mf_debug_set_stamps"):
     sys.exit("run with MFHIP_LIB pointing at the stamped build (tools/build_stamped.sh)")
@@ -41,15 +41,19 @@ CASES = [  # (label, batch, h, w, cin, cout, k, tile, splitk, with residual[, wi
     ("conv 32^2 t47", 8, 32, 32, 640, 640, 3, 47, 1, True), ("conv 32^2 1280 t48", 8, 32, 32, 1280, 640, 3, 48, 1, True),
     ("conv 16^2 t48 sk2", 8, 16, 16, 1280, 1280, 3, 48, 2, True), ("proj 32^2 t48", 8, 32, 32, 640, 640, 1, 48, 1, True),
     ("ff-out 64^2 1280->320 t48", 8, 64, 64, 1280, 320, 1, 48, 1, True),
+    # 28-: the parity mode (MF_STAMPS_PREC=f16x3)
+    ("conv 64^2 t37", 8, 64, 64, 320, 320, 3, 37, 1, True), ("conv 32^2 t14", 8, 32, 32, 640, 640, 3, 14, 1, True),
+    ("conv 32^2 t38", 8, 32, 32, 640, 640, 3, 38, 1, True), ("conv 32^2 t41", 8, 32, 32, 640, 640, 3, 41, 1, True),
+    ("proj 32^2 t41", 8, 32, 32, 640, 640, 1, 41, 1, True),
 ]
 
 
 def run(label, b, h, w, ci, co, k, tile, sk, with_res, with_bias=True, with_temb=False):
-    x = torch.randn(b, h, w, ci, device="cuda").bfloat16()
+    x = torch.randn(b, h, w, ci, device="cuda").to(prec.act)
     cw = ops.ConvWeight(torch.randn(co, ci, k, k) * 0.02, torch.randn(co) if with_bias else None, prec, "cuda")
-    res = torch.randn(b, h, w, co, device="cuda").bfloat16() if with_res else None
+    res = torch.randn(b, h, w, co, device="cuda").to(prec.act) if with_res else None
     temb = torch.randn(b, co, device="cuda") if with_temb else None
-    other = torch.randn(b, h, w, co, device="cuda").bfloat16()
+    other = torch.randn(b, h, w, co, device="cuda").to(prec.act)
     fn = lambda: ops.conv2d(x, cw, padding=k // 2, tile=tile, splitk=sk, res0=res, temb=temb)
     for _ in range(3):
         fn()
