@@ -209,6 +209,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
                  "mf_gemm_conv: batch strides must be multiples of %d elements", vec);
 
     GemmArgs a{};
+    a.howo_sh = a.wo_sh = a.ho_sh = -1;       // (set with the geometry below; the resident-patch tiles return before that)
     {
         static unsigned* ovf = mf_ovf_flag_gemm();
         a.ovf = ovf;
@@ -225,6 +226,10 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.ld0b = (int)(d->lda0 * aes); a.ld1b = (int)(d->lda1 * aes);
     a.Hin = d->h_in; a.Win = d->w_in; a.Ho = d->h_out; a.Wo = d->w_out; a.HoWo = d->h_out * d->w_out;
     a.KW = d->kw; a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.ups = d->upsample;
+    {
+        auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (v > 0 && (1 << s) == v) ? s : -1; };
+        a.howo_sh = lg(a.HoWo); a.wo_sh = lg(a.Wo); a.ho_sh = lg(a.Ho);
+    }
     a.w = (const char*)d->w; a.ldw = d->ldw;
     const int64_t M64 = (int64_t)d->batch * d->h_out * d->w_out;
     MF_CHECK_ARG(M64 < (1ll << 31), "mf_gemm_conv: M too large");
@@ -382,6 +387,10 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
                   d->w_out == d->w_in;
     a.tiles_n = cdiv(a.N, tc.bn);
     a.tiles_m = cdiv(a.M, tc.bm);
+    {   // division-free prologue: shifts for the power-of-two extents, a magic multiplier for the dx-reuse window pitch
+        const int weff = a.Wo < tc.bm ? a.Wo : tc.bm;
+        a.wfr_magic = (unsigned)((1u << 20) / (unsigned)(weff + 2)) + 1u;
+    }
     {   // staged epilogue rows (GemmArgs::epb): warp-specialised tiles, the vector epilogue, per-column bias, no split-K slabs;
         // a time embedding needs Ho * Wo a power of two and the tile's images inside the rows the tile reserves
         static const bool off = getenv("MFHIP_NO_EPB") != nullptr;          // A/B switch

@@ -37,6 +37,10 @@
 #ifndef MF_XTAP
 #define MF_XTAP 1
 #endif
+// developer switch: 0 issues the dx-reuse A window together with the tap that opens its group (round 4) instead of one tap earlier
+#ifndef MF_AEARLY
+#define MF_AEARLY 1
+#endif
 
 namespace mfgemm {
 
@@ -90,6 +94,10 @@ struct GemmArgs {
     // the time-embedding row of each image the tile touches) are fetched into LDS by the staging waves' FIRST DMAs, so the
     // epilogue's item loops contain no global load: loads and stores share vmcnt and return in order, and a bias load issued after
     // the previous item's store used to wait for that store's round trip (~1.5 us per 64-item chunk, stamped).
+    // prologue without integer divisions (each costs ~30 VALU instructions and a kernel's start-up held a dozen of them): log2 of the
+    // extents that are powers of two (-1: not one — the division stays), and a magic multiplier for the dx-reuse window's row pitch
+    int howo_sh, wo_sh, ho_sh;      // Ho * Wo, Wo, Ho
+    unsigned wfr_magic;             // floor(2^20 / (min(Wo, 256) + 2)) + 1: x / pitch == (x * magic) >> 20 for x < 4096 (dx-reuse window rows)
     int epb;                 // 1: the rows are staged (the host checked the geometry: epb_layout below)
     int epb_sh;              // log2(Ho * Wo) (a power of two whenever temb is staged): image of output row m = m >> epb_sh
     unsigned* ovf;           // device flag raised when an MF_F16X3 operand exceeded the fp16 range (mf_common.h)
@@ -100,6 +108,8 @@ struct GemmArgs {
     const float* ln_cs; float ln_eps;
     char* vt_out; int vt_n0, vt_tokens; int64_t vt_ld;
 };
+
+__device__ __forceinline__ int div_sh(int x, int d, int sh) { return sh >= 0 ? x >> sh : x / d; }
 
 // res1 shared by batch replicas (the BrushNet residual of both classifier-free-guidance halves): a handful of replicas,
 // so a subtract loop, not a division
@@ -114,7 +124,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int64_t zo, in
     if (p.rs) v *= p.rs[zq * p.rs_zs + m];
     if (p.cs) v *= p.cs[zq * p.cs_zs + n];
     if (p.bias) v += p.bias_mode ? p.bias[m] : p.bias[n];
-    if (p.temb) v += p.temb[(int64_t)(m / p.HoWo) * p.ld_temb + n];
+    if (p.temb) v += p.temb[(int64_t)div_sh(m, p.HoWo, p.howo_sh) * p.ld_temb + n];
     v *= p.alpha;
     if (p.res0) v += load_as_f32(p.res0, p.res0_dt, (int64_t)m * p.ld_res0 + n);
     if (p.res1) v += load_as_f32(p.res1, p.res1_dt, (int64_t)res1_row(p, m) * p.ld_res1 + n);
@@ -169,7 +179,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
     if (p.temb) {
         float t[8];
         if (et) load8_as_f32(et, MF_F32, 0, t);
-        else load8_as_f32((const char*)p.temb, MF_F32, (int64_t)(m / p.HoWo) * p.ld_temb + n, t);
+        else load8_as_f32((const char*)p.temb, MF_F32, (int64_t)div_sh(m, p.HoWo, p.howo_sh) * p.ld_temb + n, t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += t[j];
     }
@@ -420,21 +430,21 @@ void gemm_conv_kernel(const GemmArgs p) {
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
     const int per_split = p.tiles_m * p.tiles_n;
-    const int ksplit = bid / per_split;
+    const int ksplit = bid >= per_split ? bid / per_split : 0;
     int tile_m, tile_n;
     {
         const int r = bid - ksplit * per_split;
         const int Li = p.ord_mfast ? p.tiles_m : p.tiles_n, Lo = p.ord_mfast ? p.tiles_n : p.tiles_m;
-        const int panel = r / (Lo * p.ord_pw), rp = r - panel * Lo * p.ord_pw;
+        const int panel = r >= Lo * p.ord_pw ? r / (Lo * p.ord_pw) : 0, rp = r - panel * Lo * p.ord_pw;
         int w = Li - panel * p.ord_pw;
         if (w > p.ord_pw) w = p.ord_pw;
-        const int o = rp / w, i = panel * p.ord_pw + (rp - o * w);
+        const int o = w == 1 ? rp : rp / w, i = panel * p.ord_pw + (rp - o * w);
         tile_m = p.ord_mfast ? i : o;
         tile_n = p.ord_mfast ? o : i;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
-    const int zq = z / p.zdiv, zr = z - zq * p.zdiv;
+    const int zq = z ? z / p.zdiv : 0, zr = z - zq * p.zdiv;
 
     // ---- staged epilogue rows (see GemmArgs::epb): the staging waves' first DMAs ----------------------------------------
     constexpr int EPB_NIMG = epb_nimg(BM, BN, STAGES, DXR, WS), EPB_PITCH = epb_pitch(BN), EPB_OFF = epb_off(BM, BN, STAGES, DXR, WS);
@@ -478,9 +488,9 @@ void gemm_conv_kernel(const GemmArgs p) {
                 a_iy0[i] = 0;
                 a_ix0[i] = 0;
             } else {
-                const int b = m / p.HoWo;
+                const int b = div_sh(m, p.HoWo, p.howo_sh);
                 const int r = m - b * p.HoWo;
-                const int oy = r / p.Wo;
+                const int oy = div_sh(r, p.Wo, p.wo_sh);
                 const int ox = r - oy * p.Wo;
                 a_pix[i] = b * p.Hin * p.Win;
                 a_iy0[i] = oy * p.stride - p.pad_t;
@@ -508,9 +518,9 @@ void gemm_conv_kernel(const GemmArgs p) {
     int kk = kt_begin * BK + chunk * VEC;        // this thread's K element index in the current tile
     int c, ky, kx;
     {
-        const int tap = kk / p.Ctot;
+        const int tap = kk >= p.Ctot ? kk / p.Ctot : 0;
         c = kk - tap * p.Ctot;
-        ky = tap / p.KW;
+        ky = tap ? tap / p.KW : 0;
         kx = tap - ky * p.KW;
     }
 
@@ -577,14 +587,14 @@ void gemm_conv_kernel(const GemmArgs p) {
         }
     };
     auto fast_init = [&]() {
-        const int nb = p.M / p.HoWo;                                    // images in the batch
+        const int nb = div_sh(p.M, p.HoWo, p.howo_sh);                  // images in the batch
         srdA0 = make_srd(a0, (unsigned)((nb * p.Hin * p.Win - 1) * p.ld0b + p.C0 * AES));
         srdA1 = make_srd(a1, (unsigned)((nb * p.Hin * p.Win - 1) * p.ld1b + (p.Ctot - p.C0) * AES));
         srdW = make_srd(wbase, (unsigned)(((int64_t)(p.N - 1) * p.ldw + p.K) * ES));
         const int k0 = kt_begin * BK;
-        const int tap = k0 / p.Ctot;
+        const int tap = k0 ? k0 / p.Ctot : 0;
         const int c0 = k0 - tap * p.Ctot;
-        f_ky = tap / p.KW; f_kx = tap - f_ky * p.KW;
+        f_ky = tap ? tap / p.KW : 0; f_kx = tap - f_ky * p.KW;
         f_seg = c0 >= p.C0;
         f_cin = f_seg ? c0 - p.C0 : c0;
         f_left = ((f_seg ? p.Ctot - p.C0 : p.C0) - f_cin) / BK;
@@ -977,16 +987,17 @@ void gemm_conv_kernel(const GemmArgs p) {
             const int nck = p.Ctot / BK;                           // K chunks per tap
             const int weff = p.Wo < BM ? p.Wo : BM;                // pixels of one image row inside the tile
             const int wfr = weff + 2;                              // ... plus the frame
-            const int nrows_img = p.M / p.Wo;                      // image rows in the whole batch
-            const int gy0 = m0 / p.Wo, gx0 = p.Wo < BM ? 0 : m0 - gy0 * p.Wo;
+            const int weff_sh = p.Wo < BM ? p.wo_sh : 31 - __builtin_clz(BM);       // log2(weff) when Wo is a power of two
+            const int nrows_img = div_sh(p.M, p.Wo, p.wo_sh);      // image rows in the whole batch
+            const int gy0 = div_sh(m0, p.Wo, p.wo_sh), gx0 = p.Wo < BM ? 0 : m0 - gy0 * p.Wo;
             int ay[A3_IT], apix[A3_IT];
 #pragma unroll
             for (int i = 0; i < A3_IT; ++i) {
                 const int r = lrow + i * RPP;                      // LDS row of the window
-                const int ir = r / wfr, c = r - ir * wfr;
+                const int ir = (int)(((unsigned)r * p.wfr_magic) >> 20), c = r - ir * wfr;      // r / wfr (r < BM + 32)
                 const int gy = gy0 + ir, x = gx0 + c - 1;
                 if (ir * weff < BM && gy < nrows_img && (unsigned)x < (unsigned)p.Wo) {
-                    const int b = gy / p.Ho;
+                    const int b = div_sh(gy, p.Ho, p.ho_sh);
                     ay[i] = gy - b * p.Ho;
                     apix[i] = gy * p.Wo + x;                       // pixel index at ky = 1
                 } else {
@@ -1000,33 +1011,45 @@ void gemm_conv_kernel(const GemmArgs p) {
                 const int n = n0 + lrow + i * RPP;
                 w3[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + chunk * VEC) * ES) : 0x80000000u;
             }
-            const int nb = p.M / p.HoWo;
+            const int nb = div_sh(p.M, p.HoWo, p.howo_sh);
             const srd_t sA0 = make_srd(a0, (unsigned)((nb * p.Hin * p.Win - 1) * p.ld0b + p.C0 * AES));
             const srd_t sA1 = make_srd(a1, (unsigned)((nb * p.Hin * p.Win - 1) * p.ld1b + (p.Ctot - p.C0) * AES));
             const srd_t sW = make_srd(wbase, (unsigned)(((int64_t)(p.N - 1) * p.ldw + p.K) * ES));
             const unsigned ldsb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem) + wave * 1024;
             // issue state: group (ky, global chunk) and kx of the next tile to stage; kt_begin is a multiple of 3
-            int i_ky = (kt_begin / 3) / nck, i_cg = (kt_begin / 3) - i_ky * nck, i_kx = 0, i_grp = 0;
-            auto issue3 = [&](int wstage) {
-                if (i_kx == 0) {
-                    const int c = i_cg * BK;
-                    const bool seg = c >= p.C0;
-                    const int ldb = seg ? p.ld1b : p.ld0b;
-                    const int ccb = ((seg ? c - p.C0 : c) + chunk * VEC) * AES;
-                    const srd_t srd = seg ? sA1 : sA0;
-                    const unsigned la = ldsb + (i_grp & 1) * AB;
+            int i_ky = kt_begin ? (kt_begin / 3) / nck : 0, i_cg = (kt_begin / 3) - i_ky * nck, i_kx = 0, i_grp = 0;
+            // AE (warp-specialised forms): the A window of group g + 1 is issued one tap EARLIER, behind the W tile of group g's last tap
+            // — its buffer has been free since barrier #3g, and a tap that carries a window (A3_IT more DMAs) then has three taps of
+            // flight time instead of two: the staging waves used to wait for exactly those taps (stamps, round 5: 26 % of the loop)
+            constexpr bool AE = WS && (MF_AEARLY != 0);
+            int i_tap = 0;
+            auto issue_a = [&](int ky, int cg, int grp) {
+                const int c = cg * BK;
+                const bool seg = c >= p.C0;
+                const int ldb = seg ? p.ld1b : p.ld0b;
+                const int ccb = ((seg ? c - p.C0 : c) + chunk * VEC) * AES;
+                const srd_t srd = seg ? sA1 : sA0;
+                const unsigned la = ldsb + (grp & 1) * AB;
 #pragma unroll
-                    for (int i = 0; i < A3_IT; ++i) {
-                        const int iy = ay[i] + i_ky - 1;
-                        const bool ok = (unsigned)iy < (unsigned)p.Hin;
-                        const unsigned off = ok ? (unsigned)((apix[i] + (i_ky - 1) * p.Win) * ldb + ccb) : 0x80000000u;
-                        dma16_buf(off, srd, la + i * RPP * 128);
-                    }
+                for (int i = 0; i < A3_IT; ++i) {
+                    const int iy = ay[i] + ky - 1;
+                    const bool ok = (unsigned)iy < (unsigned)p.Hin;
+                    const unsigned off = ok ? (unsigned)((apix[i] + (ky - 1) * p.Win) * ldb + ccb) : 0x80000000u;
+                    dma16_buf(off, srd, la + i * RPP * 128);
                 }
+            };
+            auto issue3 = [&](int wstage) {
+                if (AE ? i_tap == 0 : i_kx == 0) issue_a(i_ky, i_cg, i_grp);
                 const unsigned wk = (unsigned)(((i_ky * 3 + i_kx) * p.Ctot + i_cg * BK) * ES);
                 const unsigned lb = ldsb + 2 * AB + wstage * WB;
 #pragma unroll
                 for (int i = 0; i < B_IT; ++i) dma16_buf(w3[i] + wk, sW, lb + i * RPP * 128);
+                if (AE && i_kx == 2 && i_tap + 1 < nt) {           // behind this group's last W tile: the next group's window
+                    int n_cg = i_cg + 1, n_ky = i_ky;
+                    if (n_cg == nck) { n_cg = 0; ++n_ky; }
+                    issue_a(n_ky, n_cg, i_grp + 1);
+                }
+                ++i_tap;
                 if (++i_kx == 3) {
                     i_kx = 0; ++i_grp;
                     if (++i_cg == nck) { i_cg = 0; ++i_ky; }
@@ -1036,14 +1059,14 @@ void gemm_conv_kernel(const GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int m = wm * WM + i * 32 + frow;
-                const int ir = m / weff;
+                const int ir = p.wo_sh >= 0 ? m >> weff_sh : m / weff;
                 arow0[i] = ir * wfr + (m - ir * weff);
             }
             int arow16[2 * MT];                                    // the same for the 16-row fragments of the M16 form
 #pragma unroll
             for (int t = 0; t < 2 * MT; ++t) {
                 const int m = wm * WM + t * 16 + r16;
-                const int ir = m / weff;
+                const int ir = p.wo_sh >= 0 ? m >> weff_sh : m / weff;
                 arow16[t] = ir * wfr + (m - ir * weff);
             }
             auto compute3 = [&](int abuf, int wstage, int kx) {
@@ -1144,11 +1167,17 @@ void gemm_conv_kernel(const GemmArgs p) {
                     };
                     // wait until tap `need` has landed: everything issued after it may stay in flight.  Those are at most
                     // PFD - 1 <= 2 taps, at most one of which opens a group (and carries the A window's DMAs too).
+                    // AE: a window rides BEHIND the W tile of tap q when q % 3 == 2 (and tap q + 1 exists), so it may also stay in flight
+                    // when it was issued with `need` itself
                     auto wait_for = [&](int need) {
                         const int newer = issued - 1 - need;       // taps issued after `need`
                         bool with_a = false;
-                        for (int q = need + 1; q < issued; ++q) with_a |= (q % 3 == 0);
-                        if (newer <= 0) wait_vmcnt<0>();
+                        if constexpr (AE) {
+                            for (int q = need; q < issued; ++q) with_a |= (q % 3 == 2 && q + 1 < nt);
+                        } else {
+                            for (int q = need + 1; q < issued; ++q) with_a |= (q % 3 == 0);
+                        }
+                        if (newer <= 0) { if (with_a) wait_vmcnt<A3_IT>(); else wait_vmcnt<0>(); }
                         else if (newer == 1) { if (with_a) wait_vmcnt<B_IT + A3_IT>(); else wait_vmcnt<B_IT>(); }
                         else { if (with_a) wait_vmcnt<2 * B_IT + A3_IT>(); else wait_vmcnt<2 * B_IT>(); }
                     };

@@ -322,6 +322,7 @@ KEY_LOG: Optional[list] = None      # developer hook: the tune key of every auto
 # leaves room for the other stream's blocks wins under overlap, a whole-CU ring tile wins alone (tools/tune_step.py) — so the tune
 # cache may hold "<key>@<ctx>" entries beside the plain one; a missing tagged entry falls back to the plain key.
 TUNE_CTX: Optional[str] = None
+_NO_TUNE_CTX = os.environ.get("MFHIP_NO_TUNE_CTX", "0") == "1"     # A/B switch: ignore the position-tagged entries
 # The package ships a cache tuned on MI355X (read-only); new winners go to a per-user file (MFHIP_TUNE_CACHE, default
 # ~/.cache/mfhip/tune_cache.json) that is overlaid on it.  Both carry the library's tile-table version: when tiles are
 # renumbered (mf_gemm_tile_table_version changes) stale indices are dropped instead of being trusted.
@@ -549,7 +550,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
                 nz, int(splitk == 1) if not fused else 1, act, h_out, w_out) + ((w_split,) if code in (MF_F16X3, MF_BF16X3) else ()) \
             + ((("ln", "vt", "lnvt")[fused - 1],) if fused else ())
         cfg = None
-        if TUNE_CTX is not None:
+        if TUNE_CTX is not None and not _NO_TUNE_CTX:
             ks_ctx = _tune_key(tkey) + "@" + TUNE_CTX
             cfg = _tune_load().get(ks_ctx)
             if KEY_LOG is not None:
