@@ -50,7 +50,6 @@ __device__ __forceinline__ f32x16_t mfma16(const uint4& a, const uint4& b, const
 template <int HD, bool DB, bool SP = false, bool F16 = false>
 __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2)) void attn_fwd_kernel(const AttnArgs p) {
     static_assert(!(SP && F16), "F16 is the single-plane form");
-    constexpr int HDT = F16 ? MF_F16 : MF_BF16;       // 16-bit type of the operands / P / the output
     constexpr unsigned ONE2 = F16 ? 0x3C003C00u : 0x3F803F80u;   // (1.0, 1.0)
     constexpr int NP = SP ? 2 : 1;            // operand planes (hi, lo)
     constexpr int OES = SP ? 4 : 2;           // output element size
@@ -133,8 +132,8 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x0, x1;
-                    unpack_h2(w[e], HDT, x0, x1);
-                    w[e] = pack_h2(x0 * p.c, x1 * p.c, HDT);
+                    unpack_h2<F16>(w[e], x0, x1);
+                    w[e] = pack_h2<F16>(x0 * p.c, x1 * p.c);
                 }
             }
             qf[pl][ks] = v;
@@ -262,14 +261,14 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
                 // the offset the matrix pipe can subtract exactly: three 16-bit pieces (bf16: 24 bits; fp16: 33, the last piece
                 // may be an fp16 subnormal — the matrix pipe keeps those)
                 float f0, f1, f2, dummy;
-                const unsigned b0 = pack_h2(want, 0.0f, HDT) & 0xffffu;
-                unpack_h2(b0, HDT, f0, dummy);
+                const unsigned b0 = pack_h2<F16>(want, 0.0f) & 0xffffu;
+                unpack_h2<F16>(b0, f0, dummy);
                 const float r1 = want - f0;
-                const unsigned b1 = pack_h2(r1, 0.0f, HDT) & 0xffffu;
-                unpack_h2(b1, HDT, f1, dummy);
+                const unsigned b1 = pack_h2<F16>(r1, 0.0f) & 0xffffu;
+                unpack_h2<F16>(b1, f1, dummy);
                 const float r2 = r1 - f1;
-                const unsigned b2 = pack_h2(r2, 0.0f, HDT) & 0xffffu;
-                unpack_h2(b2, HDT, f2, dummy);
+                const unsigned b2 = pack_h2<F16>(r2, 0.0f) & 0xffffu;
+                unpack_h2<F16>(b2, f2, dummy);
                 const float m_rep = f0 + f1 + f2;
                 const float dlt = m_rep - m;
                 m = m_rep;
@@ -342,10 +341,10 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
                     pf[1][2 * tt + s] = uint4{lw[0], lw[1], lw[2], lw[3]};
                 } else {
                     uint4 u;
-                    u.x = pack_h2(st[tt][8 * s + 0], st[tt][8 * s + 1], HDT);
-                    u.y = pack_h2(st[tt][8 * s + 2], st[tt][8 * s + 3], HDT);
-                    u.z = pack_h2(st[tt][8 * s + 4], st[tt][8 * s + 5], HDT);
-                    u.w = pack_h2(st[tt][8 * s + 6], st[tt][8 * s + 7], HDT);
+                    u.x = pack_h2<F16>(st[tt][8 * s + 0], st[tt][8 * s + 1]);
+                    u.y = pack_h2<F16>(st[tt][8 * s + 2], st[tt][8 * s + 3]);
+                    u.z = pack_h2<F16>(st[tt][8 * s + 4], st[tt][8 * s + 5]);
+                    u.w = pack_h2<F16>(st[tt][8 * s + 6], st[tt][8 * s + 7]);
                     pf[0][2 * tt + s] = u;
                 }
             }
@@ -383,8 +382,8 @@ __global__ __launch_bounds__(256, (HD <= 80 && !SP) ? 3 : (SP && HD > 64 ? 1 : 2
                     make_float4(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
             } else {
                 uint2 u;
-                u.x = pack_h2(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv, HDT);
-                u.y = pack_h2(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv, HDT);
+                u.x = pack_h2<F16>(o[d][4 * g + 0] * inv, o[d][4 * g + 1] * inv);
+                u.y = pack_h2<F16>(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(Os + r * RBO + (32 * d + 8 * g + 4 * h) * 2) = u;
             }
         }

@@ -325,7 +325,7 @@ void conv3x3_halo_kernel(const GemmArgs p) {
                         for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
                     }
                 } else if (p.vec_ok && n + 8 <= p.N) {
-                    epilogue_store8(p, 0, m, n, v);
+                    epilogue_store8<false>(p, 0, m, n, v);
                 } else {
                     for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, 0, m, n + jj, v[jj]);
                 }
@@ -596,7 +596,7 @@ void conv3x3_pingpong_kernel(const GemmArgs p) {
                         for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
                     }
                 } else if (p.vec_ok && n + 8 <= p.N) {
-                    epilogue_store8(p, 0, m, n, v);
+                    epilogue_store8<false>(p, 0, m, n, v);
                 } else {
                     for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, 0, m, n + jj, v[jj]);
                 }

@@ -78,7 +78,7 @@ static bool launch16_c(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
     }
 }
 
-// tiles 37-40, 47, 49, 51: warp-specialised dx-reuse 3x3 convs (compute waves + four staging waves)
+// tiles 37-40, 47, 49, 51 (+ 53, 55, 59, 61, 63, 65): warp-specialised dx-reuse 3x3 convs (compute waves + four staging waves)
 template <int DT>
 static bool launch16_ws_dx(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
     switch (tile) {
@@ -89,11 +89,19 @@ static bool launch16_ws_dx(int tile, const GemmArgs& a, dim3 grid, hipStream_t s
         case 47: launch_one<DT, 128, 160, 4, 2, false, 3, true, false, false, true, true>(a, grid, s); return true;
         case 49: launch_one<DT, 256, 160, 4, 2, false, 3, true, false, false, true, true>(a, grid, s); return true;
         case 51: launch_one<DT, 128, 160, 2, 2, false, 3, true, false, false, true, true>(a, grid, s); return true;
+        // the round-5 loop forms (MF_FX_ALL) of 47, 40, 49, 51
+        case 53: launch_one<DT, 128, 160, 4, 2, false, 3, true, false, false, true, true, false, MF_FX_ALL>(a, grid, s); return true;
+        case 55: launch_one<DT, 128, 160, 4, 1, false, 3, true, false, true, true, false, false, MF_FX_ALL>(a, grid, s); return true;
+        case 59: launch_one<DT, 256, 160, 4, 2, false, 3, true, false, false, true, true, false, MF_FX_ALL>(a, grid, s); return true;
+        case 61: launch_one<DT, 128, 160, 2, 2, false, 3, true, false, false, true, true, false, MF_FX_ALL>(a, grid, s); return true;
+        // four compute waves of 64x160 / 64x128 on the k16-granular cross-tile pipeline
+        case 63: launch_one<DT, 256, 160, 4, 1, false, 3, true, false, false, true, false, false, MF_FX_XQ | MF_FX_EPB | MF_FX_AE>(a, grid, s); return true;
+        case 65: launch_one<DT, 256, 128, 4, 1, false, 3, true, false, false, true, false, false, MF_FX_XQ | MF_FX_EPB | MF_FX_AE>(a, grid, s); return true;
         default: return false;
     }
 }
 
-// tiles 41-46, 48, 50, 52: the warp-specialised form of the plain ring (1x1, strided, upsampled calls)
+// tiles 41-46, 48, 50, 52 (+ 54, 56-58, 60, 62, 64, 66): the warp-specialised form of the plain ring (1x1, strided, upsampled calls)
 template <int DT>
 static bool launch16_ws_ring(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
     if constexpr (DT == MF_BF16) {
@@ -115,6 +123,15 @@ static bool launch16_ws_ring(int tile, const GemmArgs& a, dim3 grid, hipStream_t
         case 48: launch_one<DT, 128, 160, 4, 2, false, 3, false, false, false, true, true>(a, grid, s); return true;
         case 50: launch_one<DT, 256, 160, 4, 2, false, 3, false, false, false, true, true>(a, grid, s); return true;
         case 52: launch_one<DT, 128, 160, 2, 2, false, 3, false, false, false, true, true>(a, grid, s); return true;
+        // the round-5 loop forms (MF_FX_ALL) of 48, 43, 44, 46, 50, 52
+        case 54: launch_one<DT, 128, 160, 4, 2, false, 3, false, false, false, true, true, false, MF_FX_ALL>(a, grid, s); return true;
+        case 56: launch_one<DT, 128, 160, 4, 1, false, 3, false, false, true, true, false, false, MF_FX_ALL>(a, grid, s); return true;
+        case 57: launch_one<DT, 128, 128, 2, 2, false, 3, false, false, false, true, false, false, MF_FX_ALL>(a, grid, s); return true;
+        case 58: launch_one<DT, 256, 128, 4, 2, false, 3, false, false, true, true, false, false, MF_FX_ALL>(a, grid, s); return true;
+        case 60: launch_one<DT, 256, 160, 4, 2, false, 3, false, false, false, true, true, false, MF_FX_ALL>(a, grid, s); return true;
+        case 62: launch_one<DT, 128, 160, 2, 2, false, 3, false, false, false, true, true, false, MF_FX_ALL>(a, grid, s); return true;
+        case 64: launch_one<DT, 256, 160, 4, 1, false, 3, false, false, false, true, false, false, MF_FX_XQ | MF_FX_EPB | MF_FX_AE>(a, grid, s); return true;
+        case 66: launch_one<DT, 256, 128, 4, 1, false, 3, false, false, false, true, false, false, MF_FX_XQ | MF_FX_EPB | MF_FX_AE>(a, grid, s); return true;
         default: return false;
     }
 }

@@ -10,6 +10,7 @@ __device__ unsigned g_split_ovf_gemm;     // raised when an MF_F16X3 operand exc
 unsigned long long* g_stamps_host = nullptr;
 #endif
 
+template <bool F16>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int64_t mn = (int64_t)p.M * p.N;
     if (p.vec_ok) {           // N % 8 == 0: 8 channels per thread, 16/32-byte accesses everywhere
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
             }
             const int zq = z / p.zdiv, zr = z - zq * p.zdiv;
-            epilogue_store8(p, zq * p.o_zs_o + zr * p.o_zs_i, m, n, v, false, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, zq);
+            epilogue_store8<F16>(p, zq * p.o_zs_o + zr * p.o_zs_i, m, n, v, false, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, zq);
         }
         return;
     }
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-struct TileCfg { int bm, bn, threads, stages, halo, dxr; };   // halo: rows of output pixels per tile of conv3x3_halo_kernel (0 = implicit GEMM)
+struct TileCfg { int bm, bn, threads, stages, halo, dxr, fx; };   // fx: MF_FX_* bits of the instantiation (gemm_conv_kernel.h)   // halo: rows of output pixels per tile of conv3x3_halo_kernel (0 = implicit GEMM)
 // keep in sync with launch_tile()
 const TileCfg kTiles[] = {
     {128, 128, 256, 2},  // 1
@@ -104,16 +105,37 @@ const TileCfg kTiles[] = {
     {256, 128, 256, 3},        // 46  = 45 on 16x16x32 MFMAs
     {128, 160, 256, 2, 0, 1},  // 47  = 38 / 40 with EIGHT compute waves (4x2 of 32x80, 16x16x32 MFMAs only) + 4 staging
     {128, 160, 256, 3},        // 48  = 41 / 43 with eight compute waves of 32x80 + 4 staging
-    // 49-52 (round 5): 64x80 wave tiles on 16x16x32 MFMAs — 9 fragment reads per 20 MFMAs instead of 12 (32x160) or 14 (32x80) —
-    // with the cross-tile fragment pipeline (gemm_conv_kernel.h, XT)
+    // 49-52 (round 5): 64x80 wave tiles on 16x16x32 MFMAs — 9 fragment reads per 20 MFMAs instead of 12 (32x160) or 14 (32x80)
     {256, 160, 256, 2, 0, 1},  // 49  dx-reuse conv, 4x2 compute waves of 64x80 + 4 staging (the successor of 37 / 39)
     {256, 160, 256, 3},        // 50  plain ring, 4x2 compute waves of 64x80 + 4 staging (the successor of 42)
     {128, 160, 256, 2, 0, 1},  // 51  dx-reuse conv, 2x2 compute waves of 64x80 + 4 staging
     {128, 160, 256, 3},        // 52  plain ring, 2x2 compute waves of 64x80 + 4 staging
+    // 53-62 (round 5): the round-5 loop forms (MF_FX_ALL: cross-tile fragment pipeline, staged epilogue rows, early A window) of
+    // 47, 48, 40, 43, 44, 46, 49, 50, 51, 52.  Separate numbers because the forms cost 20-80 VGPRs (a wave per SIMD on most tiles):
+    // faster alone, not always faster beside the other stream's blocks — the step tuner decides per call site
+    {128, 160, 256, 2, 0, 1, 7},  // 53  = 47
+    {128, 160, 256, 3, 0, 0, 7},  // 54  = 48
+    {128, 160, 256, 2, 0, 1, 7},  // 55  = 40
+    {128, 160, 256, 3, 0, 0, 7},  // 56  = 43
+    {128, 128, 256, 3, 0, 0, 7},  // 57  = 44
+    {256, 128, 256, 3, 0, 0, 7},  // 58  = 46
+    {256, 160, 256, 2, 0, 1, 7},  // 59  = 49
+    {256, 160, 256, 3, 0, 0, 7},  // 60  = 50
+    {128, 160, 256, 2, 0, 1, 7},  // 61  = 51
+    {128, 160, 256, 3, 0, 0, 7},  // 62  = 52
+    // 63-66 (round 5): FOUR compute waves of 64x160 / 64x128 (32x32x16 MFMAs, 160 / 128 accumulators per lane) + four staging waves,
+    // two waves per SIMD at 256 registers, with the cross-tile pipeline at k16 granularity (MF_FX_XQ): the wave tile whose LDS reads
+    // fit under its MFMAs (gemm_conv_kernel.h, XQ)
+    {256, 160, 256, 2, 0, 1, 14},  // 63  dx-reuse conv, 4x1 compute waves of 64x160
+    {256, 160, 256, 3, 0, 0, 14},  // 64  plain ring, 4x1 compute waves of 64x160
+    {256, 128, 256, 2, 0, 1, 14},  // 65  dx-reuse conv, 4x1 compute waves of 64x128
+    {256, 128, 256, 3, 0, 0, 14},  // 66  plain ring, 4x1 compute waves of 64x128
     // (round 3: FOUR-deep rings of 48 / 41 — 147 KB, three K tiles in flight — were built, parity-tested and offered to the tuner
     // over the whole step: picked for none of 100 shapes, gpurun_out/r03e/tune_user.json; removed again)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+inline bool tile_ws(int tile) { return tile >= 37 && tile <= kNumTiles; }                          // compute waves + four staging waves
+inline bool tile_ws_ring(int tile) { return tile_ws(tile) && kTiles[tile - 1].dxr == 0; }           // ... of the plain ring (any call)
 
 // tiles whose kernels have an in-launch split-K combine (keep in sync with the launch_skf cases below)
 bool tile_has_skf(int tile, int dtype, int w_split, bool a_f32) {
@@ -246,6 +268,12 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(a.res1_rows == 0 || a.M % a.res1_rows == 0, "mf_gemm_conv: res1_rows=%d must divide M=%d", d->res1_rows, a.M);
     a.alpha = d->alpha; a.act = d->act;
     a.out = (char*)d->out; a.out_dt = d->out_dtype; a.ldc = d->ldc;
+    {   // the 16-bit flavour is a compile-time property of the kernels (DT == MF_F16): fp16 results / residuals only in the fp16 mode
+        const int r0 = d->res0 ? d->res0_dtype : -1, r1 = d->res1 ? d->res1_dtype : -1;
+        MF_CHECK_ARG(d->dtype == MF_F16 ? !mf_any_bf16(d->out_dtype, r0, r1) : !mf_any_f16(d->out_dtype, r0, r1),
+                     "mf_gemm_conv: fp16 outputs / residuals go with dtype MF_F16 and bf16 ones with the other modes (dtype %d, out %d, res %d %d)",
+                     d->dtype, d->out_dtype, r0, r1);
+    }
     a.ln_cs = d->ln_colsum; a.ln_eps = d->ln_eps;
     a.vt_out = (char*)d->vt_out; a.vt_n0 = d->vt_n0; a.vt_tokens = d->vt_tokens; a.vt_ld = d->vt_ld;
     if (d->ln_colsum || d->vt_out) {
@@ -253,8 +281,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         MF_CHECK_ARG(mf_is16(d->dtype) && d->a_dtype == d->dtype && d->kh == 1 && d->kw == 1 && d->c1 == 0 && d->nz == 1 &&
                          (d->splitk == 0 || d->splitk == 1) && d->a_scale == nullptr && d->w_scale == nullptr,
                      "mf_gemm_conv: ln_colsum / vt_out need a plain bf16 / fp16 1x1 GEMM (one A segment, no batching, no split-K, no scales)");
-        MF_CHECK_ARG(d->tile == 0 || (d->tile >= 41 && d->tile <= 48 && d->tile != 47) || d->tile == 50 || d->tile == 52,
-                     "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (the warp-specialised ring tiles 41-46, 48, 50, 52 do)", d->tile);
+        MF_CHECK_ARG(d->tile == 0 || tile_ws_ring(d->tile),
+                     "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (the warp-specialised ring tiles 41-46, 48, 50, 52, 54, 56-58, 60, 62 do)", d->tile);
         MF_CHECK_ARG(!d->ln_colsum || (mf_aligned16(d->ln_colsum) && d->n % 8 == 0 && d->ln_eps > 0.0f), "mf_gemm_conv: ln_colsum must be 16-byte aligned, n %% 8 == 0, ln_eps > 0");
         if (d->vt_out) {
             MF_CHECK_ARG(mf_is16(d->out_dtype) && mf_aligned16(d->vt_out) && d->vt_tokens > 0 && d->vt_tokens % 8 == 0 && a.M % d->vt_tokens == 0 &&
@@ -333,7 +361,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
             const int64_t total = (int64_t)a.M * a.N / (a.vec_ok ? 8 : 1);
             int blocks = (int)((total + 255) / 256);
             if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, hs, a);
+            hipLaunchKernelGGL(d->dtype == MF_F16 ? splitk_reduce_kernel<true> : splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, hs, a);
             MF_CHECK_LAUNCH("mf_gemm_conv(split-K reduce)");
         }
         return MF_OK;
@@ -394,7 +422,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     {   // staged epilogue rows (GemmArgs::epb): warp-specialised tiles, the vector epilogue, per-column bias, no split-K slabs;
         // a time embedding needs Ho * Wo a power of two and the tile's images inside the rows the tile reserves
         static const bool off = getenv("MFHIP_NO_EPB") != nullptr;          // A/B switch
-        const int nimg_max = tile >= 37 ? epb_nimg(tc.bm, tc.bn, 3, tc.dxr != 0, true) : 0;
+        const int nimg_max = (tc.fx & MF_FX_EPB) ? epb_nimg(tc.bm, tc.bn, 3, tc.dxr != 0, true) : 0;
         bool ok = !off && nimg_max > 0 && a.vec_ok && a.bias_mode == 0 && a.splitk == 1 && (a.bias || a.temb || a.ln_cs);
         a.epb_sh = 31;
         if (ok && a.temb) {
@@ -441,14 +469,14 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         launched = tile <= 6    ? launch_f16_a(tile, a, grid, s, false)
                    : tile <= 24 ? launch_f16_b(tile, a, grid, s)
                    : tile <= 36 ? launch_f16_c(tile, a, grid, s)
-                   : (tile <= 40 || tile == 47 || tile == 49 || tile == 51) ? launch_f16_ws_dx(tile, a, grid, s)
-                                                                            : launch_f16_ws_ring(tile, a, grid, s);
+                   : tc.dxr     ? launch_f16_ws_dx(tile, a, grid, s)
+                                : launch_f16_ws_ring(tile, a, grid, s);
     } else if (d->dtype == MF_BF16) {
         launched = (a_f32 || tile <= 6) ? launch_bf16_a(tile, a, grid, s, a_f32)
                    : tile <= 24         ? launch_bf16_b(tile, a, grid, s)
                    : tile <= 36         ? launch_bf16_c(tile, a, grid, s)
-                   : (tile <= 40 || tile == 47 || tile == 49 || tile == 51) ? launch_bf16_ws_dx(tile, a, grid, s)
-                                                : launch_bf16_ws_ring(tile, a, grid, s);
+                   : tc.dxr             ? launch_bf16_ws_dx(tile, a, grid, s)
+                                        : launch_bf16_ws_ring(tile, a, grid, s);
     } else {
         launched = tile <= 12 ? launch_f32_a(tile, a, grid, s) : launch_f32_b(tile, a, grid, s);
     }
@@ -459,7 +487,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(d->dtype == MF_F16 ? splitk_reduce_kernel<true> : splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
         MF_CHECK_LAUNCH("mf_gemm_conv(split-K reduce)");
     }
     return MF_OK;

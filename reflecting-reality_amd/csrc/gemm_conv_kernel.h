@@ -132,13 +132,14 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, int64_t zo, in
     store_from_f32(p.out, p.out_dt, zo + (int64_t)m * p.ldc + n, v);
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ void load8_as_f32(const char* p, int dt, int64_t idx, float* o) {
     if (dt == MF_F32) {
         const float4 a = *reinterpret_cast<const float4*>(p + idx * 4);
         const float4 b = *reinterpret_cast<const float4*>(p + idx * 4 + 16);
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     } else {
-        unpack_h8(*reinterpret_cast<const uint4*>(p + idx * 2), dt, o);
+        unpack_h8<F16>(*reinterpret_cast<const uint4*>(p + idx * 2), o);
     }
 }
 
@@ -153,6 +154,8 @@ __device__ __forceinline__ void unpack8_bf16(const uint4& u, float* o) {
 // `pre`: the bf16 residual vectors of this item were fetched ahead of the LDS transposition (q0 / q1).
 // `eb` (warp-specialised tiles with staged epilogue rows): LDS address of this item's 8 columns in the bias row; `et`: in the
 // time-embedding row of the item's image (rows are `pitch` floats apart: see epb_off).
+// F16: the 16-bit flavour of the launch (fp16 storage mode), a compile-time property of the instantiation (DT == MF_F16).
+template <bool F16>
 __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, int m, int n, float* v, bool pre = false,
                                                 const uint4& q0 = uint4{0, 0, 0, 0}, const uint4& q1 = uint4{0, 0, 0, 0}, int zq = 0,
                                                 const char* eb = nullptr, const char* et = nullptr) {
@@ -187,15 +190,15 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
     if (p.res0) {
         float r[8];
-        if (pre) unpack_h8(q0, p.res0_dt, r);
-        else load8_as_f32(p.res0, p.res0_dt, (int64_t)m * p.ld_res0 + n, r);
+        if (pre) unpack_h8<F16>(q0, r);
+        else load8_as_f32<F16>(p.res0, p.res0_dt, (int64_t)m * p.ld_res0 + n, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
     if (p.res1) {
         float r[8];
-        if (pre) unpack_h8(q1, p.res1_dt, r);
-        else load8_as_f32(p.res1, p.res1_dt, (int64_t)res1_row(p, m) * p.ld_res1 + n, r);
+        if (pre) unpack_h8<F16>(q1, r);
+        else load8_as_f32<F16>(p.res1, p.res1_dt, (int64_t)res1_row(p, m) * p.ld_res1 + n, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
@@ -227,8 +230,8 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
             *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(g[0], g[1], g[2], g[3]);
         } else {
             uint2 u;
-            u.x = pack_h2(g[0], g[1], p.out_dt);
-            u.y = pack_h2(g[2], g[3], p.out_dt);
+            u.x = pack_h2<F16>(g[0], g[1]);
+            u.y = pack_h2<F16>(g[2], g[3]);
             *reinterpret_cast<uint2*>(p.out + o * 2) = u;
         }
         return;
@@ -238,7 +241,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, int64_t zo, i
         *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p.out + o * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        *reinterpret_cast<uint4*>(p.out + o * 2) = pack_h8(v, p.out_dt);
+        *reinterpret_cast<uint4*>(p.out + o * 2) = pack_h8<F16>(v);
     }
 }
 
@@ -280,6 +283,16 @@ __device__ __forceinline__ f32x16_t mfma32x16(bf16x8_t a, bf16x8_t b, f32x16_t c
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// Feature bits of an instantiation (template argument FX).  The three round-5 loop forms change the register allocation of the whole
+// kernel (the cross-tile pipeline keeps two fragment sets: +20 ... +80 VGPRs, a wave per SIMD less on most tiles), and in the denoise
+// step a block shares its CU with the other stream's blocks — so they are separate tile numbers the tuner may pick, not a rewrite of
+// the round-4 tiles: FX = 0 compiles to the round-4 loops.
+#define MF_FX_XT 1     // cross-tile fragment software pipeline of the warp-specialised 16-bit loops
+#define MF_FX_EPB 2    // bias / LayerNorm column sums / time-embedding rows staged in LDS by the staging waves' first DMAs
+#define MF_FX_AE 4     // dx-reuse convs: the A window of group g + 1 issued one tap early
+#define MF_FX_ALL 7
+#define MF_FX_XQ 8     // the cross-tile pipeline at k16 granularity (32x32x16 forms with 64-row wave tiles: two sets of MT + NT fragments)
+
 // LDS layout of the staged epilogue rows of a warp-specialised tile: [bias][ln_colsum][temb of image 0 .. nimg-1], fp32, each row
 // padded to whole 64-float DMA pieces; placed behind the ring (and the LayerNorm statistics).  nimg = 0: the tile has no room.
 constexpr int epb_pitch(int bn) { return (bn + 63) / 64 * 64; }
@@ -308,7 +321,7 @@ constexpr int min_waves(int bm, int bn, int stages, int nthr) {
 // block's barrier, ONE lane's agent-scope release + drain, the relaxed agent-scope ticket; the last arriver's ONE agent-scope
 // acquire + drain, a barrier, then plain loads by every wave.  Correct for any placement of a tile's slices over XCDs / CUs.
 // The last arriver re-arms the ticket, so the counters are zero again when the launch ends.
-template <int BM, int BN, int NT_ALL>
+template <int BM, int BN, int NT_ALL, bool F16>
 __device__ __forceinline__ void splitk_combine_tail(const GemmArgs& p, char* smem, int tile_m, int tile_n, int z, int zq, int64_t zo, int t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's slab stores have left
     __syncthreads();                                                     // ... and every other wave's (the LDS is free too)
@@ -344,7 +357,7 @@ __device__ __forceinline__ void splitk_combine_tail(const GemmArgs& p, char* sme
                 const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)s * p.nz * mn + 4);
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
             }
-            epilogue_store8(p, zo, m, n, v, false, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, zq);
+            epilogue_store8<F16>(p, zo, m, n, v, false, uint4{0, 0, 0, 0}, uint4{0, 0, 0, 0}, zq);
         } else {
             for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) {
                 float v = 0.0f;
@@ -370,7 +383,7 @@ __device__ __forceinline__ void splitk_combine_tail(const GemmArgs& p, char* sme
 // sit at their register / SGPR budget, and the tail's extra scalar state costs the 256 x 160 forms 368 bytes of scratch and
 // several others a wave per SIMD even when it never runs; only the tiles that small-M, deep-K calls use carry an SKF twin.
 template <int DT, int BM, int BN, int WAVES_M, int WAVES_N, bool A_F32, int STAGES, bool DXR = false, bool WPK = false, bool M16 = false,
-          bool WS = false, bool P16 = false, bool SKF = false>
+          bool WS = false, bool P16 = false, bool SKF = false, int FX = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64 + (WS ? 256 : 0),
                              WS ? (WAVES_M * WAVES_N + 4) / 4 : min_waves(BM + (DXR ? 32 : 0), BN, STAGES, WAVES_M* WAVES_N * 64))
 void gemm_conv_kernel(const GemmArgs p) {
@@ -447,7 +460,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     const int zq = z ? z / p.zdiv : 0, zr = z - zq * p.zdiv;
 
     // ---- staged epilogue rows (see GemmArgs::epb): the staging waves' first DMAs ----------------------------------------
-    constexpr int EPB_NIMG = epb_nimg(BM, BN, STAGES, DXR, WS), EPB_PITCH = epb_pitch(BN), EPB_OFF = epb_off(BM, BN, STAGES, DXR, WS);
+    constexpr int EPB_NIMG = (FX & MF_FX_EPB) ? epb_nimg(BM, BN, STAGES, DXR, WS) : 0, EPB_PITCH = epb_pitch(BN), EPB_OFF = epb_off(BM, BN, STAGES, DXR, WS);
     const bool epb = EPB_NIMG > 0 && p.epb != 0;
     if constexpr (EPB_NIMG > 0) {
         if (producer && epb) {
@@ -903,22 +916,39 @@ void gemm_conv_kernel(const GemmArgs p) {
     // consumers now arrive when tile k - 1's READS are complete instead of its MFMAs.  Same accumulation order: bit-identical.
     // Not for 8 x 1 compute waves of 32x160 (tiles 37 / 39 / 42): two sets of 12 fragments beside 80 accumulators exceed the 168
     // registers of three waves per SIMD and spill INSIDE the loop; tiles 49 / 50 are their 4 x 2 (64x80) successors.
-    constexpr bool XT = WS && H16 && !A_F32 && (MF_XTAP != 0) && !(WAVES_M == 8 && WAVES_N == 1);
-    constexpr int XNA = !XT ? 1 : (P16 ? MT16 : 2 * MT), XNB = !XT ? 1 : (P16 ? NT16 : 2 * NT);
+    // XQ: the same pipeline at k16 granularity for the 32x32x16 forms — a K tile is FOUR parts, part q in register set q & 1, the barrier
+    // between the MFMAs of parts 2 and 3.  Two sets of MT + NT fragments instead of 2 MT + 2 NT: 64x160 wave tiles (160 accumulators +
+    // 56 fragment registers) fit the 256 registers of two waves per SIMD, i.e. FOUR compute waves of 64x160 + four staging waves per
+    // 256x160 block.  Why that shape: a wave tile of WM x WN reads (WM + WN) x 32 bytes of LDS per k16 and multiplies for WM x WN / 32
+    // clocks; over four SIMDs 32x80 needs 179 B/clk, 32x160 154, 64x80 115, 64x160 90 of the CU's 128 B/clk — the smaller wave tiles
+    // are LDS-bound before the DMAs even take their share (stamps, round 5: tile 48 936 clocks per K tile against 640 of MFMA).
+    constexpr bool XQ = (FX & MF_FX_XQ) != 0 && WS && H16 && !A_F32 && !M16 && !P16;
+    constexpr bool XT = XQ || ((FX & MF_FX_XT) != 0 && WS && H16 && !A_F32 && (MF_XTAP != 0) && !(WAVES_M == 8 && WAVES_N == 1));
+    constexpr int XNA = !XT ? 1 : XQ ? MT : (P16 ? MT16 : 2 * MT), XNB = !XT ? 1 : XQ ? NT : (P16 ? NT16 : 2 * NT);
     uint4 xa[2][XNA], xb[2][XNB];
-    // fragments of half H (compile-time) of one K tile.  arow(t): LDS row of this lane's row of A fragment t (P16 / M16: 16-row
-    // fragments, r16; else 32-row fragments, frow); Ab: the A buffer; Bb: the W tile's first row of this wave (lane row included).
-    auto xt_load = [&](auto H, const char* Ab, auto arow, const char* Bb) {
-        constexpr int hh = decltype(H)::value;
-        if constexpr (P16 || M16) {
+    // fragments of part P (compile-time; XT: half P of two, XQ: k16 step P of four) of one K tile into register set S.  arow(t): LDS row
+    // of this lane's row of A fragment t (P16 / M16: 16-row fragments, r16; else 32-row fragments, frow); Ab: the A buffer; Bb: the W
+    // tile's first row of this wave (lane row included).
+    auto xt_load = [&](auto S, auto P, const char* Ab, auto arow, const char* Bb) {
+        constexpr int ss = decltype(S)::value, hh = decltype(P)::value;
+        if constexpr (XQ) {
+            const int ch = 2 * hh + fh;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = arow(i);
+                xa[ss][i] = *reinterpret_cast<const uint4*>(Ab + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) xb[ss][j] = *reinterpret_cast<const uint4*>(Bb + j * 32 * 128 + ((ch ^ fkey) << 4));
+        } else if constexpr (P16 || M16) {
             const int key16 = (r16 >> 1) & 7;
 #pragma unroll
             for (int t = 0; t < XNA; ++t) {
                 const int r = arow(t);
-                xa[hh][t] = *reinterpret_cast<const uint4*>(Ab + r * 128 + (((4 * hh + kg) ^ ((r >> 1) & 7)) << 4));
+                xa[ss][t] = *reinterpret_cast<const uint4*>(Ab + r * 128 + (((4 * hh + kg) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int t = 0; t < XNB; ++t) xb[hh][t] = *reinterpret_cast<const uint4*>(Bb + t * 16 * 128 + (((4 * hh + kg) ^ key16) << 4));
+            for (int t = 0; t < XNB; ++t) xb[ss][t] = *reinterpret_cast<const uint4*>(Bb + t * 16 * 128 + (((4 * hh + kg) ^ key16) << 4));
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -926,16 +956,22 @@ void gemm_conv_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int r = arow(i);
-                    xa[hh][kk * MT + i] = *reinterpret_cast<const uint4*>(Ab + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
+                    xa[ss][kk * MT + i] = *reinterpret_cast<const uint4*>(Ab + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
                 }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) xb[hh][kk * NT + j] = *reinterpret_cast<const uint4*>(Bb + j * 32 * 128 + ((ch ^ fkey) << 4));
+                for (int j = 0; j < NT; ++j) xb[ss][kk * NT + j] = *reinterpret_cast<const uint4*>(Bb + j * 32 * 128 + ((ch ^ fkey) << 4));
             }
         }
     };
-    auto xt_mma = [&](auto H) {
-        constexpr int hh = decltype(H)::value;
-        if constexpr (P16) {
+    auto xt_mma = [&](auto S) {
+        constexpr int hh = decltype(S)::value;
+        if constexpr (XQ) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = mfma32x16<DT>(__builtin_bit_cast(bf16x8_t, xa[hh][i]), __builtin_bit_cast(bf16x8_t, xb[hh][j]), acc[i][j]);
+        } else if constexpr (P16) {
 #pragma unroll
             for (int a = 0; a < MT16; ++a)
 #pragma unroll
@@ -966,6 +1002,49 @@ void gemm_conv_kernel(const GemmArgs p) {
     };
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
+    using H2 = std::integral_constant<int, 2>;
+    using H3 = std::integral_constant<int, 3>;
+    // the consumer loop of the cross-tile pipeline.  ld(S, P): part P of the current tile into set S; adv(): step to the next tile.
+    // (the last tile is peeled: a straight-line loop body lets hipcc's waitcnt pass count the reads in flight across the back edge
+    // instead of draining lgkmcnt(0) in front of the first MFMA)
+    auto xt_loop = [&](auto&& ld, auto&& adv) {
+        auto head = [&]() {              // every part of a tile but the last: the next part's reads fly under this part's MFMAs
+            ld(H1{}, H1{});
+            __builtin_amdgcn_sched_barrier(0);
+            xt_mma(H0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (XQ) {
+                ld(H0{}, H2{});
+                __builtin_amdgcn_sched_barrier(0);
+                xt_mma(H1{});
+                __builtin_amdgcn_sched_barrier(0);
+                ld(H1{}, H3{});
+                __builtin_amdgcn_sched_barrier(0);
+                xt_mma(H0{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        ld(H0{}, H0{});
+        [[maybe_unused]] unsigned long long w_bar = 0;
+        MF_CLK(tl0);
+        for (int t = 0; t + 1 < nt; ++t) {
+            head();
+            adv();
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): every read of tile t has returned
+            MF_CLK(tb0);
+            __builtin_amdgcn_s_barrier();               // #(t + 1): tile t + 1 has landed
+            MF_CLK(tb1);
+            MF_SUM(w_bar, tb0, tb1);
+            ld(H0{}, H0{});
+            __builtin_amdgcn_sched_barrier(0);
+            xt_mma(H1{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        head();
+        xt_mma(H1{});
+        MF_CLK(tl1);
+        MF_PUT(13, w_bar); MF_PUT(14, tl1 - tl0); MF_PUT(15, (unsigned long long)nt);
+    };
 
     // ---- main loop ------------------------------------------------------------------------
     MF_STAMP(1);
@@ -1021,7 +1100,7 @@ void gemm_conv_kernel(const GemmArgs p) {
             // AE (warp-specialised forms): the A window of group g + 1 is issued one tap EARLIER, behind the W tile of group g's last tap
             // — its buffer has been free since barrier #3g, and a tap that carries a window (A3_IT more DMAs) then has three taps of
             // flight time instead of two: the staging waves used to wait for exactly those taps (stamps, round 5: 26 % of the loop)
-            constexpr bool AE = WS && (MF_AEARLY != 0);
+            constexpr bool AE = (FX & MF_FX_AE) != 0 && WS && (MF_AEARLY != 0);
             int i_tap = 0;
             auto issue_a = [&](int ky, int cg, int grp) {
                 const int c = cg * BK;
@@ -1204,41 +1283,17 @@ void gemm_conv_kernel(const GemmArgs p) {
                     MF_STAMP(2);
                     if constexpr (XT) {
                         // tap (c_grp, c_st, c_kx): A window buffer, W stage and the window's row shift
-                        auto ld = [&](auto H) {
+                        auto ld = [&](auto S, auto P) {
                             const int kx = c_kx;
                             const char* Ab = smem + (c_grp & 1) * AB;
                             const char* Bb = smem + 2 * AB + c_st * WB + (wn * WN + ((P16 || M16) ? r16 : frow)) * 128;
-                            if constexpr (P16 || M16) xt_load(H, Ab, [&](int t) { return arow16[t] + kx; }, Bb);
-                            else xt_load(H, Ab, [&](int i) { return arow0[i] + kx; }, Bb);
+                            if constexpr (P16 || M16) xt_load(S, P, Ab, [&](int t) { return arow16[t] + kx; }, Bb);
+                            else xt_load(S, P, Ab, [&](int i) { return arow0[i] + kx; }, Bb);
                         };
-                        // (the last tap is peeled: a straight-line loop body lets hipcc's waitcnt pass count the reads in flight
-                        // across the back edge instead of draining lgkmcnt(0) in front of the first MFMA)
-                        ld(H0{});
-                        [[maybe_unused]] unsigned long long w_bar = 0;
-                        MF_CLK(tl0);
-                        for (int t = 0; t + 1 < nt; ++t) {
-                            ld(H1{});
-                            __builtin_amdgcn_sched_barrier(0);
-                            xt_mma(H0{});
-                            __builtin_amdgcn_sched_barrier(0);
+                        xt_loop(ld, [&]() {
                             c_st = c_st == WST - 1 ? 0 : c_st + 1;
                             if (++c_kx == 3) { c_kx = 0; ++c_grp; }
-                            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): every read of tap t has returned
-                            MF_CLK(tb0);
-                            __builtin_amdgcn_s_barrier();               // #(t + 1): tap t + 1 has landed
-                            MF_CLK(tb1);
-                            MF_SUM(w_bar, tb0, tb1);
-                            ld(H0{});
-                            __builtin_amdgcn_sched_barrier(0);
-                            xt_mma(H1{});
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        ld(H1{});
-                        __builtin_amdgcn_sched_barrier(0);
-                        xt_mma(H0{});
-                        xt_mma(H1{});
-                        MF_CLK(tl1);
-                        MF_PUT(13, w_bar); MF_PUT(14, tl1 - tl0); MF_PUT(15, (unsigned long long)nt);
+                        });
                     } else
                     for (int t = 0; t < nt; ++t) {
                         compute3(c_grp & 1, c_st, c_kx);
@@ -1382,37 +1437,13 @@ void gemm_conv_kernel(const GemmArgs p) {
                     MF_STAMP(2);
                     if constexpr (XT) {
                         const int arb = wm * WM + ((P16 || M16) ? r16 : frow);      // this lane's row of A fragment 0
-                        auto ld = [&](auto H) {
+                        auto ld = [&](auto S, auto P) {
                             const char* Ab = smem + st_c * STAGE_BYTES;
                             const char* Bb = Ab + BM * 128 + (wn * WN + ((P16 || M16) ? r16 : frow)) * 128;
-                            if constexpr (P16 || M16) xt_load(H, Ab, [&](int t) { return arb + t * 16; }, Bb);
-                            else xt_load(H, Ab, [&](int i) { return arb + i * 32; }, Bb);
+                            if constexpr (P16 || M16) xt_load(S, P, Ab, [&](int t) { return arb + t * 16; }, Bb);
+                            else xt_load(S, P, Ab, [&](int i) { return arb + i * 32; }, Bb);
                         };
-                        ld(H0{});
-                        [[maybe_unused]] unsigned long long w_bar = 0;
-                        MF_CLK(tl0);
-                        for (int t = 0; t + 1 < nt; ++t) {             // (last tile peeled: see the dx-reuse loop)
-                            ld(H1{});
-                            __builtin_amdgcn_sched_barrier(0);
-                            xt_mma(H0{});
-                            __builtin_amdgcn_sched_barrier(0);
-                            st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
-                            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): every read of tile t has returned
-                            MF_CLK(tb0);
-                            __builtin_amdgcn_s_barrier();               // #(t + 1): tile t + 1 has landed
-                            MF_CLK(tb1);
-                            MF_SUM(w_bar, tb0, tb1);
-                            ld(H0{});
-                            __builtin_amdgcn_sched_barrier(0);
-                            xt_mma(H1{});
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        ld(H1{});
-                        __builtin_amdgcn_sched_barrier(0);
-                        xt_mma(H0{});
-                        xt_mma(H1{});
-                        MF_CLK(tl1);
-                        MF_PUT(13, w_bar); MF_PUT(14, tl1 - tl0); MF_PUT(15, (unsigned long long)nt);
+                        xt_loop(ld, [&]() { st_c = st_c == STAGES - 1 ? 0 : st_c + 1; });
                     } else
                     for (int t = 0; t < nt; ++t) {
                         compute(st_c);
@@ -1565,7 +1596,7 @@ void gemm_conv_kernel(const GemmArgs p) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) tv[j] = (tv[j] + b) * p.alpha;
                         const int img = mt / p.vt_tokens, tok = mt - img * p.vt_tokens;
-                        const uint4 o = pack_h8(tv, p.out_dt);
+                        const uint4 o = pack_h8<DT == MF_F16>(tv);
                         *reinterpret_cast<uint4*>(p.vt_out + (((int64_t)img * (p.N - p.vt_n0) + (nt_ - p.vt_n0)) * p.vt_ld + tok) * 2) = o;
                     }
                     continue;
@@ -1604,9 +1635,9 @@ void gemm_conv_kernel(const GemmArgs p) {
                     } else if (p.vec_ok && n + 8 <= p.N) {
                         if (epb) {
                             const char* eb = smem + EPB_OFF + (n - n0) * 4;
-                            epilogue_store8(p, zo, m, n, v, res_pre, q0[u], q1[u], zq, eb, eb + (2 + (m >> p.epb_sh) - (m0 >> p.epb_sh)) * (EPB_PITCH * 4));
+                            epilogue_store8<DT == MF_F16>(p, zo, m, n, v, res_pre, q0[u], q1[u], zq, eb, eb + (2 + (m >> p.epb_sh) - (m0 >> p.epb_sh)) * (EPB_PITCH * 4));
                         } else {
-                            epilogue_store8(p, zo, m, n, v, res_pre, q0[u], q1[u], zq);
+                            epilogue_store8<DT == MF_F16>(p, zo, m, n, v, res_pre, q0[u], q1[u], zq);
                         }
                     } else {
                         for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj], zq);
@@ -1622,7 +1653,7 @@ void gemm_conv_kernel(const GemmArgs p) {
         MF_STAMP_DRAIN();
         MF_STAMP(5);
         if constexpr (SKF) {
-            if (ws) splitk_combine_tail<BM, BN, NTHR + 256>(p, smem, tile_m, tile_n, z, zq, zo, (int)threadIdx.x);
+            if (ws) splitk_combine_tail<BM, BN, NTHR + 256, DT == MF_F16>(p, smem, tile_m, tile_n, z, zq, zo, (int)threadIdx.x);
         }
         MF_STAMP(6);
         return;
@@ -1691,7 +1722,7 @@ void gemm_conv_kernel(const GemmArgs p) {
                         for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) ws[(int64_t)m * p.N + n + jj] = v[jj];
                     }
                 } else if (p.vec_ok && n + 8 <= p.N) {
-                    epilogue_store8(p, zo, m, n, v, res_pre, q0[it0 / 64], q1[it0 / 64], zq);
+                    epilogue_store8<DT == MF_F16>(p, zo, m, n, v, res_pre, q0[it0 / 64], q1[it0 / 64], zq);
                 } else {
                     for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj], zq);
                 }
@@ -1703,17 +1734,17 @@ void gemm_conv_kernel(const GemmArgs p) {
     MF_STAMP_DRAIN();
     MF_STAMP(5);
     if constexpr (SKF) {
-        if (ws) splitk_combine_tail<BM, BN, NTHR>(p, smem, tile_m, tile_n, z, zq, zo, (int)threadIdx.x);
+        if (ws) splitk_combine_tail<BM, BN, NTHR, DT == MF_F16>(p, smem, tile_m, tile_n, z, zq, zo, (int)threadIdx.x);
     }
     MF_STAMP(6);
 }
 
 template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false,
-          bool P16 = false, bool SKF = false>
+          bool P16 = false, bool SKF = false, int FX = 0>
 void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     // warp-specialised ring tiles keep BM (mean, rstd) pairs of a folded LayerNorm past the ring
     constexpr int smem_k = DX ? 2 * (BM + (WS ? 32 : WMv * WNv * 8)) * 128 + (WS ? ST : 2) * BN * 128 : ST * (BM + BN) * 128 + (WS ? BM * 8 : 0);
-    constexpr int smem_e = epb_nimg(BM, BN, ST, DX, WS) > 0 ? (2 + epb_nimg(BM, BN, ST, DX, WS)) * epb_pitch(BN) * 4 : 0;   // staged epilogue rows
+    constexpr int smem_e = (FX & MF_FX_EPB) && epb_nimg(BM, BN, ST, DX, WS) > 0 ? (2 + epb_nimg(BM, BN, ST, DX, WS)) * epb_pitch(BN) * 4 : 0;   // staged epilogue rows
     static_assert(smem_k == epb_off(BM, BN, ST, DX, WS) || !WS, "epb_off must equal the ring's footprint");
     static_assert(smem_k + smem_e <= 160 * 1024, "LDS");
     // experiment switch: MFHIP_SMEM_MIN=<bytes> raises the LDS request (occupancy control for ring-depth A/B runs)
@@ -1721,19 +1752,19 @@ void launch_one(const GemmArgs& a, dim3 grid, hipStream_t s) {
     const int smem = smem_k + smem_e > smem_min ? smem_k + smem_e : smem_min;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, SKF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, SKF, FX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, SKF>), grid, dim3(WMv * WNv * 64 + (WS ? 256 : 0)), smem, s, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, SKF, FX>), grid, dim3(WMv * WNv * 64 + (WS ? 256 : 0)), smem, s, a);
 }
 
 // a tile with an SKF twin: the twin when the call carries tickets, the plain kernel otherwise
 template <int DT, int BM, int BN, int WMv, int WNv, bool AF, int ST, bool DX = false, bool WPK = false, bool M16 = false, bool WS = false,
-          bool P16 = false>
+          bool P16 = false, int FX = 0>
 void launch_skf(const GemmArgs& a, dim3 grid, hipStream_t s) {
-    if (a.sk_tickets) launch_one<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, true>(a, grid, s);
-    else launch_one<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, false>(a, grid, s);
+    if (a.sk_tickets) launch_one<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, true, FX>(a, grid, s);
+    else launch_one<DT, BM, BN, WMv, WNv, AF, ST, DX, WPK, M16, WS, P16, false, FX>(a, grid, s);
 }
 
 // ---- tile groups, one translation unit each (false: the tile is not instantiated in that group) ----------------------

@@ -53,21 +53,33 @@ __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {          // n
     const mf_f32x2_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mf_f16x2_t));
 }
-__device__ __forceinline__ uint32_t pack_h2(float a, float b, int dt) { return dt == MF_F16 ? pack_f16x2(a, b) : pack_bf16x2(a, b); }
-__device__ __forceinline__ void unpack_h2(uint32_t u, int dt, float& a, float& b) {
-    if (dt == MF_F16) {
+// Kernels take the 16-bit flavour as a template argument (F16): a run-time test per packed pair splits the unrolled load / store
+// batches of the memory-bound kernels into basic blocks (measured: GroupNorm +20 %, LayerNorm +25 %, every GEMM epilogue slower).
+template <bool F16>
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+    if constexpr (F16) return pack_f16x2(a, b);
+    else return pack_bf16x2(a, b);
+}
+template <bool F16>
+__device__ __forceinline__ void unpack_h2(uint32_t u, float& a, float& b) {
+    if constexpr (F16) {
         const mf_f16x2_t h = __builtin_bit_cast(mf_f16x2_t, u);
         a = (float)h[0]; b = (float)h[1];
     } else {
         a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u);
     }
 }
-__device__ __forceinline__ void unpack_h8(const uint4& u, int dt, float* o) {
-    unpack_h2(u.x, dt, o[0], o[1]); unpack_h2(u.y, dt, o[2], o[3]); unpack_h2(u.z, dt, o[4], o[5]); unpack_h2(u.w, dt, o[6], o[7]);
+template <bool F16>
+__device__ __forceinline__ void unpack_h8(const uint4& u, float* o) {
+    unpack_h2<F16>(u.x, o[0], o[1]); unpack_h2<F16>(u.y, o[2], o[3]); unpack_h2<F16>(u.z, o[4], o[5]); unpack_h2<F16>(u.w, o[6], o[7]);
 }
-__device__ __forceinline__ uint4 pack_h8(const float* v, int dt) {
-    return uint4{pack_h2(v[0], v[1], dt), pack_h2(v[2], v[3], dt), pack_h2(v[4], v[5], dt), pack_h2(v[6], v[7], dt)};
+template <bool F16>
+__device__ __forceinline__ uint4 pack_h8(const float* v) {
+    return uint4{pack_h2<F16>(v[0], v[1]), pack_h2<F16>(v[2], v[3]), pack_h2<F16>(v[4], v[5]), pack_h2<F16>(v[6], v[7])};
 }
+// the 16-bit flavour of one launch: every 16-bit operand is fp16, or every one is bf16 (host-side check of the entry points)
+static inline bool mf_any_f16(int a, int b = -1, int c = -1, int d = -1) { return a == MF_F16 || b == MF_F16 || c == MF_F16 || d == MF_F16; }
+static inline bool mf_any_bf16(int a, int b = -1, int c = -1, int d = -1) { return a == MF_BF16 || b == MF_BF16 || c == MF_BF16 || d == MF_BF16; }
 
 // dtype-generic scalar load/store (dt is wave-uniform at every call site)
 __device__ __forceinline__ float load_as_f32(const void* p, int dt, int64_t i) {

@@ -23,49 +23,53 @@ struct GnArgs {
     float* stats_out;   // nullable [batch][G][2]: (mean, rstd) of every group, kept for mf_groupnorm_bwd (training)
 };
 
+template <bool F16>
 __device__ __forceinline__ float4 load4(const char* p, int dt, int64_t idx) {
     if (dt == MF_F32) return *reinterpret_cast<const float4*>(p + idx * 4);
     const uint2 u = *reinterpret_cast<const uint2*>(p + idx * 2);
     float4 r;
-    unpack_h2(u.x, dt, r.x, r.y);
-    unpack_h2(u.y, dt, r.z, r.w);
+    unpack_h2<F16>(u.x, r.x, r.y);
+    unpack_h2<F16>(u.y, r.z, r.w);
     return r;
 }
+template <bool F16>
 __device__ __forceinline__ void store4(char* p, int dt, int64_t idx, float4 v) {
     if (dt == MF_F32) {
         *reinterpret_cast<float4*>(p + idx * 4) = v;
     } else {
         uint2 u;
-        u.x = pack_h2(v.x, v.y, dt);
-        u.y = pack_h2(v.z, v.w, dt);
+        u.x = pack_h2<F16>(v.x, v.y);
+        u.y = pack_h2<F16>(v.z, v.w);
         *reinterpret_cast<uint2*>(p + idx * 2) = u;
     }
 }
 
+template <bool F16>
 __device__ __forceinline__ void load8(const char* p, int dt, int64_t idx, float* o) {
     if (dt == MF_F32) {
         const float4 a = *reinterpret_cast<const float4*>(p + idx * 4);
         const float4 b = *reinterpret_cast<const float4*>(p + idx * 4 + 16);
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     } else {
-        unpack_h8(*reinterpret_cast<const uint4*>(p + idx * 2), dt, o);
+        unpack_h8<F16>(*reinterpret_cast<const uint4*>(p + idx * 2), o);
     }
 }
+template <bool F16>
 __device__ __forceinline__ void store8(char* p, int dt, int64_t idx, const float* v) {
     if (dt == MF_F32) {
         *reinterpret_cast<float4*>(p + idx * 4) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p + idx * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        *reinterpret_cast<uint4*>(p + idx * 2) = pack_h8(v, dt);
+        *reinterpret_cast<uint4*>(p + idx * 2) = pack_h8<F16>(v);
     }
 }
 
-template <int VW>
+template <int VW, bool F16>
 __device__ __forceinline__ void loadv(const char* p, int dt, float* o) {
     if (VW == 8) {
-        load8(p, dt, 0, o);
+        load8<F16>(p, dt, 0, o);
     } else {
-        const float4 t = load4(p, dt, 0);
+        const float4 t = load4<F16>(p, dt, 0);
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
     }
 }
@@ -77,7 +81,7 @@ __device__ __forceinline__ void loadv(const char* p, int dt, float* o) {
 //
 // Pass 1, grid (nchunks, batch): per-(thread-row, channel) fp32 sums -> LDS -> one (mean, M2) per group of the
 // chunk, in double.  No atomics: bitwise reproducible.
-template <int VW, int U = 4>
+template <int VW, int U = 4, bool F16 = false>
 __global__ __launch_bounds__(GN_BLK) void gn_stats_kernel(const GnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* chan = reinterpret_cast<float2*>(smem_raw);   // [rif][C] (sum, sum of squares)
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(GN_BLK) void gn_stats_kernel(const GnArgs p) {
             for (; r + (U - 1) * p.rif < r1; r += U * p.rif, ptr += U * step) {
                 float v[U][VW];
 #pragma unroll
-                for (int u = 0; u < U; ++u) loadv<VW>(ptr + u * step, p.in_dt, v[u]);
+                for (int u = 0; u < U; ++u) loadv<VW, F16>(ptr + u * step, p.in_dt, v[u]);
 #pragma unroll
                 for (int u = 0; u < U; u += 4)
 #pragma unroll
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(GN_BLK) void gn_stats_kernel(const GnArgs p) {
             }
             for (; r < r1; r += p.rif, ptr += step) {
                 float v0[VW];
-                loadv<VW>(ptr, p.in_dt, v0);
+                loadv<VW, F16>(ptr, p.in_dt, v0);
 #pragma unroll
                 for (int e = 0; e < VW; ++e) { s[e] += v0[e]; ss[e] += v0[e] * v0[e]; }
             }
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
 }
 
 // Pass 2, grid (row blocks, batch): pure streaming y = silu(x*a[c] + b[c]) with the thread's a/b in registers.
-template <int VW, int U = 4>
+template <int VW, int U = 4, bool F16 = false>
 __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int rows_per_block) {
     const int b = blockIdx.y, t = threadIdx.x;
     const int lcol = t % p.tpr, trow = t / p.tpr;
@@ -245,8 +249,8 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
         else { base = p.x1; ld = p.C1; cc = c - p.C0; }
         float sa[VW], sb[VW];
         if (p.fuse_finalize) {
-            loadv<VW>(reinterpret_cast<const char*>(p.gamma + c), MF_F32, sa);
-            loadv<VW>(reinterpret_cast<const char*>(p.beta + c), MF_F32, sb);
+            loadv<VW, F16>(reinterpret_cast<const char*>(p.gamma + c), MF_F32, sa);
+            loadv<VW, F16>(reinterpret_cast<const char*>(p.beta + c), MF_F32, sb);
 #pragma unroll
             for (int e = 0; e < VW; ++e) {
                 const int g = (c + e) / p.cpg;
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
                 sb[e] = sb[e] - gm[g] * sa[e];
             }
         } else {
-            loadv<VW>(reinterpret_cast<const char*>(ab + c), MF_F32, sa);
-            loadv<VW>(reinterpret_cast<const char*>(ab + p.C + c), MF_F32, sb);
+            loadv<VW, F16>(reinterpret_cast<const char*>(ab + c), MF_F32, sa);
+            loadv<VW, F16>(reinterpret_cast<const char*>(ab + p.C + c), MF_F32, sb);
         }
         const int64_t step = (int64_t)p.rif * ld * esz, ostep = (int64_t)p.rif * p.C * osz;
         const char* ptr = base + (((int64_t)b * p.HW + r0 + trow) * ld + cc) * esz;
@@ -267,20 +271,20 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
                 if (p.silu) y = fast_silu ? silu_f(y) : silu_precise(y);
                 v[e] = y;
             }
-            if (VW == 8) store8(o, p.out_dt, 0, v);
-            else store4(o, p.out_dt, 0, make_float4(v[0], v[1], v[2], v[3]));
+            if (VW == 8) store8<F16>(o, p.out_dt, 0, v);
+            else store4<F16>(o, p.out_dt, 0, make_float4(v[0], v[1], v[2], v[3]));
         };
         int r = r0 + trow;
         for (; r + (U - 1) * p.rif < r1; r += U * p.rif, ptr += U * step, optr += U * ostep) {
             float v[U][VW];
 #pragma unroll
-            for (int u = 0; u < U; ++u) loadv<VW>(ptr + u * step, p.in_dt, v[u]);      // U independent 16-byte loads in flight
+            for (int u = 0; u < U; ++u) loadv<VW, F16>(ptr + u * step, p.in_dt, v[u]);      // U independent 16-byte loads in flight
 #pragma unroll
             for (int u = 0; u < U; ++u) finish(v[u], optr + u * ostep);
         }
         for (; r < r1; r += p.rif, ptr += step, optr += ostep) {
             float v0[VW];
-            loadv<VW>(ptr, p.in_dt, v0);
+            loadv<VW, F16>(ptr, p.in_dt, v0);
             finish(v0, optr);
         }
     }
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
 // Thread t = lane * nv + vcol keeps vector column vcol of rows lane, lane + P, ... (at most ROWS): per-channel fp32
 // (sum, sum of squares) -> LDS -> one wave per group combines them in double in a fixed order (bitwise
 // reproducible) -> y = silu(x * a[c] + b[c]) from the registers.
-template <int ROWS>
+template <int ROWS, bool F16 = false>
 __global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, int nv, int P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2* chan = reinterpret_cast<float2*>(smem_raw);              // [P][SC or SC/8] (sum, sum of squares)
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, i
     if (active) {
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            if (lane + i * P < p.HW) load8(ptr + i * step, p.in_dt, 0, v[i]);
+            if (lane + i * P < p.HW) load8<F16>(ptr + i * step, p.in_dt, 0, v[i]);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = 0.0f;
@@ -372,8 +376,8 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, i
     __syncthreads();
     if (!active) return;
     float sa[8], sb[8];
-    load8(reinterpret_cast<const char*>(p.gamma + c), MF_F32, 0, sa);
-    load8(reinterpret_cast<const char*>(p.beta + c), MF_F32, 0, sb);
+    load8<false>(reinterpret_cast<const char*>(p.gamma + c), MF_F32, 0, sa);
+    load8<false>(reinterpret_cast<const char*>(p.beta + c), MF_F32, 0, sb);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int g = (vcol * 8 + e) / p.cpg;
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, i
                 if (p.silu) y = fast_silu ? silu_f(y) : silu_precise(y);
                 v[i][e] = y;
             }
-            store8(optr + i * ostep, p.out_dt, 0, v[i]);
+            store8<F16>(optr + i * ostep, p.out_dt, 0, v[i]);
         }
     }
 }
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, i
 // Half a wave per row (two rows per wave, 8 per block), 8-channel (16-byte) vectors: C % 8 == 0, C <= 2048.
 // For the transformer widths of the path (320 / 640 / 1280) this moves twice the bytes per instruction of the
 // 4-channel kernel below and halves the dependent shuffle chain (5 steps inside 32 lanes).
+template <bool F16>
 __global__ __launch_bounds__(256) void layernorm8_kernel(const char* x, int in_dt, char* out, int out_dt,
                                                          const float* gamma, const float* beta, int64_t rows, int C,
                                                          float eps) {
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(256) void layernorm8_kernel(const char* x, int in_d
     for (int j = 0; j < MAXV; ++j) {
         const int c8 = l32 + 32 * j;
         if (live && c8 < c8n) {
-            load8(x, in_dt, row * C + c8 * 8, v[j]);
+            load8<F16>(x, in_dt, row * C + c8 * 8, v[j]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += v[j][e];
         } else {
@@ -443,16 +448,17 @@ __global__ __launch_bounds__(256) void layernorm8_kernel(const char* x, int in_d
         if (c8 < c8n) {
             const int c = c8 * 8;
             float g[8], bb[8], y[8];
-            load8(reinterpret_cast<const char*>(gamma), MF_F32, c, g);
-            load8(reinterpret_cast<const char*>(beta), MF_F32, c, bb);
+            load8<false>(reinterpret_cast<const char*>(gamma), MF_F32, c, g);
+            load8<false>(reinterpret_cast<const char*>(beta), MF_F32, c, bb);
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = (v[j][e] - mean) * rstd * g[e] + bb[e];
-            store8(out, out_dt, row * C + c, y);
+            store8<F16>(out, out_dt, row * C + c, y);
         }
     }
 }
 
 // One wave per row, up to 8 x 256 channels.
+template <bool F16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const char* x, int in_dt, char* out, int out_dt,
                                                         const float* gamma, const float* beta, int64_t rows, int C,
                                                         float eps) {
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* x, int in_dt
     for (int j = 0; j < MAXV; ++j) {
         const int c4 = lane + 64 * j;
         if (c4 < c4n) {
-            v[j] = load4(x, in_dt, row * C + c4 * 4);
+            v[j] = load4<F16>(x, in_dt, row * C + c4 * 4);
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         } else {
             v[j] = make_float4(0, 0, 0, 0);
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* x, int in_dt
             y.y = (v[j].y - mean) * rstd * g.y + bb.y;
             y.z = (v[j].z - mean) * rstd * g.z + bb.z;
             y.w = (v[j].w - mean) * rstd * g.w + bb.w;
-            store4(out, out_dt, row * C + c, y);
+            store4<F16>(out, out_dt, row * C + c, y);
         }
     }
 }
@@ -540,6 +546,8 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     MF_CHECK_ARG(d->groups > 0 && C % d->groups == 0, "mf_groupnorm: C=%d not divisible by groups=%d", C, d->groups);
     MF_CHECK_ARG(d->c0 % 4 == 0 && d->c1 % 4 == 0, "mf_groupnorm: channel counts must be multiples of 4");
     MF_CHECK_ARG(d->batch >= 1 && d->hw >= 1, "mf_groupnorm: bad batch/hw");
+    MF_CHECK_ARG(!(mf_any_f16(d->in_dtype, d->out_dtype) && mf_any_bf16(d->in_dtype, d->out_dtype)), "mf_groupnorm: fp16 and bf16 operands in one launch");
+    const bool f16 = mf_any_f16(d->in_dtype, d->out_dtype);
     GnArgs a{};
     a.x0 = (const char*)d->x0; a.x1 = (const char*)d->x1;
     a.C0 = d->c0; a.C1 = d->c1; a.C = C; a.in_dt = d->in_dtype; a.HW = d->hw; a.G = d->groups;
@@ -573,7 +581,8 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
         if (!two_pass && vw == 8 && d->hw <= P * rows && C % sc == 0 && sc / a.cpg <= 8 && nthr <= 1024 && smem <= 64 * 1024 &&
             mf_aligned16(d->gamma) && mf_aligned16(d->beta) && mf_aligned16(d->x0) && mf_aligned16(d->out) &&
             (!d->x1 || mf_aligned16(d->x1))) {
-            hipLaunchKernelGGL(gn_slab_kernel<4>, dim3(C / sc, d->batch), dim3(nthr), smem, s, a, sc, nv, P);
+            if (f16) hipLaunchKernelGGL((gn_slab_kernel<4, true>), dim3(C / sc, d->batch), dim3(nthr), smem, s, a, sc, nv, P);
+            else hipLaunchKernelGGL((gn_slab_kernel<4, false>), dim3(C / sc, d->batch), dim3(nthr), smem, s, a, sc, nv, P);
             MF_CHECK_LAUNCH("mf_groupnorm(slab)");
             return MF_OK;
         }
@@ -592,19 +601,17 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     if (rows_per_block < 4 * a.rif) rows_per_block = 4 * a.rif;
     const int nblk = (d->hw + rows_per_block - 1) / rows_per_block;
     static const int gn_u = getenv("MFHIP_GN_UNROLL") ? atoi(getenv("MFHIP_GN_UNROLL")) : 4;      // developer sweep: 4 or 8 rows in flight
-    if (vw == 8) {
-        if (gn_u == 8) hipLaunchKernelGGL((gn_stats_kernel<8, 8>), dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
-        else hipLaunchKernelGGL((gn_stats_kernel<8, 4>), dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
-        MF_CHECK_LAUNCH("mf_groupnorm(stats)");
-        if (!a.fuse_finalize) hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
-        if (gn_u == 8) hipLaunchKernelGGL((gn_apply_kernel<8, 8>), dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
-        else hipLaunchKernelGGL((gn_apply_kernel<8, 4>), dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
-    } else {
-        hipLaunchKernelGGL(gn_stats_kernel<4>, dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);
-        MF_CHECK_LAUNCH("mf_groupnorm(stats)");
-        if (!a.fuse_finalize) hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);
-        hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);
-    }
+#define MF_GN_LAUNCH(VW_, U_, F_)                                                                                              \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL((gn_stats_kernel<VW_, U_, F_>), dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);                   \
+        MF_CHECK_LAUNCH("mf_groupnorm(stats)");                                                                                   \
+        if (!a.fuse_finalize) hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);                     \
+        hipLaunchKernelGGL((gn_apply_kernel<VW_, U_, F_>), dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);            \
+    } while (0)
+    if (vw == 8 && gn_u == 8) { if (f16) MF_GN_LAUNCH(8, 8, true); else MF_GN_LAUNCH(8, 8, false); }
+    else if (vw == 8) { if (f16) MF_GN_LAUNCH(8, 4, true); else MF_GN_LAUNCH(8, 4, false); }
+    else { if (f16) MF_GN_LAUNCH(4, 4, true); else MF_GN_LAUNCH(4, 4, false); }
+#undef MF_GN_LAUNCH
     MF_CHECK_LAUNCH("mf_groupnorm(apply)");
     return MF_OK;
 }
@@ -615,12 +622,12 @@ extern "C" int mf_layernorm(const void* x, int32_t in_dtype, void* out, int32_t 
     MF_CHECK_ARG(c % 4 == 0 && c >= 4 && c <= 2048, "mf_layernorm: C=%d must be a multiple of 4 and <= 2048", c);
     if (rows <= 0) return MF_OK;
     static const bool ln4 = getenv("MFHIP_LN4") != nullptr;     // A/B switch: the 4-channel kernel
-    if (!ln4 && c % 8 == 0 && mf_aligned16(x) && mf_aligned16(out) && mf_aligned16(gamma) && mf_aligned16(beta))
-        hipLaunchKernelGGL(layernorm8_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
-                           (const char*)x, in_dtype, (char*)out, out_dtype, gamma, beta, rows, c, eps);
-    else
-        hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const char*)x, in_dtype, (char*)out, out_dtype, gamma, beta, rows, c, eps);
+    MF_CHECK_ARG(!(mf_any_f16(in_dtype, out_dtype) && mf_any_bf16(in_dtype, out_dtype)), "mf_layernorm: fp16 and bf16 operands in one launch");
+    const bool f16 = mf_any_f16(in_dtype, out_dtype);
+    const bool v8 = !ln4 && c % 8 == 0 && mf_aligned16(x) && mf_aligned16(out) && mf_aligned16(gamma) && mf_aligned16(beta);
+    const dim3 grid((unsigned)(v8 ? (rows + 7) / 8 : (rows + 3) / 4));
+    auto* kern = v8 ? (f16 ? layernorm8_kernel<true> : layernorm8_kernel<false>) : (f16 ? layernorm_kernel<true> : layernorm_kernel<false>);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, (const char*)x, in_dtype, (char*)out, out_dtype, gamma, beta, rows, c, eps);
     MF_CHECK_LAUNCH("mf_layernorm");
     return MF_OK;
 }

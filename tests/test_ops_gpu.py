@@ -43,7 +43,7 @@ SPLIT_TILES = (0, 1, 2, 3, 6, 7, 14, 41, 44)  # tiles instantiated for f16x3 wit
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
-@pytest.mark.parametrize("tile", list(range(16)) + [25, 26, 29, 30, 31, 32, 33, 34, 35, 36, 41, 42, 43, 44, 45, 46, 48, 50, 52])
+@pytest.mark.parametrize("tile", list(range(16)) + [25, 26, 29, 30, 31, 32, 33, 34, 35, 36, 41, 42, 43, 44, 45, 46, 48, 50, 52, 54, 56, 57, 58, 60, 62, 64, 66])
 def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     prec = ops.Precision.get(prec_name)
     if (prec.split and tile not in SPLIT_TILES) or ((25 <= tile <= 30 or tile >= 37) and prec_name == "fp32"):
@@ -63,7 +63,7 @@ def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     check(f"conv3x3[{prec_name},tile{tile}]", nchw(y), ref, atol, rtol)
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28, 37, 38, 39, 40, 47, 49, 51])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28, 37, 38, 39, 40, 47, 49, 51, 53, 55, 59, 61, 63, 65])
 @pytest.mark.parametrize("case", ["plain", "tailN", "cat", "splitk", "epilogue", "big"])
 def test_conv3x3_halo_tiles(tile, case):
     """conv3x3_halo_kernel (input patch resident in LDS, weights streamed per tap) and the 8-wave ping-pong
@@ -205,7 +205,7 @@ def test_conv_variants(prec_name, atol, rtol, case):
     check(f"conv_{case}[{prec_name}]", nchw(y), ref, atol, rtol)
 
 
-@pytest.mark.parametrize("tile", [37, 38, 39, 40, 41, 43, 44, 45, 47, 48, 49, 50, 51, 52])
+@pytest.mark.parametrize("tile", [37, 38, 39, 40, 41, 43, 44, 45, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66])
 @pytest.mark.parametrize("hw,batch", [(8, 5), (16, 3), (4, 9)])
 def test_staged_epilogue_rows_on_warp_specialised_tiles(tile, hw, batch, monkeypatch):
     """GemmArgs::epb: bias / time-embedding rows fetched into LDS by the staging waves' first DMAs.  Tiles of 128 / 256 rows over
@@ -223,7 +223,7 @@ def test_staged_epilogue_rows_on_warp_specialised_tiles(tile, hw, batch, monkeyp
     r0 = rb(torch.randn(batch, cout, hw, hw, generator=g))
     ref = F.conv2d(x, w, bias, padding=1) + temb[:, :, None, None] + r0
     cw = ops.ConvWeight(w, bias, prec, DEV)
-    dx_only = tile in (37, 38, 39, 40, 47, 49, 51)
+    dx_only = tile in (37, 38, 39, 40, 47, 49, 51, 53, 55, 59, 61, 63, 65)
     if dx_only and not ((hw <= 128 and 128 % hw == 0) or hw % 128 == 0):
         pytest.skip("dx-reuse tiles need image rows that tile the block")
     try:
@@ -235,7 +235,7 @@ def test_staged_epilogue_rows_on_warp_specialised_tiles(tile, hw, batch, monkeyp
     assert float((y.float() - y2.float()).abs().max()) <= 0.07, "staged rows differ from the global-load epilogue"
 
 
-@pytest.mark.parametrize("tile", [41, 42, 43, 44, 45, 46, 48, 50, 52])
+@pytest.mark.parametrize("tile", [41, 42, 43, 44, 45, 46, 48, 50, 52, 54, 56, 57, 58, 60, 62, 64, 66])
 @pytest.mark.parametrize("case", ["up", "s2", "cat", "1x1res"])
 def test_conv_warp_specialised_ring(tile, case):
     """The warp-specialised form of the plain ring (four staging waves + the compute waves, 3-deep LDS ring) on the fast
@@ -296,7 +296,7 @@ def test_linear(prec_name, atol, rtol, m, k, n):
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
-@pytest.mark.parametrize("tile,splitk", [(1, 1), (2, 1), (6, 3), (14, 1), (3, 2), (41, 1), (42, 2), (45, 1), (50, 2), (52, 1)])
+@pytest.mark.parametrize("tile,splitk", [(1, 1), (2, 1), (6, 3), (14, 1), (3, 2), (41, 1), (42, 2), (45, 1), (50, 2), (52, 1), (54, 1), (60, 2), (57, 1)])
 def test_linear_column_panels_and_flattened_splits(prec_name, atol, rtol, tile, splitk):
     """Wide 1x1 GEMMs run their column tiles in panels of 8 (the last panel narrower) and K splits are part of the 1-D
     block order: every (tile_m, tile_n, split) must be visited exactly once — N = 1448 gives 12 / 23 / 10 column tiles, M
@@ -642,7 +642,7 @@ def test_add_vector_and_scalar_paths():
     assert torch.equal(hip.add(a.to(DEV), a.to(DEV), torch.bfloat16).cpu(), (a.float() * 2).bfloat16())   # n % 8 != 0
 
 
-WS_RING_TILES = (0, 41, 42, 43, 44, 45, 46, 48, 50, 52)     # the tiles that serve ln_colsum / vt_out (0 = autotuned among them)
+WS_RING_TILES = (0, 41, 42, 43, 44, 45, 46, 48, 50, 52, 54, 56, 57, 58, 60, 62, 64, 66)     # the tiles that serve ln_colsum / vt_out (0 = autotuned among them)
 
 
 @pytest.mark.parametrize("tile", WS_RING_TILES)
