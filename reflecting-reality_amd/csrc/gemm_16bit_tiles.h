@@ -58,7 +58,7 @@ static bool launch16_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
     }
 }
 
-// tiles 25-30 (the 16x16x32 MFMA form of tiles 1, 14, 20, 21, 6, 2) and 31-36 (deeper rings)
+// tiles 25-30 (the 16x16x32 MFMA form of tiles 1, 14, 20, 21, 6, 2), 31-36 (deeper rings), 67-68 (2x2 waves of 64x80 on 16x16 tiles)
 template <int DT>
 static bool launch16_c(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
     switch (tile) {
@@ -74,6 +74,8 @@ static bool launch16_c(int tile, const GemmArgs& a, dim3 grid, hipStream_t s) {
         case 34: launch_one<DT, 64, 64, 2, 2, false, 4>(a, grid, s); return true;
         case 35: launch_one<DT, 64, 128, 2, 2, false, 6>(a, grid, s); return true;
         case 36: launch_one<DT, 64, 64, 2, 2, false, 6>(a, grid, s); return true;
+        case 67: launch_one<DT, 128, 160, 2, 2, false, 2, false, false, false, false, true>(a, grid, s); return true;
+        case 68: launch_one<DT, 128, 160, 2, 2, false, 2, true, false, false, false, true>(a, grid, s); return true;
         default: return false;
     }
 }

@@ -130,11 +130,15 @@ const TileCfg kTiles[] = {
     {256, 160, 256, 3, 0, 0, 14},  // 64  plain ring, 4x1 compute waves of 64x160
     {256, 128, 256, 2, 0, 1, 14},  // 65  dx-reuse conv, 4x1 compute waves of 64x128
     {256, 128, 256, 3, 0, 0, 14},  // 66  plain ring, 4x1 compute waves of 64x128
+    // 67-68 (round 5): the two-blocks-per-CU forms of 14 / 20 with 2x2 waves of 64x80 on 16x16x32 MFMAs (9 fragment reads per 20 MFMAs
+    // where the 4x1 waves of 32x160 read 12): no staging waves, two-stage ring, 74 KB
+    {128, 160, 256, 2},            // 67
+    {128, 160, 256, 2, 0, 1},      // 68
     // (round 3: FOUR-deep rings of 48 / 41 — 147 KB, three K tiles in flight — were built, parity-tested and offered to the tuner
     // over the whole step: picked for none of 100 shapes, gpurun_out/r03e/tune_user.json; removed again)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
-inline bool tile_ws(int tile) { return tile >= 37 && tile <= kNumTiles; }                          // compute waves + four staging waves
+inline bool tile_ws(int tile) { return tile >= 37 && tile <= 66; }                                 // compute waves + four staging waves
 inline bool tile_ws_ring(int tile) { return tile_ws(tile) && kTiles[tile - 1].dxr == 0; }           // ... of the plain ring (any call)
 
 // tiles whose kernels have an in-launch split-K combine (keep in sync with the launch_skf cases below)
@@ -468,13 +472,13 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     else if (d->dtype == MF_F16) {
         launched = tile <= 6    ? launch_f16_a(tile, a, grid, s, false)
                    : tile <= 24 ? launch_f16_b(tile, a, grid, s)
-                   : tile <= 36 ? launch_f16_c(tile, a, grid, s)
+                   : (tile <= 36 || !tile_ws(tile)) ? launch_f16_c(tile, a, grid, s)
                    : tc.dxr     ? launch_f16_ws_dx(tile, a, grid, s)
                                 : launch_f16_ws_ring(tile, a, grid, s);
     } else if (d->dtype == MF_BF16) {
         launched = (a_f32 || tile <= 6) ? launch_bf16_a(tile, a, grid, s, a_f32)
                    : tile <= 24         ? launch_bf16_b(tile, a, grid, s)
-                   : tile <= 36         ? launch_bf16_c(tile, a, grid, s)
+                   : (tile <= 36 || !tile_ws(tile)) ? launch_bf16_c(tile, a, grid, s)
                    : tc.dxr             ? launch_bf16_ws_dx(tile, a, grid, s)
                                         : launch_bf16_ws_ring(tile, a, grid, s);
     } else {

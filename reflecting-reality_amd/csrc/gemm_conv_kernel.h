@@ -407,7 +407,7 @@ void gemm_conv_kernel(const GemmArgs p) {
     // 128x160 block (a CU's whole share of the 32x32-level convs)
     // (round 5: 64-row wave tiles too — 4x2 waves of 64x80 on a 256x160 block read 9 fragments per 20 MFMAs where 8x1 waves of
     // 32x160 read 12, and their two register sets of the cross-tile pipeline fit the 168 registers of three waves per SIMD)
-    static_assert(!P16 || (WS && H16 && !M16 && (WM == 32 || WM == 64) && WN % 16 == 0), "P16: warp-specialised forms, 32- or 64-row wave tiles");
+    static_assert(!P16 || (H16 && !M16 && !A_F32 && (WM == 32 || WM == 64) && WN % 16 == 0), "P16: 16-bit operands, 32- or 64-row wave tiles");
     constexpr int MT = WM / 32, NT = P16 ? 1 : WN / 32;
     constexpr int MT16 = WM / 16, NT16 = WN / 16;
     constexpr int RPP = NSTG / 8;                // rows staged per pass (8 lanes per 128-B row)

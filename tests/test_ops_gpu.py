@@ -43,7 +43,7 @@ SPLIT_TILES = (0, 1, 2, 3, 6, 7, 14, 41, 44)  # tiles instantiated for f16x3 wit
 
 
 @pytest.mark.parametrize("prec_name,atol,rtol", PRECS)
-@pytest.mark.parametrize("tile", list(range(16)) + [25, 26, 29, 30, 31, 32, 33, 34, 35, 36, 41, 42, 43, 44, 45, 46, 48, 50, 52, 54, 56, 57, 58, 60, 62, 64, 66])
+@pytest.mark.parametrize("tile", list(range(16)) + [25, 26, 29, 30, 31, 32, 33, 34, 35, 36, 67, 41, 42, 43, 44, 45, 46, 48, 50, 52, 54, 56, 57, 58, 60, 62, 64, 66])
 def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     prec = ops.Precision.get(prec_name)
     if (prec.split and tile not in SPLIT_TILES) or ((25 <= tile <= 30 or tile >= 37) and prec_name == "fp32"):
@@ -63,7 +63,7 @@ def test_conv3x3_tiles(prec_name, atol, rtol, tile):
     check(f"conv3x3[{prec_name},tile{tile}]", nchw(y), ref, atol, rtol)
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28, 37, 38, 39, 40, 47, 49, 51, 53, 55, 59, 61, 63, 65])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19, 20, 21, 22, 23, 24, 27, 28, 68, 37, 38, 39, 40, 47, 49, 51, 53, 55, 59, 61, 63, 65])
 @pytest.mark.parametrize("case", ["plain", "tailN", "cat", "splitk", "epilogue", "big"])
 def test_conv3x3_halo_tiles(tile, case):
     """conv3x3_halo_kernel (input patch resident in LDS, weights streamed per tap) and the 8-wave ping-pong
