@@ -45,6 +45,11 @@ CASES = [  # (label, batch, h, w, cin, cout, k, tile, splitk, with residual[, wi
     ("conv 64^2 t37", 8, 64, 64, 320, 320, 3, 37, 1, True), ("conv 32^2 t14", 8, 32, 32, 640, 640, 3, 14, 1, True),
     ("conv 32^2 t38", 8, 32, 32, 640, 640, 3, 38, 1, True), ("conv 32^2 t41", 8, 32, 32, 640, 640, 3, 41, 1, True),
     ("proj 32^2 t41", 8, 32, 32, 640, 640, 1, 41, 1, True),
+    # 33-: the round-5 loop forms as separate tiles (53-66) against their round-4 loops, and the short-K feed-forward projection
+    ("conv 64^2 t59", 8, 64, 64, 320, 320, 3, 59, 1, True), ("conv 64^2 t63", 8, 64, 64, 320, 320, 3, 63, 1, True),
+    ("conv 32^2 t54", 8, 32, 32, 640, 640, 3, 54, 1, True), ("conv 32^2 t53", 8, 32, 32, 640, 640, 3, 53, 1, True),
+    ("ff-in 64^2 320->2560 t29", 8, 64, 64, 320, 2560, 1, 29, 1, False), ("ff-in 64^2 320->2560 t48", 8, 64, 64, 320, 2560, 1, 48, 1, False),
+    ("ff-in 64^2 320->2560 t14", 8, 64, 64, 320, 2560, 1, 14, 1, False),
 ]
 
 
