@@ -519,6 +519,8 @@ def attention_train(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
         # flash forward WITH the row statistics, flash backward (autograd.record_attention_flash): nothing of size Sq x Skv is
         # ever written in either direction.  The bf16x1 mode (fp32 storage, bf16 products) takes the same split-precision kernels:
         # finer than its own arithmetic, and the S x S tensors of the unfused form are what bounds it at 64 x 64 latents.
+        global SPLIT_KERNEL_CALLS
+        SPLIT_KERNEL_CALLS += 1
         qs, ks, vs = hip.split_halves(q.contiguous()), hip.split_halves(k.contiguous()), hip.split_halves(vt)
         out = torch.empty(b, sq, c, dtype=torch.float32, device=q.device)
         lse = torch.empty(b, heads, sq, dtype=torch.float32, device=q.device)
@@ -562,6 +564,7 @@ def attention_unfused(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads:
 
 
 FLASH_BWD_HEAD_DIMS = (8, 40)                    # mf_attention_bwd_f16x3
+SPLIT_KERNEL_CALLS = 0      # attention launches on fp16 halves so far (training.py: the bf16x1 mode only needs its fp16 range guard when this moved)
 FLASH_BWD_BF16_HEAD_DIMS = (8, 40, 80)           # mf_attention_bwd_bf16 (single planes: 80 fits in LDS)
 FLASH_BWD_MIN_TOKENS = 256                       # shorter sequences keep the unfused backward (its S x S tensors are small there)
 import os as _os

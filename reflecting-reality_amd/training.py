@@ -215,7 +215,10 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     micro = getattr(optimizer, "_micro", 0)
     sync_step = micro + 1 >= accum
     prec = model.brushnet.prec
-    guard = prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and check_overflow      # bf16x1 runs the fp16 split flash attention
+    # bf16x1 runs the fp16 split flash attention only where the bf16 flash route does not apply (short sequences, MFHIP_NO_FLASH_BWD):
+    # its guard — a host read-back, and a collective under DDP — is armed only when the previous step launched such a kernel
+    guard = check_overflow and (prec.code == hip.MF_F16X3 or (prec.code == hip.MF_BF16X1 and getattr(model, "_split_kernels_per_step", 1) > 0))
+    split_calls0 = ops.SPLIT_KERNEL_CALLS
     if micro == 0:
         optimizer.zero_grad(for_step=True)
         if guard:
@@ -285,6 +288,7 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     if grad_sync is not None:
         grad_sync.finish()
     norm, coef = clip_grad_norm_(mods, max_grad_norm, loss_scale=scale)
+    model._split_kernels_per_step = ops.SPLIT_KERNEL_CALLS - split_calls0      # (of the last micro-step: shapes repeat)
     if guard:
         # fp16 halves saturate above 65504 without producing inf / NaN (mfhip.h, mf_split_overflow): a step whose forward or
         # (loss-scaled) backward operands left that range has silently wrong gradients — it is SKIPPED, like a GradScaler
@@ -335,6 +339,7 @@ class GraphedTrainStep:
         self.warmup, self.calls, self.graph = max(int(warmup), 1), 0, None
         self.lr_scheduler = lr_scheduler
         self._arena_key = None
+        self.split_kernels = 1          # fp16-split attention launches in the captured step (bf16x1: arms the range guard; set at capture)
 
     def _arenas(self):
         """What the captured kernels point into: the weight / gradient arenas of both networks."""
@@ -363,6 +368,7 @@ class GraphedTrainStep:
 
     def _body(self):
         model, prec = self.model, self.model.brushnet.prec
+        split_calls0 = ops.SPLIT_KERNEL_CALLS
         mods = model.get_trainable_modules()
         self.opt.zero_grad(for_step=True)
         tape = autograd.Tape(prec.tape_code)
@@ -403,6 +409,7 @@ class GraphedTrainStep:
             self._cut(None, None)           # everything issued so far ends a segment; the exchanges are awaited between replays
             gs.scale()
         norm, coef = clip_grad_norm_(mods, self.max_grad_norm, loss_scale=scale)
+        self.split_kernels = ops.SPLIT_KERNEL_CALLS - split_calls0
         return loss, norm, coef
 
     # -- a chain of graphs with the gradient exchange between them ----------------------------------------------------------
@@ -496,7 +503,7 @@ class GraphedTrainStep:
                 if tuple(t.shape) != tuple(ref.shape):
                     raise ValueError(f"GraphedTrainStep: input shape {tuple(t.shape)} != the captured {tuple(ref.shape)}")
             self._stage(latents, noise, timesteps, encoder_hidden_states, conditioning_latents)
-        guard = prec.code in (hip.MF_F16X3, hip.MF_BF16X1) and self.check_overflow
+        guard = self.check_overflow and (prec.code == hip.MF_F16X3 or (prec.code == hip.MF_BF16X1 and self.split_kernels > 0))
         if guard:
             hip.split_overflow(reset=True)
         if self.segments is not None:
