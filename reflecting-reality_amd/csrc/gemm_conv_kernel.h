@@ -107,6 +107,7 @@ struct GemmArgs {
     // rstd[m] * (acc - mean[m] * ln_cs[n]).  vt_out: columns n >= vt_n0 are written TRANSPOSED ([image][n - vt_n0][token]).
     const float* ln_cs; float ln_eps;
     char* vt_out; int vt_n0, vt_tokens; int64_t vt_ld;
+    int nloop;               // tile 69 (gemm_nloop.hip): output tiles of 160 columns one block walks
 };
 
 __device__ __forceinline__ int div_sh(int x, int d, int sh) { return sh >= 0 ? x >> sh : x / d; }
@@ -1768,6 +1769,7 @@ void launch_skf(const GemmArgs& a, dim3 grid, hipStream_t s) {
 }
 
 // ---- tile groups, one translation unit each (false: the tile is not instantiated in that group) ----------------------
+bool launch_nloop(int dtype, const GemmArgs& a, hipStream_t s);                                 // 69: the persistent short-K GEMM (gemm_nloop.hip)
 bool launch_bf16_a(int tile, const GemmArgs& a, dim3 grid, hipStream_t s, bool a_f32);   // tiles 1-6 (+ fp32 activations, + in-launch split-K twins)
 bool launch_bf16_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);               // 7-15, 20-24
 bool launch_bf16_c(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);               // 25-36
