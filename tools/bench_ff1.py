@@ -28,6 +28,16 @@ for rows, c in ((32768, 320), (8192, 640), (2048, 1280)):
         except hip.MfhipError:
             pass
     print(line, flush=True)
+    # the same GEMM with nothing for the epilogue to load (no bias, no LayerNorm fold): what the loads in the storing waves cost
+    lw0 = ops.ConvWeight(w[:4 * c], None, prec, dev)
+    line = f"plain {rows}x{c}->{4 * c}, no bias:"
+    for t in TILES:
+        try:
+            us = timed(lambda: ops.linear(x, lw0, tile=t))
+            line += f"  t{t} {us:6.1f}"
+        except hip.MfhipError:
+            pass
+    print(line, flush=True)
     # the block's other Linears: to_q (folded LayerNorm), to_out / proj_out (+ residual), ff.net.2 (K = 4 C, + residual)
     res = torch.randn(rows, c, generator=g).to(dev, prec.act)
     for label, k, n, ln, r in (("to_q ln", c, c, True, False), ("to_out +res", c, c, False, True), ("ff2 +res", 4 * c, c, False, True)):
