@@ -88,6 +88,11 @@ n_steps_logged = 2
 base_of = lambda k: k.split("@")[0]          # "<key>@<ctx>" (hip.TUNE_CTX): the isolated ranking is the plain key's
 share = {k: (rankings[base_of(k)][0][0] / 8.0 * c / n_steps_logged) for k, c in keys.items() if base_of(k) in rankings}      # ms per step
 order = sorted(share, key=lambda k: -share[k])
+if os.environ.get("MF_TUNE_STEP_SHARES"):          # the step's GEMM time by key (count per step x best isolated time), largest first
+    with open(os.environ["MF_TUNE_STEP_SHARES"], "w") as f:
+        for k in order:
+            r0 = rankings[base_of(k)][0]
+            f.write(f"{share[k] * 1e3:9.1f} us/step  {keys[k] / n_steps_logged:5.1f} x {r0[0] / 8.0 * 1e3:7.1f} us  tile {r0[1]} sk {r0[2]}  {k}\n")
 print(f"[tune_step] {len(order)} GEMM keys in the step; isolated sum {sum(share.values()):.2f} ms per step (graph-timed, 8 launches each)", flush=True)
 
 cache = hip._tune_load()
