@@ -124,13 +124,9 @@ def self_launch(argv, n):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks as CHILD processes (this parent has
     not touched the GPU and only waits: a process that has initialised the GPU must never exec another program) and relay
     their output; rank 0 prints the JSON line."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    from reflecting_reality_amd.distributed import torchrun_argv      # imports torch only: nothing touches the GPU
+    cmd = torchrun_argv(n) + [os.path.abspath(__file__)] + argv      # the rendezvous store binds its own free port
     log(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -36,6 +36,19 @@ def init_process_group(backend: str = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def torchrun_argv(nproc: int) -> List[str]:
+    """The `python -m torch.distributed.run` prefix for `nproc` ranks on this node WITHOUT a caller-chosen port.
+
+    A port found by bind(0) / close and then handed to `--master-port` can be taken by another process in between
+    (EADDRINUSE on a busy box).  The c10d rendezvous on endpoint port 0 lets the agent's TCPStore bind a free port itself and
+    keep it open; the workers re-use that store (MASTER_PORT is the store's port), so there is no window.  127.0.0.1 twice:
+    the container hostname may not resolve."""
+    import sys
+    import uuid
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}",
+            "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", f"--rdzv-id={uuid.uuid4().hex}", "--local-addr=127.0.0.1"]
+
+
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """[start, end) of this rank's contiguous share (accelerate.PartialState.split_between_processes)."""
     per, extra = divmod(n_items, world)

@@ -27,20 +27,19 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
-def _free_port() -> int:
-    import socket
-    with socket.socket() as sk:          # a fixed port collides with a lingering TIME_WAIT socket of a previous run
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+def _torchrun(nproc: int):
+    """torchrun prefix whose rendezvous store binds its own free port (no probe-then-release window)."""
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    from reflecting_reality_amd.distributed import torchrun_argv
+    return torchrun_argv(nproc)
 
 
 def test_two_rank_gloo_sharding_and_timing(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RESULT_DIR=str(tmp_path))
-    for attempt in range(3):             # the rendezvous port can be taken between the probe and torchrun's bind
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    env = dict(os.environ, RESULT_DIR=str(tmp_path))
+    for attempt in range(3):             # (kept from the probed-port days; the c10d rendezvous needs no retry)
+        cmd = _torchrun(2) + [str(script)]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
         if out.returncode == 0:
             break
@@ -133,10 +132,9 @@ def test_bucketed_gradient_allreduce_equals_the_mean_of_the_ranks(tmp_path):
     import json
     script = tmp_path / "grad_worker.py"
     script.write_text(GRAD_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RESULT_DIR=str(tmp_path))
+    env = dict(os.environ, RESULT_DIR=str(tmp_path))
     for attempt in range(3):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+        cmd = _torchrun(2) + [str(script)]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
         if out.returncode == 0:
             break
@@ -178,10 +176,9 @@ def test_cold_tune_cache_is_filled_by_rank_zero_only(tmp_path):
     import json
     script = tmp_path / "tune_worker.py"
     script.write_text(TUNE_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RESULT_DIR=str(tmp_path))
+    env = dict(os.environ, RESULT_DIR=str(tmp_path))
     for attempt in range(3):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-               "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+        cmd = _torchrun(2) + [str(script)]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
         if out.returncode == 0:
             break

@@ -780,13 +780,9 @@ def test_data_parallel_training_two_ranks_equal_one_process_on_the_joint_batch(t
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ddp_worker.py"
     script.write_text(DDP_WORKER % (root, root))
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RESULT_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=900, env=env)
+    from reflecting_reality_amd.distributed import torchrun_argv          # rendezvous on a port the store binds itself
+    env = dict(os.environ, RESULT_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(torchrun_argv(2) + [str(script)], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     r0, r1 = (json.load(open(tmp_path / f"ddp{r}.json")) for r in range(2))
     w0, w1 = (torch.load(tmp_path / f"w{r}.pt") for r in range(2))
@@ -801,7 +797,7 @@ def test_data_parallel_training_two_ranks_equal_one_process_on_the_joint_batch(t
 
 
 @pytest.mark.parametrize("train_unet,b", [(False, 8), (True, 4)])
-def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync(train_unet, b):
+def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync(train_unet, b, tmp_path):
     """BASELINE.json configs[3] at its own size: the MirrorFusion fine-tune step at per-GPU batch 8 x 512 x 512 (64 x 64 latents),
     full-size SD1.5 UNet (frozen) + BrushNet (trainable), f16x3 contractions, clip 1.0, AdamW (train_brushnet_mirror.py:1407-1466).
     No reference gradient exists at this size (the reference's autograd on the CPU would take hours), so the step is pinned by
@@ -811,7 +807,6 @@ def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync(train_
     unsynchronised step — the DDP path of distributed.GradBuckets changes nothing but the exchange.
     train_unet=True is --train_base_unet (train_brushnet_mirror.py:1073-1075) at full size: both nets train (batch 4 here; the
     exchange then carries both gradient arenas, 2.48 + 3.44 GB), and the UNet's weights must move too."""
-    import socket
     import torch.distributed as dist
     from reflecting_reality_amd import distributed as D
     from reflecting_reality_amd.configs import SD15_UNET, brushnet_config
@@ -858,11 +853,9 @@ def test_baseline_config3_full_size_step_determinism_and_forced_rccl_sync(train_
     b_out, b_w, _, _ = run()
     assert a_out == b_out and torch.equal(a_w, b_w), "two identical training runs must be bit-identical"
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     os.environ["MF_FORCE_GRAD_SYNC"] = "1"
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    # a file store: no port to probe, release and lose to another process (EADDRINUSE on the driver's box in round 5)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv_store", rank=0, world_size=1)
     try:
         def factory(model):
             s = D.GradBuckets(model.get_trainable_modules())
@@ -880,19 +873,15 @@ def test_bench_train_under_torchrun_with_rccl_reports_all_reduce():
     with the default backend (RCCL) and MF_FORCE_GRAD_SYNC=1 on this one GPU: the rendezvous, the bucketed exchange under
     the backward pass and time_all_reduce() all run over RCCL, and the JSON line carries all_reduce.ms."""
     import json
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MF_BENCH_BACKEND")}
+    from reflecting_reality_amd.distributed import torchrun_argv
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MF_BENCH_BACKEND")}
     env["MF_FORCE_GRAD_SYNC"] = "1"
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "train", "--steps", "1",
-                          "--warmup", "1", "--batch", "2", "--size", "256"], capture_output=True, text=True, timeout=1500, env=env)
+    out = subprocess.run(torchrun_argv(1) + [os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "train", "--steps", "1",
+                                             "--warmup", "1", "--batch", "2", "--size", "256"], capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -1164,22 +1153,19 @@ def test_baseline_config3_full_size_step_against_the_reference_backward(prec, ta
     torch.cuda.empty_cache()
 
 
-def test_graphed_step_with_gradient_sync_is_a_chain_of_graphs_and_equals_the_eager_step():
+def test_graphed_step_with_gradient_sync_is_a_chain_of_graphs_and_equals_the_eager_step(tmp_path):
     """GraphedTrainStep with a GradBuckets gradient exchange.  RCCL calls are never captured: the step is a
     chain of graphs cut where the backward pass releases a gradient bucket, the bucket's all-reduce is issued between two
     replays.  Run here with the exchange forced through RCCL on this one rank (MF_FORCE_GRAD_SYNC=1, small buckets so that the
     tiny BrushNet has several): >= 3 segments, and loss, norm and weights bit-identical to the eager synchronised step over five
     steps with changing inputs."""
-    import socket
     import torch.distributed as dist
     from reflecting_reality_amd import distributed as D
     from reflecting_reality_amd.training import GraphedTrainStep
     ns = DDPMScheduler(**SD_SCHED)
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     os.environ["MF_FORCE_GRAD_SYNC"] = "1"
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    # a file store: no port to probe, release and lose to another process (EADDRINUSE on the driver's box in round 5)
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv_store", rank=0, world_size=1)
     try:
         def run(graphed):
             model = _model("f16x3").prepare_training()

@@ -15,17 +15,11 @@ cd "$root" || exit 1
 export HSA_ENABLE_IPC_MODE_LEGACY=0 NCCL_DEBUG=${NCCL_DEBUG:-INFO} NCCL_DEBUG_SUBSYS=${NCCL_DEBUG_SUBSYS:-INIT}
 ngpu=$(python -c "import torch; print(torch.cuda.device_count())")
 echo "[run_8gpu] $ngpu GPUs visible"
-port=29600
 run() {   # n, tag, bench args...
   n=$1; tag=$2; shift 2
-  port=$((port + 1))
   if [ "$n" -gt "$ngpu" ]; then echo "[run_8gpu] skip $tag: needs $n GPUs"; return; fi
-  if [ "$n" -eq 1 ]; then
-    python bench.py --gpus 1 "$@" > "$out/$tag.json" 2> "$out/$tag.err"
-  else
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" \
-        bench.py --gpus "$n" "$@" > "$out/$tag.json" 2> "$out/$tag.err"
-  fi
+  # bench.py --gpus N launches its own ranks (distributed.torchrun_argv: c10d rendezvous on a port the store binds itself)
+  python bench.py --gpus "$n" "$@" > "$out/$tag.json" 2> "$out/$tag.err"
   rc=$?
   # RCCL must have seen every rank: its INIT log names the communicator's size
   ranks=$(grep -ao "nranks [0-9]*" "$out/$tag.err" | sort -u | tail -n 1)
