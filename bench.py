@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_IMAGE_STEP = {512: 2489.2, 256: 581.0}      # BASELINE.md §2 (CFG on): BrushNet 882.6 + UNet 1606.5 @512
 PEAK_BF16_TFLOPS = 2500.0                             # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0                              # dense e4m3 (block-scaled MFMA forms): 2 x the bf16 rate
 
 
 def log(*a):
@@ -243,6 +244,13 @@ def train_main(a, D):
                             "note": "one un-overlapped bucketed all-reduce of the gradient arenas (64 Mi-float buckets), measured after the timed steps; "
                                     "in the step it runs on a side stream under the backward pass"} if ar_ms else None),
             "achieved_tflops": round(b * gflop * 1e9 / step_s / 1e12, 2),
+            # the whole step (forward, data and weight gradients, norms, clip, AdamW) against the dense bf16 MFMA peak: the
+            # algorithmic contraction FLOPs of the step / its wall time.  fp32 mode: fp32 MFMA peak; f16x3: three MFMAs per product
+            "roofline": {"bound": "mfma", "kernel": "whole training step (gemm_conv_kernel forward + dgrad, conv_wgrad, flash backward)",
+                         "achieved": round(b * gflop * 1e9 / step_s / 1e12, 2), "peak": PEAK_F32_TFLOPS if prec == "fp32" else PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(b * gflop * 1e9 / step_s / 1e12 / (PEAK_F32_TFLOPS if prec == "fp32" else PEAK_BF16_TFLOPS), 4),
+                         "traffic": None, "algorithmic_gflop_per_step": round(b * gflop, 1),
+                         "note": "per sample 3 x 441.3 (BrushNet forward + dgrad + wgrad) + 2 x 803.3 (frozen UNet forward + dgrad) GFLOP, BASELINE.md"},
             "algorithmic_gflop_per_sample": round(gflop, 1), "last_loss": round(float(loss), 5), "last_grad_norm": round(float(norm), 5)}),
             flush=True)
         hip.tune_save()
@@ -389,11 +397,21 @@ def main():
             pipe.unet(x2, 981, pe, added_cond_kwargs=added, down_block_add_samples=d, mid_block_add_sample=m,
                       up_block_add_samples=u)
         n_launch, secs, flops = hip.profile_end()
+        attn_flops = hip.PROFILE_ATTN_FLOPS
         # algorithmic bytes: activations read once, weights once, output written once (bf16 = 2 B)
         alg_bytes = 0.0
-        for _, _, (m, n, k, kh, stride, ups, nz, _tile, _sk) in hip.LAST_PROFILE:
+        # each launch priced at the dense MFMA peak of ITS operand type (SDXL's fp8 mode: the transformer Linears run on e4m3
+        # operands, 5 PF; convs and everything else on bf16, 2.5 PF): ideal_s = sum flops_i / peak_i, frac = ideal_s / measured
+        ideal_s, flops_fp8 = 0.0, 0.0
+        for _, fl, (m, n, k, kh, stride, ups, nz, _tile, _sk, dt) in hip.LAST_PROFILE:
             a_px = m * stride * stride / (4.0 if ups else 1.0)
-            alg_bytes += nz * 2.0 * (a_px * k / (kh * kh) + n * k + m * n)
+            esz = 1.0 if dt == hip.MF_FP8 else 2.0
+            alg_bytes += nz * (esz * (a_px * k / (kh * kh) + n * k) + 2.0 * m * n)
+            pk = PEAK_FP8_TFLOPS if dt == hip.MF_FP8 else (PEAK_F32_TFLOPS if dt == hip.MF_F32 else PEAK_BF16_TFLOPS)
+            ideal_s += fl / (pk * 1e12)
+            flops_fp8 += fl if dt == hip.MF_FP8 else 0.0
+        if flops_fp8 > 0:
+            peak = round(flops / ideal_s / 1e12, 1)          # FLOP-weighted harmonic blend of the two peaks
         traffic, traffic_src = None, None
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         pmc = next((q for q in (os.path.join(pdir, f"r0{r}_pmc_gemm_family.json") for r in (5, 4, 3)) if os.path.exists(q)), "")
@@ -408,12 +426,20 @@ def main():
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes / n_launch),
                     "launches_per_denoise_step": n_launch, "avg_launch_us": round(secs / n_launch * 1e6, 2),
                     "flop_per_denoise_step": flops,
+                    "fp8_flop_share": round(flops_fp8 / flops, 4) if flops_fp8 > 0 else None,
+                    "peak_note": (f"FLOP-weighted blend of the dense fp8 ({PEAK_FP8_TFLOPS:.0f} TF/s, e4m3 transformer Linears) and bf16 "
+                                  f"({PEAK_BF16_TFLOPS:.0f} TF/s, everything else) MFMA peaks: sum flops / sum (flops_i / peak_i)") if flops_fp8 > 0 else None,
                     "denoise_step": ({"ms": round(step_s * 1e3, 3), "achieved": round(step_tflops, 2),
                                       "frac": round(step_tflops / peak, 4), "algorithmic_gflop_per_image_step": gflop}
                                      if gflop else
-                                     {"ms": round(step_s * 1e3, 3), "achieved": round(flops / step_s / 1e12, 2),
-                                      "frac": round(flops / step_s / 1e12 / peak, 4),
-                                      "note": "conv/GEMM FLOPs only (attention not counted)"})}
+                                     # no published census for this config: the live one of the instantiated model — every
+                                     # mf_gemm_conv launch's 2MNK plus 4 B H Sq Skv d of every flash-attention launch of the step
+                                     {"ms": round(step_s * 1e3, 3), "achieved": round((flops + attn_flops) / step_s / 1e12, 2),
+                                      "frac": round((ideal_s + attn_flops / (PEAK_BF16_TFLOPS * 1e12)) / step_s, 4),
+                                      "algorithmic_gflop_per_image_step": round((flops + attn_flops) / a.batch / 1e9, 1),
+                                      "attention_gflop_per_image_step": round(attn_flops / a.batch / 1e9, 1),
+                                      "note": "live FLOP census of the instantiated config (conv / GEMM + flash attention, both CFG halves); "
+                                              "frac = time at each launch's own dense MFMA peak (fp8 Linears 5 PF, the rest 2.5 PF) / step time"})}
 
     host_inputs = None
     if rank == 0 and world == 1 and a.inputs == "device" and not a.no_profile and not xl:
@@ -529,10 +555,10 @@ def main():
         # keeps its HIP context; nothing is exec'ed): configs[3] per-GPU training step, configs[4] SDXL + BrushNet-XL in fp8
         import subprocess
 
-        def child(args, keys):
+        def child(args, keys, profile=False):
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), *args, "--no-cpu-baseline", "--no-parity-mode", "--no-profile",
-                                    "--no-extra-legs"], capture_output=True, text=True, timeout=900)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), *args, "--no-cpu-baseline", "--no-parity-mode",
+                                    *([] if profile else ["--no-profile"]), "--no-extra-legs"], capture_output=True, text=True, timeout=900)
                 line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{") and '"metric"' in l), None)
                 if line is None:
                     return {"error": (r.stderr or r.stdout)[-300:]}
@@ -542,9 +568,10 @@ def main():
                 return {"error": f"{type(e).__name__}: {e}"[:300]}
 
         train_leg = child(["--mode", "train", "--precision", "bf16", "--steps", "8", "--warmup", "3"],
-                          ("metric", "value", "unit", "ms_per_step", "dtype", "achieved_tflops", "algorithmic_gflop_per_sample", "config"))
+                          ("metric", "value", "unit", "ms_per_step", "dtype", "roofline", "achieved_tflops", "algorithmic_gflop_per_sample", "config"))
+        # (--no-parity-mode also switches off the xl child's secondary passes; its own FLOP census / HIP-event pass stays on)
         sdxl_leg = child(["--model", "sdxl", "--precision", "fp8", "--steps", "2", "--warmup", "1"],
-                         ("metric", "value", "unit", "ms_per_step", "dtype", "config"))
+                         ("metric", "value", "unit", "ms_per_step", "dtype", "roofline", "config"), profile=True)
 
     cpu = None
     if want_cpu:

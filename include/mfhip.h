@@ -59,7 +59,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 16
+#define MF_ABI_VERSION 17
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -158,6 +158,18 @@ typedef struct mf_gemm_desc {
      * dirty partials disappear.  Built into the tiles small-M / deep-K calls use (1, 2, 3, 6 and the warp-specialised rings 41,
      * 43, 44, 48 in bf16; 1, 2, 3, 6, 41, 44 in MF_F16X3); any other tile, or NULL, keeps the reduce launch — same result. */
     uint32_t* sk_tickets; int32_t sk_ticket_cap;
+    /* GroupNorm statistics from the producer (round 6; resnet.py:337-338,381,393, transformer_2d.py:158: every GroupNorm of the
+     * path reads the output of one of these launches).  gn_part != NULL: besides `out`, the call leaves per-channel partial sums
+     * of the FINAL output values (after bias / temb / residuals / activation; fp32, taken before the storage rounding when the
+     * epilogue produces them) in gn_part as float pairs
+     *     gn_part[(m / R) * n_channels + n] = (sum, sum of squares) over output rows [R * (m / R), R * (m / R) + R) of channel n,
+     * and writes R (> 0, a divisor of h_out * w_out, so a block of rows lies inside one image) to *gn_part_rows (a HOST int).
+     * mf_groupnorm takes (gn_part, R) as part0 / part1 and skips its statistics pass over the tensor.  Produced inside the GEMM's
+     * epilogue (R = the tile's rows; fixed summation order, bit-reproducible) when the launch has no split-K reduce and the tile
+     * is an implicit-GEMM tile with h_out * w_out a multiple of its rows; otherwise by one extra column-sum launch over the
+     * stored output (R = 128, 64 or 32) — same contract.  Needs n % 8 == 0, nz == 1, h_out * w_out % 32 == 0, no GEGLU, no
+     * vt_out, and gn_part_floats >= 2 * n * (M / 32) (enough for the smallest R). */
+    float* gn_part; int64_t gn_part_floats; int32_t* gn_part_rows;
 } mf_gemm_desc;
 
 int mf_gemm_conv(const mf_gemm_desc* d, void* stream);
@@ -186,6 +198,12 @@ typedef struct mf_groupnorm_desc {
     void* out; int32_t out_dtype;     /* [batch][hw][c0+c1] */
     float* ws;
     float* stats_out;                 /* nullable [batch][groups][2]: (mean, rstd) of every group, for mf_groupnorm_bwd's stats_in */
+    /* Statistics handed over by the producer(s) of x0 / x1 (mf_gemm_desc.gn_part and the R it reported): per-channel (sum, sum of
+     * squares) of every block of part_rows rows.  When every present segment has its partials (and hw > 256: below that the
+     * one-launch form keeps the rows in registers anyway) the statistics pass over the tensor is replaced by a small finalize
+     * launch over the partials; otherwise they are ignored.  NULL = compute the statistics from the tensor. */
+    const float* part0; int32_t part0_rows;
+    const float* part1; int32_t part1_rows;
 } mf_groupnorm_desc;
 int mf_groupnorm(const mf_groupnorm_desc* d, void* stream);
 int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups, int32_t channels);

@@ -48,6 +48,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
+// mf_gemm_desc.gn_part for launches whose epilogue cannot produce it (split-K reduce, resident-patch and persistent tiles, image
+// sizes the tile's rows do not divide): per-channel (sum, sum of squares) of every block of R rows of the STORED output.  grid
+// (M / R, ceil(N / 256)); a thread owns one column (coalesced 2- / 4-byte loads across the block), fixed order.
+__global__ __launch_bounds__(256) void gn_colsum_kernel(const char* out, int out_dt, int64_t ldc, int M, int N, int R, float2* part) {
+    const int n = blockIdx.y * 256 + threadIdx.x, rb = blockIdx.x;
+    if (n >= N) return;
+    float a = 0.0f, b = 0.0f;
+    const int m1 = (rb + 1) * R < M ? (rb + 1) * R : M;
+    for (int m = rb * R; m < m1; ++m) {
+        const float x = load_as_f32(out, out_dt, (int64_t)m * ldc + n);
+        a += x; b = fmaf(x, x, b);
+    }
+    part[(int64_t)rb * N + n] = make_float2(a, b);
+}
+
 struct TileCfg { int bm, bn, threads, stages, halo, dxr, fx; };   // fx: MF_FX_* bits of the instantiation (gemm_conv_kernel.h)   // halo: rows of output pixels per tile of conv3x3_halo_kernel (0 = implicit GEMM)
 // keep in sync with launch_tile()
 const TileCfg kTiles[] = {
@@ -221,6 +236,9 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     MF_CHECK_ARG(d->a0 && d->w && d->out, "mf_gemm_conv: null a0/w/out");
     MF_CHECK_ARG(d->a_dtype == d->dtype || (d->a_dtype == MF_F32 && d->dtype != MF_F32),
                  "mf_gemm_conv: a_dtype %d incompatible with compute dtype %d", d->a_dtype, d->dtype);
+    // fp32 activations are converted on load only by the bf16 kernels (a_f32 below): the fp16 instantiations have no converting
+    // path and would read the fp32 bytes as fp16 pairs
+    MF_CHECK_ARG(d->dtype != MF_F16 || d->a_dtype == MF_F16, "mf_gemm_conv: MF_F16 compute takes fp16 activations (a_dtype %d): cast first", d->a_dtype);
     MF_CHECK_ARG(d->c0 > 0 && d->c1 >= 0 && (d->a1 != nullptr) == (d->c1 > 0), "mf_gemm_conv: bad c0/c1/a1");
     MF_CHECK_ARG(d->c0 % vec == 0 && d->c1 % vec == 0, "mf_gemm_conv: channels (%d,%d) must be multiples of %d",
                  d->c0, d->c1, vec);
@@ -305,6 +323,23 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
                  "mf_gemm_conv: the GEGLU epilogue needs n %% 8 == 0, ldc %% 4 == 0, no residuals and no forced split-K");
     MF_CHECK_ARG(d->nz == 1 || (d->res0 == nullptr && d->res1 == nullptr && d->temb == nullptr),
                  "mf_gemm_conv: residual/temb epilogue is not defined for batched (nz > 1) calls");
+    // GroupNorm partial sums of the output (mf_gemm_desc.gn_part): R rows per block, in the epilogue or by gn_colsum_kernel
+    const int gn_hw = d->h_out * d->w_out;
+    const int gn_r_fallback = gn_hw % 128 == 0 ? 128 : (gn_hw % 64 == 0 ? 64 : 32);
+    if (d->gn_part) {
+        MF_CHECK_ARG(d->gn_part_rows != nullptr && d->n % 8 == 0 && d->nz == 1 && gn_hw % 32 == 0 && d->act != MF_ACT_GEGLU4 && !d->vt_out &&
+                         d->ldc >= d->n && d->o_zs_o == 0 && d->o_zs_i == 0 && mf_aligned16(d->gn_part) &&
+                         d->gn_part_floats >= 2ll * d->n * (M64 / 32),
+                     "mf_gemm_conv: gn_part needs gn_part_rows, n %% 8 == 0, nz == 1, h_out * w_out %% 32 == 0, no GEGLU / vt_out, and "
+                     "2 * n * (M / 32) = %lld floats (got %lld)", (long long)(2ll * d->n * (M64 / 32)), (long long)d->gn_part_floats);
+    }
+    auto gn_fallback = [&](hipStream_t st) -> int {     // after the launch(es) that wrote `out`
+        hipLaunchKernelGGL(gn_colsum_kernel, dim3((unsigned)(a.M / gn_r_fallback), (unsigned)cdiv(a.N, 256)), dim3(256), 0, st,
+                           (const char*)d->out, d->out_dtype, d->ldc, a.M, a.N, gn_r_fallback, (float2*)d->gn_part);
+        *d->gn_part_rows = gn_r_fallback;
+        MF_CHECK_LAUNCH("mf_gemm_conv(gn_part column sums)");
+        return MF_OK;
+    };
     // the 8-wide vector epilogue needs 8-channel-aligned rows and 16-byte aligned bases everywhere
     a.vec_ok = (d->n % 8 == 0) && (d->ldc % (d->act == MF_ACT_GEGLU4 ? 4 : 8) == 0) && mf_aligned16(d->out) && (d->o_zs_o % 8 == 0) &&
                (d->o_zs_i % 8 == 0) &&
@@ -372,6 +407,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
             hipLaunchKernelGGL(d->dtype == MF_F16 ? splitk_reduce_kernel<true> : splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, hs, a);
             MF_CHECK_LAUNCH("mf_gemm_conv(split-K reduce)");
         }
+        if (d->gn_part) return gn_fallback(hs);
         return MF_OK;
     }
     const int bk = 128 / es;
@@ -480,8 +516,12 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         a.nloop = a.tiles_n / ranges;
         MF_CHECK_ARG(launch_nloop(d->dtype, a, (hipStream_t)stream), "mf_gemm_conv: tile %d is not instantiated for dtype %d", tile, d->dtype);
         MF_CHECK_LAUNCH("mf_gemm_conv(nloop)");
+        if (d->gn_part) return gn_fallback((hipStream_t)stream);
         return MF_OK;
     }
+    // statistics in the epilogue: the final values of a block's rows are in its LDS slabs; one image per block of rows
+    const bool gn_fused = d->gn_part != nullptr && a.splitk == 1 && a.vec_ok && gn_hw % tc.bm == 0 && a.M % tc.bm == 0;
+    a.gn_part = gn_fused ? (float2*)d->gn_part : nullptr;
     dim3 grid((unsigned)nblk, 1, (unsigned)a.nz);
     hipStream_t s = (hipStream_t)stream;
     bool launched;
@@ -513,6 +553,10 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(d->dtype == MF_F16 ? splitk_reduce_kernel<true> : splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
         MF_CHECK_LAUNCH("mf_gemm_conv(split-K reduce)");
+    }
+    if (d->gn_part) {
+        if (!gn_fused) return gn_fallback(s);
+        *d->gn_part_rows = tc.bm;
     }
     return MF_OK;
 }

@@ -108,6 +108,12 @@ struct GemmArgs {
     const float* ln_cs; float ln_eps;
     char* vt_out; int vt_n0, vt_tokens; int64_t vt_ld;
     int nloop;               // tile 69 (gemm_nloop.hip): output tiles of 160 columns one block walks
+    // GroupNorm statistics from the producer (round 6): when non-null, every block also writes the per-channel (sum, sum of squares)
+    // of the FINAL values of its BM rows (after bias / temb / residuals / activation, fp32, before the storage rounding) to
+    // gn_part[tile_m][n] — the consumer GroupNorm's statistics pass over the stored tensor disappears (norm.hip, gn_finalize_part).
+    // Fixed summation order (slab rows, then the block's wave rows): bitwise reproducible.  The host only sets it for launches the
+    // epilogue can serve (no split-K, no GEGLU, no transposed columns, N % 8 == 0, nz == 1).
+    float2* gn_part;
 };
 
 __device__ __forceinline__ int div_sh(int x, int d, int sh) { return sh >= 0 ? x >> sh : x / d; }
@@ -1507,6 +1513,11 @@ void gemm_conv_kernel(const GemmArgs p) {
         // of which fetches its chunks' residuals ahead of the barrier and then reads, finishes and stores them.
         constexpr int NCW = WAVES_M * WAVES_N, TW = NCW + 4, NCHUNK = NCW * NIT, MAXC = (NCHUNK + TW - 1) / TW;
         const int g = producer ? NCW + wave : wave;
+        const bool gn = p.gn_part != nullptr;
+        constexpr int GNP = (NCW * WN + TW * 64 - 1) / (TW * 64);      // (slab, column) pairs per thread of the statistics pass
+        float gns[GNP], gnq[GNP];
+#pragma unroll
+        for (int k = 0; k < GNP; ++k) { gns[k] = 0.0f; gnq[k] = 0.0f; }
 #pragma unroll
         for (int ih = 0; ih < MT * (32 / SR); ++ih) {
             const int i = ih / (32 / SR), half = ih % (32 / SR);
@@ -1640,15 +1651,63 @@ void gemm_conv_kernel(const GemmArgs p) {
                         } else {
                             epilogue_store8<DT == MF_F16>(p, zo, m, n, v, res_pre, q0[u], q1[u], zq);
                         }
+                        if (gn) {      // the final values go back into the slab for the column pass below
+                            char* slw = smem + sw * (SR * EP_RS) + row * EP_RS + ec * 4;
+                            *reinterpret_cast<float4*>(slw) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(slw + 16) = make_float4(v[4], v[5], v[6], v[7]);
+                        }
                     } else {
                         for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj], zq);
                     }
                 }
             }
             MF_STAMP(9 + 3 * ih);                         // (stamps: this wave's stores of round ih are issued)
-            if (ih + 1 < MT * (32 / SR)) {
+            if (gn) {
+                // column pass: the slabs now hold the round's final values; thread (g, lane) sums the SR rows of its (slab, column)
+                // pairs — the same pairs every round, so a column's sum over the wave tile's rows stays in one register pair
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int k = 0; k < GNP; ++k) {
+                    const int pid = (g + k * TW) * 64 + lane;
+                    if (pid < NCW * WN) {
+                        const int sw = pid / WN, col = pid - sw * WN;
+                        const char* sl = smem + sw * (SR * EP_RS) + col * 4;
+                        float a = 0.0f, b = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < SR; ++r) {
+                            const float x = *reinterpret_cast<const float*>(sl + r * EP_RS);
+                            a += x; b = fmaf(x, x, b);
+                        }
+                        gns[k] += a; gnq[k] += b;
+                    }
+                }
+            }
+            if (ih + 1 < MT * (32 / SR) || gn) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);      // slab reads done before the next round overwrites the slabs
                 __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (gn) {
+            // the block's WAVES_M wave rows of every column, summed in wave-row order by one thread per column
+            float2* red = reinterpret_cast<float2*>(smem);
+#pragma unroll
+            for (int k = 0; k < GNP; ++k) {
+                const int pid = (g + k * TW) * 64 + lane;
+                if (pid < NCW * WN) {
+                    const int sw = pid / WN, col = pid - sw * WN;
+                    const int swm = sw / WAVES_N, swn = sw - swm * WAVES_N;
+                    red[swm * BN + swn * WN + col] = make_float2(gns[k], gnq[k]);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            const int tcol = (int)threadIdx.x;
+            if (tcol < BN && n0 + tcol < p.N) {
+                float a = 0.0f, b = 0.0f;
+#pragma unroll
+                for (int w2 = 0; w2 < WAVES_M; ++w2) { const float2 x = red[w2 * BN + tcol]; a += x.x; b += x.y; }
+                p.gn_part[(int64_t)tile_m * p.N + n0 + tcol] = make_float2(a, b);
             }
         }
         MF_STAMP_DRAIN();
@@ -1659,6 +1718,11 @@ void gemm_conv_kernel(const GemmArgs p) {
         MF_STAMP(6);
         return;
     }
+    const bool gn = p.gn_part != nullptr;
+    constexpr int GNC = (WN + 63) / 64;          // columns per lane of the statistics pass over this wave's slab
+    float gns[GNC], gnq[GNC];
+#pragma unroll
+    for (int k = 0; k < GNC; ++k) { gns[k] = 0.0f; gnq[k] = 0.0f; }
 #pragma unroll
     for (int ih = 0; ih < MT * (32 / SR); ++ih) {
         const int i = ih / (32 / SR), half = ih % (32 / SR);     // accumulator rows [half*SR, half*SR + SR) of tile i
@@ -1724,6 +1788,10 @@ void gemm_conv_kernel(const GemmArgs p) {
                     }
                 } else if (p.vec_ok && n + 8 <= p.N) {
                     epilogue_store8<DT == MF_F16>(p, zo, m, n, v, res_pre, q0[it0 / 64], q1[it0 / 64], zq);
+                    if (gn) {      // the final values go back into the slab for the column pass below
+                        *reinterpret_cast<float4*>(slab + row * EP_RS + ec * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(slab + row * EP_RS + ec * 4 + 16) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
                 } else {
                     for (int jj = 0; jj < 8 && n + jj < p.N; ++jj) epilogue_store(p, zo, m, n + jj, v[jj], zq);
                 }
@@ -1731,6 +1799,42 @@ void gemm_conv_kernel(const GemmArgs p) {
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);          // slab reads done before the next slab overwrites it
         __builtin_amdgcn_wave_barrier();
+        if (gn) {      // column pass over this wave's slab of final values (rows past M hold zeros: their A rows were zero pages)
+#pragma unroll
+            for (int k = 0; k < GNC; ++k) {
+                const int col = lane + 64 * k;
+                if (WN % 64 == 0 || col < WN) {
+                    float a = 0.0f, b = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < SR; ++r) {
+                        const float x = *reinterpret_cast<const float*>(slab + r * EP_RS + col * 4);
+                        a += x; b = fmaf(x, x, b);
+                    }
+                    gns[k] += a; gnq[k] += b;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (gn) {
+        // the block's WAVES_M wave rows of every column, summed in wave-row order by one thread per column
+        __syncthreads();                              // every wave is done with its slab
+        float2* red = reinterpret_cast<float2*>(smem);
+#pragma unroll
+        for (int k = 0; k < GNC; ++k) {
+            const int col = lane + 64 * k;
+            if (WN % 64 == 0 || col < WN) red[wm * BN + wn * WN + col] = make_float2(gns[k], gnq[k]);
+        }
+        __syncthreads();
+        for (int tcol = (int)threadIdx.x; tcol < BN; tcol += NTHR) {
+            if (n0 + tcol < p.N) {
+                float a = 0.0f, b = 0.0f;
+#pragma unroll
+                for (int w2 = 0; w2 < WAVES_M; ++w2) { const float2 x = red[w2 * BN + tcol]; a += x.x; b += x.y; }
+                p.gn_part[(int64_t)tile_m * p.N + n0 + tcol] = make_float2(a, b);
+            }
+        }
     }
     MF_STAMP_DRAIN();
     MF_STAMP(5);

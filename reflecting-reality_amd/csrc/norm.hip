@@ -21,6 +21,8 @@ struct GnArgs {
     float* ws_ab;   // [batch][2][C] per-channel scale / shift (separate-finalize path)
     int fuse_finalize;
     float* stats_out;   // nullable [batch][G][2]: (mean, rstd) of every group, kept for mf_groupnorm_bwd (training)
+    // statistics handed over by the producers (mf_gemm_desc.gn_part): per-channel (sum, sum of squares) of every block of rows
+    const float2* part0; const float2* part1; int pr0, pr1;
 };
 
 template <bool F16>
@@ -214,6 +216,70 @@ __global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
     float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
     for (int c = t; c < p.C; c += blockDim.x) {
         const int g = c / p.cpg;
+        const float a = gr[g] * p.gamma[c];
+        ab[c] = a;
+        ab[p.C + c] = p.beta[c] - gm[g] * a;
+    }
+}
+
+// Pass 1 replaced (round 6): the producing GEMMs left per-channel (sum, sum of squares) of every block of pr rows of their output
+// (gemm_conv_kernel.h, GemmArgs::gn_part), so the statistics pass over the tensor is this launch over HW / pr * C float pairs per
+// image.  grid (batch, slices): a block takes a contiguous run of groups; a thread sums one channel's blocks in block order
+// (double), 8 lanes then combine a group's channels in a fixed order — every bit is reproducible.  Writes the per-channel
+// affine y = x * a[c] + b[c] like gn_finalize_kernel.
+__global__ __launch_bounds__(GN_BLK) void gn_finalize_part_kernel(const GnArgs p, int gps) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double2* chan = reinterpret_cast<double2*>(smem_raw);          // [gps * cpg] per-channel (sum, sum of squares) of this image
+    __shared__ float gm[64], gr[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int g0 = blockIdx.y * gps;
+    int g1 = g0 + gps;
+    if (g1 > p.G) g1 = p.G;
+    const int c0 = g0 * p.cpg, nc = (g1 - g0) * p.cpg;
+    for (int j = t; j < nc; j += blockDim.x) {
+        const int c = c0 + j;
+        const float2* src; int nb; int64_t ld;
+        if (c < p.C0) { nb = p.HW / p.pr0; ld = p.C0; src = p.part0 + (int64_t)b * nb * ld + c; }
+        else { nb = p.HW / p.pr1; ld = p.C1; src = p.part1 + (int64_t)b * nb * ld + (c - p.C0); }
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nb; ++k) {
+            const float2 v = src[(int64_t)k * ld];
+            s += (double)v.x; q += (double)v.y;
+        }
+        chan[j] = make_double2(s, q);
+    }
+    __syncthreads();
+    {
+        const int l = t & 7;
+        for (int g = g0 + (t >> 3); g < g1; g += (int)blockDim.x >> 3) {
+            double s = 0.0, q = 0.0;
+            for (int it = l; it < p.cpg; it += 8) {
+                const double2 v = chan[(g - g0) * p.cpg + it];
+                s += v.x; q += v.y;
+            }
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                s += __shfl_xor(s, off, 8);
+                q += __shfl_xor(q, off, 8);
+            }
+            if (l == 0) {
+                const double n = (double)p.HW * p.cpg;
+                const double mean = s / n;
+                double m2 = q - s * mean;
+                if (m2 < 0.0) m2 = 0.0;
+                gm[g - g0] = (float)mean;
+                gr[g - g0] = (float)(1.0 / sqrt(m2 / n + (double)p.eps));
+                if (p.stats_out) {
+                    p.stats_out[((int64_t)b * p.G + g) * 2] = gm[g - g0];
+                    p.stats_out[((int64_t)b * p.G + g) * 2 + 1] = gr[g - g0];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
+    for (int j = t; j < nc; j += blockDim.x) {
+        const int c = c0 + j, g = j / p.cpg;
         const float a = gr[g] * p.gamma[c];
         ab[c] = a;
         ab[p.C + c] = p.beta[c] - gm[g] * a;
@@ -587,6 +653,11 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
             return MF_OK;
         }
     }
+    // statistics from the producers' partial sums: every present segment has them and their row blocks divide the image
+    const bool from_parts = d->part0 != nullptr && d->part0_rows > 0 && d->hw % d->part0_rows == 0 &&
+                            (d->c1 == 0 || (d->part1 != nullptr && d->part1_rows > 0 && d->hw % d->part1_rows == 0));
+    a.part0 = (const float2*)d->part0; a.part1 = (const float2*)d->part1; a.pr0 = d->part0_rows; a.pr1 = d->part1_rows;
+    if (from_parts) a.fuse_finalize = 0;
     a.cvn = C / vw;
     a.tpr = a.cvn < GN_BLK ? a.cvn : GN_BLK;
     a.rif = GN_BLK / a.tpr;
@@ -601,11 +672,17 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     if (rows_per_block < 4 * a.rif) rows_per_block = 4 * a.rif;
     const int nblk = (d->hw + rows_per_block - 1) / rows_per_block;
     static const int gn_u = getenv("MFHIP_GN_UNROLL") ? atoi(getenv("MFHIP_GN_UNROLL")) : 4;      // developer sweep: 4 or 8 rows in flight
+    const int gn_slices = d->groups >= 32 ? 4 : 1, gn_gps = (d->groups + gn_slices - 1) / gn_slices;
 #define MF_GN_LAUNCH(VW_, U_, F_)                                                                                              \
     do {                                                                                                                          \
-        hipLaunchKernelGGL((gn_stats_kernel<VW_, U_, F_>), dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);                   \
-        MF_CHECK_LAUNCH("mf_groupnorm(stats)");                                                                                   \
-        if (!a.fuse_finalize) hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);                     \
+        if (from_parts) {                                                                                                         \
+            hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(d->batch, gn_slices), dim3(GN_BLK), (size_t)gn_gps * a.cpg * sizeof(double2), s, a, gn_gps); \
+            MF_CHECK_LAUNCH("mf_groupnorm(finalize from partial sums)");                                                          \
+        } else {                                                                                                                  \
+            hipLaunchKernelGGL((gn_stats_kernel<VW_, U_, F_>), dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);               \
+            MF_CHECK_LAUNCH("mf_groupnorm(stats)");                                                                               \
+            if (!a.fuse_finalize) hipLaunchKernelGGL(gn_finalize_kernel, dim3(d->batch), dim3(GN_BLK), 0, s, a);                 \
+        }                                                                                                                         \
         hipLaunchKernelGGL((gn_apply_kernel<VW_, U_, F_>), dim3(nblk, d->batch), dim3(nthr), 0, s, a, rows_per_block);            \
     } while (0)
     if (vw == 8 && gn_u == 8) { if (f16) MF_GN_LAUNCH(8, 8, true); else MF_GN_LAUNCH(8, 8, false); }

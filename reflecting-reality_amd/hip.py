@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1, MF_F16 = 0, 1, 2, 3, 4, 5, 6
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class MfhipError(RuntimeError):
@@ -52,6 +52,7 @@ class GemmDesc(C.Structure):
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("vt_out", C.c_void_p), ("vt_n0", C.c_int32), ("vt_tokens", C.c_int32), ("vt_ld", C.c_int64),
         ("sk_tickets", C.c_void_p), ("sk_ticket_cap", C.c_int32),
+        ("gn_part", C.c_void_p), ("gn_part_floats", C.c_int64), ("gn_part_rows", C.c_void_p),
     ]
 
 
@@ -116,6 +117,7 @@ class GroupNormDesc(C.Structure):
         ("silu", C.c_int32),
         ("out", C.c_void_p), ("out_dtype", C.c_int32),
         ("ws", C.c_void_p), ("stats_out", C.c_void_p),
+        ("part0", C.c_void_p), ("part0_rows", C.c_int32), ("part1", C.c_void_p), ("part1_rows", C.c_int32),
     ]
 
 
@@ -285,9 +287,13 @@ SPLITK_WS_FLOATS = 16 * 1024 * 1024  # 64 MiB of fp32 slabs
 PROFILE = None
 
 
+PROFILE_ATTN_FLOPS = 0.0      # 4 * batch * heads * Sq * Skv * d of every flash-attention launch between profile_begin / profile_end
+
+
 def profile_begin():
-    global PROFILE
+    global PROFILE, PROFILE_ATTN_FLOPS
     PROFILE = []
+    PROFILE_ATTN_FLOPS = 0.0
 
 
 def profile_end():
@@ -313,6 +319,8 @@ AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
 # profiles/r04_splitk_in_launch.txt) the last-arriver form with an agent-scope release per block is 8-15 us SLOWER than the reduce
 # launch it replaces on every small-M shape of the step (each block's release writes back its XCD's L2: ~45 ns per block, serialised).
 SK_FUSED = os.environ.get("MFHIP_SK_FUSED", "0") == "1"
+# GroupNorm statistics from the producing GEMM's epilogue (mf_gemm_desc.gn_part -> mf_groupnorm_desc.part0 / part1).  A/B switch.
+GN_FROM_PARTS = os.environ.get("MFHIP_GN_FROM_PARTS", "1") != "0"
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
 TUNE_GRAPH = os.environ.get("MFHIP_TUNE_GRAPH", "0") == "1"   # developer switch: time candidates from a hipGraph (see _tuned_config)
 TUNE_LOG: Optional[dict] = None     # developer hook (tools/tune_step.py): every candidate's time of every key tuned while it is a dict
@@ -486,7 +494,8 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
               nz: int = 1, zdiv: int = 1, a_zs=(0, 0), w_zs=(0, 0), o_zs=(0, 0),
               a_scale: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None, a_scale_zs: int = 0,
               w_scale_zs: int = 0, splitk: int = 0, tile: int = 0, ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-              vt_out: Optional[torch.Tensor] = None, vt_n0: int = 0, vt_tokens: int = 0, sk_fused: bool = False) -> torch.Tensor:
+              vt_out: Optional[torch.Tensor] = None, vt_n0: int = 0, vt_tokens: int = 0, sk_fused: bool = False,
+              gn_part: bool = False) -> torch.Tensor:
     """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements.  `dtype`: a torch
     dtype (bf16 / fp32 compute) or an MF_* compute code (the split codes take fp32 a0 and, with w_split=1, a weight
     from ops.split_pack)."""
@@ -568,13 +577,23 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     elif sk_fused and splitk > 1:
         tk = sk_tickets(out.device)
         d.sk_tickets, d.sk_ticket_cap = tk.data_ptr(), tk.numel()
+    part = part_rows = None
+    if gn_part:
+        # GroupNorm statistics from this launch (mf_gemm_desc.gn_part): per-channel partial sums of the output, attached to `out`
+        # as out._gn_part = (fp32 buffer, rows per block) for groupnorm() to pick up.  Set after the tuner ran (it times plain launches).
+        m_rows = batch * h_out * w_out
+        part = torch.empty(2 * n * (m_rows // 32), dtype=torch.float32, device=out.device)
+        part_rows = C.c_int32(0)
+        d.gn_part, d.gn_part_floats, d.gn_part_rows = part.data_ptr(), part.numel(), C.addressof(part_rows)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _check(load().mf_gemm_conv(C.byref(d), _stream()), "mf_gemm_conv")
         e1.record()
         PROFILE.append((e0, e1, 2.0 * batch * h_out * w_out * n * kh * kw * (c0 + c1) * nz,
-                        (batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), nz, d.tile, d.splitk)))
+                        (batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), nz, d.tile, d.splitk, int(code))))
+        if part is not None:
+            out._gn_part = (part, int(part_rows.value))
         return out
     rc = load().mf_gemm_conv(C.byref(d), _stream())
     if rc != 0 and tkey is not None and d.tile != 0:
@@ -583,6 +602,8 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         d.tile, d.splitk, d.sk_tickets, d.sk_ticket_cap = 0, splitk, None, 0
         rc = load().mf_gemm_conv(C.byref(d), _stream())
     _check(rc, "mf_gemm_conv")
+    if part is not None:
+        out._gn_part = (part, int(part_rows.value))
     return out
 
 
@@ -614,6 +635,13 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, grou
         if stats_out.numel() != b * groups * 2 or not stats_out.is_contiguous():
             raise MfhipError("groupnorm: stats_out is a contiguous [batch, groups, 2] tensor")
         d.stats_out = stats_out.data_ptr()
+    if GN_FROM_PARTS and hw > 256:
+        # statistics handed over by the producing GEMMs (gemm_conv(..., gn_part=True) attached them to its output tensor)
+        p0, p1 = getattr(x0, "_gn_part", None), (getattr(x1, "_gn_part", None) if x1 is not None else None)
+        if p0 is not None and (x1 is None or p1 is not None):
+            d.part0, d.part0_rows = p0[0].data_ptr(), p0[1]
+            if p1 is not None:
+                d.part1, d.part1_rows = p1[0].data_ptr(), p1[1]
     _check(lib.mf_groupnorm(C.byref(d), _stream()), "mf_groupnorm")
     return out
 
@@ -646,6 +674,9 @@ def attention_bf16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torc
                    lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`lse` (fp32 [batch, heads, sq], written): the row statistic of the flash backward (mf_attention_bf16_lse)."""
     _req_cuda(q, k, vt, out, lse)
+    if PROFILE is not None:               # bench.py's FLOP census (no timing here: the GEMM family is the timed one)
+        global PROFILE_ATTN_FLOPS
+        PROFILE_ATTN_FLOPS += 4.0 * batch * heads * sq * skv * head_dim
     if q.dtype == torch.float16:          # the fp16 storage mode: the same kernel on the f16 MFMA forms (inference: no row statistics)
         if lse is not None or not (k.dtype == vt.dtype == out.dtype == torch.float16):
             raise MfhipError("attention_bf16: fp16 operands take fp16 k / vt / out and no lse")

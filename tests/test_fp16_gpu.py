@@ -50,6 +50,20 @@ def test_precision_surface():
     assert ops.Precision.get("fp16").code == hip.dt_code(torch.float16)
 
 
+def test_fp32_activations_are_refused_by_the_fp16_kernels():
+    """the fp16 instantiations have no fp32-converting load (only the bf16 ones do), so an fp32 activation with an
+    fp16 weight must be refused by the C ABI — it used to be read as fp16 pairs and give garbage."""
+    g = torch.Generator().manual_seed(3)
+    w = rh(torch.randn(64, 32, 3, 3, generator=g) * 0.05)
+    cw = ops.ConvWeight(w, torch.zeros(64), prec(), DEV)
+    x32 = torch.randn(1, 8, 8, 32, generator=g).to(DEV)
+    with pytest.raises(hip.MfhipError, match="fp16 activations"):
+        ops.conv2d(x32, cw)
+    lw = ops.ConvWeight(rh(torch.randn(64, 32, generator=g)).view(64, 32, 1, 1), torch.zeros(64), prec(), DEV)
+    with pytest.raises(hip.MfhipError, match="fp16 activations"):
+        ops.linear(torch.randn(16, 32, generator=g).to(DEV), lw)
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 14, 15, 25, 26, 29, 30, 31, 34, 36, 67, 41, 42, 43, 44, 45, 46, 48, 50, 52, 54, 56, 57, 58, 60, 62, 64, 66])
 def test_conv3x3_tiles(tile):
     g = torch.Generator().manual_seed(1)

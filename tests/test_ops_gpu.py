@@ -832,3 +832,124 @@ def test_in_launch_split_k_combine_under_uneven_load_and_graph_replay():
             gr.replay()
             assert torch.equal(out, ref), f"tile {tile} splitk {sk} replay {rep}"
         assert int(hip._tickets[torch.cuda.current_device()][0].abs().sum()) == 0
+
+
+# ---- round 6: GroupNorm statistics from the producing GEMM's epilogue (mf_gemm_desc.gn_part -> mf_groupnorm_desc.part0 / part1) ----
+GN_PART_TILES = [0, 1, 2, 3, 5, 6, 9, 13, 14, 15, 16, 20, 21, 25, 26, 27, 29, 31, 34, 37, 38, 40, 41, 42, 44, 45, 47, 48, 49, 50, 51, 52, 53, 54,
+                 57, 58, 59, 60, 62, 63, 64, 66, 67, 68]
+
+
+def _colsum_ref(y_nhwc: torch.Tensor, rows: int):
+    """(sum, sum of squares) of every block of `rows` output rows, per channel, in float64."""
+    n = y_nhwc.shape[-1]
+    y = y_nhwc.double().reshape(-1, rows, n)
+    return torch.stack([y.sum(1), (y * y).sum(1)], dim=-1)          # [blocks, n, 2]
+
+
+@pytest.mark.parametrize("prec_name", ["bf16", "fp16", "f16x3", "fp32"])
+@pytest.mark.parametrize("tile", GN_PART_TILES)
+def test_conv_leaves_groupnorm_partial_sums_of_its_final_output(prec_name, tile):
+    """A conv with temb + two residuals + alpha and gn_part=True: the partial sums attached to the output equal the per-channel
+    (sum, sum of squares) of the STORED output over blocks of R rows, R reported by the library (the tile's rows when the
+    epilogue produced them, 128 / 64 / 32 from the column-sum launch otherwise), and they are bit-identical from run to run."""
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(7)
+    b, h, w, cin, n = 2, 32, 32, 64, 320            # hw = 1024: one image per block of rows for every tile (BM <= 256)
+    x = torch.randn(b, h, w, cin, generator=g)
+    wt = torch.randn(n, cin, 3, 3, generator=g) * 0.05
+    bias = torch.randn(n, generator=g)
+    temb = torch.randn(b, n, generator=g).to(DEV)
+    r0 = torch.randn(b, h, w, n, generator=g)
+    r1 = torch.randn(b, h, w, n, generator=g)
+    cw = ops.ConvWeight(wt, bias, prec, DEV)
+    args = dict(temb=temb, res0=r0.to(DEV, prec.act), res1=r1.to(DEV, prec.act), alpha=0.5, gn_part=True, tile=tile)
+    try:
+        y = ops.conv2d(x.to(DEV, prec.act), cw, **args)
+    except hip.MfhipError as e:
+        assert "not instantiated" in str(e) or "does not apply" in str(e), e     # a tile this precision does not have
+        return
+    part, rows = y._gn_part
+    assert rows in (32, 64, 128, 192, 256) and (h * w) % rows == 0
+    nb = b * h * w // rows
+    got = part[: nb * n * 2].view(nb, n, 2).double().cpu()
+    ref = _colsum_ref(y.float().cpu(), rows)
+    # the epilogue sums the fp32 values BEFORE the storage rounding: 16-bit storage moves a sum of `rows` values by <= rows * 2^-9 |y|
+    ulp = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}.get(prec_name, 2.0 ** -22)
+    scale_s = float(y.float().abs().max()) * rows
+    scale_q = float(y.float().abs().max()) ** 2 * rows
+    es, eq = (got[..., 0] - ref[..., 0]).abs().max().item(), (got[..., 1] - ref[..., 1]).abs().max().item()
+    print(f"gn_part[{prec_name}, tile {tile}]: rows per block {rows}, |sum err| {es:.3e} (scale {scale_s:.1f}), |sumsq err| {eq:.3e} (scale {scale_q:.1f})")
+    assert es <= 0.25 * ulp * scale_s + 1e-3 and eq <= 0.5 * ulp * scale_q + 1e-3
+    y2 = ops.conv2d(x.to(DEV, prec.act), cw, **args)
+    assert y2._gn_part[1] == rows and torch.equal(y2._gn_part[0][: nb * n * 2], part[: nb * n * 2]) and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("case", ["splitk", "odd_hw", "1x1", "up", "s2"])
+def test_groupnorm_partial_sums_fallback_and_variants(case):
+    """Launches whose epilogue cannot produce the sums (split-K reduce; an image size the tile's rows do not divide) leave them
+    through the column-sum launch: same contract.  1x1 / upsampled / strided convs produce them in the epilogue."""
+    prec = ops.Precision.get("bf16")
+    g = torch.Generator().manual_seed(11)
+    b, h, w, cin, n = (2, 24, 12, 64, 64) if case == "odd_hw" else (2, 32, 32, 64, 128)
+    x = rb(torch.randn(b, h, w, cin, generator=g))
+    kw = dict(gn_part=True)
+    if case == "splitk":
+        kw.update(splitk=2, tile=1)
+    if case == "odd_hw":
+        kw.update(tile=14)                        # hw = 288 = 2.25 x 128 rows: a row block would straddle two images
+    if case == "up":
+        kw.update(upsample=True)
+    if case == "s2":
+        kw.update(stride=2, padding=1)
+    k = 1 if case == "1x1" else 3
+    if case == "1x1":
+        kw.update(padding=0)
+    cw = ops.ConvWeight(rb(torch.randn(n, cin, k, k, generator=g) * 0.05), torch.randn(n, generator=g), prec, DEV)
+    # hw must exceed 256 for ops.conv2d to ask (below that GroupNorm is one launch): call the descriptor level for the small case
+    y = ops.conv2d(x.to(DEV, prec.act), cw, **kw)
+    if case == "s2":
+        assert not hasattr(y, "_gn_part")         # 16 x 16 output: GroupNorm's one-launch form, nothing asked
+        return
+    part, rows = y._gn_part
+    hw = y.shape[1] * y.shape[2]
+    assert hw % rows == 0 and (case not in ("splitk", "odd_hw") or rows in (32, 64, 128))
+    nb = y.shape[0] * hw // rows
+    got = part[: nb * n * 2].view(nb, n, 2).double().cpu()
+    ref = _colsum_ref(y.float().cpu(), rows)
+    tol_s, tol_q = 2.0 ** -9 * rows * float(y.float().abs().max()), 2.0 ** -8 * rows * float(y.float().abs().max()) ** 2
+    assert (got[..., 0] - ref[..., 0]).abs().max() <= tol_s and (got[..., 1] - ref[..., 1]).abs().max() <= tol_q
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("c0,c1,hw,silu", [(320, 0, 4096, True), (640, 320, 1024, True), (1280, 640, 1024, False), (320, 0, 1024, False)])
+def test_groupnorm_from_producer_partial_sums(dt, c0, c1, hw, silu):
+    """mf_groupnorm with part0 / part1: the same result as computing the statistics from the tensor (to the rounding of the
+    statistic), for one and two segments whose row blocks differ (256 and 128 rows), groups straddling the segment border
+    (960 = 640 + 320 channels: 30 per group), and bit-identical from run to run."""
+    g = torch.Generator().manual_seed(5)
+    b, groups = 2, 32
+    x0 = (torch.randn(b, hw, c0, generator=g) * 1.5 + 0.7).to(DEV, dt)
+    x1 = (torch.randn(b, hw, c1, generator=g) * 0.5 - 0.3).to(DEV, dt) if c1 else None
+    gamma, beta = torch.randn(c0 + c1, generator=g).to(DEV), torch.randn(c0 + c1, generator=g).to(DEV)
+
+    def parts(x, rows):
+        v = x.float().view(-1, rows, x.shape[-1])
+        return torch.stack([v.sum(1), (v * v).sum(1)], dim=-1).contiguous().view(-1), rows
+
+    x0._gn_part = parts(x0, 256)
+    if x1 is not None:
+        x1._gn_part = parts(x1, 128)
+    y = hip.groupnorm(x0, gamma, beta, groups=groups, eps=1e-5, silu=silu, out_dtype=dt, x1=x1)
+    y2 = hip.groupnorm(x0, gamma, beta, groups=groups, eps=1e-5, silu=silu, out_dtype=dt, x1=x1)
+    assert torch.equal(y, y2)
+    del x0._gn_part
+    ref = hip.groupnorm(x0, gamma, beta, groups=groups, eps=1e-5, silu=silu, out_dtype=dt, x1=x1)
+    xc = torch.cat([x0, x1], -1).float().cpu() if x1 is not None else x0.float().cpu()
+    tref = F.group_norm(xc.permute(0, 2, 1), groups, gamma.cpu(), beta.cpu(), 1e-5).permute(0, 2, 1)
+    if silu:
+        tref = F.silu(tref)
+    tol = {torch.bfloat16: 3e-2, torch.float16: 4e-3, torch.float32: 2e-5}[dt]
+    check(f"groupnorm_from_parts[{dt}]", y, tref, tol, tol)
+    d = (y.float() - ref.float()).abs().max().item()
+    print(f"from partial sums vs own statistics pass: max diff {d:.3e}")
+    assert d <= tol

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-end measurement session (gpurun: bash tools/gpu_session.sh <tag> bash tools/measure_round.sh): every GPU test, smoke(), the default bench line, kernel stats of the same command, the counter passes, stamps
+: "${GRAFT_REPO_ROOT:?run through gpurun}"; : "${MF_SESSION_OUT:?run through tools/gpu_session.sh}"
 cd "$GRAFT_REPO_ROOT" || exit 1
 out="$MF_SESSION_OUT"
 timeout 3000 python -m pytest tests -x -q -m gpu > "$out/pytest_gpu.txt" 2>&1; echo "pytest -m gpu rc $?"; tail -n 4 "$out/pytest_gpu.txt"

@@ -1,5 +1,6 @@
 #!/bin/bash
 # counter passes over ONE launch shape (tools/one_nloop.py <tile>): where do the cycles of the persistent short-K GEMM go?
+: "${GRAFT_REPO_ROOT:?run through gpurun}"; : "${MF_SESSION_OUT:?run through tools/gpu_session.sh}"
 cd "$GRAFT_REPO_ROOT" || exit 1
 out="$MF_SESSION_OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
