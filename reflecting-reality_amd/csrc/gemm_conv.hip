@@ -152,12 +152,16 @@ const TileCfg kTiles[] = {
     // 69 (round 5): the persistent short-K GEMM of gemm_nloop.hip — 64 rows of A per block, a range of 160-column output tiles per
     // block, the epilogue of tile j under the main loop of tile j + 1 (4 compute + 4 staging + 4 epilogue waves)
     {64, 160, 256, 3},             // 69
+    // 70 (round 6): gemm_pers.hip — 128 rows of A per block, a range of 160-column output tiles, EIGHT compute waves (two per SIMD) of
+    // 32 x 80 + four staging + four epilogue waves on a two-deep ring beside a whole fp32 slab: the epilogue of tile j under tile j + 1
+    {128, 160, 256, 2},            // 70
     // (round 3: FOUR-deep rings of 48 / 41 — 147 KB, three K tiles in flight — were built, parity-tested and offered to the tuner
     // over the whole step: picked for none of 100 shapes, gpurun_out/r03e/tune_user.json; removed again)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 inline bool tile_ws(int tile) { return tile >= 37 && tile <= 66; }                                 // compute waves + four staging waves
 constexpr int kNloopTile = 69;
+constexpr int kPersTile = 70;
 inline bool tile_ws_ring(int tile) { return tile_ws(tile) && kTiles[tile - 1].dxr == 0; }           // ... of the plain ring (any call)
 
 // tiles whose kernels have an in-launch split-K combine (keep in sync with the launch_skf cases below)
@@ -307,7 +311,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         MF_CHECK_ARG(mf_is16(d->dtype) && d->a_dtype == d->dtype && d->kh == 1 && d->kw == 1 && d->c1 == 0 && d->nz == 1 &&
                          (d->splitk == 0 || d->splitk == 1) && d->a_scale == nullptr && d->w_scale == nullptr,
                      "mf_gemm_conv: ln_colsum / vt_out need a plain bf16 / fp16 1x1 GEMM (one A segment, no batching, no split-K, no scales)");
-        MF_CHECK_ARG(d->tile == 0 || tile_ws_ring(d->tile) || (d->tile == kNloopTile && !d->vt_out),
+        MF_CHECK_ARG(d->tile == 0 || tile_ws_ring(d->tile) || ((d->tile == kNloopTile || d->tile == kPersTile) && !d->vt_out),
                      "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (the warp-specialised ring tiles 41-46, 48, 50, 52, 54, 56-58, 60, 62 do)", d->tile);
         MF_CHECK_ARG(!d->ln_colsum || (mf_aligned16(d->ln_colsum) && d->n % 8 == 0 && d->ln_eps > 0.0f), "mf_gemm_conv: ln_colsum must be 16-byte aligned, n %% 8 == 0, ln_eps > 0");
         if (d->vt_out) {
@@ -428,7 +432,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     if (splitk == 0) {
         // heuristic: fill the 256 CUs when the output grid alone cannot, keeping >= 4 K-tiles per split
         splitk = 1;
-        if (tiles_mn <= 192 && a.nkt >= 8 && d->ws != nullptr && d->act != MF_ACT_GEGLU4 && !d->ln_colsum && !d->vt_out && tile != kNloopTile) {
+        if (tiles_mn <= 192 && a.nkt >= 8 && d->ws != nullptr && d->act != MF_ACT_GEGLU4 && !d->ln_colsum && !d->vt_out && tile != kNloopTile && tile != kPersTile) {
             splitk = (int)((384 + tiles_mn - 1) / tiles_mn);
             if (splitk > a.nkt / 4) splitk = a.nkt / 4;
             const int64_t per_split = (int64_t)a.nz * a.M * a.N;
@@ -522,6 +526,24 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     // statistics in the epilogue: the final values of a block's rows are in its LDS slabs; one image per block of rows
     const bool gn_fused = d->gn_part != nullptr && a.splitk == 1 && a.vec_ok && gn_hw % tc.bm == 0 && a.M % tc.bm == 0;
     a.gn_part = gn_fused ? (float2*)d->gn_part : nullptr;
+    if (tile == kPersTile) {
+        const bool ok = mf_is16(d->dtype) && !a_f32 && a.pointwise && d->c1 == 0 && a.nz == 1 && a.splitk == 1 && a.M % 128 == 0 && a.N % 160 == 0 &&
+                        a.K % 64 == 0 && a.nkt >= 2 && a.vec_ok && a.bias_mode == 0 && !a.temb && !a.vt_out && !a.rs && !a.cs && a.fast && !a.res1 && (!a.res0 || a.res0_dt != MF_F32) &&
+                        (int64_t)a.M * a.ld0b < (1ll << 31) - (1 << 20);
+        MF_CHECK_ARG(ok, "mf_gemm_conv: tile %d (persistent 128-row GEMM) takes a 1x1 bf16 / fp16 call with M %% 128 == 0, N %% 160 == 0, K %% 64 == 0, "
+                         "K >= 128, one A segment, per-column bias, one residual at most, no time embedding / scales / transposed columns / split-K", tile);
+        // column ranges per row tile: enough blocks for the chip (one block per CU: the kernel takes all of its LDS), as many
+        // output tiles per block as that leaves — the epilogue of every tile but a block's last runs under the next main loop
+        static const int forced = getenv("MFHIP_PERS_RANGES") ? atoi(getenv("MFHIP_PERS_RANGES")) : 0;        // developer sweep
+        int ranges = 1;
+        while (a.tiles_m * ranges < 256 && a.tiles_n % (ranges * 2) == 0) ranges *= 2;
+        if (forced > 0 && a.tiles_n % forced == 0) ranges = forced;
+        a.nloop = a.tiles_n / ranges;
+        MF_CHECK_ARG(launch_pers(d->dtype, a, (hipStream_t)stream), "mf_gemm_conv: tile %d is not instantiated for dtype %d", tile, d->dtype);
+        MF_CHECK_LAUNCH("mf_gemm_conv(pers)");
+        if (d->gn_part) return gn_fallback((hipStream_t)stream);
+        return MF_OK;
+    }
     dim3 grid((unsigned)nblk, 1, (unsigned)a.nz);
     hipStream_t s = (hipStream_t)stream;
     bool launched;

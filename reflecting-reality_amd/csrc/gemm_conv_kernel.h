@@ -1874,6 +1874,7 @@ void launch_skf(const GemmArgs& a, dim3 grid, hipStream_t s) {
 
 // ---- tile groups, one translation unit each (false: the tile is not instantiated in that group) ----------------------
 bool launch_nloop(int dtype, const GemmArgs& a, hipStream_t s);                                 // 69: the persistent short-K GEMM (gemm_nloop.hip)
+bool launch_pers(int dtype, const GemmArgs& a, hipStream_t s);                                  // 70: its 128-row successor, 16 waves (gemm_pers.hip)
 bool launch_bf16_a(int tile, const GemmArgs& a, dim3 grid, hipStream_t s, bool a_f32);   // tiles 1-6 (+ fp32 activations, + in-launch split-K twins)
 bool launch_bf16_b(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);               // 7-15, 20-24
 bool launch_bf16_c(int tile, const GemmArgs& a, dim3 grid, hipStream_t s);               // 25-36

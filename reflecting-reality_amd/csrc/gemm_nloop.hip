@@ -203,18 +203,20 @@ __global__ __launch_bounds__(768, 1) void gemm_nloop_kernel(const GemmArgs p) {
 
 bool launch_nloop(int dtype, const GemmArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.tiles_m * (a.tiles_n / a.nloop)));
-    static bool attr_bf16 = false, attr_f16 = false;
-    if (dtype == MF_BF16) {
-        if (!attr_bf16) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nloop_kernel<MF_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, NL_SMEM); attr_bf16 = true; }
-        hipLaunchKernelGGL(gemm_nloop_kernel<MF_BF16>, grid, dim3(768), NL_SMEM, s, a);
-        return true;
+    if (dtype != MF_BF16 && dtype != MF_F16) return false;
+    // the dynamic-LDS attribute is per function AND per device: one flag per (flavour, device), the call's result checked
+    static bool attr[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const int fl = dtype == MF_F16 ? 1 : 0;
+    if (!attr[fl][dev]) {
+        const void* fn = fl ? reinterpret_cast<const void*>(&gemm_nloop_kernel<MF_F16>) : reinterpret_cast<const void*>(&gemm_nloop_kernel<MF_BF16>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NL_SMEM) != hipSuccess) return false;
+        attr[fl][dev] = true;
     }
-    if (dtype == MF_F16) {
-        if (!attr_f16) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nloop_kernel<MF_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, NL_SMEM); attr_f16 = true; }
-        hipLaunchKernelGGL(gemm_nloop_kernel<MF_F16>, grid, dim3(768), NL_SMEM, s, a);
-        return true;
-    }
-    return false;
+    if (fl) hipLaunchKernelGGL(gemm_nloop_kernel<MF_F16>, grid, dim3(768), NL_SMEM, s, a);
+    else hipLaunchKernelGGL(gemm_nloop_kernel<MF_BF16>, grid, dim3(768), NL_SMEM, s, a);
+    return true;
 }
 
 }  // namespace mfgemm

@@ -672,11 +672,15 @@ def test_linear_with_folded_layernorm(tile, rows, c, n, mode):
     check(f"linear_ln[{mode},{rows}x{c}->{n},tile{tile}]", y, ref, 3e-2, 2e-2)
 
 
+@pytest.mark.parametrize("ptile", [69, 70])
 @pytest.mark.parametrize("prec_name", ["bf16", "fp16"])
 @pytest.mark.parametrize("rows,c,n,mode,with_ln", [(2048, 320, 2 * 2560, "geglu", True), (8192, 320, 2 * 1280, "geglu", True), (1024, 640, 640, "res", False),
-                                                   (16384, 128, 640, "linear", True), (4096, 192, 480, "silu", False), (2048, 1280, 1280, "res", True)])
-def test_persistent_short_k_gemm(prec_name, rows, c, n, mode, with_ln):
-    """Tile 69 (csrc/gemm_nloop.hip): a block keeps 64 rows of A and walks a range of 160-column output tiles, the epilogue of tile j
+                                                   (16384, 128, 640, "linear", True), (4096, 192, 480, "silu", False), (2048, 1280, 1280, "res", True),
+                                                   (32768, 320, 320, "res", False), (8192, 640, 2 * 2560, "geglu", False), (256, 320, 1600, "linear", True)])
+def test_persistent_short_k_gemm(prec_name, rows, c, n, mode, with_ln, ptile):
+    """Tile 70 (csrc/gemm_pers.hip, round 6): the same structure on 128 rows with EIGHT compute waves + four staging + four epilogue
+    waves, a two-deep ring beside a whole 128 x 160 fp32 slab, and the epilogue's global operands fetched a tile ahead.
+    Tile 69 (csrc/gemm_nloop.hip): a block keeps 64 rows of A and walks a range of 160-column output tiles, the epilogue of tile j
     running on its own waves under the main loop of tile j + 1.  Cases: two to sixteen output tiles per block, one (only the shared last
     slab), an odd count; two, three, five, ten and twenty K tiles per output tile (two: every chunk of a slab in ONE barrier interval);
     GEGLU, residual, SiLU, plain epilogues; with and without a folded LayerNorm; both 16-bit storage types.  Reference: fp32 on the
@@ -696,7 +700,7 @@ def test_persistent_short_k_gemm(prec_name, rows, c, n, mode, with_ln):
         hh, gate = F.linear(xn, wr, b).chunk(2, dim=-1)
         ref = hh * F.gelu(gate)
         gw = ops.geglu_weight(w, b, prec, DEV, ln=ln)
-        y, y48 = ops.linear_geglu(xd, gw, tile=69), ops.linear_geglu(xd, gw, tile=48)
+        y, y48 = ops.linear_geglu(xd, gw, tile=ptile), ops.linear_geglu(xd, gw, tile=48)
     else:
         res = rnd(torch.randn(rows, n, generator=g)) if mode == "res" else None
         ref = F.linear(xn, wr, b) + (res if res is not None else 0.0)
@@ -706,12 +710,12 @@ def test_persistent_short_k_gemm(prec_name, rows, c, n, mode, with_ln):
         kw = dict(res0=res.to(DEV, prec.act) if res is not None else None)
         if mode == "silu":
             kw["act"] = hip.ACT_SILU
-        y, y48 = ops.linear(xd, lw, tile=69, **kw), ops.linear(xd, lw, tile=48, **kw)
+        y, y48 = ops.linear(xd, lw, tile=ptile, **kw), ops.linear(xd, lw, tile=48, **kw)
     tol = (3e-2, 2e-2) if prec_name == "bf16" else (6e-3, 4e-3)
-    check(f"nloop[{prec_name},{mode},{rows}x{c}->{n}]", y, ref, *tol)
+    check(f"persistent tile {ptile}[{prec_name},{mode},{rows}x{c}->{n}]", y, ref, *tol)
     # against the ring tile: the same products summed in another order, then one rounding to 16 bits
     d = (y.float() - y48.float()).abs().max().item()
-    assert d <= (2.0 ** -6 if prec_name == "bf16" else 2.0 ** -9) * max(1.0, ref.abs().max().item()), f"tile 69 vs tile 48: {d}"
+    assert d <= (2.0 ** -6 if prec_name == "bf16" else 2.0 ** -9) * max(1.0, ref.abs().max().item()), f"tile {ptile} vs tile 48: {d}"
 
 
 def test_persistent_short_k_gemm_is_refused_where_it_cannot_run():
@@ -724,6 +728,19 @@ def test_persistent_short_k_gemm_is_refused_where_it_cannot_run():
         ops.linear(torch.randn(128, 320, device=DEV).bfloat16(), ops.ConvWeight(torch.randn(200, 320), None, prec, DEV), tile=69)
     with pytest.raises(hip.MfhipError, match="persistent short-K"):              # one K tile
         ops.linear(torch.randn(128, 64, device=DEV).bfloat16(), ops.ConvWeight(torch.randn(160, 64), None, prec, DEV), tile=69)
+
+
+def test_persistent_128_row_gemm_is_refused_where_it_cannot_run():
+    prec = ops.Precision.get("bf16")
+    lw = ops.ConvWeight(torch.randn(320, 320), None, prec, DEV)
+    with pytest.raises(hip.MfhipError, match="persistent 128-row"):              # M % 128 != 0
+        ops.linear(torch.randn(192, 320, device=DEV).bfloat16(), lw, tile=70)
+    with pytest.raises(hip.MfhipError, match="persistent 128-row"):              # N % 160 != 0
+        ops.linear(torch.randn(128, 320, device=DEV).bfloat16(), ops.ConvWeight(torch.randn(200, 320), None, prec, DEV), tile=70)
+    with pytest.raises(hip.MfhipError, match="persistent 128-row"):              # a 3 x 3 convolution
+        ops.conv2d(torch.randn(1, 16, 8, 64, device=DEV).bfloat16(), ops.ConvWeight(torch.randn(160, 64, 3, 3), None, prec, DEV), tile=70)
+    with pytest.raises(hip.MfhipError, match="persistent 128-row|bf16"):         # fp32 mode
+        ops.linear(torch.randn(128, 320, device=DEV), ops.ConvWeight(torch.randn(320, 320), None, ops.Precision.get("fp32"), DEV), tile=70)
 
 
 def test_folded_layernorm_is_refused_where_it_cannot_run():

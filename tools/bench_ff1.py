@@ -13,12 +13,21 @@ hip.AUTOTUNE = False
 dev = torch.device("cuda:0")
 prec = ops.Precision.get(sys.argv[1] if len(sys.argv) > 1 else "bf16")
 g = torch.Generator().manual_seed(0)
-TILES = (69, 29, 30, 14, 26, 48, 54, 67, 3, 1)
+TILES = (70, 69, 29, 30, 14, 26, 48, 54, 67, 6, 3, 1)
 print("precision", prec.name)
 for rows, c in ((32768, 320), (8192, 640), (2048, 1280)):
     x = (torch.randn(rows, c, generator=g) * 1.3).to(dev, prec.act)
     gamma, beta = torch.ones(c), torch.zeros(c)
     w = torch.randn(8 * c, c, generator=g) / c ** 0.5
+    gw0 = ops.geglu_weight(w, torch.zeros(8 * c), prec, dev)
+    line = f"ff1 geglu (the step's form) {rows}x{c}->{8 * c}:"
+    for t in TILES:
+        try:
+            us = timed(lambda: ops.linear_geglu(x, gw0, tile=t))
+            line += f"  t{t} {us:6.1f}"
+        except hip.MfhipError:
+            pass
+    print(line, flush=True)
     gw = ops.geglu_weight(w, torch.zeros(8 * c), prec, dev, ln=(gamma, beta, 1e-5))
     line = f"ff1 ln+geglu {rows}x{c}->{8 * c}:"
     for t in TILES:
