@@ -125,6 +125,55 @@ class Tape:
         self.grads.clear()
 
 
+def checkpoint(fn: Callable[[], torch.Tensor]) -> torch.Tensor:
+    """Activation recomputation for one block (torch.utils.checkpoint as the reference's blocks use it under
+    `--gradient_checkpointing`: unet_2d_blocks.py:1167-1196, 2597-2622; brushnet.py:674-676; train_brushnet_mirror.py:1153-1155).
+
+    `fn()` runs the block's forward and returns its one output tensor.  With a tape set, the forward runs on a THROW-AWAY tape
+    (the same operators, kernels and code paths as a recorded forward: everything that asks `ops.TAPE is not None` sees a tape),
+    whose closures — and with them every intermediate activation of the block — are dropped at once; the real tape gets ONE
+    closure that holds the block's inputs (through fn) and, in the backward pass, runs fn again on a sub-tape that shares the
+    real tape's gradient table, seeds the recomputed output with the output's gradient and plays the sub-tape back.  Same
+    kernels on the same values in the same order: gradients are bit-identical to the un-checkpointed step (tests)."""
+    from . import ops
+    tape = ops.TAPE
+    if tape is None:
+        return fn()
+    scratch = Tape(tape.code)
+    scratch.stop = tape.stop
+    ops.TAPE = scratch
+    try:
+        out = fn()
+    finally:
+        ops.TAPE = tape
+    scratch.ops.clear()
+    scratch.colsum_done.clear()
+    del scratch
+
+    def bwd():
+        g = tape.take(out)
+        if g is None:
+            return
+        sub = Tape(tape.code)
+        sub.grads, sub.stop, sub.on_param_grad = tape.grads, tape.stop, tape.on_param_grad
+        sub.dgrad_rebuilt, sub.colsum_done = tape.dgrad_rebuilt, tape.colsum_done
+        prev = ops.TAPE
+        ops.TAPE = sub
+        try:
+            out2 = fn()
+        finally:
+            ops.TAPE = prev
+        if out2.numel() != g.numel():
+            raise hip.MfhipError("checkpoint: the recomputed block output differs in size from the recorded one")
+        sub.grads[_key(out2)] = g
+        for f in reversed(sub.ops):
+            f()
+        sub.ops.clear()
+
+    tape.record(bwd)
+    return out
+
+
 # =====================================================================================================================
 # backward closures
 # =====================================================================================================================

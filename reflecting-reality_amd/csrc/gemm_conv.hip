@@ -528,10 +528,10 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.gn_part = gn_fused ? (float2*)d->gn_part : nullptr;
     if (tile == kPersTile) {
         const bool ok = mf_is16(d->dtype) && !a_f32 && a.pointwise && d->c1 == 0 && a.nz == 1 && a.splitk == 1 && a.M % 128 == 0 && a.N % 160 == 0 &&
-                        a.K % 64 == 0 && a.nkt >= 2 && a.vec_ok && a.bias_mode == 0 && !a.temb && !a.vt_out && !a.rs && !a.cs && a.fast && !a.res1 && (!a.res0 || a.res0_dt != MF_F32) &&
+                        a.K % 64 == 0 && a.nkt >= 2 && a.vec_ok && a.bias_mode == 0 && !a.temb && !a.vt_out && !a.rs && !a.cs && a.fast && !a.res1 && (!a.res0 || a.res0_dt != MF_F32) && a.out_dt != MF_F32 &&
                         (int64_t)a.M * a.ld0b < (1ll << 31) - (1 << 20);
         MF_CHECK_ARG(ok, "mf_gemm_conv: tile %d (persistent 128-row GEMM) takes a 1x1 bf16 / fp16 call with M %% 128 == 0, N %% 160 == 0, K %% 64 == 0, "
-                         "K >= 128, one A segment, per-column bias, one residual at most, no time embedding / scales / transposed columns / split-K", tile);
+                         "K >= 128, one A segment, 16-bit output (and residual), per-column bias, one residual at most, no time embedding / scales / transposed columns / split-K", tile);
         // column ranges per row tile: enough blocks for the chip (one block per CU: the kernel takes all of its LDS), as many
         // output tiles per block as that leaves — the epilogue of every tile but a block's last runs under the next main loop
         static const int forced = getenv("MFHIP_PERS_RANGES") ? atoi(getenv("MFHIP_PERS_RANGES")) : 0;        // developer sweep

@@ -5,23 +5,36 @@
 // in its main loop, and because a launch is one wave of blocks that all start together, every CU reaches its epilogue at the same
 // time — the memory system idles through the main loops and then takes a burst of all the stores (and residual loads) at once
 // (profiles/r05_gemm_phase_stamps.txt: 15 us of epilogue behind 47 us of main loop on the 64 x 64 convs, 12 behind 7 on the 1x1s).
-// Here a block keeps a RANGE of 160-column output tiles of its 128 rows, and dedicated epilogue waves turn the slab of tile j into
-// output rows while the compute waves multiply tile j + 1: stores trickle out under the main loop, nothing bursts.
+// Here a block keeps a RANGE of 160-column output tiles of its 128 rows, and the slab of tile j is turned into output rows while
+// tile j + 1 is multiplied: stores trickle out under the main loop, nothing bursts.
 //
 // Roles (1024 threads = 16 waves, four per SIMD, <= 128 VGPRs each):
 //   waves 0-7   compute: 4 x 2 wave tiles of 32 x 80 = 2 x 5 tiles of 16 x 16 (v_mfma_f32_16x16x32), two compute waves per SIMD so
-//               that one's fragment reads fly under the other's MFMAs (tile 69 had one and lost for it);
-//   waves 8-11  staging: LDS-DMA of the A (128 x 128 B) and W (160 x 128 B) tiles into a 2-deep ring (the fp32 slab of a whole
-//               128 x 160 tile takes 82 KB of the 160, so the ring cannot be three deep), running through all the block's output
-//               tiles without a drain;
-//   waves 12-15 epilogue: LayerNorm fold, bias, residual, SiLU / GEGLU, cast, 16-byte stores (gemm_conv_kernel's epilogue_store8)
-//               of slab chunks BETWEEN the barriers of the next tile's K steps.  Everything the epilogue reads from global memory
-//               (residual vectors, bias and column-sum rows) is fetched one tile ahead, right after the previous tile's stores were
-//               issued: loads and stores share vmcnt and return in order, so a load issued between stores would wait for them.
+//               that one's fragment reads fly under the other's MFMAs (tile 69 had one and lost for it).  When an output tile is
+//               finished they apply what needs the fp32 accumulator — the LayerNorm fold rstd * (acc - mean * colsum), bias, alpha —
+//               in the accumulator layout and write the tile to the slab ROUNDED TO THE 16-BIT STORAGE TYPE.  That rounding is the
+//               reference's own: in its bf16 / fp16 runs a Linear's output is a 16-bit tensor before the residual add or the GEGLU
+//               that follows (attention.py:1188-1201, activations.py:100-103); gemm_conv_kernel's fp32 slabs round once, later.
+//               A 16-bit slab is 42 KB instead of 82: the ring beside it is THREE deep again (two K tiles in flight, as in the
+//               warp-specialised tiles) — with the fp32 slab of the first version the two-deep ring ran 1540 clocks per K tile;
+//   waves 8-11  staging: LDS-DMA of the A (128 x 128 B) and W (160 x 128 B) tiles, counted vmcnt, one barrier per K tile, running
+//               through all the block's output tiles without a drain;
+//   waves 12-15 epilogue: (row, 8 columns) items of the slab -> residual add, SiLU / GEGLU, cast, 16-byte stores.  The GEGLU of a
+//               K = 320 tile is as much vector work as its main loop is matrix work (measured: 85 us of epilogue alone on four waves
+//               against 59 us of main loop for the 64 x 64 feed-forward), so the compute waves take 16 of a tile's 40 chunks,
+//               one per barrier interval, behind their MFMAs.
+// No wave that stores ever WAITS for a global load issued after one of its stores: loads and stores share vmcnt and return in order,
+// so that wait is a wait for the store's round trip — and hipcc places the wait for a conditionally loaded value behind the join of
+// the branches even on the path that loaded nothing (measured on the first version: 2.5 us per chunk).  Residual vectors are fetched a
+// tile ahead and handed to the compiler as asm-defined values; bias and column-sum rows come through LDS; the chunk code has no
+// global load on any path.
 //
 // Every wave arrives at every barrier.  Barrier #g (g = 0 .. G - 1, G = tiles x K tiles) means "K tile g has landed and K tile g - 1
-// is no longer read"; the slab of output tile j is written before barrier #(last(j) + 1) and read between barriers #(last(j) + 1)
-// and #(last(j) + nkt) — the compute waves write the next slab only after the latter.  After barrier #G all waves share the last slab.
+// is no longer read"; interval g lies between barriers #g and #(g + 1).  Output tile j is multiplied during intervals j nkt ..
+// (j + 1) nkt - 1; its accumulators are written to the slab at the START of interval (j + 1) nkt (the LayerNorm statistics of the
+// block's rows, gathered from the A tiles of output tile 0 as they pass through LDS, are complete by then), read during the
+// nkt - 1 intervals that follow, and the next tile overwrites the slab at the start of interval (j + 2) nkt.  After barrier #G the
+// compute waves write the last slab and all sixteen waves share it.
 #include <hip/hip_runtime.h>
 
 #include "gemm_conv_kernel.h"
@@ -30,96 +43,66 @@ namespace mfgemm {
 
 namespace {
 
-constexpr int PB_BM = 128, PB_BN = 160, PB_STAGES = 2;
+constexpr int PB_BM = 128, PB_BN = 160, PB_STAGES = 3, PB_PF = PB_STAGES - 1;
 constexpr int PB_STAGE_BYTES = (PB_BM + PB_BN) * 128;               // 36 KB: [A tile 128 rows][W tile 160 rows], 128 bytes of K per row
-constexpr int PB_SLAB_RS = (PB_BN + 4) * 4;                         // slab row stride (bytes): 160 fp32 + 16 bytes (bank spread)
-constexpr int PB_SLAB_OFF = PB_STAGES * PB_STAGE_BYTES;             // 73728
-constexpr int PB_LNST_OFF = PB_SLAB_OFF + PB_BM * PB_SLAB_RS;       // + 83968
-constexpr int PB_EROW_OFF = PB_LNST_OFF + PB_BM * 8;                // + 1024: per epilogue wave [bias row][column-sum row], 160 fp32 each
+constexpr int PB_SLAB_RS = PB_BN * 2 + 16;                          // slab row stride (bytes): 160 16-bit values + 16 bytes
+constexpr int PB_SLAB_OFF = PB_STAGES * PB_STAGE_BYTES;             // 110592
+constexpr int PB_LNST_OFF = PB_SLAB_OFF + PB_BM * PB_SLAB_RS;       // + 43008
+constexpr int PB_EROW_OFF = PB_LNST_OFF + PB_BM * 8;                // + 1024: two buffers (output tile parity) of [bias row][column-sum row], 160 fp32 each
 constexpr int PB_EROW_BYTES = 2 * PB_BN * 4;
-constexpr int PB_SMEM = PB_EROW_OFF + 4 * PB_EROW_BYTES;            // 163840 = all 160 KB
+constexpr int PB_SMEM = PB_EROW_OFF + 2 * PB_EROW_BYTES;            // 157184
 static_assert(PB_SMEM <= 160 * 1024, "LDS");
 constexpr int PB_CPR = PB_BN / 8;                                   // 20 (row, 8-column) items per row
 constexpr int PB_CHUNKS = PB_BM * PB_CPR / 64;                      // 40 chunks of 64 items per output tile
-constexpr int PB_CPW = PB_CHUNKS / 4;                               // 10 per epilogue wave
+constexpr int PB_CE = 6, PB_CC = 2;                                 // chunks per epilogue wave / per compute wave
+static_assert(4 * PB_CE + 8 * PB_CC == PB_CHUNKS, "chunk ownership covers the slab");
 
-// The epilogue of one (row, 8 columns) item with NO global load in it — not even on a path that is never taken: hipcc places the wait
-// for a conditionally loaded value behind the join of the branches, as vmcnt(0), and since loads and stores share that counter every
-// item would then wait for the previous item's store to come back (measured: 2.5 us per chunk, 740 us for a 125 us GEMM, with
-// epilogue_store8's `if (p.rs) ... if (p.temb) ...` ladder in the chunk code).  Bias comes from the wave's LDS row (zeros when the
-// call has none), the 16-bit residual from registers fetched a tile ahead; the host refuses everything else for this tile.
-template <bool F16, bool RES, bool GEGLU, bool LN>
-__device__ __forceinline__ void pers_store8(const GemmArgs& p, int m, int n, const char* sp, const char* eb, const char* ec, float2 st, const uint4& q0) {
-    // sp: the item's 8 fp32 accumulators in the slab; eb / ec: its 8 bias values / 8 LayerNorm column sums in the wave's LDS rows;
-    // st: (mean, rstd) of its row.  Worked in two halves of four columns so that at most a dozen values are live beside the
-    // prefetched residual vectors (the RES variants sit at the 128-register budget of a sixteen-wave block).
-    float v[8];
-    uint32_t pk[4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float4 a = *reinterpret_cast<const float4*>(sp + 16 * h);
-        const float4 b = *reinterpret_cast<const float4*>(eb + 16 * h);
-        float x[4] = {a.x, a.y, a.z, a.w};
-        if constexpr (LN) {                                          // rstd * (acc - mean * colsum)
-            const float4 c = *reinterpret_cast<const float4*>(ec + 16 * h);
-            x[0] = st.y * (x[0] - st.x * c.x); x[1] = st.y * (x[1] - st.x * c.y); x[2] = st.y * (x[2] - st.x * c.z); x[3] = st.y * (x[3] - st.x * c.w);
-        }
-        x[0] = (x[0] + b.x) * p.alpha; x[1] = (x[1] + b.y) * p.alpha; x[2] = (x[2] + b.z) * p.alpha; x[3] = (x[3] + b.w) * p.alpha;
-        if constexpr (RES) {
-            float r0, r1, r2, r3;
-            unpack_h2<F16>(h ? q0.z : q0.x, r0, r1);
-            unpack_h2<F16>(h ? q0.w : q0.y, r2, r3);
-            x[0] += r0; x[1] += r1; x[2] += r2; x[3] += r3;
-        }
-        if (!GEGLU && p.act == MF_ACT_SILU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = silu_precise(x[j]);
-        }
-        if constexpr (GEGLU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * h + j] = x[j];
-        } else if (p.out_dt == MF_F32) {
-            *reinterpret_cast<float4*>(p.out + ((int64_t)m * p.ldc + n + 4 * h) * 4) = make_float4(x[0], x[1], x[2], x[3]);
-        } else {
-            pk[2 * h] = pack_h2<F16>(x[0], x[1]);
-            pk[2 * h + 1] = pack_h2<F16>(x[2], x[3]);
-        }
-    }
+// One (row, 8 columns) item: 16 bytes of the slab -> [+ residual] -> [SiLU | GEGLU] -> 16 (GEGLU: 8) bytes of output.  No global load.
+template <bool F16, bool RES, bool GEGLU>
+__device__ __forceinline__ void pers_item(const GemmArgs& p, int m, int n, const char* sp, const uint4& q) {
+    const uint4 s = *reinterpret_cast<const uint4*>(sp);
     if constexpr (GEGLU) {
         // weight rows are interleaved [4 values | 4 gates]: out[n/2 + j] = v[j] * gelu_erf(v[4 + j])  (activations.py:100-103); erf by
-        // Abramowitz-Stegun 7.1.26 for a 16-bit output, erff for fp32: epilogue_store8's arithmetic, instruction for instruction
-        float g[4];
-        if (p.out_dt != MF_F32) {
+        // Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): epilogue_store8's arithmetic for a 16-bit output
+        float v[8], g[4];
+        unpack_h8<F16>(s, v);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x = v[4 + j];
-                const float z = fabsf(x) * 0.70710678118654752440f;
-                const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-                const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-                const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-                g[j] = v[j] * (0.5f * x + 0.5f * fabsf(x) * e);
+        for (int j = 0; j < 4; ++j) {
+            const float x = v[4 + j];
+            const float z = fabsf(x) * 0.70710678118654752440f;
+            const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+            const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+            const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+            g[j] = v[j] * (0.5f * x + 0.5f * fabsf(x) * e);
+        }
+        uint2 u;
+        u.x = pack_h2<F16>(g[0], g[1]);
+        u.y = pack_h2<F16>(g[2], g[3]);
+        *reinterpret_cast<uint2*>(p.out + ((int64_t)m * p.ldc + (n >> 1)) * 2) = u;
+    } else {
+        uint4 o = s;
+        if (RES || p.act == MF_ACT_SILU) {
+            float v[8];
+            unpack_h8<F16>(s, v);
+            if constexpr (RES) {
+                float r[8];
+                unpack_h8<F16>(q, r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += r[j];
             }
-        } else {
+            if (p.act == MF_ACT_SILU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = v[j] * (0.5f * v[4 + j] * (1.0f + erff(v[4 + j] * 0.70710678118654752440f)));
+                for (int j = 0; j < 8; ++j) v[j] = silu_precise(v[j]);
+            }
+            o = pack_h8<F16>(v);
         }
-        const int64_t o = (int64_t)m * p.ldc + (n >> 1);
-        if (p.out_dt == MF_F32) {
-            *reinterpret_cast<float4*>(p.out + o * 4) = make_float4(g[0], g[1], g[2], g[3]);
-        } else {
-            uint2 u;
-            u.x = pack_h2<F16>(g[0], g[1]);
-            u.y = pack_h2<F16>(g[2], g[3]);
-            *reinterpret_cast<uint2*>(p.out + o * 2) = u;
-        }
-    } else if (p.out_dt != MF_F32) {
-        *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldc + n) * 2) = uint4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<uint4*>(p.out + ((int64_t)m * p.ldc + n) * 2) = o;
     }
 }
 
-// RES / GEGLU / LN: compile-time properties of the call (16-bit residual fetched ahead; GEGLU epilogue; folded LayerNorm).  One kernel
-// with run-time flags keeps the live ranges of all three in one register allocation — 40 registers of residual vectors beside the
-// GEGLU temporaries spilled, and a spill reload in the chunk code is a scratch LOAD behind the stores: the wait this file is about.
+// RES / GEGLU / LN: compile-time properties of the call (16-bit residual fetched ahead; GEGLU epilogue; folded LayerNorm): with
+// run-time flags the live ranges of all three share one register allocation and the chunk code spills — a scratch reload there is
+// a global load behind the stores, the very wait this file is about.
 template <int DT, bool RES, bool GEGLU, bool LN>
 __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -138,6 +121,30 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
     const int nkt = p.nkt, G = p.nloop * nkt;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)smem);
     float2* lnst = reinterpret_cast<float2*>(smem + PB_LNST_OFF);    // (mean, rstd) of the block's rows (folded LayerNorm)
+    const int dbg = p.dbg_epi;      // developer switches (MFHIP_DBG_EPI): 1 no chunk work, 2 no fragment reads / MFMAs, 4 no DMA — garbage results, same barriers
+
+    // ---- chunks of the slab: who owns which, and the work on one ------------------------------------------------------------------
+    // chunk c = 64 items, item it = 64 c + lane = (row it / 20, column group it % 20).  Epilogue wave e owns chunks 6 e .. 6 e + 5,
+    // compute wave w owns 24 + 2 w and 25 + 2 w.  A wave's chunks of output tile j are worked on in the intervals after the slab was
+    // published; their 16-bit residual vectors were requested one tile earlier.
+    auto item_coords = [&](int c, int& row, int& cg) {
+        int it = c * 64 + lane;
+        asm volatile("" : "+v"(it));                                 // opaque: keeps the per-chunk address chains out of the loop-invariant hoist (they spilled)
+        row = it / PB_CPR;
+        cg = it - row * PB_CPR;
+    };
+    auto do_chunk = [&](int c, int n0, const uint4& qv) {
+        int row, cg;
+        item_coords(c, row, cg);
+        uint4 q = qv;
+        if constexpr (RES) asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));   // opaque: the unpacking of all prefetched vectors was hoisted out of the loop (80 registers)
+        pers_item<F16, RES, GEGLU>(p, m0 + row, n0 + cg * 8, smem + PB_SLAB_OFF + row * PB_SLAB_RS + cg * 16, q);
+    };
+    auto fetch_res = [&](int c, int n0) -> uint4 {
+        int row, cg;
+        item_coords(c, row, cg);
+        return *reinterpret_cast<const uint4*>(p.res0 + ((int64_t)(m0 + row) * p.ld_res0 + n0 + cg * 8) * 2);
+    };
 
     if (role == 1) {
         // ---- staging waves: A tile 16 DMAs of 8 rows (four per wave), W tile 20 (five per wave), swizzle applied to the SOURCE chunk ----
@@ -158,23 +165,31 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
         const unsigned wstep = (unsigned)PB_BN * (unsigned)(p.ldw * 2);           // one output tile further
         int i_kt = 0, i_st = 0;
         unsigned wbase = 0;
-        const bool dbg_nodma = (p.dbg_epi & 4) != 0;                 // developer switch (MFHIP_DBG_EPI=4): no DMA — what the loop costs without its loads
+        const bool nodma = (dbg & 4) != 0;
         auto issue = [&]() {
             const unsigned ldsS = lds0 + i_st * PB_STAGE_BYTES;
-            if (dbg_nodma) { i_st ^= 1; if (++i_kt == nkt) { i_kt = 0; wbase += wstep; } return; }
+            if (!nodma) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dma16_buf(offA[i] + i_kt * 128, sA, ldsS + ((4 * rw + i) * 8) * 128);
+                for (int i = 0; i < 4; ++i) dma16_buf(offA[i] + i_kt * 128, sA, ldsS + ((4 * rw + i) * 8) * 128);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) dma16_buf(offW[i] + wbase + i_kt * 128, sW, ldsS + PB_BM * 128 + ((5 * rw + i) * 8) * 128);
-            i_st ^= 1;
+                for (int i = 0; i < 5; ++i) dma16_buf(offW[i] + wbase + i_kt * 128, sW, ldsS + PB_BM * 128 + ((5 * rw + i) * 8) * 128);
+            }
+            i_st = i_st == PB_STAGES - 1 ? 0 : i_st + 1;
             if (++i_kt == nkt) { i_kt = 0; wbase += wstep; }
         };
-        issue();                                                     // K tile 0
-        wait_vmcnt<0>();
+        auto wait_newer = [&](int newer) {                           // all of this wave's DMAs but those of the `newer` youngest tiles have landed
+            if (newer >= 2) wait_vmcnt<18>();
+            else if (newer == 1) wait_vmcnt<9>();
+            else wait_vmcnt<0>();
+        };
+        static_assert(PB_PF <= 2, "wait_newer covers 0 .. 2 younger tiles");
+        for (int k = 0; k < PB_PF && k < G; ++k) issue();
+        wait_newer((G < PB_PF ? G : PB_PF) - 1);
         __builtin_amdgcn_s_barrier();                                // #0
         for (int g = 0; g + 1 < G; ++g) {
-            issue();                                                 // K tile g + 1 into the stage tile g - 1 has left
-            wait_vmcnt<0>();
+            if (g + PB_PF < G) issue();                              // K tile g + PB_PF into the stage of tile g - 1
+            const int youngest = g + PB_PF < G ? g + PB_PF : G - 1;
+            wait_newer(youngest - (g + 1));
             __builtin_amdgcn_s_barrier();                            // #(g + 1)
         }
         __builtin_amdgcn_s_barrier();                                // #G
@@ -187,114 +202,154 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 5; ++b) acc[a][b] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-        int st = 0, kt = 0;
-        __builtin_amdgcn_s_barrier();                                // #0
-        const bool dbg_nomma = (p.dbg_epi & 2) != 0;                 // developer switch (MFHIP_DBG_EPI=2): no fragment reads / MFMAs
-        for (int g = 0; g < G; ++g) {
-            if (dbg_nomma) {
-                st ^= 1;
-                if (++kt == nkt) kt = 0;
-                __builtin_amdgcn_s_barrier();
-                continue;
-            }
-            const char* A16 = smem + st * PB_STAGE_BYTES + (wm * 32 + r16) * 128;
-            const char* B16 = smem + st * PB_STAGE_BYTES + PB_BM * 128 + (wn * 80 + r16) * 128;
-            uint4 fa[2][2], fb[2][5];
+        // The products are taken TRANSPOSED — the W fragment is the MFMA's A operand, the activation fragment its B operand (both are
+        // read the same way: row r16, k chunk kg) — so that element r of acc[a][b] is row 16 a + r16, COLUMN 16 b + 4 kg + r of the wave
+        // tile: a lane holds four consecutive output channels of one pixel, i.e. 8 contiguous bytes of the 16-bit slab.  (With the usual
+        // order a lane holds four rows of one column and the slab write is 2-byte stores or a lane-pair exchange with selects: measured
+        // 1.3 us per output tile on the two compute waves of a SIMD, half of a K = 320 tile's main loop.)
+        // accumulators -> slab; `jt`: the output tile (relative to nt0) they belong to: its bias / column-sum rows sit in row buffer jt & 1.
+        auto dump = [&](int jt) {
+            const char* er = smem + PB_EROW_OFF + (jt & 1) * PB_EROW_BYTES;
+            const float alpha = p.alpha;
+            float2 rst[2];                                           // (mean, rstd) of this lane's two rows
+            if constexpr (LN) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a) fa[ks][a] = *reinterpret_cast<const uint4*>(A16 + a * 16 * 128 + (((4 * ks + kg) ^ key16) << 4));
-#pragma unroll
-                for (int b = 0; b < 5; ++b) fb[ks][b] = *reinterpret_cast<const uint4*>(B16 + b * 16 * 128 + (((4 * ks + kg) ^ key16) << 4));
+                for (int a = 0; a < 2; ++a) rst[a] = lnst[wm * 32 + 16 * a + r16];
             }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int b = 0; b < 5; ++b) {
+                const int col = wn * 80 + 16 * b + 4 * kg;
+                const float4 bias = *reinterpret_cast<const float4*>(er + col * 4);
+                float4 cs = make_float4(0, 0, 0, 0);
+                if constexpr (LN) cs = *reinterpret_cast<const float4*>(er + PB_BN * 4 + col * 4);
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 5; ++b)
-                        acc[a][b] = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, fa[ks][a]), __builtin_bit_cast(bf16x8_t, fb[ks][b]), acc[a][b], 0, 0, 0);
-            st ^= 1;
-            if (++kt == nkt) {
-                // output tile finished: accumulators -> slab (element r of acc[a][b]: row 16 a + 4 kg + r, column 16 b + r16 of the wave tile).
-                // The epilogue waves finished the previous slab before they arrived at barrier #g (see the header).
-                kt = 0;
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 5; ++b) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            *reinterpret_cast<float*>(smem + PB_SLAB_OFF + (wm * 32 + 16 * a + 4 * kg + r) * PB_SLAB_RS + (wn * 80 + 16 * b + r16) * 4) = acc[a][b][r];
-                        acc[a][b] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int a = 0; a < 2; ++a) {
+                    float x[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                    if constexpr (LN) {                              // rstd * (acc - mean * colsum)
+                        x[0] = rst[a].y * (x[0] - rst[a].x * cs.x); x[1] = rst[a].y * (x[1] - rst[a].x * cs.y);
+                        x[2] = rst[a].y * (x[2] - rst[a].x * cs.z); x[3] = rst[a].y * (x[3] - rst[a].x * cs.w);
                     }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): fragment reads (and slab writes) of this step are complete
-            __builtin_amdgcn_s_barrier();                            // #(g + 1)
-        }
-    } else {
-        // ---- epilogue waves ------------------------------------------------------------------------------------------------------------
-        char* erow = smem + PB_EROW_OFF + rw * PB_EROW_BYTES;        // this wave's own [bias][column sums] rows of the tile it works on
-        constexpr bool pre = RES;                                    // 16-bit residual vectors are fetched a tile ahead
-        uint4 q0[RES ? PB_CPW : 1];
-        float4 pb = make_float4(0, 0, 0, 0), pc = make_float4(0, 0, 0, 0);   // lanes 0-39: four bias / column-sum values of the NEXT tile
-        // requests for output tile `jt` (relative to nt0): residual vectors of this wave's ten chunks, bias and column-sum rows
-        auto prefetch = [&](int jt) {
-            const int n0 = (nt0 + jt) * PB_BN;
-            if constexpr (pre) {
-#pragma unroll
-                for (int i = 0; i < PB_CPW; ++i) {
-                    int it = (rw + 4 * i) * 64 + lane;
-                    asm volatile("" : "+v"(it));                     // opaque: keeps the ten address chains out of the loop-invariant hoist (they spilled)
-                    const int row = it / PB_CPR, cg = it - row * PB_CPR;
-                    q0[i] = *reinterpret_cast<const uint4*>(p.res0 + ((int64_t)(m0 + row) * p.ld_res0 + n0 + cg * 8) * 2);
+                    x[0] = (x[0] + bias.x) * alpha; x[1] = (x[1] + bias.y) * alpha; x[2] = (x[2] + bias.z) * alpha; x[3] = (x[3] + bias.w) * alpha;
+                    uint2 h;
+                    h.x = pack_h2<F16>(x[0], x[1]);
+                    h.y = pack_h2<F16>(x[2], x[3]);
+                    *reinterpret_cast<uint2*>(smem + PB_SLAB_OFF + (wm * 32 + 16 * a + r16) * PB_SLAB_RS + col * 2) = h;
+                    acc[a][b] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
-            if (lane < PB_BN / 4) {
+        };
+        uint4 q[RES ? PB_CC : 1];
+        auto prefetch = [&](int jt) {                                // residual vectors of this wave's chunks of output tile jt
+            if constexpr (RES) {
+                const int n0 = (nt0 + jt) * PB_BN;
+#pragma unroll
+                for (int i = 0; i < PB_CC; ++i) q[i] = fetch_res(4 * PB_CE + PB_CC * rw + i, n0);
+            }
+        };
+        if (p.nloop > 1) prefetch(0);
+        const int avail = nkt - 1, per = (PB_CC + avail - 1) / avail;          // intervals a slab is readable for (nkt >= 2: host check); chunks per interval
+        int st = 0, kt = 0, jt = 0, pend_n0 = -1, done = 0;          // jt: the output tile interval g belongs to
+        const bool nomma = (dbg & 2) != 0;
+        __builtin_amdgcn_s_barrier();                                // #0
+        for (int g = 0; g < G; ++g) {
+            const bool dumping = kt == 0 && g > 0;                   // the first interval of output tile jt: tile jt - 1's accumulators leave
+            if (dumping) dump(jt - 1);
+            if (!nomma) {
+                const char* A16 = smem + st * PB_STAGE_BYTES + (wm * 32 + r16) * 128;
+                const char* B16 = smem + st * PB_STAGE_BYTES + PB_BM * 128 + (wn * 80 + r16) * 128;
+                uint4 fa[2][2], fb[2][5];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) fa[ks][a] = *reinterpret_cast<const uint4*>(A16 + a * 16 * 128 + (((4 * ks + kg) ^ key16) << 4));
+#pragma unroll
+                    for (int b = 0; b < 5; ++b) fb[ks][b] = *reinterpret_cast<const uint4*>(B16 + b * 16 * 128 + (((4 * ks + kg) ^ key16) << 4));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 5; ++b)
+                            acc[a][b] = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, fb[ks][b]), __builtin_bit_cast(bf16x8_t, fa[ks][a]), acc[a][b], 0, 0, 0);   // transposed: see dump
+            }
+            st = st == PB_STAGES - 1 ? 0 : st + 1;
+            // this wave's share of the previous tile's slab, behind the MFMAs (issued, not yet retired: the vector work overlaps them)
+            if (pend_n0 >= 0 && !dumping) {
+                if (done == 0) {
+                    if constexpr (RES) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the prefetch has landed (this wave's last store is a tile old) ...
+#pragma unroll
+                        for (int i = 0; i < PB_CC; ++i) asm volatile("" : "+v"(q[i].x), "+v"(q[i].y), "+v"(q[i].z), "+v"(q[i].w));   // ... and the compiler need not wait for it again, behind a store
+                    }
+                }
+#pragma unroll 1
+                for (int i = 0; i < per && done < PB_CC; ++i, ++done) {
+                    if (dbg & 1) continue;
+                    if (done == 0) do_chunk(4 * PB_CE + PB_CC * rw, pend_n0, q[0]);
+                    else do_chunk(4 * PB_CE + PB_CC * rw + 1, pend_n0, q[RES ? 1 : 0]);
+                }
+                if (done == PB_CC) {
+                    pend_n0 = -1;
+                    if (jt < p.nloop - 1) prefetch(jt);              // of the tile being multiplied now; behind this tile's stores, waited for a tile later
+                }
+            }
+            if (dumping) { pend_n0 = (nt0 + jt - 1) * PB_BN; done = 0; }          // readable from the next interval on
+            if (++kt == nkt) { kt = 0; ++jt; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): fragment reads, slab writes and slab reads of this step are complete
+            __builtin_amdgcn_s_barrier();                            // #(g + 1)
+        }
+        dump(p.nloop - 1);                                           // the last tile: its LayerNorm statistics / rows are in place since barrier #G
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    } else {
+        // ---- epilogue waves ------------------------------------------------------------------------------------------------------------
+        uint4 q[RES ? PB_CE : 1];
+        float4 pb = make_float4(0, 0, 0, 0), pc = make_float4(0, 0, 0, 0);   // wave 12, lanes 0-39: four bias / column-sum values of a later tile
+        const bool rows_duty = rw == 0 && (p.bias != nullptr || LN);
+        auto prefetch = [&](int jt) {                                // residual vectors of this wave's chunks of output tile jt
+            if constexpr (RES) {
+                const int n0 = (nt0 + jt) * PB_BN;
+#pragma unroll
+                for (int i = 0; i < PB_CE; ++i) q[i] = fetch_res(PB_CE * rw + i, n0);
+            }
+        };
+        auto fetch_rows = [&](int jt) {                              // (wave 12) bias and column-sum rows of output tile jt -> registers
+            if (rows_duty && lane < PB_BN / 4) {
+                const int n0 = (nt0 + jt) * PB_BN;
                 if (p.bias) pb = *reinterpret_cast<const float4*>(p.bias + n0 + lane * 4);
                 if constexpr (LN) pc = *reinterpret_cast<const float4*>(p.ln_cs + n0 + lane * 4);
             }
         };
-        // the prefetched rows of the tile about to be worked on -> this wave's LDS rows (wave-private: no barrier)
-        auto publish_rows = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the prefetch (and, behind it in program order, nothing else) has landed
-            // ... and the compiler is told so: it tracks a load's destination registers as pending until a wait IT placed, and a wait
-            // before the first use of q0[i] inside chunk i would be a vmcnt(0) behind chunk i - 1's store.  Passing the registers
-            // through an empty asm makes them values defined here.
-            if constexpr (RES) {
-#pragma unroll
-                for (int i = 0; i < PB_CPW; ++i) asm volatile("" : "+v"(q0[i].x), "+v"(q0[i].y), "+v"(q0[i].z), "+v"(q0[i].w));
+        auto publish_rows = [&](int jt) {                            // (wave 12) ... -> row buffer jt & 1 (the caller has waited for them)
+            if (rw == 0 && lane < PB_BN / 4) {
+                char* er = smem + PB_EROW_OFF + (jt & 1) * PB_EROW_BYTES;
+                *reinterpret_cast<float4*>(er + lane * 16) = pb;
+                *reinterpret_cast<float4*>(er + PB_BN * 4 + lane * 16) = pc;
             }
-            if (lane < PB_BN / 4) {
-                *reinterpret_cast<float4*>(erow + lane * 16) = pb;
-                *reinterpret_cast<float4*>(erow + PB_BN * 4 + lane * 16) = pc;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
         };
-        auto do_chunk = [&](int i, int n0) {
-            int it = (rw + 4 * i) * 64 + lane;
-            asm volatile("" : "+v"(it));                             // opaque (see prefetch)
-            const int row = it / PB_CPR, cg = it - row * PB_CPR;
-            const int m = m0 + row, n = n0 + cg * 8;
-            const char* sp = smem + PB_SLAB_OFF + row * PB_SLAB_RS + cg * 32;
-            float2 st = make_float2(0.0f, 1.0f);
-            if constexpr (LN) st = lnst[row];
-            uint4 q = q0[RES ? i : 0];
-            if constexpr (RES) asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));   // opaque: the bf16 -> fp32 unpacking of all ten vectors was hoisted out of the chunk loop (80 registers)
-            pers_store8<F16, RES, GEGLU, LN>(p, m, n, sp, erow + cg * 32, erow + PB_BN * 4 + cg * 32, st, q);
-        };
-        if (p.nloop > 1) prefetch(0);
-        const int cpi = (PB_CPW + nkt - 2) / (nkt - 1);              // chunks per barrier interval (nkt >= 2: host check)
-        int pending_n0 = -1, done = 0, kt = 0, jt = 0;
-        __builtin_amdgcn_s_barrier();                                // #0
+        // rows of output tiles 0 and 1 before the first barrier (the first dump is nkt barriers away); tile j + 2's rows are published
+        // while tile j's slab is worked on (its dump has read buffer j & 1 by then) and requested one tile before that
+        fetch_rows(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish_rows(0);
+        if (p.nloop > 1) {
+            fetch_rows(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publish_rows(1);
+            if (p.nloop > 2) fetch_rows(2);
+            prefetch(0);
+        }
         // folded LayerNorm: (sum, sum of squares) of the block's 128 rows, taken from the A tiles as they pass through LDS during the
         // first output tile's K steps (no global load in these waves): 32 rows per wave, two lanes per row, 64 bytes each per K tile
         float ls1 = 0.0f, ls2 = 0.0f;
         const int lrow = rw * 32 + (lane >> 1), lhalf = lane & 1;
+        const int avail = nkt - 1, per = (PB_CE + avail - 1) / avail;
+        int pend_n0 = -1, pend_jt = 0, done = 0, kt = 0, jt = 0, st = 0;       // jt: the output tile interval g belongs to
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();                                // #0
         for (int g = 0; g < G; ++g) {
             if (LN && g < nkt) {
-                const char* ar = smem + (g & 1) * PB_STAGE_BYTES + lrow * 128 + lhalf * 64;      // (the swizzle permutes a row's chunks: a sum does not care)
+                const char* ar = smem + st * PB_STAGE_BYTES + lrow * 128 + lhalf * 64;      // (the swizzle permutes a row's chunks: a sum does not care)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float x[8];
@@ -310,51 +365,55 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
                     if (lhalf == 0) lnst[lrow] = make_float2(mean, 1.0f / sqrtf(var + p.ln_eps));
                 }
             }
-            if (pending_n0 >= 0 && (p.dbg_epi & 1)) pending_n0 = -1;     // developer switch (MFHIP_DBG_EPI=1): the epilogue waves only keep the barriers
-            if (pending_n0 >= 0) {
-                if (done == 0) publish_rows();
-#pragma unroll 1
-                for (int i = 0; i < cpi && done < PB_CPW; ++i, ++done) {
-                    // (a switch keeps q0[] in registers: the chunk index must be a compile-time constant)
-                    switch (done) {
-                        case 0: do_chunk(0, pending_n0); break; case 1: do_chunk(1, pending_n0); break;
-                        case 2: do_chunk(2, pending_n0); break; case 3: do_chunk(3, pending_n0); break;
-                        case 4: do_chunk(4, pending_n0); break; case 5: do_chunk(5, pending_n0); break;
-                        case 6: do_chunk(6, pending_n0); break; case 7: do_chunk(7, pending_n0); break;
-                        case 8: do_chunk(8, pending_n0); break; default: do_chunk(9, pending_n0); break;
+            st = st == PB_STAGES - 1 ? 0 : st + 1;
+            if (pend_n0 >= 0) {
+                if (done == 0) {
+                    if (RES || rows_duty) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // residual vectors / rows requested a tile ago (this wave's last store is older still)
+                    if constexpr (RES) {
+#pragma unroll
+                        for (int i = 0; i < PB_CE; ++i) asm volatile("" : "+v"(q[i].x), "+v"(q[i].y), "+v"(q[i].z), "+v"(q[i].w));
+                    }
+                    if (pend_jt + 2 < p.nloop) {                     // rows of tile pend_jt + 2 into the buffer tile pend_jt's dump has read
+                        asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w), "+v"(pc.x), "+v"(pc.y), "+v"(pc.z), "+v"(pc.w));
+                        publish_rows(pend_jt + 2);
+                        if (pend_jt + 3 < p.nloop) fetch_rows(pend_jt + 3);
                     }
                 }
-                if (done == PB_CPW) {
-                    pending_n0 = -1;
-                    if (jt < p.nloop - 1) prefetch(jt);              // operands of the tile being multiplied now, behind this tile's stores (the last tile's slab is shared by all waves below)
+#pragma unroll 1
+                for (int i = 0; i < per && done < PB_CE; ++i, ++done) {
+                    if (dbg & 1) continue;
+                    // (a switch keeps q[] in registers: the chunk index must be a compile-time constant)
+                    switch (done) {
+                        case 0: do_chunk(PB_CE * rw + 0, pend_n0, q[0]); break;
+                        case 1: do_chunk(PB_CE * rw + 1, pend_n0, q[RES ? 1 : 0]); break;
+                        case 2: do_chunk(PB_CE * rw + 2, pend_n0, q[RES ? 2 : 0]); break;
+                        case 3: do_chunk(PB_CE * rw + 3, pend_n0, q[RES ? 3 : 0]); break;
+                        case 4: do_chunk(PB_CE * rw + 4, pend_n0, q[RES ? 4 : 0]); break;
+                        default: do_chunk(PB_CE * rw + 5, pend_n0, q[RES ? 5 : 0]); break;
+                    }
+                }
+                if (done == PB_CE) {
+                    pend_n0 = -1;
+                    if (pend_jt + 1 < p.nloop - 1) prefetch(pend_jt + 1);      // behind this tile's stores, waited for a tile later
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                      // the slab reads issued so far have returned
+            __builtin_amdgcn_s_waitcnt(0xc07f);                      // the LDS reads / writes issued so far are complete
             __builtin_amdgcn_s_barrier();                            // #(g + 1)
-            if (++kt == nkt) {                                       // the compute waves wrote output tile jt's slab before this barrier
-                kt = 0;
-                if (g + 1 < G) { pending_n0 = (nt0 + jt) * PB_BN; done = 0; }
-                ++jt;
-            }
+            // the compute waves wrote output tile jt - 1's slab during this interval when it was the first of tile jt: readable from the next on
+            if (kt == 0 && jt > 0) { pend_n0 = (nt0 + jt - 1) * PB_BN; pend_jt = jt - 1; done = 0; }
+            if (++kt == nkt) { kt = 0; ++jt; }
         }
     }
-    // ---- the last slab: all sixteen waves (plain loads of the epilogue operands: nothing left to hide them under) ----------------------
+    // ---- the last slab: all sixteen waves (plain loads of the residual: nothing left to hide them under) --------------------------------
+    __builtin_amdgcn_s_barrier();                                    // the compute waves' last dump is in the slab
     {
         const int n0 = (nt0 + p.nloop - 1) * PB_BN;
         for (int c = wave; c < PB_CHUNKS; c += 16) {
-            const int it = c * 64 + lane;
-            const int row = it / PB_CPR, cg = it - row * PB_CPR;
-            const int m = m0 + row, n = n0 + cg * 8;
-            const char* sp = smem + PB_SLAB_OFF + row * PB_SLAB_RS + cg * 32;
-            float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 16);
-            if (p.ln_cs) {
-                const float2 st = lnst[row];
-                const float4 c0 = *reinterpret_cast<const float4*>(p.ln_cs + n), c1 = *reinterpret_cast<const float4*>(p.ln_cs + n + 4);
-                lo.x = st.y * (lo.x - st.x * c0.x); lo.y = st.y * (lo.y - st.x * c0.y); lo.z = st.y * (lo.z - st.x * c0.z); lo.w = st.y * (lo.w - st.x * c0.w);
-                hi.x = st.y * (hi.x - st.x * c1.x); hi.y = st.y * (hi.y - st.x * c1.y); hi.z = st.y * (hi.z - st.x * c1.z); hi.w = st.y * (hi.w - st.x * c1.w);
-            }
-            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            epilogue_store8<F16>(p, 0, m, n, v);
+            int row, cg;
+            item_coords(c, row, cg);
+            uint4 q = uint4{0, 0, 0, 0};
+            if constexpr (RES) q = *reinterpret_cast<const uint4*>(p.res0 + ((int64_t)(m0 + row) * p.ld_res0 + n0 + cg * 8) * 2);
+            if (!(dbg & 1)) pers_item<F16, RES, GEGLU>(p, m0 + row, n0 + cg * 8, smem + PB_SLAB_OFF + row * PB_SLAB_RS + cg * 16, q);
         }
     }
 }

@@ -227,26 +227,43 @@ __global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
 // image.  grid (batch, slices): a block takes a contiguous run of groups; a thread sums one channel's blocks in block order
 // (double), 8 lanes then combine a group's channels in a fixed order — every bit is reproducible.  Writes the per-channel
 // affine y = x * a[c] + b[c] like gn_finalize_kernel.
-__global__ __launch_bounds__(GN_BLK) void gn_finalize_part_kernel(const GnArgs p, int gps) {
+__global__ __launch_bounds__(GN_BLK) void gn_finalize_part_kernel(const GnArgs p, int gps, int kparts) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double2* chan = reinterpret_cast<double2*>(smem_raw);          // [gps * cpg] per-channel (sum, sum of squares) of this image
+    double2* chan = reinterpret_cast<double2*>(smem_raw);          // [kparts][gps * cpg] partial (sum, sum of squares), then row 0 = the totals
     __shared__ float gm[64], gr[64];
     const int b = blockIdx.x, t = threadIdx.x;
     const int g0 = blockIdx.y * gps;
     int g1 = g0 + gps;
     if (g1 > p.G) g1 = p.G;
-    const int c0 = g0 * p.cpg, nc = (g1 - g0) * p.cpg;
-    for (int j = t; j < nc; j += blockDim.x) {
+    const int c0 = g0 * p.cpg, nc = (g1 - g0) * p.cpg, ncmax = gps * p.cpg;
+    // thread (channel j, part kp) sums the blocks kp, kp + kparts, ... of its channel: the launch is latency-bound (the partial sums
+    // come from other XCDs' L2s through the fabric), so the loads of a channel are spread over kparts threads and issued together —
+    // one thread per channel walking 32 blocks measured 11 us, as long as the statistics pass this launch replaces
+    for (int idx = t; idx < nc * kparts; idx += blockDim.x) {
+        const int kp = idx / nc, j = idx - kp * nc;
         const int c = c0 + j;
         const float2* src; int nb; int64_t ld;
         if (c < p.C0) { nb = p.HW / p.pr0; ld = p.C0; src = p.part0 + (int64_t)b * nb * ld + c; }
         else { nb = p.HW / p.pr1; ld = p.C1; src = p.part1 + (int64_t)b * nb * ld + (c - p.C0); }
         double s = 0.0, q = 0.0;
-        for (int k = 0; k < nb; ++k) {
+        int k = kp;
+        for (; k + 3 * kparts < nb; k += 4 * kparts) {             // four independent loads in flight
+            const float2 v0 = src[(int64_t)k * ld], v1 = src[(int64_t)(k + kparts) * ld], v2 = src[(int64_t)(k + 2 * kparts) * ld],
+                         v3 = src[(int64_t)(k + 3 * kparts) * ld];
+            s += (double)v0.x; q += (double)v0.y; s += (double)v1.x; q += (double)v1.y;
+            s += (double)v2.x; q += (double)v2.y; s += (double)v3.x; q += (double)v3.y;
+        }
+        for (; k < nb; k += kparts) {
             const float2 v = src[(int64_t)k * ld];
             s += (double)v.x; q += (double)v.y;
         }
-        chan[j] = make_double2(s, q);
+        chan[kp * ncmax + j] = make_double2(s, q);
+    }
+    __syncthreads();
+    for (int j = t; j < nc; j += blockDim.x) {                     // parts in order: reproducible
+        double s = 0.0, q = 0.0;
+        for (int kp = 0; kp < kparts; ++kp) { const double2 v = chan[kp * ncmax + j]; s += v.x; q += v.y; }
+        chan[j] = make_double2(s, q);                              // (row 0 is written by the thread that read column j of every row)
     }
     __syncthreads();
     {
@@ -654,8 +671,9 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
         }
     }
     // statistics from the producers' partial sums: every present segment has them and their row blocks divide the image
-    const bool from_parts = d->part0 != nullptr && d->part0_rows > 0 && d->hw % d->part0_rows == 0 &&
-                            (d->c1 == 0 || (d->part1 != nullptr && d->part1_rows > 0 && d->hw % d->part1_rows == 0));
+    // (at most 128 partial blocks per image: the finalize launch walks them serially per channel)
+    const bool from_parts = d->part0 != nullptr && d->part0_rows > 0 && d->hw % d->part0_rows == 0 && d->hw / d->part0_rows <= 128 &&
+                            (d->c1 == 0 || (d->part1 != nullptr && d->part1_rows > 0 && d->hw % d->part1_rows == 0 && d->hw / d->part1_rows <= 128));
     a.part0 = (const float2*)d->part0; a.part1 = (const float2*)d->part1; a.pr0 = d->part0_rows; a.pr1 = d->part1_rows;
     if (from_parts) a.fuse_finalize = 0;
     a.cvn = C / vw;
@@ -672,11 +690,20 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     if (rows_per_block < 4 * a.rif) rows_per_block = 4 * a.rif;
     const int nblk = (d->hw + rows_per_block - 1) / rows_per_block;
     static const int gn_u = getenv("MFHIP_GN_UNROLL") ? atoi(getenv("MFHIP_GN_UNROLL")) : 4;      // developer sweep: 4 or 8 rows in flight
-    const int gn_slices = d->groups >= 32 ? 4 : 1, gn_gps = (d->groups + gn_slices - 1) / gn_slices;
+    // finalize from partial sums: 8 slices of the groups per image, and as many threads per channel as the block has room for
+    const int gn_slices = d->groups >= 32 ? 8 : 1, gn_gps = (d->groups + gn_slices - 1) / gn_slices;
+    int gn_kparts = GN_BLK / (gn_gps * a.cpg);
+    {
+        const int nb0 = from_parts ? d->hw / d->part0_rows : 1, nb1 = (from_parts && d->c1) ? d->hw / d->part1_rows : nb0;
+        const int nbmin = nb0 < nb1 ? nb0 : nb1;
+        if (gn_kparts > nbmin) gn_kparts = nbmin;
+        if (gn_kparts < 1) gn_kparts = 1;
+        while ((size_t)gn_kparts * gn_gps * a.cpg * sizeof(double2) > 48 * 1024 && gn_kparts > 1) --gn_kparts;
+    }
 #define MF_GN_LAUNCH(VW_, U_, F_)                                                                                              \
     do {                                                                                                                          \
         if (from_parts) {                                                                                                         \
-            hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(d->batch, gn_slices), dim3(GN_BLK), (size_t)gn_gps * a.cpg * sizeof(double2), s, a, gn_gps); \
+            hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(d->batch, gn_slices), dim3(GN_BLK), (size_t)gn_kparts * gn_gps * a.cpg * sizeof(double2), s, a, gn_gps, gn_kparts); \
             MF_CHECK_LAUNCH("mf_groupnorm(finalize from partial sums)");                                                          \
         } else {                                                                                                                  \
             hipLaunchKernelGGL((gn_stats_kernel<VW_, U_, F_>), dim3(a.nchunks, d->batch), dim3(nthr), smem1, s, a);               \

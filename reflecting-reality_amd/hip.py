@@ -319,6 +319,30 @@ AUTOTUNE = os.environ.get("MFHIP_AUTOTUNE", "1") != "0"
 # profiles/r04_splitk_in_launch.txt) the last-arriver form with an agent-scope release per block is 8-15 us SLOWER than the reduce
 # launch it replaces on every small-M shape of the step (each block's release writes back its XCD's L2: ~45 ns per block, serialised).
 SK_FUSED = os.environ.get("MFHIP_SK_FUSED", "0") == "1"
+# Route the 1x1 GEMMs whose blocks would walk >= 2 output tiles to the persistent tile 70 instead of the cached tile.  A/B switch.
+PREFER_PERS = os.environ.get("MFHIP_PREFER_PERS", "1") != "0"
+PERS_TILE = 70
+PERS_MIN_NLOOP = int(os.environ.get("MFHIP_PERS_MIN_NLOOP", "2"))
+
+
+def _pers_applies(m, n, k, kh, kw, stride, pad_t, pad_l, upsample, h_in, h_out, w_in, w_out, c1, nz, temb, res0, res1, out, a0, bias_mode,
+                  a_scale, w_scale) -> bool:
+    """The call is one tile 70 serves (mf_gemm_conv's own check, gemm_conv.cpp kPersTile) AND its grid gives every block at least
+    PERS_MIN_NLOOP output tiles (the library's range choice: double the column ranges while there are fewer than 256 blocks)."""
+    if not (kh == 1 and kw == 1 and stride == 1 and pad_t == 0 and pad_l == 0 and not upsample and h_in == h_out and w_in == w_out):
+        return False
+    if c1 or nz != 1 or temb is not None or res1 is not None or bias_mode or a_scale is not None or w_scale is not None:
+        return False
+    if m % 128 or n % 160 or k % 64 or k < 128 or out.dtype not in (torch.bfloat16, torch.float16) or a0.dtype != out.dtype:
+        return False
+    if res0 is not None and res0.dtype != out.dtype:
+        return False
+    tiles_m, tiles_n, ranges = m // 128, n // 160, 1
+    while tiles_m * ranges < 256 and tiles_n % (ranges * 2) == 0:
+        ranges *= 2
+    return tiles_n // ranges >= PERS_MIN_NLOOP
+
+
 # GroupNorm statistics from the producing GEMM's epilogue (mf_gemm_desc.gn_part -> mf_groupnorm_desc.part0 / part1).  A/B switch.
 GN_FROM_PARTS = os.environ.get("MFHIP_GN_FROM_PARTS", "1") != "0"
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
@@ -577,6 +601,12 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     elif sk_fused and splitk > 1:
         tk = sk_tickets(out.device)
         d.sk_tickets, d.sk_ticket_cap = tk.data_ptr(), tk.numel()
+    if (PREFER_PERS and tile == 0 and splitk in (0, 1) and code in (MF_BF16, MF_F16) and vt_out is None and not gn_part
+            and _pers_applies(batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, kw, stride, pad_t, pad_l, upsample, h_in, h_out, w_in, w_out, c1, nz,
+                              temb, res0, res1, out, a0, bias_mode, a_scale, w_scale)):
+        # the persistent 128-row GEMM (tile 70) where a block walks two or more output tiles: the epilogue of every tile but the
+        # last runs under the next main loop (csrc/gemm_pers.hip; tools/bench_ff1.py for the per-shape table)
+        d.tile, d.splitk, d.sk_tickets, d.sk_ticket_cap = PERS_TILE, 1, None, 0
     part = part_rows = None
     if gn_part:
         # GroupNorm statistics from this launch (mf_gemm_desc.gn_part): per-channel partial sums of the output, attached to `out`

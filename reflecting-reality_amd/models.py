@@ -342,18 +342,21 @@ class HipModel:
         return self
 
     def enable_gradient_checkpointing(self):
-        """brushnet.py:674-676 / train_brushnet_mirror.py:1153-1155 (`--gradient_checkpointing`).  NOT built: the backward tape
-        keeps every activation (a per-GPU batch of 8 at 512 x 512 holds ~60 GB of fp32 activations, 288 GB of HBM are there),
-        and nothing is recomputed except the attention probabilities, which are never stored.  A memory switch that silently
-        does nothing would let a user raise the batch size until the run dies elsewhere, so this raises like every other
-        unbuilt switch; a caller that knows its batch fits sets `model.allow_noop_gradient_checkpointing = True` first and
-        gets the recorded flag with no recomputation."""
-        if not getattr(self, "allow_noop_gradient_checkpointing", False):
-            raise NotImplementedError(
-                "enable_gradient_checkpointing (brushnet.py:674-676): activation recomputation is not built — the tape keeps "
-                "every activation (~7.5 GB per sample at 512 x 512 in fp32; batch 8 uses ~60 of 288 GB).  Drop "
-                "--gradient_checkpointing, or set model.allow_noop_gradient_checkpointing = True to accept the flag as a no-op.")
+        """brushnet.py:674-676 / unet_2d_condition.py `enable_gradient_checkpointing`, called by train_brushnet_mirror.py:1153-1155
+        under `--gradient_checkpointing`.  Built since round 6 at the reference's granularity (every ResnetBlock2D and every
+        Transformer2DModel of the down / mid / up blocks, unet_2d_blocks.py:1167-1196, 2597-2622): the block's forward runs on a
+        throw-away tape, only its inputs are kept, and the backward pass runs the block again (autograd.checkpoint).  Gradients
+        are bit-identical to the un-checkpointed step; a step costs one more forward of the checkpointed blocks."""
         self.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self.gradient_checkpointing = False
+
+    def _ckpt(self, fn):
+        """fn() under activation recomputation when this model trains with gradient checkpointing on (else just fn())."""
+        if self.gradient_checkpointing and ops.TAPE is not None:
+            return autograd.checkpoint(fn)
+        return fn()
 
     def save_pretrained(self, path: str, **unused):
         from safetensors.torch import save_file
@@ -643,6 +646,10 @@ class _UNetCore(HipModel):
 
     def _resnet(self, p: str, x: torch.Tensor, temb_all, x1: Optional[torch.Tensor] = None,
                 inj: Optional[torch.Tensor] = None, eps: Optional[float] = None) -> torch.Tensor:
+        return self._ckpt(lambda: self._resnet_impl(p, x, temb_all, x1, inj, eps))
+
+    def _resnet_impl(self, p: str, x: torch.Tensor, temb_all, x1: Optional[torch.Tensor] = None,
+                     inj: Optional[torch.Tensor] = None, eps: Optional[float] = None) -> torch.Tensor:
         """ResnetBlock2D (resnet.py:329-405) on NHWC x (or the never-materialised cat([x, x1], C)), with the
         BrushNet injection add fused into conv2's epilogue."""
         g = self.config["norm_num_groups"]
@@ -779,6 +786,10 @@ class _UNetCore(HipModel):
 
     def _transformer(self, p: str, x: torch.Tensor, ehs: torch.Tensor, heads: int,
                      inj: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self._ckpt(lambda: self._transformer_impl(p, x, ehs, heads, inj))
+
+    def _transformer_impl(self, p: str, x: torch.Tensor, ehs: torch.Tensor, heads: int,
+                          inj: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Transformer2DModel + BasicTransformerBlock(s) (transformer_2d.py:334-430, attention.py:291-412)."""
         P = self.P
         bsz, hh, ww, c = x.shape

@@ -231,7 +231,9 @@ def _shared_rows(res1: Optional[torch.Tensor], m_out: int, n: int) -> int:
 def _want_gn_part(asked: bool, hw: int, n: int) -> bool:
     """GroupNorm statistics from the producing launch: inference only, where GroupNorm runs as separate statistics / apply
     launches (hw > 256: below that one launch keeps the rows in registers), shapes the C ABI takes."""
-    return bool(asked) and TAPE is None and hip.GN_FROM_PARTS and hw > 256 and hw % 32 == 0 and n % 8 == 0
+    # (hw <= 4096: the finalize launch walks an image's hw / rows partial blocks serially per channel — 16 to 32 of them at the UNet's
+    # 64 x 64 / 32 x 32 levels; the VAE's 512 x 512 level would be 2048, measured 8 ms slower per pass)
+    return bool(asked) and TAPE is None and hip.GN_FROM_PARTS and 256 < hw <= 4096 and hw % 32 == 0 and n % 8 == 0
 
 
 def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
