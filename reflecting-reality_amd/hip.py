@@ -343,6 +343,17 @@ def _pers_applies(m, n, k, kh, kw, stride, pad_t, pad_l, upsample, h_in, h_out, 
     return tiles_n // ranges >= PERS_MIN_NLOOP
 
 
+def pers_linear(m: int, n: int, k: int, dtype: torch.dtype) -> bool:
+    """Would a plain Linear of this shape (16-bit, no time embedding, at most one residual) go to the persistent tile 70?  models.py asks
+    before it picks a form only that tile serves well (a LayerNorm folded into the GEGLU projection)."""
+    if not PREFER_PERS or dtype not in (torch.bfloat16, torch.float16) or m % 128 or n % 160 or k % 64 or k < 128:
+        return False
+    tiles_m, tiles_n, ranges = m // 128, n // 160, 1
+    while tiles_m * ranges < 256 and tiles_n % (ranges * 2) == 0:
+        ranges *= 2
+    return tiles_n // ranges >= PERS_MIN_NLOOP
+
+
 # GroupNorm statistics from the producing GEMM's epilogue (mf_gemm_desc.gn_part -> mf_groupnorm_desc.part0 / part1).  A/B switch.
 GN_FROM_PARTS = os.environ.get("MFHIP_GN_FROM_PARTS", "1") != "0"
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
@@ -578,7 +589,15 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         d.vt_out, d.vt_n0, d.vt_tokens, d.vt_ld = _ptr(vt_out), vt_n0, vt_tokens, vt_out.shape[-1]
         fused |= 2
     tkey = None
-    if tile == 0 and splitk in (0, 1) and AUTOTUNE:
+    use_pers = (PREFER_PERS and tile == 0 and splitk in (0, 1) and code in (MF_BF16, MF_F16) and vt_out is None and not gn_part
+                and _pers_applies(batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, kw, stride, pad_t, pad_l, upsample, h_in, h_out, w_in, w_out, c1, nz,
+                                  temb, res0, res1, out, a0, bias_mode, a_scale, w_scale))
+    if use_pers:
+        # the persistent 128-row GEMM (tile 70) where a block walks two or more output tiles: the epilogue of every tile but the
+        # last runs under the next main loop (csrc/gemm_pers.hip; tools/bench_ff1.py for the per-shape table).  Not a tuner candidate
+        # for these calls: it wins them by 5-35 % in isolation and the step agrees (same-box A/B, profiles/r06_ab_switches.txt)
+        d.tile, d.splitk = PERS_TILE, 1
+    elif tile == 0 and splitk in (0, 1) and AUTOTUNE:
         tkey = (code, d.a_dtype, batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), int(c1 > 0),
                 nz, int(splitk == 1) if not fused else 1, act, h_out, w_out) + ((w_split,) if code in (MF_F16X3, MF_BF16X3) else ()) \
             + ((("ln", "vt", "lnvt")[fused - 1],) if fused else ())
@@ -601,12 +620,6 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
     elif sk_fused and splitk > 1:
         tk = sk_tickets(out.device)
         d.sk_tickets, d.sk_ticket_cap = tk.data_ptr(), tk.numel()
-    if (PREFER_PERS and tile == 0 and splitk in (0, 1) and code in (MF_BF16, MF_F16) and vt_out is None and not gn_part
-            and _pers_applies(batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, kw, stride, pad_t, pad_l, upsample, h_in, h_out, w_in, w_out, c1, nz,
-                              temb, res0, res1, out, a0, bias_mode, a_scale, w_scale)):
-        # the persistent 128-row GEMM (tile 70) where a block walks two or more output tiles: the epilogue of every tile but the
-        # last runs under the next main loop (csrc/gemm_pers.hip; tools/bench_ff1.py for the per-shape table)
-        d.tile, d.splitk, d.sk_tickets, d.sk_ticket_cap = PERS_TILE, 1, None, 0
     part = part_rows = None
     if gn_part:
         # GroupNorm statistics from this launch (mf_gemm_desc.gn_part): per-channel partial sums of the output, attached to `out`

@@ -29,6 +29,22 @@ from .ops import ConvWeight, Precision
 F32 = torch.float32
 
 
+def _scoped_tune_ctx(fn):
+    """hip.TUNE_CTX (the position tag of the tuner's keys) is a module global the forwards set as they go: whatever a forward leaves
+    behind — also when it raises half-way — must not tag the NEXT model's lookups (ADVICE r5).  Restores the caller's value on every exit;
+    with `fresh` the body starts untagged (the VAE: its keys have no position)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        prev = hip.TUNE_CTX
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            hip.TUNE_CTX = prev
+    return wrapped
+
+
 class FrozenConfig(dict):
     """config.json view with attribute access (reference: configuration_utils.FrozenDict)."""
 
@@ -354,7 +370,7 @@ class HipModel:
 
     def _ckpt(self, fn):
         """fn() under activation recomputation when this model trains with gradient checkpointing on (else just fn())."""
-        if self.gradient_checkpointing and ops.TAPE is not None:
+        if getattr(self, "gradient_checkpointing", False) and ops.TAPE is not None:
             return autograd.checkpoint(fn)
         return fn()
 
@@ -562,6 +578,11 @@ class _UNetCore(HipModel):
                                                                       sd[b + "attn1.to_v.weight"]], 0), None, self.prec, self.device,
                                                            ln=ln("norm1"))
                 self.P[b + "attn2.to_q_ln"] = ConvWeight(sd[b + "attn2.to_q.weight"], None, self.prec, self.device, ln=ln("norm2"))
+                # norm3 -> GEGLU projection (round 6): on the ring tiles the fold lost at every level (sixteen column tiles repeat the row
+                # statistics, and the GEGLU epilogue wants small tiles); the persistent tile 70 gathers them once per block from the A
+                # tiles it stages anyway (tools/bench_ff1.py: 32768 x 320 -> 2560 +4 us against a 12 us LayerNorm launch)
+                self.P[b + "ff.net.0.proj_ln"] = ops.geglu_weight(sd[b + "ff.net.0.proj.weight"], sd[b + "ff.net.0.proj.bias"],
+                                                                  self.prec, self.device, ln=ln("norm3"))
             i += 1
         self.tdepth[p] = i
 
@@ -691,6 +712,7 @@ class _UNetCore(HipModel):
         return out, join
 
     ln_fold = os.environ.get("MFHIP_NO_LNFOLD") != "1"      # A/B switch for the folded LayerNorms / fused q | k | v (bf16 inference)
+    ff_ln_fold = os.environ.get("MFHIP_NO_FF_LNFOLD") != "1"   # A/B switch: norm3 folded into the GEGLU projection where tile 70 runs it
 
     def _attention(self, b: str, x: torch.Tensor, ctx: Optional[torch.Tensor], heads: int, residual: torch.Tensor,
                    fold: bool = False) -> torch.Tensor:
@@ -819,8 +841,12 @@ class _UNetCore(HipModel):
                     h = self._attention(b + "attn2.", h, ehs, heads, h, fold=True)
                 else:
                     h = self._attention(b + "attn2.", ops.layernorm(h, P[b + "norm2"], 1e-5, self.prec.act), ehs, heads, h)
-                n = ops.layernorm(h, P[b + "norm3"], 1e-5, self.prec.act)
-                h = ops.linear(ops.linear_geglu(n, P[b + "ff.net.0.proj"]), P[b + "ff.net.2"], res0=h)
+                ffl = P.get(b + "ff.net.0.proj_ln")
+                if ffl is not None and self.ff_ln_fold and hip.pers_linear(bsz * tokens, ffl.n, c, self.prec.act):
+                    gg = ops.linear_geglu(h, ffl)                 # norm3 folded: the persistent GEMM gathers the row statistics
+                else:
+                    gg = ops.linear_geglu(ops.layernorm(h, P[b + "norm3"], 1e-5, self.prec.act), P[b + "ff.net.0.proj"])
+                h = ops.linear(gg, P[b + "ff.net.2"], res0=h)
                 continue
             n = ops.layernorm(h, P[b + "norm1"], 1e-5, self._operand_dtype(), fp8=P[b + "attn1.to_out.0"].fp8)
             h = self._attention(b + "attn1.", n, None, heads, h)
@@ -1064,6 +1090,7 @@ class BrushNetModel(_UNetCore):
             elif k.startswith("brushnet_") and k.endswith(".weight"):
                 self.P[k[: -len(".weight")]] = self._conv(sd, k[: -len(".weight")])
 
+    @_scoped_tune_ctx
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: Optional[torch.Tensor] = None,
                 brushnet_cond: torch.Tensor = None, conditioning_scale: float = 1.0, class_labels=None,
                 timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
@@ -1287,6 +1314,7 @@ class UNet2DConditionModel(_UNetCore):
         self.P["conv_out"] = self._conv(sd, "conv_out")
         self._cross_kv, self._ehs_key, self._ehs_gen, self._ehs_val, self._ehs_ref = {}, None, 0, None, None
 
+    @_scoped_tune_ctx
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, class_labels=None,
                 timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
@@ -1537,6 +1565,7 @@ class AutoencoderKL(HipModel):
     def _moments(self, x: torch.Tensor) -> torch.Tensor:
         c = self.config
         n = len(c["block_out_channels"])
+        hip.TUNE_CTX = None                                      # the VAE's tune keys carry no position tag
         h = from_nchw(hip.h2d(x, self.device).float(), self.prec, self.cin_pad)
         h = ops.conv2d(h, self.P["encoder.conv_in"], gn_part=True)
         for i in range(n):
@@ -1550,13 +1579,16 @@ class AutoencoderKL(HipModel):
         h = ops.conv2d(h, self.P["encoder.conv_out"])
         return ops.conv2d(h, self.P["quant_conv"], padding=0, out_dtype=F32)
 
+    @_scoped_tune_ctx
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         d = DiagonalGaussianDistribution(self._moments(x), self.config["latent_channels"])
         return AutoencoderKLOutput(latent_dist=d) if return_dict else (d,)
 
+    @_scoped_tune_ctx
     def decode(self, z: torch.Tensor, return_dict: bool = True, generator=None):
         c = self.config
         n = len(c["block_out_channels"])
+        hip.TUNE_CTX = None                                      # the VAE's tune keys carry no position tag
         h = from_nchw(z.to(self.device).float(), self.prec, self.lat_pad)
         h = ops.conv2d(h, self.P["post_quant_conv"], padding=0)
         h = ops.conv2d(h, self.P["decoder.conv_in"], gn_part=True)
