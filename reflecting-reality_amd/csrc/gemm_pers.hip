@@ -50,8 +50,11 @@ constexpr int PB_SLAB_OFF = PB_STAGES * PB_STAGE_BYTES;             // 110592
 constexpr int PB_LNST_OFF = PB_SLAB_OFF + PB_BM * PB_SLAB_RS;       // + 43008
 constexpr int PB_EROW_OFF = PB_LNST_OFF + PB_BM * 8;                // + 1024: two buffers (output tile parity) of [bias row][column-sum row], 160 fp32 each
 constexpr int PB_EROW_BYTES = 2 * PB_BN * 4;
-constexpr int PB_SMEM = PB_EROW_OFF + 2 * PB_EROW_BYTES;            // 157184
-static_assert(PB_SMEM <= 160 * 1024, "LDS");
+constexpr int PB_LUT_OFF = PB_EROW_OFF + 2 * PB_EROW_BYTES;         // 157184: GEGLU variants: the normal CDF on [-6, 6) in steps of 1 / 64
+constexpr int PB_LUT_N = 768;                                       // entries (Phi(x_i), Phi(x_i+1) - Phi(x_i)), 8 bytes each
+constexpr int PB_SMEM = PB_LUT_OFF;                                 // 157184 without the table
+constexpr int PB_SMEM_GEGLU = PB_LUT_OFF + PB_LUT_N * 8;            // 163328 with it
+static_assert(PB_SMEM_GEGLU <= 160 * 1024, "LDS");
 constexpr int PB_CPR = PB_BN / 8;                                   // 20 (row, 8-column) items per row
 constexpr int PB_CHUNKS = PB_BM * PB_CPR / 64;                      // 40 chunks of 64 items per output tile
 constexpr int PB_CE = 6, PB_CC = 2;                                 // chunks per epilogue wave / per compute wave
@@ -59,21 +62,23 @@ static_assert(4 * PB_CE + 8 * PB_CC == PB_CHUNKS, "chunk ownership covers the sl
 
 // One (row, 8 columns) item: 16 bytes of the slab -> [+ residual] -> [SiLU | GEGLU] -> 16 (GEGLU: 8) bytes of output.  No global load.
 template <bool F16, bool RES, bool GEGLU>
-__device__ __forceinline__ void pers_item(const GemmArgs& p, int m, int n, const char* sp, const uint4& q) {
+__device__ __forceinline__ void pers_item(const GemmArgs& p, int m, int n, const char* sp, const uint4& q, const char* lut) {
     const uint4 s = *reinterpret_cast<const uint4*>(sp);
     if constexpr (GEGLU) {
-        // weight rows are interleaved [4 values | 4 gates]: out[n/2 + j] = v[j] * gelu_erf(v[4 + j])  (activations.py:100-103); erf by
-        // Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): epilogue_store8's arithmetic for a 16-bit output
+        // weight rows are interleaved [4 values | 4 gates]: out[n/2 + j] = v[j] * gelu_erf(v[4 + j]) = v[j] * x * Phi(x)  (activations.py:100-103).
+        // Phi from a table in LDS (768 steps of 1 / 64 over [-6, 6), linear interpolation: |error| <= 7.4e-6 = h^2 / 8 max |Phi''|; the gate
+        // is a 16-bit value here and the product is rounded to 16 bits): nine vector instructions and one LDS read per value where the
+        // erf of Abramowitz-Stegun 7.1.26 (epilogue_store8) takes twenty with two transcendentals — the GEGLU of a K = 320 tile is as
+        // much vector work as its main loop is matrix work (header), so this is the launch's critical path.
         float v[8], g[4];
         unpack_h8<F16>(s, v);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float x = v[4 + j];
-            const float z = fabsf(x) * 0.70710678118654752440f;
-            const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-            const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-            const float e = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-            g[j] = v[j] * (0.5f * x + 0.5f * fabsf(x) * e);
+            const float u = fmaf(__builtin_amdgcn_fmed3f(x, -6.0f, 5.984375f), 64.0f, 384.0f);     // [0, 767]
+            const float fr = __builtin_amdgcn_fractf(u);
+            const float2 e = *reinterpret_cast<const float2*>(lut + (int)(u - fr) * 8);
+            g[j] = v[j] * (x * fmaf(fr, e.y, e.x));
         }
         uint2 u;
         u.x = pack_h2<F16>(g[0], g[1]);
@@ -123,6 +128,16 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
     float2* lnst = reinterpret_cast<float2*>(smem + PB_LNST_OFF);    // (mean, rstd) of the block's rows (folded LayerNorm)
     const int dbg = p.dbg_epi;      // developer switches (MFHIP_DBG_EPI): 1 no chunk work, 2 no fragment reads / MFMAs, 4 no DMA — garbage results, same barriers
 
+    if constexpr (GEGLU) {
+        // the normal CDF table (see pers_item): entry i = (Phi(x_i), Phi(x_i + 1/64) - Phi(x_i)), x_i = -6 + i / 64; before barrier #0
+        if (tid < PB_LUT_N) {
+            const float x0 = -6.0f + (float)tid * 0.015625f, x1 = x0 + 0.015625f;
+            const float p0 = 0.5f * erfcf(-x0 * 0.70710678118654752440f), p1 = 0.5f * erfcf(-x1 * 0.70710678118654752440f);
+            *reinterpret_cast<float2*>(smem + PB_LUT_OFF + tid * 8) = make_float2(p0, p1 - p0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                          // written before this wave arrives at barrier #0
+    }
+
     // ---- chunks of the slab: who owns which, and the work on one ------------------------------------------------------------------
     // chunk c = 64 items, item it = 64 c + lane = (row it / 20, column group it % 20).  Epilogue wave e owns chunks 6 e .. 6 e + 5,
     // compute wave w owns 24 + 2 w and 25 + 2 w.  A wave's chunks of output tile j are worked on in the intervals after the slab was
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
         item_coords(c, row, cg);
         uint4 q = qv;
         if constexpr (RES) asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));   // opaque: the unpacking of all prefetched vectors was hoisted out of the loop (80 registers)
-        pers_item<F16, RES, GEGLU>(p, m0 + row, n0 + cg * 8, smem + PB_SLAB_OFF + row * PB_SLAB_RS + cg * 16, q);
+        pers_item<F16, RES, GEGLU>(p, m0 + row, n0 + cg * 8, smem + PB_SLAB_OFF + row * PB_SLAB_RS + cg * 16, q, smem + PB_LUT_OFF);
     };
     auto fetch_res = [&](int c, int n0) -> uint4 {
         int row, cg;
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
         __builtin_amdgcn_s_barrier();                                // #0
         for (int g = 0; g < G; ++g) {
             const bool dumping = kt == 0 && g > 0;                   // the first interval of output tile jt: tile jt - 1's accumulators leave
-            if (dumping) dump(jt - 1);
+            if (dumping && !(dbg & 8)) dump(jt - 1);
             if (!nomma) {
                 const char* A16 = smem + st * PB_STAGE_BYTES + (wm * 32 + r16) * 128;
                 const char* B16 = smem + st * PB_STAGE_BYTES + PB_BM * 128 + (wn * 80 + r16) * 128;
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
         // ---- epilogue waves ------------------------------------------------------------------------------------------------------------
         uint4 q[RES ? PB_CE : 1];
         float4 pb = make_float4(0, 0, 0, 0), pc = make_float4(0, 0, 0, 0);   // wave 12, lanes 0-39: four bias / column-sum values of a later tile
-        const bool rows_duty = rw == 0 && (p.bias != nullptr || LN);
+        constexpr bool rows_duty = true;                             // (every epilogue wave fetches the rows: see fetch_rows)
         auto prefetch = [&](int jt) {                                // residual vectors of this wave's chunks of output tile jt
             if constexpr (RES) {
                 const int n0 = (nt0 + jt) * PB_BN;
@@ -313,17 +328,21 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
                 for (int i = 0; i < PB_CE; ++i) q[i] = fetch_res(PB_CE * rw + i, n0);
             }
         };
-        auto fetch_rows = [&](int jt) {                              // (wave 12) bias and column-sum rows of output tile jt -> registers
-            if (rows_duty && lane < PB_BN / 4) {
-                const int n0 = (nt0 + jt) * PB_BN;
-                if (p.bias) pb = *reinterpret_cast<const float4*>(p.bias + n0 + lane * 4);
-                if constexpr (LN) pc = *reinterpret_cast<const float4*>(p.ln_cs + n0 + lane * 4);
-            }
+        // bias and column-sum rows of output tile jt -> registers.  Unconditional, by every lane of every epilogue wave (lanes past the row
+        // re-read its start, a call without bias reads the weight's first bytes and publishes zeros): a load under a lane mask or a branch
+        // is merged with the old value by a register copy, and hipcc waits for the load — vmcnt(0), behind this wave's stores — right there
+        // (measured: wave 12 stalled every block ~1.5 us per output tile).  Only wave 12 publishes.
+        const float* brow = p.bias ? p.bias : reinterpret_cast<const float*>(p.w);
+        const int rlane = lane < PB_BN / 4 ? lane : lane - PB_BN / 4;          // 0 .. 39
+        auto fetch_rows = [&](int jt) {
+            const int n0 = (nt0 + jt) * PB_BN;
+            pb = *reinterpret_cast<const float4*>(brow + n0 + rlane * 4);
+            if constexpr (LN) pc = *reinterpret_cast<const float4*>(p.ln_cs + n0 + rlane * 4);
         };
         auto publish_rows = [&](int jt) {                            // (wave 12) ... -> row buffer jt & 1 (the caller has waited for them)
             if (rw == 0 && lane < PB_BN / 4) {
                 char* er = smem + PB_EROW_OFF + (jt & 1) * PB_EROW_BYTES;
-                *reinterpret_cast<float4*>(er + lane * 16) = pb;
+                *reinterpret_cast<float4*>(er + lane * 16) = p.bias ? pb : make_float4(0, 0, 0, 0);
                 *reinterpret_cast<float4*>(er + PB_BN * 4 + lane * 16) = pc;
             }
         };
@@ -336,9 +355,9 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
             fetch_rows(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             publish_rows(1);
-            if (p.nloop > 2) fetch_rows(2);
             prefetch(0);
         }
+        fetch_rows(p.nloop > 2 ? 2 : p.nloop - 1);
         // folded LayerNorm: (sum, sum of squares) of the block's 128 rows, taken from the A tiles as they pass through LDS during the
         // first output tile's K steps (no global load in these waves): 32 rows per wave, two lanes per row, 64 bytes each per K tile
         float ls1 = 0.0f, ls2 = 0.0f;
@@ -373,11 +392,9 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
 #pragma unroll
                         for (int i = 0; i < PB_CE; ++i) asm volatile("" : "+v"(q[i].x), "+v"(q[i].y), "+v"(q[i].z), "+v"(q[i].w));
                     }
-                    if (pend_jt + 2 < p.nloop) {                     // rows of tile pend_jt + 2 into the buffer tile pend_jt's dump has read
-                        asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w), "+v"(pc.x), "+v"(pc.y), "+v"(pc.z), "+v"(pc.w));
-                        publish_rows(pend_jt + 2);
-                        if (pend_jt + 3 < p.nloop) fetch_rows(pend_jt + 3);
-                    }
+                    asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w), "+v"(pc.x), "+v"(pc.y), "+v"(pc.z), "+v"(pc.w));
+                    if (pend_jt + 2 < p.nloop) publish_rows(pend_jt + 2);     // rows of tile pend_jt + 2 into the buffer tile pend_jt's dump has read
+                    fetch_rows(pend_jt + 3 < p.nloop ? pend_jt + 3 : p.nloop - 1);      // (unconditional: see fetch_rows)
                 }
 #pragma unroll 1
                 for (int i = 0; i < per && done < PB_CE; ++i, ++done) {
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
             item_coords(c, row, cg);
             uint4 q = uint4{0, 0, 0, 0};
             if constexpr (RES) q = *reinterpret_cast<const uint4*>(p.res0 + ((int64_t)(m0 + row) * p.ld_res0 + n0 + cg * 8) * 2);
-            if (!(dbg & 1)) pers_item<F16, RES, GEGLU>(p, m0 + row, n0 + cg * 8, smem + PB_SLAB_OFF + row * PB_SLAB_RS + cg * 16, q);
+            if (!(dbg & 1)) pers_item<F16, RES, GEGLU>(p, m0 + row, n0 + cg * 8, smem + PB_SLAB_OFF + row * PB_SLAB_RS + cg * 16, q, smem + PB_LUT_OFF);
         }
     }
 }
@@ -438,11 +455,11 @@ bool launch_pers(int dtype, const GemmArgs& a, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     if (!attr[fl][variant][dev]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM) != hipSuccess) return false;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM_GEGLU) != hipSuccess) return false;
         attr[fl][variant][dev] = true;
     }
     void* args[] = {const_cast<GemmArgs*>(&a)};
-    return hipLaunchKernel(fn, dim3((unsigned)(a.tiles_m * (a.tiles_n / a.nloop))), dim3(1024), args, PB_SMEM, s) == hipSuccess;
+    return hipLaunchKernel(fn, dim3((unsigned)(a.tiles_m * (a.tiles_n / a.nloop))), dim3(1024), args, geglu ? PB_SMEM_GEGLU : PB_SMEM, s) == hipSuccess;
 }
 
 }  // namespace mfgemm

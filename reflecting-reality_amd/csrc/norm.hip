@@ -236,6 +236,8 @@ __global__ __launch_bounds__(GN_BLK) void gn_finalize_part_kernel(const GnArgs p
     int g1 = g0 + gps;
     if (g1 > p.G) g1 = p.G;
     const int c0 = g0 * p.cpg, nc = (g1 - g0) * p.cpg, ncmax = gps * p.cpg;
+    // (the affine parameters of the last stage are requested first: their latency hides under the partial sums')
+    const float gam = t < nc ? p.gamma[c0 + t] : 0.0f, bet = t < nc ? p.beta[c0 + t] : 0.0f;
     // thread (channel j, part kp) sums the blocks kp, kp + kparts, ... of its channel: the launch is latency-bound (the partial sums
     // come from other XCDs' L2s through the fabric), so the loads of a channel are spread over kparts threads and issued together —
     // one thread per channel walking 32 blocks measured 11 us, as long as the statistics pass this launch replaces
@@ -297,9 +299,9 @@ __global__ __launch_bounds__(GN_BLK) void gn_finalize_part_kernel(const GnArgs p
     float* ab = p.ws_ab + (int64_t)b * 2 * p.C;
     for (int j = t; j < nc; j += blockDim.x) {
         const int c = c0 + j, g = j / p.cpg;
-        const float a = gr[g] * p.gamma[c];
+        const float a = gr[g] * (j == t ? gam : p.gamma[c]);
         ab[c] = a;
-        ab[p.C + c] = p.beta[c] - gm[g] * a;
+        ab[p.C + c] = (j == t ? bet : p.beta[c]) - gm[g] * a;
     }
 }
 
