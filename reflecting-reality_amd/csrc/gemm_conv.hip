@@ -342,7 +342,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
         MF_CHECK_ARG(mf_is16(d->dtype) && d->a_dtype == d->dtype && d->kh == 1 && d->kw == 1 && d->c1 == 0 && d->nz == 1 &&
                          (d->splitk == 0 || d->splitk == 1) && d->a_scale == nullptr && d->w_scale == nullptr,
                      "mf_gemm_conv: ln_colsum / vt_out need a plain bf16 / fp16 1x1 GEMM (one A segment, no batching, no split-K, no scales)");
-        MF_CHECK_ARG(d->tile == 0 || tile_ws_ring(d->tile) || ((d->tile == kNloopTile || d->tile == kPersTile) && !d->vt_out),
+        MF_CHECK_ARG(d->tile == 0 || tile_ws_ring(d->tile) || (d->tile == kNloopTile && !d->vt_out) || d->tile == kPersTile,
                      "mf_gemm_conv: tile %d does not serve ln_colsum / vt_out (the warp-specialised ring tiles 41-46, 48, 50, 52, 54, 56-58, 60, 62 do)", d->tile);
         MF_CHECK_ARG(!d->ln_colsum || (mf_aligned16(d->ln_colsum) && d->n % 8 == 0 && d->ln_eps > 0.0f), "mf_gemm_conv: ln_colsum must be 16-byte aligned, n %% 8 == 0, ln_eps > 0");
         if (d->vt_out) {
@@ -564,7 +564,8 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     a.gn_part = gn_fused ? (float2*)d->gn_part : nullptr;
     if (tile == kPersTile) {
         const bool ok = mf_is16(d->dtype) && !a_f32 && a.pointwise && d->c1 == 0 && a.nz == 1 && a.splitk == 1 && a.M % 128 == 0 && a.N % 160 == 0 &&
-                        a.K % 64 == 0 && a.nkt >= 2 && a.vec_ok && a.bias_mode == 0 && !a.temb && !a.vt_out && !a.rs && !a.cs && a.fast && !a.res1 && (!a.res0 || a.res0_dt != MF_F32) && a.out_dt != MF_F32 &&
+                        a.K % 64 == 0 && a.nkt >= 2 && a.vec_ok && a.bias_mode == 0 && !a.temb && !a.rs && !a.cs && a.fast && !a.res1 && (!a.res0 || a.res0_dt != MF_F32) && a.out_dt != MF_F32 &&
+                        (!a.vt_out || (a.vt_n0 % 160 == 0 && a.vt_tokens % 8 == 0 && a.act == MF_ACT_NONE && !a.res0)) &&
                         (int64_t)a.M * a.ld0b < (1ll << 31) - (1 << 20);
         MF_CHECK_ARG(ok, "mf_gemm_conv: tile %d (persistent 128-row GEMM) takes a 1x1 bf16 / fp16 call with M %% 128 == 0, N %% 160 == 0, K %% 64 == 0, "
                          "K >= 128, one A segment, 16-bit output (and residual), per-column bias, one residual at most, no time embedding / scales / transposed columns / split-K", tile);

@@ -47,13 +47,16 @@ constexpr int PB_BM = 128, PB_BN = 160, PB_STAGES = 3, PB_PF = PB_STAGES - 1;
 constexpr int PB_STAGE_BYTES = (PB_BM + PB_BN) * 128;               // 36 KB: [A tile 128 rows][W tile 160 rows], 128 bytes of K per row
 constexpr int PB_SLAB_RS = PB_BN * 2 + 16;                          // slab row stride (bytes): 160 16-bit values + 16 bytes
 constexpr int PB_SLAB_OFF = PB_STAGES * PB_STAGE_BYTES;             // 110592
-constexpr int PB_LNST_OFF = PB_SLAB_OFF + PB_BM * PB_SLAB_RS;       // + 43008
+constexpr int PB_SLAB_RST = PB_BM * 2 + 16;                         // transposed slab (V^T tiles): [column][128 rows] 16-bit, 272 bytes per column
+constexpr int PB_SLAB_BYTES = PB_BN * PB_SLAB_RST;                  // 43520 >= 128 * 336
+static_assert(PB_SLAB_BYTES >= PB_BM * PB_SLAB_RS, "the slab region holds either layout");
+constexpr int PB_LNST_OFF = PB_SLAB_OFF + PB_SLAB_BYTES;            // + 43520
 constexpr int PB_EROW_OFF = PB_LNST_OFF + PB_BM * 8;                // + 1024: two buffers (output tile parity) of [bias row][column-sum row], 160 fp32 each
 constexpr int PB_EROW_BYTES = 2 * PB_BN * 4;
-constexpr int PB_LUT_OFF = PB_EROW_OFF + 2 * PB_EROW_BYTES;         // 157184: GEGLU variants: the normal CDF on [-6, 6) in steps of 1 / 64
+constexpr int PB_LUT_OFF = PB_EROW_OFF + 2 * PB_EROW_BYTES;         // 157696: GEGLU variants: the normal CDF on [-6, 6) in steps of 1 / 64
 constexpr int PB_LUT_N = 768;                                       // entries (Phi(x_i), Phi(x_i+1) - Phi(x_i)), 8 bytes each
-constexpr int PB_SMEM = PB_LUT_OFF;                                 // 157184 without the table
-constexpr int PB_SMEM_GEGLU = PB_LUT_OFF + PB_LUT_N * 8;            // 163328 with it
+constexpr int PB_SMEM = PB_LUT_OFF;                                 // 157696 without the table
+constexpr int PB_SMEM_GEGLU = PB_LUT_OFF + PB_LUT_N * 8;            // 163840 with it: all of the 160 KB
 static_assert(PB_SMEM_GEGLU <= 160 * 1024, "LDS");
 constexpr int PB_CPR = PB_BN / 8;                                   // 20 (row, 8-column) items per row
 constexpr int PB_CHUNKS = PB_BM * PB_CPR / 64;                      // 40 chunks of 64 items per output tile
@@ -105,10 +108,19 @@ __device__ __forceinline__ void pers_item(const GemmArgs& p, int m, int n, const
     }
 }
 
+// One item of a V^T tile (mf_gemm_desc.vt_out: the V third of a fused q | k | v projection, written [image][channel][token]): 8
+// consecutive tokens of one channel = 16 contiguous bytes of the TRANSPOSED slab = 16 contiguous bytes of V^T.
+__device__ __forceinline__ void pers_item_vt(const GemmArgs& p, int m, int n, const char* sp) {
+    const uint4 s = *reinterpret_cast<const uint4*>(sp);
+    const int img = m / p.vt_tokens, tok = m - img * p.vt_tokens;
+    *reinterpret_cast<uint4*>(p.vt_out + (((int64_t)img * (p.N - p.vt_n0) + (n - p.vt_n0)) * p.vt_ld + tok) * 2) = s;
+}
+
 // RES / GEGLU / LN: compile-time properties of the call (16-bit residual fetched ahead; GEGLU epilogue; folded LayerNorm): with
 // run-time flags the live ranges of all three share one register allocation and the chunk code spills — a scratch reload there is
 // a global load behind the stores, the very wait this file is about.
-template <int DT, bool RES, bool GEGLU, bool LN>
+// VT: columns n >= p.vt_n0 (whole output tiles: vt_n0 % 160 == 0) are V^T tiles.
+template <int DT, bool RES, bool GEGLU, bool LN, bool VT>
 __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool F16 = DT == MF_F16;
@@ -149,6 +161,13 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
         cg = it - row * PB_CPR;
     };
     auto do_chunk = [&](int c, int n0, const uint4& qv) {
+        if (VT && n0 >= p.vt_n0) {                                   // a V^T tile: item = (column it / 16, rows 8 (it % 16) ..)
+            int it = c * 64 + lane;
+            asm volatile("" : "+v"(it));
+            const int col = it >> 4, rg = it & 15;
+            pers_item_vt(p, m0 + rg * 8, n0 + col, smem + PB_SLAB_OFF + col * PB_SLAB_RST + rg * 16);
+            return;
+        }
         int row, cg;
         item_coords(c, row, cg);
         uint4 q = qv;
@@ -223,7 +242,46 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
         // order a lane holds four rows of one column and the slab write is 2-byte stores or a lane-pair exchange with selects: measured
         // 1.3 us per output tile on the two compute waves of a SIMD, half of a K = 320 tile's main loop.)
         // accumulators -> slab; `jt`: the output tile (relative to nt0) they belong to: its bias / column-sum rows sit in row buffer jt & 1.
-        auto dump = [&](int jt) {
+        // V^T tiles go to the TRANSPOSED slab [column][128 rows].  The accumulators are the same (a lane: four channels of one pixel): for
+        // each channel the sixteen lanes of a row group hold sixteen consecutive pixels, so neighbouring lanes (pixels P, P + 1) trade
+        // halves — the even lane keeps channels 0-1 of both pixels, the odd lane channels 2-3 — and every lane writes two dwords.
+        // (No second operand order in the main loop: a run-time choice between two MFMA blocks spilled the fragments.)
+        auto dump_vt = [&](int jt) {
+            const char* er = smem + PB_EROW_OFF + (jt & 1) * PB_EROW_BYTES;
+            const float alpha = p.alpha;
+            const int odd = r16 & 1;
+            float2 rst[2];
+            if constexpr (LN) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) rst[a] = lnst[wm * 32 + 16 * a + r16];
+            }
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const int col = wn * 80 + 16 * b + 4 * kg;
+                const float4 bias = *reinterpret_cast<const float4*>(er + col * 4);
+                float4 cs = make_float4(0, 0, 0, 0);
+                if constexpr (LN) cs = *reinterpret_cast<const float4*>(er + PB_BN * 4 + col * 4);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float x[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                    if constexpr (LN) {
+                        x[0] = rst[a].y * (x[0] - rst[a].x * cs.x); x[1] = rst[a].y * (x[1] - rst[a].x * cs.y);
+                        x[2] = rst[a].y * (x[2] - rst[a].x * cs.z); x[3] = rst[a].y * (x[3] - rst[a].x * cs.w);
+                    }
+                    x[0] = (x[0] + bias.x) * alpha; x[1] = (x[1] + bias.y) * alpha; x[2] = (x[2] + bias.z) * alpha; x[3] = (x[3] + bias.w) * alpha;
+                    const float s0 = odd ? x[0] : x[2], s1 = odd ? x[1] : x[3];                    // what the partner takes
+                    const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+                    const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+                    const uint32_t d0 = pack_h2<F16>(odd ? g0 : x[0], odd ? x[2] : g0);            // channel col + 2 odd: pixels (P & ~1, P | 1)
+                    const uint32_t d1 = pack_h2<F16>(odd ? g1 : x[1], odd ? x[3] : g1);            // channel col + 2 odd + 1
+                    char* sp = smem + PB_SLAB_OFF + (col + 2 * odd) * PB_SLAB_RST + (wm * 32 + 16 * a + (r16 & ~1)) * 2;
+                    *reinterpret_cast<uint32_t*>(sp) = d0;
+                    *reinterpret_cast<uint32_t*>(sp + PB_SLAB_RST) = d1;
+                    acc[a][b] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+        };
+        auto dump_plain = [&](int jt) {
             const char* er = smem + PB_EROW_OFF + (jt & 1) * PB_EROW_BYTES;
             const float alpha = p.alpha;
             float2 rst[2];                                           // (mean, rstd) of this lane's two rows
@@ -252,6 +310,11 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
                     acc[a][b] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
+        };
+        auto is_vt = [&](int jt) -> bool { return VT && (nt0 + jt) * PB_BN >= p.vt_n0; };
+        auto dump = [&](int jt) {
+            if (is_vt(jt)) dump_vt(jt);
+            else dump_plain(jt);
         };
         uint4 q[RES ? PB_CC : 1];
         auto prefetch = [&](int jt) {                                // residual vectors of this wave's chunks of output tile jt
@@ -286,7 +349,7 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int b = 0; b < 5; ++b)
-                            acc[a][b] = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, fb[ks][b]), __builtin_bit_cast(bf16x8_t, fa[ks][a]), acc[a][b], 0, 0, 0);   // transposed: see dump
+                            acc[a][b] = mfma16x32<DT>(__builtin_bit_cast(bf16x8_t, fb[ks][b]), __builtin_bit_cast(bf16x8_t, fa[ks][a]), acc[a][b], 0, 0, 0);   // transposed: see dump_plain
             }
             st = st == PB_STAGES - 1 ? 0 : st + 1;
             // this wave's share of the previous tile's slab, behind the MFMAs (issued, not yet retired: the vector work overlaps them)
@@ -426,6 +489,10 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
     {
         const int n0 = (nt0 + p.nloop - 1) * PB_BN;
         for (int c = wave; c < PB_CHUNKS; c += 16) {
+            if (VT && n0 >= p.vt_n0) {
+                if (!(dbg & 1)) do_chunk(c, n0, uint4{0, 0, 0, 0});
+                continue;
+            }
             int row, cg;
             item_coords(c, row, cg);
             uint4 q = uint4{0, 0, 0, 0};
@@ -438,20 +505,21 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
 }  // namespace
 
 template <int DT>
-static const void* pers_fn(bool res, bool geglu, bool ln) {
-    if (geglu) return ln ? reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, true, true>) : reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, true, false>);
-    if (res) return ln ? reinterpret_cast<const void*>(&gemm_pers_kernel<DT, true, false, true>) : reinterpret_cast<const void*>(&gemm_pers_kernel<DT, true, false, false>);
-    return ln ? reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, false, true>) : reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, false, false>);
+static const void* pers_fn(bool res, bool geglu, bool ln, bool vt) {
+    if (vt) return ln ? reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, false, true, true>) : reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, false, false, true>);
+    if (geglu) return ln ? reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, true, true, false>) : reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, true, false, false>);
+    if (res) return ln ? reinterpret_cast<const void*>(&gemm_pers_kernel<DT, true, false, true, false>) : reinterpret_cast<const void*>(&gemm_pers_kernel<DT, true, false, false, false>);
+    return ln ? reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, false, true, false>) : reinterpret_cast<const void*>(&gemm_pers_kernel<DT, false, false, false, false>);
 }
 
 bool launch_pers(int dtype, const GemmArgs& a, hipStream_t s) {
     if (dtype != MF_BF16 && dtype != MF_F16) return false;
-    const bool geglu = a.act == MF_ACT_GEGLU4, res = a.res0 != nullptr, ln = a.ln_cs != nullptr;
-    if (geglu && res) return false;
-    const int fl = dtype == MF_F16 ? 1 : 0, variant = (geglu ? 4 : (res ? 2 : 0)) + (ln ? 1 : 0);
-    const void* fn = fl ? pers_fn<MF_F16>(res, geglu, ln) : pers_fn<MF_BF16>(res, geglu, ln);
+    const bool geglu = a.act == MF_ACT_GEGLU4, res = a.res0 != nullptr, ln = a.ln_cs != nullptr, vt = a.vt_out != nullptr;
+    if ((geglu && res) || (vt && (geglu || res))) return false;
+    const int fl = dtype == MF_F16 ? 1 : 0, variant = (vt ? 6 : geglu ? 4 : (res ? 2 : 0)) + (ln ? 1 : 0);
+    const void* fn = fl ? pers_fn<MF_F16>(res, geglu, ln, vt) : pers_fn<MF_BF16>(res, geglu, ln, vt);
     // the dynamic-LDS attribute is per function AND per device: one flag per (flavour, variant, device), the call's result checked
-    static bool attr[2][6][64] = {};
+    static bool attr[2][8][64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     if (!attr[fl][variant][dev]) {

@@ -589,7 +589,8 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         d.vt_out, d.vt_n0, d.vt_tokens, d.vt_ld = _ptr(vt_out), vt_n0, vt_tokens, vt_out.shape[-1]
         fused |= 2
     tkey = None
-    use_pers = (PREFER_PERS and tile == 0 and splitk in (0, 1) and code in (MF_BF16, MF_F16) and vt_out is None and not gn_part
+    use_pers = (PREFER_PERS and tile == 0 and splitk in (0, 1) and code in (MF_BF16, MF_F16) and not gn_part
+                and (vt_out is None or (vt_n0 % 160 == 0 and vt_tokens % 8 == 0 and res0 is None and act == ACT_NONE))
                 and _pers_applies(batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, kw, stride, pad_t, pad_l, upsample, h_in, h_out, w_in, w_out, c1, nz,
                                   temb, res0, res1, out, a0, bias_mode, a_scale, w_scale))
     if use_pers:

@@ -833,6 +833,9 @@ class _UNetCore(HipModel):
                 #                                    GEGLU epilogue prefers the small tiles): stays a LayerNorm launch
                 tokens = hh * ww
                 f_qkv, f_q = tokens <= 1024, tokens >= 256
+                # (round 6: on the persistent tile 70 the fused q | k | v^T also pays at 64 x 64 — the row statistics are gathered once
+                # per block, and the V^T launch and the LayerNorm launch both go)
+                f_qkv = f_qkv or (self.ff_ln_fold and hip.pers_linear(bsz * tokens, 3 * c, c, self.prec.act))
                 if f_qkv:
                     h = self._attention(b + "attn1.", h, None, heads, h, fold=True)
                 else:

@@ -753,12 +753,17 @@ def test_folded_layernorm_is_refused_where_it_cannot_run():
         ops.ConvWeight(torch.randn(64, 64), None, ops.Precision.get("f16x3"), DEV, ln=(torch.ones(64), torch.zeros(64), 1e-5))
 
 
-@pytest.mark.parametrize("tile", WS_RING_TILES)
+@pytest.mark.parametrize("tile", WS_RING_TILES + (70,))
 @pytest.mark.parametrize("batch,tokens,c,with_ln", [(2, 4096, 320, True), (2, 1024, 640, True), (3, 256, 1280, True), (2, 64, 1280, True),
-                                                    (2, 1024, 320, False)])
+                                                    (2, 1024, 320, False), (8, 4096, 320, True), (1, 128, 320, False)])
 def test_fused_qkv_projection_with_transposed_v(tile, batch, tokens, c, with_ln):
     """Self-attention's to_q | to_k | to_v as ONE GEMM (attention_processor.py:1246-1254): q | k leave as [B, S, 2C], the V third
-    leaves the epilogue transposed as V^T [B, C, S] (what mf_attention_bf16 reads), norm1 folded in."""
+    leaves the epilogue transposed as V^T [B, C, S] (what mf_attention_bf16 reads), norm1 folded in.  Tile 70 (round 6): the V tiles
+    of the persistent GEMM go through a transposed slab; a block's range may mix q | k and V tiles, start inside V, or be one tile."""
+    if tile == 70 and (batch * tokens) % 128:
+        with pytest.raises(hip.MfhipError, match="persistent 128-row"):
+            ops.linear_qkv(torch.zeros(batch, tokens, c, device=DEV).bfloat16(), ops.ConvWeight(torch.zeros(3 * c, c), None, ops.Precision.get("bf16"), DEV), tile=70)
+        return
     prec = ops.Precision.get("bf16")
     g = torch.Generator().manual_seed(32)
     x = rb(torch.randn(batch, tokens, c, generator=g) * 1.3 - 0.4)

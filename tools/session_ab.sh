@@ -1,9 +1,9 @@
 #!/bin/bash
-# gpurun: bash tools/gpu_session.sh <tag> bash tools/session_ab.sh — same-box A/B of the round-6 switches on the default bench workload
+# gpurun: bash tools/gpu_session.sh <tag> bash tools/session_ab.sh — model / pipeline parity tests, then same-box A/B of the round-6 switches on the default bench workload
 : "${GRAFT_REPO_ROOT:?run through gpurun}"; : "${MF_SESSION_OUT:?run through tools/gpu_session.sh}"
 cd "$GRAFT_REPO_ROOT" || exit 1
 out="$MF_SESSION_OUT"
-timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "groupnorm or partial_sums" > "$out/pytest_gn.txt" 2>&1; echo "pytest rc $?"; tail -n 3 "$out/pytest_gn.txt"
+timeout 1500 python -m pytest tests/test_layers_gpu.py tests/test_models_gpu.py tests/test_pipeline_gpu.py tests/test_fp16_gpu.py -q -m gpu > "$out/pytest_models.txt" 2>&1; echo "pytest rc $?"; tail -n 6 "$out/pytest_models.txt"
 run() {  # tag, env...
   tag=$1; shift
   env "$@" timeout 900 python bench.py --no-extra-legs --no-parity-mode --no-cpu-baseline --steps 3 --warmup 1 > "$out/bench_$tag.json" 2> "$out/bench_$tag.err"
@@ -17,7 +17,7 @@ except Exception as e:
 PY
 }
 run base MFHIP_PREFER_PERS=0 MFHIP_GN_FROM_PARTS=0
-run gn MFHIP_PREFER_PERS=0 MFHIP_GN_FROM_PARTS=1
-run pers MFHIP_PREFER_PERS=1 MFHIP_GN_FROM_PARTS=0
-run gn_pers MFHIP_PREFER_PERS=1 MFHIP_GN_FROM_PARTS=1
+run all
+run all_no_fold MFHIP_NO_FF_LNFOLD=1
 run base2 MFHIP_PREFER_PERS=0 MFHIP_GN_FROM_PARTS=0
+run all2
