@@ -59,7 +59,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 17
+#define MF_ABI_VERSION 18
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -170,6 +170,13 @@ typedef struct mf_gemm_desc {
      * stored output (R = 128, 64 or 32) — same contract.  Needs n % 8 == 0, nz == 1, h_out * w_out % 32 == 0, no GEGLU, no
      * vt_out, and gn_part_floats >= 2 * n * (M / 32) (enough for the smallest R). */
     float* gn_part; int64_t gn_part_floats; int32_t* gn_part_rows;
+    /* gn_groups > 0 (with gn_part): the consumer is a GroupNorm over exactly this tensor with gn_groups groups (the common case: every
+     * norm of the path but the decoder's concatenated ones).  When the epilogue produces the sums and the tile's columns hold whole
+     * groups (n / gn_groups divides the tile's column count: the 160-column tiles for 320 / 640 / 1280 channels in 32 groups), it also
+     * leaves PER-GROUP sums behind the per-channel ones,
+     *     gn_part[2 * n * (M / R) + 2 * ((m / R) * gn_groups + g)] = (sum, sum of squares) over rows [R (m / R), +R) of group g,
+     * and writes 1 to *gn_grouped (a HOST int, else 0): mf_groupnorm then needs no finalize launch at all (grp0 below). */
+    int32_t gn_groups; int32_t* gn_grouped;
 } mf_gemm_desc;
 
 int mf_gemm_conv(const mf_gemm_desc* d, void* stream);
@@ -204,6 +211,10 @@ typedef struct mf_groupnorm_desc {
      * launch over the partials; otherwise they are ignored.  NULL = compute the statistics from the tensor. */
     const float* part0; int32_t part0_rows;
     const float* part1; int32_t part1_rows;
+    /* Per-GROUP sums of x0 from its producer (mf_gemm_desc.gn_groups == groups, *gn_grouped == 1): float pairs [batch * hw / grp0_rows]
+     * [groups].  One segment only (x1 == NULL), at most 64 row blocks per image: every block of the apply pass combines its image's
+     * blocks itself (fixed order, double) and the normalisation is ONE launch. */
+    const float* grp0; int32_t grp0_rows;
 } mf_groupnorm_desc;
 int mf_groupnorm(const mf_groupnorm_desc* d, void* stream);
 int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups, int32_t channels);

@@ -368,6 +368,7 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
                      "mf_gemm_conv: gn_part needs gn_part_rows, n %% 8 == 0, nz == 1, h_out * w_out %% 32 == 0, no GEGLU / vt_out, and "
                      "2 * n * (M / 32) = %lld floats (got %lld)", (long long)(2ll * d->n * (M64 / 32)), (long long)d->gn_part_floats);
     }
+    if (d->gn_grouped) *d->gn_grouped = 0;
     auto gn_fallback = [&](hipStream_t st) -> int {     // after the launch(es) that wrote `out`
         if (mf_is16(d->out_dtype) && d->ldc % 8 == 0 && mf_aligned16(d->out)) {
             const dim3 g8((unsigned)(a.M / gn_r_fallback), (unsigned)cdiv(a.N, 256));
@@ -562,6 +563,15 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     // statistics in the epilogue: the final values of a block's rows are in its LDS slabs; one image per block of rows
     const bool gn_fused = d->gn_part != nullptr && a.splitk == 1 && a.vec_ok && gn_hw % tc.bm == 0 && a.M % tc.bm == 0;
     a.gn_part = gn_fused ? (float2*)d->gn_part : nullptr;
+    // per-group sums too: the consumer's groups are whole inside a tile's columns (and the LDS of the smallest tiles has room for
+    // one more row of column totals: (WAVES_M + 1) * BN float pairs)
+    bool gn_grouped = false;
+    if (gn_fused && d->gn_groups > 0 && a.N % d->gn_groups == 0) {
+        const int cpg = a.N / d->gn_groups;
+        gn_grouped = tc.bn % cpg == 0 && tc.bm >= 64 && (int64_t)2 * (a.N + d->gn_groups) * (a.M / tc.bm) <= d->gn_part_floats;
+        if (gn_grouped) { a.gn_grp = a.gn_part + (int64_t)a.N * (a.M / tc.bm); a.gn_cpg = cpg; }
+    }
+    if (d->gn_grouped) *d->gn_grouped = gn_grouped ? 1 : 0;
     if (tile == kPersTile) {
         const bool ok = mf_is16(d->dtype) && !a_f32 && a.pointwise && d->c1 == 0 && a.nz == 1 && a.splitk == 1 && a.M % 128 == 0 && a.N % 160 == 0 &&
                         a.K % 64 == 0 && a.nkt >= 2 && a.vec_ok && a.bias_mode == 0 && !a.temb && !a.rs && !a.cs && a.fast && !a.res1 && (!a.res0 || a.res0_dt != MF_F32) && a.out_dt != MF_F32 &&

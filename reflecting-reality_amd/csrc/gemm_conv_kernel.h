@@ -114,6 +114,9 @@ struct GemmArgs {
     // Fixed summation order (slab rows, then the block's wave rows): bitwise reproducible.  The host only sets it for launches the
     // epilogue can serve (no split-K, no GEGLU, no transposed columns, N % 8 == 0, nz == 1).
     float2* gn_part;
+    // ... and per-GROUP sums gn_grp[tile_m * (N / gn_cpg) + group] when the consumer's groups are whole inside a tile's columns
+    // (BN % gn_cpg == 0; the host checks): the consumer GroupNorm then needs no finalize launch
+    float2* gn_grp; int gn_cpg;
 };
 
 __device__ __forceinline__ int div_sh(int x, int d, int sh) { return sh >= 0 ? x >> sh : x / d; }
@@ -1703,11 +1706,23 @@ void gemm_conv_kernel(const GemmArgs p) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_s_barrier();
             const int tcol = (int)threadIdx.x;
+            float a = 0.0f, b = 0.0f;
             if (tcol < BN && n0 + tcol < p.N) {
-                float a = 0.0f, b = 0.0f;
 #pragma unroll
                 for (int w2 = 0; w2 < WAVES_M; ++w2) { const float2 x = red[w2 * BN + tcol]; a += x.x; b += x.y; }
                 p.gn_part[(int64_t)tile_m * p.N + n0 + tcol] = make_float2(a, b);
+            }
+            if (p.gn_grp) {       // whole groups of gn_cpg columns inside this tile: their sums, columns in order
+                float2* tot = red + WAVES_M * BN;
+                if (tcol < BN) tot[tcol] = make_float2(a, b);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                const int cpg = p.gn_cpg, c0g = tcol * cpg;
+                if (c0g < BN && n0 + c0g < p.N) {
+                    float ga = 0.0f, gb = 0.0f;
+                    for (int j = 0; j < cpg; ++j) { const float2 x = tot[c0g + j]; ga += x.x; gb += x.y; }
+                    p.gn_grp[(int64_t)tile_m * (p.N / cpg) + (n0 + c0g) / cpg] = make_float2(ga, gb);
+                }
             }
         }
         MF_STAMP_DRAIN();
@@ -1827,12 +1842,25 @@ void gemm_conv_kernel(const GemmArgs p) {
             if (WN % 64 == 0 || col < WN) red[wm * BN + wn * WN + col] = make_float2(gns[k], gnq[k]);
         }
         __syncthreads();
+        float2* tot = red + WAVES_M * BN;
         for (int tcol = (int)threadIdx.x; tcol < BN; tcol += NTHR) {
+            float a = 0.0f, b = 0.0f;
             if (n0 + tcol < p.N) {
-                float a = 0.0f, b = 0.0f;
 #pragma unroll
                 for (int w2 = 0; w2 < WAVES_M; ++w2) { const float2 x = red[w2 * BN + tcol]; a += x.x; b += x.y; }
                 p.gn_part[(int64_t)tile_m * p.N + n0 + tcol] = make_float2(a, b);
+            }
+            if (p.gn_grp) tot[tcol] = make_float2(a, b);
+        }
+        if (p.gn_grp) {           // whole groups of gn_cpg columns inside this tile: their sums, columns in order
+            __syncthreads();
+            const int cpg = p.gn_cpg;
+            for (int c0g = (int)threadIdx.x * cpg; c0g < BN; c0g += NTHR * cpg) {
+                if (n0 + c0g < p.N) {
+                    float ga = 0.0f, gb = 0.0f;
+                    for (int j = 0; j < cpg; ++j) { const float2 x = tot[c0g + j]; ga += x.x; gb += x.y; }
+                    p.gn_grp[(int64_t)tile_m * (p.N / cpg) + (n0 + c0g) / cpg] = make_float2(ga, gb);
+                }
             }
         }
     }

@@ -180,6 +180,10 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
         return *reinterpret_cast<const uint4*>(p.res0 + ((int64_t)(m0 + row) * p.ld_res0 + n0 + cg * 8) * 2);
     };
 
+    // developer switches (MFHIP_DBG_EPI bits 16 / 32 / 64): static priority 1 for the compute / staging / epilogue waves
+    if ((dbg & 16) && role == 0) __builtin_amdgcn_s_setprio(1);
+    if ((dbg & 32) && role == 1) __builtin_amdgcn_s_setprio(1);
+    if ((dbg & 64) && role == 2) __builtin_amdgcn_s_setprio(1);
     if (role == 1) {
         // ---- staging waves: A tile 16 DMAs of 8 rows (four per wave), W tile 20 (five per wave), swizzle applied to the SOURCE chunk ----
         const srd_t sA = make_srd(p.a0, (unsigned)((int64_t)p.M * p.ld0b));

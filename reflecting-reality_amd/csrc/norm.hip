@@ -23,6 +23,7 @@ struct GnArgs {
     float* stats_out;   // nullable [batch][G][2]: (mean, rstd) of every group, kept for mf_groupnorm_bwd (training)
     // statistics handed over by the producers (mf_gemm_desc.gn_part): per-channel (sum, sum of squares) of every block of rows
     const float2* part0; const float2* part1; int pr0, pr1;
+    const float2* grp0; int nch0;      // per-GROUP sums of x0 from its producer: [batch][nch0][G]; fuse_finalize == 2
 };
 
 template <bool F16>
@@ -203,6 +204,37 @@ __device__ __forceinline__ void gn_group_mean_rstd(const GnArgs& p, int b, float
     }
 }
 
+// (mean, rstd) of every group of sample b from the per-(row block, group) sums the producing GEMM left (GnArgs::grp0): 8 lanes per
+// group, each over blocks j, j + 8, ... in double; fixed-order butterflies, so every block that evaluates it gets the same bits.
+__device__ __forceinline__ void gn_group_from_sums(const GnArgs& p, int b, float* gm, float* gr) {
+    const int t = threadIdx.x;
+    for (int g0 = 0; g0 < p.G; g0 += (int)blockDim.x >> 3) {
+        const int g = g0 + (t >> 3), j = t & 7;
+        const bool on = g < p.G;
+        double s = 0.0, q = 0.0;
+        if (on) {
+            const float2* src = p.grp0 + (int64_t)b * p.nch0 * p.G + g;
+            for (int k = j; k < p.nch0; k += 8) {
+                const float2 v = src[(int64_t)k * p.G];
+                s += (double)v.x; q += (double)v.y;
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            s += __shfl_xor(s, off, 8);
+            q += __shfl_xor(q, off, 8);
+        }
+        if (on && j == 0) {
+            const double n = (double)p.HW * p.cpg;
+            const double mean = s / n;
+            double m2 = q - s * mean;
+            if (m2 < 0.0) m2 = 0.0;
+            gm[g] = (float)mean;
+            gr[g] = (float)(1.0 / sqrt(m2 / n + (double)p.eps));
+        }
+    }
+}
+
 __global__ __launch_bounds__(GN_BLK) void gn_finalize_kernel(const GnArgs p) {
     __shared__ float gm[64], gr[64];
     const int b = blockIdx.x, t = threadIdx.x;
@@ -312,7 +344,8 @@ __global__ __launch_bounds__(GN_BLK) void gn_apply_kernel(const GnArgs p, int ro
     const int lcol = t % p.tpr, trow = t / p.tpr;
     __shared__ float gm[64], gr[64];
     if (p.fuse_finalize) {       // every block combines the chunk statistics itself: one launch (and its gap) less
-        gn_group_mean_rstd(p, b, gm, gr);
+        if (p.fuse_finalize == 2) gn_group_from_sums(p, b, gm, gr);
+        else gn_group_mean_rstd(p, b, gm, gr);
         __syncthreads();
         if (p.stats_out && blockIdx.x == 0)
             for (int g = t; g < p.G; g += blockDim.x) {
@@ -678,6 +711,10 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
                             (d->c1 == 0 || (d->part1 != nullptr && d->part1_rows > 0 && d->hw % d->part1_rows == 0 && d->hw / d->part1_rows <= 128));
     a.part0 = (const float2*)d->part0; a.part1 = (const float2*)d->part1; a.pr0 = d->part0_rows; a.pr1 = d->part1_rows;
     if (from_parts) a.fuse_finalize = 0;
+    // per-GROUP sums from the producer: no statistics pass and no finalize launch — every apply block combines its image's row blocks
+    const bool from_groups = d->grp0 != nullptr && d->c1 == 0 && d->grp0_rows > 0 && d->hw % d->grp0_rows == 0 && d->hw / d->grp0_rows <= 64 &&
+                             mf_aligned16(d->gamma) && mf_aligned16(d->beta);
+    if (from_groups) { a.grp0 = (const float2*)d->grp0; a.nch0 = d->hw / d->grp0_rows; a.fuse_finalize = 2; }
     a.cvn = C / vw;
     a.tpr = a.cvn < GN_BLK ? a.cvn : GN_BLK;
     a.rif = GN_BLK / a.tpr;
@@ -704,7 +741,8 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
     }
 #define MF_GN_LAUNCH(VW_, U_, F_)                                                                                              \
     do {                                                                                                                          \
-        if (from_parts) {                                                                                                         \
+        if (from_groups) {                                                                                                        \
+        } else if (from_parts) {                                                                                                  \
             hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(d->batch, gn_slices), dim3(GN_BLK), (size_t)gn_kparts * gn_gps * a.cpg * sizeof(double2), s, a, gn_gps, gn_kparts); \
             MF_CHECK_LAUNCH("mf_groupnorm(finalize from partial sums)");                                                          \
         } else {                                                                                                                  \

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Tuple
+from typing import Optional, Tuple, Union
 
 import torch
 
@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1, MF_F16 = 0, 1, 2, 3, 4, 5, 6
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class MfhipError(RuntimeError):
@@ -53,6 +53,7 @@ class GemmDesc(C.Structure):
         ("vt_out", C.c_void_p), ("vt_n0", C.c_int32), ("vt_tokens", C.c_int32), ("vt_ld", C.c_int64),
         ("sk_tickets", C.c_void_p), ("sk_ticket_cap", C.c_int32),
         ("gn_part", C.c_void_p), ("gn_part_floats", C.c_int64), ("gn_part_rows", C.c_void_p),
+        ("gn_groups", C.c_int32), ("gn_grouped", C.c_void_p),
     ]
 
 
@@ -118,6 +119,7 @@ class GroupNormDesc(C.Structure):
         ("out", C.c_void_p), ("out_dtype", C.c_int32),
         ("ws", C.c_void_p), ("stats_out", C.c_void_p),
         ("part0", C.c_void_p), ("part0_rows", C.c_int32), ("part1", C.c_void_p), ("part1_rows", C.c_int32),
+        ("grp0", C.c_void_p), ("grp0_rows", C.c_int32),
     ]
 
 
@@ -356,6 +358,7 @@ def pers_linear(m: int, n: int, k: int, dtype: torch.dtype) -> bool:
 
 # GroupNorm statistics from the producing GEMM's epilogue (mf_gemm_desc.gn_part -> mf_groupnorm_desc.part0 / part1).  A/B switch.
 GN_FROM_PARTS = os.environ.get("MFHIP_GN_FROM_PARTS", "1") != "0"
+GN_FROM_GROUPS = os.environ.get("MFHIP_GN_FROM_GROUPS", "1") != "0"     # ... per-group sums: no finalize launch either.  A/B switch.
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
 TUNE_GRAPH = os.environ.get("MFHIP_TUNE_GRAPH", "0") == "1"   # developer switch: time candidates from a hipGraph (see _tuned_config)
 TUNE_LOG: Optional[dict] = None     # developer hook (tools/tune_step.py): every candidate's time of every key tuned while it is a dict
@@ -530,7 +533,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
               a_scale: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None, a_scale_zs: int = 0,
               w_scale_zs: int = 0, splitk: int = 0, tile: int = 0, ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
               vt_out: Optional[torch.Tensor] = None, vt_n0: int = 0, vt_tokens: int = 0, sk_fused: bool = False,
-              gn_part: bool = False) -> torch.Tensor:
+              gn_part: Union[bool, int] = False) -> torch.Tensor:
     """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements.  `dtype`: a torch
     dtype (bf16 / fp32 compute) or an MF_* compute code (the split codes take fp32 a0 and, with w_split=1, a weight
     from ops.split_pack)."""
@@ -627,8 +630,10 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         # as out._gn_part = (fp32 buffer, rows per block) for groupnorm() to pick up.  Set after the tuner ran (it times plain launches).
         m_rows = batch * h_out * w_out
         part = torch.empty(2 * n * (m_rows // 32), dtype=torch.float32, device=out.device)
-        part_rows = C.c_int32(0)
+        part_rows, grouped = C.c_int32(0), C.c_int32(0)
         d.gn_part, d.gn_part_floats, d.gn_part_rows = part.data_ptr(), part.numel(), C.addressof(part_rows)
+        # gn_part = the consumer GroupNorm's group count (an int > 1): per-group sums too where the tile allows (no finalize launch then)
+        d.gn_groups, d.gn_grouped = (int(gn_part) if (gn_part is not True and int(gn_part) > 1) else 0), C.addressof(grouped)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -637,7 +642,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         PROFILE.append((e0, e1, 2.0 * batch * h_out * w_out * n * kh * kw * (c0 + c1) * nz,
                         (batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), nz, d.tile, d.splitk, int(code))))
         if part is not None:
-            out._gn_part = (part, int(part_rows.value))
+            out._gn_part = (part, int(part_rows.value), int(d.gn_groups) if grouped.value else 0)
         return out
     rc = load().mf_gemm_conv(C.byref(d), _stream())
     if rc != 0 and tkey is not None and d.tile != 0:
@@ -647,7 +652,8 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         rc = load().mf_gemm_conv(C.byref(d), _stream())
     _check(rc, "mf_gemm_conv")
     if part is not None:
-        out._gn_part = (part, int(part_rows.value))
+        # (buffer, rows per block, G): G > 0 = per-group sums of G groups follow the per-channel ones at float 2 * n * (M / rows)
+        out._gn_part = (part, int(part_rows.value), int(d.gn_groups) if grouped.value else 0)
     return out
 
 
@@ -686,6 +692,8 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, grou
             d.part0, d.part0_rows = p0[0].data_ptr(), p0[1]
             if p1 is not None:
                 d.part1, d.part1_rows = p1[0].data_ptr(), p1[1]
+            if x1 is None and len(p0) > 2 and p0[2] == groups and GN_FROM_GROUPS:
+                d.grp0, d.grp0_rows = p0[0].data_ptr() + 4 * 2 * c0 * (b * hw // p0[1]), p0[1]
     _check(lib.mf_groupnorm(C.byref(d), _stream()), "mf_groupnorm")
     return out
 

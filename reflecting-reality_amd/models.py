@@ -683,11 +683,11 @@ class _UNetCore(HipModel):
         else:
             sc = x
         h = ops.groupnorm(x, P[p + "norm1"], groups=g, eps=eps, silu=True, out_dtype=self._operand_dtype(), x1=x1)
-        h = ops.conv2d(h, P[p + "conv1"], temb=self._temb(temb_all, p), gn_part=True)
+        h = ops.conv2d(h, P[p + "conv1"], temb=self._temb(temb_all, p), gn_part=self.config["norm_num_groups"])
         h = ops.groupnorm(h, P[p + "norm2"], groups=g, eps=eps, silu=True, out_dtype=self._operand_dtype())
         if join is not None:
             join()
-        return ops.conv2d(h, P[p + "conv2"], res0=sc, res1=inj, gn_part=True)
+        return ops.conv2d(h, P[p + "conv2"], res0=sc, res1=inj, gn_part=self.config["norm_num_groups"])
 
     aux_stream: Optional["torch.cuda.Stream"] = None
 
@@ -870,12 +870,12 @@ class _UNetCore(HipModel):
             fused = self._fused_proj_out(p, inj)
             if fused is not None and inj.feature.shape == x.shape:
                 inj.wait()
-                return ops.conv2d(h.view(bsz, hh, ww, c), fused, padding=0, x1=inj.feature, res0=x, gn_part=True)
+                return ops.conv2d(h.view(bsz, hh, ww, c), fused, padding=0, x1=inj.feature, res0=x, gn_part=self.config["norm_num_groups"])
             inj = inj.materialize()
         if P[p + "proj_out"].fp8:
             return ops.linear(h, P[p + "proj_out"], res0=x.view(bsz, hh * ww, c),
                               res1=inj.view(-1, hh * ww, c) if inj is not None else None).view(bsz, hh, ww, c)
-        return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj, gn_part=True)
+        return ops.conv2d(h.view(bsz, hh, ww, c), P[p + "proj_out"], padding=0, res0=x, res1=inj, gn_part=self.config["norm_num_groups"])
 
     def _fused_proj_out(self, p: str, lz: "LazyResidual") -> Optional[ConvWeight]:
         """[W_proj_out | scale * W_zero_conv] over K = 2C with bias b_po + scale * b_zc, built once per (layer, BrushNet weights,
@@ -1164,7 +1164,7 @@ class BrushNetModel(_UNetCore):
                           self.cin_pad, self.prec.act)                                            # :810 cat + pad
         if ops.TAPE is not None:
             ops.TAPE.no_grad(x)            # the batch's own inputs need no gradient
-        x = ops.conv2d(x, self.P["conv_in_condition"], gn_part=True)
+        x = ops.conv2d(x, self.P["conv_in_condition"], gn_part=self.config["norm_num_groups"])
 
         def zero_conv(name: str, r: torch.Tensor):
             if lazy and name in lazy and ops.TAPE is None and not guess_mode:
@@ -1184,7 +1184,7 @@ class BrushNetModel(_UNetCore):
                 down.append(x)
                 d.append(zero_conv(f"brushnet_down_blocks.{len(d)}", x))
             if i != n - 1:
-                x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1, gn_part=True)
+                x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1, gn_part=self.config["norm_num_groups"])
                 down.append(x)
                 d.append(zero_conv(f"brushnet_down_blocks.{len(d)}", x))
         for j in range(2):                                                                        # MidBlock2D
@@ -1197,7 +1197,7 @@ class BrushNetModel(_UNetCore):
                 x = self._resnet(f"up_blocks.{i}.resnets.{j}.", x, temb, x1=skips.pop())
                 u.append(zero_conv(f"brushnet_up_blocks.{len(u)}", x))
             if i != n - 1:
-                x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True, gn_part=True)
+                x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True, gn_part=self.config["norm_num_groups"])
                 u.append(zero_conv(f"brushnet_up_blocks.{len(u)}", x))
         return d, m, u
 
@@ -1346,7 +1346,7 @@ class UNet2DConditionModel(_UNetCore):
         if ops.TAPE is not None:
             ops.TAPE.no_grad(x, ehs)
         hip.TUNE_CTX = "e" if ops.TAPE is None else None
-        x = ops.conv2d(x, self.P["conv_in"], gn_part=True)
+        x = ops.conv2d(x, self.P["conv_in"], gn_part=self.config["norm_num_groups"])
         skips = [x]                                                                                 # :1215 pre-add
         if is_brushnet:
             x = ops.add(x, self._inj(down_block_add_samples.pop(0)), self.prec.act)                 # :1218
@@ -1366,7 +1366,7 @@ class UNet2DConditionModel(_UNetCore):
                 skips.append(x)                                                                     # post-add (:1388-1391)
             if i != n - 1:
                 inj = take(down_block_add_samples) if is_brushnet else None
-                x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1, res1=inj, gn_part=True)
+                x = ops.conv2d(x, self.P[f"down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=1, res1=inj, gn_part=self.config["norm_num_groups"])
                 skips.append(x)
         x = self._resnet("mid_block.resnets.0.", x, temb)
         x = self._transformer("mid_block.attentions.0.", x, ehs, self._heads(n - 1))
@@ -1386,7 +1386,7 @@ class UNet2DConditionModel(_UNetCore):
                     x = self._resnet(f"up_blocks.{i}.resnets.{j}.", x, temb, x1=sk, inj=inj)
             if i != n - 1:
                 inj = take(up_block_add_samples) if is_brushnet else None
-                x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True, res1=inj, gn_part=True)
+                x = ops.conv2d(x, self.P[f"up_blocks.{i}.upsamplers.0.conv"], upsample=True, res1=inj, gn_part=self.config["norm_num_groups"])
         x = ops.groupnorm(x, self.P["conv_norm_out"], groups=c["norm_num_groups"], eps=c["norm_eps"], silu=True,
                           out_dtype=self.prec.act)
         y = ops.conv2d(x, self.P["conv_out"], out_dtype=F32)
@@ -1544,10 +1544,10 @@ class AutoencoderKL(HipModel):
         g = self.config["norm_num_groups"]
         P = self.P
         h = ops.groupnorm(x, P[p + "norm1"], groups=g, eps=1e-6, silu=True, out_dtype=self.prec.act)
-        h = ops.conv2d(h, P[p + "conv1"], gn_part=True)
+        h = ops.conv2d(h, P[p + "conv1"], gn_part=self.config["norm_num_groups"])
         h = ops.groupnorm(h, P[p + "norm2"], groups=g, eps=1e-6, silu=True, out_dtype=self.prec.act)
         sc = ops.conv2d(x, P[p + "conv_shortcut"], padding=0) if p + "conv_shortcut" in P else x
-        return ops.conv2d(h, P[p + "conv2"], res0=sc, gn_part=True)
+        return ops.conv2d(h, P[p + "conv2"], res0=sc, gn_part=self.config["norm_num_groups"])
 
     def _mid(self, p, x):
         """UNetMidBlock2D (unet_2d_blocks.py:601-753): resnet, 1-head spatial self-attention, resnet."""
@@ -1570,12 +1570,12 @@ class AutoencoderKL(HipModel):
         n = len(c["block_out_channels"])
         hip.TUNE_CTX = None                                      # the VAE's tune keys carry no position tag
         h = from_nchw(hip.h2d(x, self.device).float(), self.prec, self.cin_pad)
-        h = ops.conv2d(h, self.P["encoder.conv_in"], gn_part=True)
+        h = ops.conv2d(h, self.P["encoder.conv_in"], gn_part=self.config["norm_num_groups"])
         for i in range(n):
             for j in range(c["layers_per_block"]):
                 h = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}.", h)
             if i != n - 1:   # Downsample2D(padding=0): asymmetric (0,1,0,1) pad (downsampling.py:140-142)
-                h = ops.conv2d(h, self.P[f"encoder.down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=(0, 0, 1, 1), gn_part=True)
+                h = ops.conv2d(h, self.P[f"encoder.down_blocks.{i}.downsamplers.0.conv"], stride=2, padding=(0, 0, 1, 1), gn_part=self.config["norm_num_groups"])
         h = self._mid("encoder.mid_block.", h)
         h = ops.groupnorm(h, self.P["encoder.conv_norm_out"], groups=c["norm_num_groups"], eps=1e-6, silu=True,
                           out_dtype=self.prec.act)
@@ -1594,13 +1594,13 @@ class AutoencoderKL(HipModel):
         hip.TUNE_CTX = None                                      # the VAE's tune keys carry no position tag
         h = from_nchw(z.to(self.device).float(), self.prec, self.lat_pad)
         h = ops.conv2d(h, self.P["post_quant_conv"], padding=0)
-        h = ops.conv2d(h, self.P["decoder.conv_in"], gn_part=True)
+        h = ops.conv2d(h, self.P["decoder.conv_in"], gn_part=self.config["norm_num_groups"])
         h = self._mid("decoder.mid_block.", h)
         for i in range(n):
             for j in range(c["layers_per_block"] + 1):
                 h = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}.", h)
             if i != n - 1:
-                h = ops.conv2d(h, self.P[f"decoder.up_blocks.{i}.upsamplers.0.conv"], upsample=True, gn_part=True)
+                h = ops.conv2d(h, self.P[f"decoder.up_blocks.{i}.upsamplers.0.conv"], upsample=True, gn_part=self.config["norm_num_groups"])
         h = ops.groupnorm(h, self.P["decoder.conv_norm_out"], groups=c["norm_num_groups"], eps=1e-6, silu=True,
                           out_dtype=self.prec.act)
         y = ops.conv2d(h, self.P["decoder.conv_out"], out_dtype=F32)

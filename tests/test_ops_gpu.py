@@ -884,13 +884,13 @@ def test_conv_leaves_groupnorm_partial_sums_of_its_final_output(prec_name, tile)
     r0 = torch.randn(b, h, w, n, generator=g)
     r1 = torch.randn(b, h, w, n, generator=g)
     cw = ops.ConvWeight(wt, bias, prec, DEV)
-    args = dict(temb=temb, res0=r0.to(DEV, prec.act), res1=r1.to(DEV, prec.act), alpha=0.5, gn_part=True, tile=tile)
+    args = dict(temb=temb, res0=r0.to(DEV, prec.act), res1=r1.to(DEV, prec.act), alpha=0.5, gn_part=32, tile=tile)
     try:
         y = ops.conv2d(x.to(DEV, prec.act), cw, **args)
     except hip.MfhipError as e:
         assert "not instantiated" in str(e) or "does not apply" in str(e), e     # a tile this precision does not have
         return
-    part, rows = y._gn_part
+    part, rows, grouped = y._gn_part
     assert rows in (32, 64, 128, 192, 256) and (h * w) % rows == 0
     nb = b * h * w // rows
     got = part[: nb * n * 2].view(nb, n, 2).double().cpu()
@@ -902,8 +902,14 @@ def test_conv_leaves_groupnorm_partial_sums_of_its_final_output(prec_name, tile)
     es, eq = (got[..., 0] - ref[..., 0]).abs().max().item(), (got[..., 1] - ref[..., 1]).abs().max().item()
     print(f"gn_part[{prec_name}, tile {tile}]: rows per block {rows}, |sum err| {es:.3e} (scale {scale_s:.1f}), |sumsq err| {eq:.3e} (scale {scale_q:.1f})")
     assert es <= 0.25 * ulp * scale_s + 1e-3 and eq <= 0.5 * ulp * scale_q + 1e-3
+    if grouped:      # per-group sums of the 32 groups behind the per-channel ones: the same numbers, summed over each group's 10 channels
+        assert grouped == 32
+        gg = part[nb * n * 2: nb * n * 2 + nb * 32 * 2].view(nb, 32, 2).double().cpu()
+        gref = ref.view(nb, 32, n // 32, 2).sum(2)
+        egs, egq = (gg[..., 0] - gref[..., 0]).abs().max().item(), (gg[..., 1] - gref[..., 1]).abs().max().item()
+        assert egs <= 0.25 * ulp * scale_s * 10 + 1e-3 and egq <= 0.5 * ulp * scale_q * 10 + 1e-3, (egs, egq)
     y2 = ops.conv2d(x.to(DEV, prec.act), cw, **args)
-    assert y2._gn_part[1] == rows and torch.equal(y2._gn_part[0][: nb * n * 2], part[: nb * n * 2]) and torch.equal(y2, y)
+    assert y2._gn_part[1:] == (rows, grouped) and torch.equal(y2._gn_part[0][: nb * (n + 32) * 2], part[: nb * (n + 32) * 2]) and torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("case", ["splitk", "odd_hw", "1x1", "up", "s2"])
@@ -932,7 +938,7 @@ def test_groupnorm_partial_sums_fallback_and_variants(case):
     if case == "s2":
         assert not hasattr(y, "_gn_part")         # 16 x 16 output: GroupNorm's one-launch form, nothing asked
         return
-    part, rows = y._gn_part
+    part, rows = y._gn_part[:2]
     hw = y.shape[1] * y.shape[2]
     assert hw % rows == 0 and (case not in ("splitk", "odd_hw") or rows in (32, 64, 128))
     nb = y.shape[0] * hw // rows
@@ -940,6 +946,32 @@ def test_groupnorm_partial_sums_fallback_and_variants(case):
     ref = _colsum_ref(y.float().cpu(), rows)
     tol_s, tol_q = 2.0 ** -9 * rows * float(y.float().abs().max()), 2.0 ** -8 * rows * float(y.float().abs().max()) ** 2
     assert (got[..., 0] - ref[..., 0]).abs().max() <= tol_s and (got[..., 1] - ref[..., 1]).abs().max() <= tol_q
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("c,hw,rows,silu", [(320, 4096, 256, True), (640, 1024, 128, True), (1280, 1024, 128, False), (320, 4096, 64, False)])
+def test_groupnorm_from_producer_group_sums_is_one_launch(dt, c, hw, rows, silu):
+    """mf_groupnorm with grp0 (per-group sums of every block of `rows` rows, as a GEMM with gn_groups leaves them): no statistics
+    pass and no finalize launch; the result equals the other two routes to the rounding of the statistic and is bit-reproducible."""
+    g = torch.Generator().manual_seed(6)
+    b, groups = 2, 32
+    x = (torch.randn(b, hw, c, generator=g) * 1.5 + 0.7).to(DEV, dt)
+    gamma, beta = torch.randn(c, generator=g).to(DEV), torch.randn(c, generator=g).to(DEV)
+    v = x.float().view(-1, rows, c)
+    chan = torch.stack([v.sum(1), (v * v).sum(1)], dim=-1)                               # [blocks, c, 2]
+    grp = chan.view(-1, groups, c // groups, 2).sum(2)                                   # [blocks, groups, 2]
+    x._gn_part = (torch.cat([chan.reshape(-1), grp.reshape(-1)]).contiguous(), rows, groups)
+    y = hip.groupnorm(x, gamma, beta, groups=groups, eps=1e-5, silu=silu, out_dtype=dt)
+    y2 = hip.groupnorm(x, gamma, beta, groups=groups, eps=1e-5, silu=silu, out_dtype=dt)
+    assert torch.equal(y, y2)
+    del x._gn_part
+    ref = hip.groupnorm(x, gamma, beta, groups=groups, eps=1e-5, silu=silu, out_dtype=dt)
+    tref = F.group_norm(x.float().cpu().permute(0, 2, 1), groups, gamma.cpu(), beta.cpu(), 1e-5).permute(0, 2, 1)
+    if silu:
+        tref = F.silu(tref)
+    tol = {torch.bfloat16: 3e-2, torch.float32: 2e-5}[dt]
+    check(f"groupnorm_from_groups[{dt}]", y, tref, tol, tol)
+    assert (y.float() - ref.float()).abs().max().item() <= tol
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])

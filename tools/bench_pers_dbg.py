@@ -28,7 +28,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(" | ".join(out), flush=True)
     sys.exit(0)
 
-for bits, what in ((0, "everything on"), (1, "no epilogue chunks"), (2, "no MFMA / fragment reads"), (4, "no DMA"), (5, "no epilogue, no DMA"), (6, "no MFMA, no DMA"), (7, "barriers only + dump"), (15, "barriers only, no dump"), (8, "everything but the dump")):
+for bits, what in ((0, "everything on"), (1, "no epilogue chunks"), (2, "no MFMA / fragment reads"), (4, "no DMA"), (5, "no epilogue, no DMA"), (6, "no MFMA, no DMA"), (7, "barriers only + dump"), (15, "barriers only, no dump"), (8, "everything but the dump"),
+                   (16, "all on, compute waves at priority 1"), (32, "all on, staging waves at priority 1"), (64, "all on, epilogue waves at priority 1"), (48, "all on, compute + staging at priority 1")):
     env = dict(os.environ, MFHIP_DBG_EPI=str(bits))
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], capture_output=True, text=True, env=env)
     print(f"MFHIP_DBG_EPI={bits} ({what}): {r.stdout.strip() or r.stderr[-300:]}", flush=True)

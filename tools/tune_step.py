@@ -113,7 +113,7 @@ for k in [k for _ in range(a.passes) for k in order]:
     r = rankings[base_of(k)]
     best_iso = r[0][0]
     alts = [c for c in r[:a.top] if c[0] <= best_iso * (1.0 + a.within)]
-    cur = tuple(cache.get(k) or cache[base_of(k)])
+    cur = tuple(cache.get(k) or cache.get(base_of(k)) or r[0][1:])       # (a key only ever looked up under its position tag has no plain entry)
     for (dt, t, s, mode) in alts:
         if evals >= a.max_evals:
             break
