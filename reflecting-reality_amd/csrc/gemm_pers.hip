@@ -181,7 +181,10 @@ __global__ __launch_bounds__(1024) void gemm_pers_kernel(const GemmArgs p) {
     };
 
     // developer switches (MFHIP_DBG_EPI bits 16 / 32 / 64): static priority 1 for the compute / staging / epilogue waves
-    if ((dbg & 16) && role == 0) __builtin_amdgcn_s_setprio(1);
+    // GEGLU variants: the compute waves run at priority 1 — their MFMAs and fragment reads then win the issue port over the
+    // epilogue waves' (and their own partners') GEGLU arithmetic, which has slack; measured 112 -> 98 us on the 64 x 64 feed-forward,
+    // neutral on the other variants (profiles/r06_tile70_time_breakdown.txt)
+    if ((GEGLU || (dbg & 16)) && role == 0) __builtin_amdgcn_s_setprio(1);
     if ((dbg & 32) && role == 1) __builtin_amdgcn_s_setprio(1);
     if ((dbg & 64) && role == 2) __builtin_amdgcn_s_setprio(1);
     if (role == 1) {

@@ -909,7 +909,7 @@ def test_conv_leaves_groupnorm_partial_sums_of_its_final_output(prec_name, tile)
         egs, egq = (gg[..., 0] - gref[..., 0]).abs().max().item(), (gg[..., 1] - gref[..., 1]).abs().max().item()
         assert egs <= 0.25 * ulp * scale_s * 10 + 1e-3 and egq <= 0.5 * ulp * scale_q * 10 + 1e-3, (egs, egq)
     y2 = ops.conv2d(x.to(DEV, prec.act), cw, **args)
-    assert y2._gn_part[1:] == (rows, grouped) and torch.equal(y2._gn_part[0][: nb * (n + 32) * 2], part[: nb * (n + 32) * 2]) and torch.equal(y2, y)
+    assert y2._gn_part[1:] == (rows, grouped) and torch.equal(y2._gn_part[0][: nb * (n + grouped) * 2], part[: nb * (n + grouped) * 2]) and torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("case", ["splitk", "odd_hw", "1x1", "up", "s2"])
