@@ -414,7 +414,7 @@ def main():
             peak = round(flops / ideal_s / 1e12, 1)          # FLOP-weighted harmonic blend of the two peaks
         traffic, traffic_src = None, None
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        pmc = next((q for q in (os.path.join(pdir, f"r0{r}_pmc_gemm_family.json") for r in (5, 4, 3)) if os.path.exists(q)), "")
+        pmc = next((q for q in (os.path.join(pdir, f"r0{r}_pmc_gemm_family.json") for r in (6, 5, 4, 3)) if os.path.exists(q)), "")
         if os.path.exists(pmc) and a.batch == 4 and a.size == 512 and a.precision == "bf16" and not xl:
             with open(pmc) as f:
                 pj = json.load(f)

@@ -441,6 +441,11 @@ void gemm_conv_kernel(const GemmArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    if constexpr (WS) {
+        // developer switches (MFHIP_DBG_EPI bits 16 / 32): static priority 1 for the compute / the staging waves of a warp-specialised block
+        if ((p.dbg_epi & 16) && !producer) __builtin_amdgcn_s_setprio(1);
+        if ((p.dbg_epi & 32) && producer) __builtin_amdgcn_s_setprio(1);
+    }
 
     // XCD-aware order: the 8 XCDs take blocks round-robin, so give each XCD a contiguous run of the LOGICAL order
     // (K split outermost, then the tiles of one split; blockIdx.x counts all of them).  The order inside a split is

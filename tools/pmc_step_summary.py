@@ -11,7 +11,7 @@ def family_sum(d):
     # the last forward starts at the second-to-last timestep_embedding kernel (BrushNet's, then the UNet's)
     marks = [i for i, r in enumerate(rows) if "timestep_embedding" in r["Kernel_Name"]]
     rows = rows[marks[-2]:]
-    fam = [r for r in rows if "gemm_conv_kernel" in r["Kernel_Name"] or "conv3x3_halo" in r["Kernel_Name"]]
+    fam = [r for r in rows if "gemm_conv_kernel" in r["Kernel_Name"] or "conv3x3_halo" in r["Kernel_Name"] or "gemm_pers_kernel" in r["Kernel_Name"] or "gemm_nloop_kernel" in r["Kernel_Name"]]
     return sum(float(r["Counter_Value"]) for r in fam), len(fam)
 
 
@@ -26,14 +26,14 @@ def family_counters(d):
     first = marks[-2] if len(marks) >= 2 else 0        # the last forward: BrushNet's timestep embedding, then the UNet's
     out = {}
     for r in rows:
-        if int(r["Dispatch_Id"]) >= first and ("gemm_conv_kernel" in r["Kernel_Name"] or "conv3x3_halo" in r["Kernel_Name"]):
+        if int(r["Dispatch_Id"]) >= first and ("gemm_conv_kernel" in r["Kernel_Name"] or "conv3x3_halo" in r["Kernel_Name"] or "gemm_pers_kernel" in r["Kernel_Name"] or "gemm_nloop_kernel" in r["Kernel_Name"]):
             out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     return out
 
 
 fetch_kb, n = family_sum(sys.argv[1])
 write_kb, n2 = family_sum(sys.argv[2])
-out = {"kernel": "gemm_conv_kernel family (all tile instantiations), one denoise step, batch 4 x 512x512, bf16",
+out = {"kernel": "gemm_conv_kernel family (all tile instantiations, incl. the persistent tiles 69 / 70), one denoise step, batch 4 x 512x512, bf16",
        "launches": n, "fetch_bytes_per_launch": round(2.0 * fetch_kb * 1024 / n), "write_bytes_per_launch": round(write_kb * 1024 / n2),
        "traffic_bytes_per_launch": round(2.0 * fetch_kb * 1024 / n + write_kb * 1024 / n2),
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/profile_step.py; FETCH_SIZE x2 "
