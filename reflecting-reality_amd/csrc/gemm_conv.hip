@@ -23,10 +23,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             const int m = (int)(r / p.N);
             const int n = (int)(r - (int64_t)m * p.N);
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int s = 0; s < p.splitk; ++s) {
-                const float* src = p.ws + ((int64_t)s * p.nz + z) * mn + r;
-                const float4 a = *reinterpret_cast<const float4*>(src);
-                const float4 b = *reinterpret_cast<const float4*>(src + 4);
+            // four slabs' loads in flight at a time (a loop of one load + one add per slab is a chain of `splitk` fabric round trips:
+            // the slabs were written by other XCDs); the additions keep the slab order, so the sums are bit-identical
+            const int64_t sstride = (int64_t)p.nz * mn;
+            const float* src0 = p.ws + (int64_t)z * mn + r;
+            int s = 0;
+            for (; s + 4 <= p.splitk; s += 4) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = *reinterpret_cast<const float4*>(src0 + (s + u) * sstride);
+                    b[u] = *reinterpret_cast<const float4*>(src0 + (s + u) * sstride + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w; v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+                }
+            }
+            for (; s < p.splitk; ++s) {
+                const float4 a = *reinterpret_cast<const float4*>(src0 + s * sstride);
+                const float4 b = *reinterpret_cast<const float4*>(src0 + s * sstride + 4);
                 v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
             }
             const int zq = z / p.zdiv, zr = z - zq * p.zdiv;

@@ -214,9 +214,12 @@ __device__ __forceinline__ void gn_group_from_sums(const GnArgs& p, int b, float
         double s = 0.0, q = 0.0;
         if (on) {
             const float2* src = p.grp0 + (int64_t)b * p.nch0 * p.G + g;
-            for (int k = j; k < p.nch0; k += 8) {
-                const float2 v = src[(int64_t)k * p.G];
-                s += (double)v.x; q += (double)v.y;
+            for (int k0 = j; k0 < p.nch0; k0 += 32) {                  // up to four independent loads in flight (nch0 <= 64), added in order
+                float2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = k0 + 8 * u < p.nch0 ? src[(int64_t)(k0 + 8 * u) * p.G] : make_float2(0.0f, 0.0f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
             }
         }
 #pragma unroll

@@ -344,16 +344,22 @@ class StableDiffusionBrushNetPipeline:
 
     # ---- prompt --------------------------------------------------------------------------------------
     def encode_prompt(self, prompt, num_images_per_prompt, do_cfg, negative_prompt=None, prompt_embeds=None,
-                      negative_prompt_embeds=None):
-        """pipeline_brushnet.py:271-450 without LoRA / textual inversion / clip_skip."""
+                      negative_prompt_embeds=None, clip_skip: Optional[int] = None):
+        """pipeline_brushnet.py:271-450 without LoRA / textual inversion.  clip_skip (:352-370): the hidden state clip_skip layers
+        before the last one, through the text model's final LayerNorm (the text encoder is the caller's torch module: outside the
+        accelerated path)."""
         if prompt_embeds is None:
             if self.text_encoder is None or self.tokenizer is None:
                 raise ValueError("pass `prompt_embeds` or construct the pipeline with a text_encoder and tokenizer")
             def enc(txt):
                 ids = self.tokenizer(txt, padding="max_length", max_length=self.tokenizer.model_max_length,
                                      truncation=True, return_tensors="pt").input_ids
+                ids = ids.to(next(self.text_encoder.parameters()).device)
                 with torch.no_grad():
-                    return self.text_encoder(ids.to(next(self.text_encoder.parameters()).device))[0]
+                    if clip_skip is None:
+                        return self.text_encoder(ids)[0]
+                    out = self.text_encoder(ids, output_hidden_states=True)
+                    return self.text_encoder.text_model.final_layer_norm(out[-1][-(clip_skip + 1)])
             plist = [prompt] if isinstance(prompt, str) else prompt
             prompt_embeds = enc(plist)
             if do_cfg and negative_prompt_embeds is None:
@@ -470,8 +476,13 @@ class StableDiffusionBrushNetPipeline:
         callback_steps = kwargs.pop("callback_steps", None)
         if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
             raise NotImplementedError("IP-Adapter inputs are outside the BASELINE configs (SURVEY.md §2 #14)")
-        if cross_attention_kwargs or clip_skip is not None or timesteps is not None:
-            raise NotImplementedError("cross_attention_kwargs / clip_skip / custom timesteps are not built")
+        if cross_attention_kwargs:
+            raise NotImplementedError("cross_attention_kwargs (LoRA scale) are not built")
+        if timesteps is not None:
+            # retrieve_timesteps (pipeline_brushnet.py:113-119): the reference's DDIM / PNDM / UniPC `set_timesteps` take no custom
+            # schedule either and the reference raises exactly this
+            raise ValueError(f"The current scheduler class {self.scheduler.__class__}'s `set_timesteps` does not support custom"
+                             f" timestep schedules. Please check whether you are using the correct scheduler.")
         if guess_mode and type(self) is not StableDiffusionBrushNetPipeline:
             raise NotImplementedError("guess_mode is built for the SD1.5 pipeline")
         if isinstance(control_guidance_start, list) or isinstance(control_guidance_end, list):
@@ -492,7 +503,7 @@ class StableDiffusionBrushNetPipeline:
             batch_size = prompt_embeds.shape[0]
         do_cfg = self.do_classifier_free_guidance
         prompt_embeds, negative_prompt_embeds = self.encode_prompt(
-            prompt, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds)
+            prompt, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds, clip_skip=clip_skip)
         pe = torch.cat([negative_prompt_embeds, prompt_embeds]) if do_cfg else prompt_embeds         # :1103
         pe = pe.to(self.device)
         nb = batch_size * num_images_per_prompt
@@ -511,19 +522,26 @@ class StableDiffusionBrushNetPipeline:
 
         self.scheduler.set_timesteps(num_inference_steps, device=self.device)                       # :1171
         ts = self.scheduler.timesteps
+        dend = getattr(self, "_denoising_end", None)
+        if dend is not None and isinstance(dend, float) and 0.0 < dend < 1.0:                        # pipeline_brushnet_sd_xl.py:1376-1391
+            ntrain = int(self.scheduler.config["num_train_timesteps"])
+            cutoff = int(round(ntrain - dend * ntrain))
+            num_inference_steps = len([t for t in ts.tolist() if t >= cutoff])
+            ts = ts[:num_inference_steps]
         self._num_timesteps = len(ts)
         latents, _ = self.prepare_latents(nb, self.unet.config["in_channels"], height, width, generator, latents)
 
         keep = [1.0 - float(i / len(ts) < control_guidance_start or (i + 1) / len(ts) > control_guidance_end)
                 for i in range(len(ts))]                                                             # :1236-1242
-        fused_ddim = isinstance(self.scheduler, DDIMScheduler) and eta == 0.0
+        rescale = float(getattr(self, "_guidance_rescale", 0.0) or 0.0)
+        fused_ddim = isinstance(self.scheduler, DDIMScheduler) and eta == 0.0 and rescale == 0.0
         num_warmup = len(ts) - num_inference_steps * self.scheduler.order
         if _timing is not None:          # HIP events on the launch stream around the denoise loop (bench.py)
             _timing["host_before_denoise"] = time.perf_counter()
             _timing["denoise_start"] = torch.cuda.Event(enable_timing=True)
             _timing["denoise_end"] = torch.cuda.Event(enable_timing=True)
             _timing["denoise_start"].record()
-        use_graph = (self.use_hip_graph and do_cfg and callback is None and (fused_ddim or eta == 0.0)
+        use_graph = (self.use_hip_graph and do_cfg and callback is None and (fused_ddim or eta == 0.0) and rescale == 0.0
                      and all(k == 1.0 for k in keep) and len(ts) > 2 and not guess_mode)
         with self.progress_bar(total=num_inference_steps) as bar:
             if use_graph:
@@ -557,6 +575,12 @@ class StableDiffusionBrushNetPipeline:
                         latents = self.scheduler.step(None, t, latents, return_dict=False, _cfg=(eu, ec, guidance_scale))[0]
                     else:
                         noise_pred = hip.cfg_combine(eu, ec, float(guidance_scale))                 # :1310-1312
+                        if rescale > 0.0:
+                            # rescale_noise_cfg (pipeline_brushnet_sd_xl.py:1478-1480; pipeline_stable_diffusion.py:59-70): one standard
+                            # deviation per image and two scalings — a non-default switch outside the timed path, on torch's device ops
+                            dims = list(range(1, ec.ndim))
+                            std_text, std_cfg = ec.float().std(dim=dims, keepdim=True), noise_pred.float().std(dim=dims, keepdim=True)
+                            noise_pred = (rescale * (noise_pred.float() * (std_text / std_cfg)) + (1.0 - rescale) * noise_pred.float()).to(noise_pred.dtype)
                         latents = self._sched_step(noise_pred, t, latents, eta, generator)
                 else:
                     latents = self._sched_step(eps, t, latents, eta, generator)                     # :1315
@@ -794,8 +818,6 @@ class StableDiffusionXLBrushNetPipeline(StableDiffusionBrushNetPipeline):
         if prompt is not None or prompt_2 is not None or negative_prompt is not None or negative_prompt_2 is not None:
             raise NotImplementedError("the two CLIP text encoders are outside the accelerated path: pass prompt_embeds, "
                                       "negative_prompt_embeds, pooled_prompt_embeds and negative_pooled_prompt_embeds")
-        if denoising_end is not None or guidance_rescale:
-            raise NotImplementedError("denoising_end / guidance_rescale (pipeline_brushnet_sd_xl.py:1376-1391,1478-1480)")
         if prompt_embeds is None or pooled_prompt_embeds is None:
             raise ValueError("If `prompt_embeds` are provided, `pooled_prompt_embeds` also have to be passed. Make sure to "
                              "generate `pooled_prompt_embeds` from the same text encoder that was used to generate `prompt_embeds`.")
@@ -823,6 +845,8 @@ class StableDiffusionXLBrushNetPipeline(StableDiffusionBrushNetPipeline):
             text = pooled
         ids = ids.repeat(nb, 1)                                              # :1372 (sic: interleaves neg/pos rows)
         self._added_cond = dict(text_embeds=text.to(self.device), time_ids=ids.to(self.device))
+        # denoising_end (pipeline_brushnet_sd_xl.py:1376-1391) and guidance_rescale (:1478-1480) are read by the shared loop
+        self._denoising_end, self._guidance_rescale = denoising_end, float(guidance_rescale or 0.0)
         try:
             return super().__call__(image=image, mask=mask, height=height, width=width,
                                     num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
@@ -838,3 +862,4 @@ class StableDiffusionXLBrushNetPipeline(StableDiffusionBrushNetPipeline):
                                     conditioning_noise=conditioning_noise, **kwargs)
         finally:
             self._added_cond = None
+            self._denoising_end, self._guidance_rescale = None, 0.0

@@ -146,6 +146,42 @@ def test_check_inputs_error_conventions():
                       device="cpu").forward(img, 1, None, img)                  # brushnet.py:741 (after "no parameters")
 
 
+def test_clip_skip_and_custom_timesteps_follow_the_reference():
+    """clip_skip (pipeline_brushnet.py:352-370): the hidden state clip_skip layers before the last, through the text model's final
+    LayerNorm.  Custom `timesteps` (retrieve_timesteps, :113-119): the reference's DDIM / PNDM / UniPC take none and it raises
+    ValueError — so does this pipeline (before anything touches a device)."""
+    import types
+    pipe = _pipe()
+
+    class Tok:
+        model_max_length = 5
+
+        def __call__(self, txt, **kw):
+            return types.SimpleNamespace(input_ids=torch.arange(5)[None].repeat(len(txt), 1))
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1))
+            self.text_model = types.SimpleNamespace(final_layer_norm=lambda h: h * 10.0)
+
+        def forward(self, ids, output_hidden_states=False):
+            hs = tuple(torch.full((ids.shape[0], 5, 32), float(l)) for l in range(4))      # hidden states of layers 0 .. 3
+            return (hs[-1], None, hs) if output_hidden_states else (hs[-1],)
+
+    pipe.tokenizer, pipe.text_encoder = Tok(), Enc()
+    pe, npe = pipe.encode_prompt(["a"], 1, True, None)
+    assert float(pe[0, 0, 0]) == 3.0 and float(npe[0, 0, 0]) == 3.0                        # the last layer's output, as returned
+    pe, _ = pipe.encode_prompt(["a"], 1, True, None, clip_skip=1)
+    assert float(pe[0, 0, 0]) == 20.0                                                       # layer -(1 + 1) = 2, through the final norm
+    pe, _ = pipe.encode_prompt(["a"], 1, False, None, clip_skip=2)
+    assert float(pe[0, 0, 0]) == 10.0
+    img = torch.rand(1, 3, 16, 16)
+    with pytest.raises(ValueError, match="does not support custom"):
+        pipe(prompt_embeds=torch.zeros(1, 77, 32), negative_prompt_embeds=torch.zeros(1, 77, 32), image=img, mask=img[:, :1],
+             depth=img[:, :1], timesteps=[900, 500, 100], output_type="latent", height=16, width=16)
+
+
 def test_models_fail_loudly_without_gpu_or_weights():
     u = UNet2DConditionModel(dict(configs.TINY_UNET), device="cpu")
     with pytest.raises(RuntimeError):

@@ -81,6 +81,55 @@ def test_tiny_xl_pipeline(prec, tol):
                                                  "negative_pooled_prompt_embeds": torch.randn(1, 16)})
 
 
+def test_xl_denoising_end_and_guidance_rescale():
+    """pipeline_brushnet_sd_xl.py:1376-1391 (denoising_end: the schedule is cut at the discrete timestep num_train * (1 - end)) and
+    :1478-1480 / pipeline_stable_diffusion.py:59-70 (rescale_noise_cfg: the guided prediction rescaled to the text prediction's
+    standard deviation per image and mixed back with weight guidance_rescale).  Both run the eager loop; the prediction handed to
+    the scheduler is checked against the formula on the recorded (unconditional, text) pair."""
+    unet, bn, vae = build_xl("fp32")
+    pipe = StableDiffusionXLBrushNetPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None,
+                                             unet=unet, brushnet=bn, scheduler=DDIMScheduler(**SD_SCHED, clip_sample=False))
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(1, 16, 16, seed=99, cross_dim=48, vae_scale=2)
+    gp = torch.Generator().manual_seed(100)
+    pooled, npooled = torch.randn(1, 24, generator=gp), torch.randn(1, 24, generator=gp)
+    kw = dict(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], pooled_prompt_embeds=pooled,
+              negative_pooled_prompt_embeds=npooled, image=inp["image"], mask=inp["mask"], guidance_scale=5.0, output_type="latent",
+              height=16, width=16, conditioning_noise=inp["vae_noise"])
+    steps = []
+    pipe(latents=inp["latents"].clone(), num_inference_steps=10, denoising_end=0.5,
+         callback_on_step_end=lambda p, i, t, k: steps.append(int(t)) or {}, **kw)
+    full = DDIMScheduler(**SD_SCHED, clip_sample=False)
+    full.set_timesteps(10)
+    assert steps == [int(t) for t in full.timesteps if int(t) >= 500] and 0 < len(steps) < 10
+    assert pipe._denoising_end is None and pipe._guidance_rescale == 0.0                   # call-scoped
+    # guidance_rescale: record what reaches the scheduler
+    from reflecting_reality_amd import hip
+    seen = {}
+    real_cfg, real_step = hip.cfg_combine, pipe._sched_step
+
+    def cfg(eu, ec, g):
+        out = real_cfg(eu, ec, g)
+        seen["ec"], seen["cfg"] = ec.float().clone(), out.float().clone()
+        return out
+
+    def step(noise_pred, *a, **k):
+        seen["np"] = noise_pred.float().clone()
+        return real_step(noise_pred, *a, **k)
+
+    hip.cfg_combine, pipe._sched_step = cfg, step
+    try:
+        a = pipe(latents=inp["latents"].clone(), num_inference_steps=2, guidance_rescale=0.7, **kw).images.float().cpu()
+    finally:
+        hip.cfg_combine = real_cfg
+        del pipe._sched_step
+    dims = [1, 2, 3]
+    want = 0.7 * seen["cfg"] * (seen["ec"].std(dim=dims, keepdim=True) / seen["cfg"].std(dim=dims, keepdim=True)) + 0.3 * seen["cfg"]
+    assert (seen["np"] - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    b = pipe(latents=inp["latents"].clone(), num_inference_steps=2, **kw).images.float().cpu()
+    assert (a - b).abs().max().item() > 1e-4, "guidance_rescale changed nothing"
+
+
 # ---- BASELINE.json configs[4] at its own size: SDXL-base + BrushNet-XL, batch 2 x 1024 x 1024, 30-step grid -------------------
 _full = {}
 
