@@ -216,10 +216,13 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     sync_step = micro + 1 >= accum
     prec = model.brushnet.prec
     # bf16x1 runs the fp16 split flash attention only where the bf16 flash route does not apply (short sequences, MFHIP_NO_FLASH_BWD):
-    # its guard — a host read-back, and a collective under DDP — is armed only when the previous step launched such a kernel
-    guard = check_overflow and (prec.code == hip.MF_F16X3 or (prec.code == hip.MF_BF16X1 and getattr(model, "_split_kernels_per_step", 1) > 0))
-    split_calls0 = ops.SPLIT_KERNEL_CALLS
+    # its guard — a host read-back — is armed BEFORE the step when the previous step launched such a kernel and AFTER it when this
+    # step did although the previous one did not (the shapes changed between steps: ADVICE r5).  Several ranks always arm it: the
+    # guard holds a collective there, and a decision taken from rank-local launch counts could differ between ranks.
+    world = int(getattr(grad_sync, "world", 1) or 1) if grad_sync is not None else 1
+    guard = check_overflow and (prec.code == hip.MF_F16X3 or (prec.code == hip.MF_BF16X1 and (world > 1 or getattr(model, "_split_kernels_per_step", 1) > 0)))
     if micro == 0:
+        optimizer._window_split0 = ops.SPLIT_KERNEL_CALLS
         optimizer.zero_grad(for_step=True)
         if guard:
             hip.split_overflow(reset=True)     # flags raised by earlier, unrelated work do not count against this step; the
@@ -288,7 +291,10 @@ def train_step(model: MirrorFusionModel, noise_scheduler, optimizer: AdamW, late
     if grad_sync is not None:
         grad_sync.finish()
     norm, coef = clip_grad_norm_(mods, max_grad_norm, loss_scale=scale)
-    model._split_kernels_per_step = ops.SPLIT_KERNEL_CALLS - split_calls0      # (of the last micro-step: shapes repeat)
+    model._split_kernels_per_step = ops.SPLIT_KERNEL_CALLS - getattr(optimizer, "_window_split0", ops.SPLIT_KERNEL_CALLS)
+    if not guard and check_overflow and prec.code == hip.MF_BF16X1 and model._split_kernels_per_step > 0:
+        guard = True        # armed late: the flags were not reset before this window, so work before it may raise them too — at
+                            # worst one step skipped that need not have been, never a saturated gradient applied
     if guard:
         # fp16 halves saturate above 65504 without producing inf / NaN (mfhip.h, mf_split_overflow): a step whose forward or
         # (loss-scaled) backward operands left that range has silently wrong gradients — it is SKIPPED, like a GradScaler

@@ -967,6 +967,24 @@ def test_forward_overflow_skips_the_optimizer_step(graphed):
     assert opt.step_count == 3 and not torch.equal(model.brushnet.flat_w, w)
 
 
+def test_bf16x1_guard_arms_itself_when_the_shapes_start_using_fp16_halves():
+    """the bf16x1 guard was armed from the PREVIOUS step's count of fp16-split attention launches; a step that launches
+    them after a step that launched none (the resolution changed) must still read the flags and skip a saturated step."""
+    import warnings
+    ns = DDPMScheduler(**SD_SCHED)
+    model = _model("bf16x1").prepare_training()
+    opt = AdamW(model.get_trainable_modules())
+    train_step(model, ns, opt, *_skip_inputs(0))
+    assert model._split_kernels_per_step > 0, "the test model's short sequences should run the fp16-split attention"
+    model._split_kernels_per_step = 0                 # as if the previous step's shapes had all taken the bf16 flash route
+    w = model.brushnet.flat_w.clone()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        train_step(model, ns, opt, *_skip_inputs(1, overflow=True))
+    assert any("exceeded the fp16 range" in str(r.message) for r in rec), "the overflowing step was not reported"
+    assert torch.equal(model.brushnet.flat_w, w) and model._split_kernels_per_step > 0
+
+
 def test_flag_raised_between_forward_and_backward_counts(monkeypatch):
     """The discriminating form of the test above: a range-guard flag raised after the forward pass and before the backward pass
     (here by an unrelated overflowing split issued from the loss-gradient call) must still be set when train_step reads the
