@@ -59,7 +59,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 18
+#define MF_ABI_VERSION 19
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -550,6 +550,56 @@ int mf_clip_coef(const double* sumsq, float max_norm, float unscale, float* coef
  * g * grad_scale[0] (grad_scale nullable) */
 int mf_adamw(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int32_t step, const float* grad_scale, void* stream);
+
+/* ---- step programs: a whole forward pass behind ONE entry (mf_brushnet_forward / mf_unet_forward /
+ * mf_denoise_step_fused) -----------------------------------------------------------------------------------------------------
+ * The sequencing of a pass — which of the entries above, on which buffers, with which tiles — is written down ONCE by the Python
+ * side (reflecting_reality_amd/program.py: one eager pass of BrushNetModel.forward, models/brushnet.py:693-936;
+ * UNet2DConditionModel.forward, models/unets/unet_2d_condition.py:1037-1311; or the loop body of
+ * pipelines/brushnet/pipeline_brushnet.py:1250-1332) into a program file; a host with no Python loads the file, gives every buffer
+ * memory, and replays it.  A program is specialised like a hipGraph (shapes, precision, tiles, scalar arguments are the recorded
+ * ones) and, like one, is replayed on any stream and may itself be captured into a hipGraph by the host.
+ *
+ * File: a header of header_bytes (everything mf_program_load parses: magic "MFPROG1", ABI version, buffer table, calls) followed
+ * by the bytes of the constant and io buffers at the file offsets mf_program_buffer_info reports.  Buffer kinds:
+ *   MF_PROGRAM_CONST      weights in their device layouts, prompt K / V^T, tables, scratch: upload the file's bytes once
+ *   MF_PROGRAM_WORKSPACE  intermediates: any device memory of `bytes` (contents undefined between runs, data_offset -1)
+ *   MF_PROGRAM_IO         named inputs / outputs ("latents", "coef4", ...): the host's own buffers; the file holds the recorded
+ *                         pass's values, so that replaying the file as it is reproduces the recorded pass bit for bit
+ * Every buffer must be bound (16-byte aligned device memory of at least `bytes`) before mf_program_run; the library keeps the
+ * pointers, never the memory. */
+#define MF_PROGRAM_CONST 0
+#define MF_PROGRAM_WORKSPACE 1
+#define MF_PROGRAM_IO 2
+typedef struct mf_program mf_program;
+/* blob: the first header_bytes of the file (bytes 24..31 of the file, little endian); the library copies what it needs */
+int mf_program_load(const void* blob, int64_t bytes, mf_program** out);
+void mf_program_destroy(mf_program* p);
+int32_t mf_program_num_buffers(const mf_program* p);
+int mf_program_buffer_info(const mf_program* p, int32_t index, int32_t* kind, int64_t* bytes, int64_t* data_offset, const char** name);
+int32_t mf_program_find_buffer(const mf_program* p, const char* name);      /* -1: no buffer of that name */
+int mf_program_bind(mf_program* p, int32_t index, void* device_ptr);
+int32_t mf_program_num_calls(const mf_program* p);
+/* the free-form description the exporter stored (JSON: what was recorded, shapes, precision, steps of the tables); never NULL */
+const char* mf_program_meta(const mf_program* p);
+int mf_program_run(mf_program* p, void* stream);
+/* The loop body of pipeline_brushnet.py:1250-1332 — latent doubling, BrushNet, UNet with the 28 injected residuals, classifier-free
+ * guidance, DDIM update — as one call: binds the io buffers "latents" (NCHW fp32, updated IN PLACE), "coef4" (the step's
+ * {sqrt_at, sqrt_1m_at, sqrt_ap, dir_coef}, mf_cfg_ddim_step_dev), "temb_unet" / "temb_brushnet" (the step's rows of the two
+ * time-embedding tables) and runs the program.  A NULL argument keeps the buffer's current binding. */
+int mf_denoise_step_fused(mf_program* step, void* latents, const void* coef4, const void* temb_unet, const void* temb_brushnet, void* stream);
+/* UNet2DConditionModel.forward (unet_2d_condition.py:1037-1311) with BrushNet's residuals injected (:1172-1177, 1218, 1262-1284):
+ * io buffers "sample", "temb", "residual.<i>" (i < n_residuals, the order of brushnet.py:896-936: down, mid, up), "eps" (the noise
+ * prediction).  The prompt enters through the program's constants (the cross-attention K / V^T bound when it was recorded). */
+int mf_unet_forward(mf_program* unet, const void* sample, const void* temb, const void* const* residuals_in, int32_t n_residuals,
+                    void* eps_out, void* stream);
+/* BrushNetModel.forward (brushnet.py:693-936): io buffers "sample", "temb", "cond" (the 5-channel conditioning latents of
+ * pipeline_brushnet.py:1186-1215) and "residual.<i>" (written). */
+int mf_brushnet_forward(mf_program* brushnet, const void* sample, const void* temb, const void* cond, void* const* residuals_out,
+                        int32_t n_residuals, void* stream);
+/* the device copies / fills a recorded pass contains (torch made them between the launches): hipMemcpy2DAsync / hipMemsetAsync */
+int mf_memcpy2d(void* dst, int64_t dpitch, const void* src, int64_t spitch, int64_t width_bytes, int64_t height, void* stream);
+int mf_memset(void* dst, int32_t value, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

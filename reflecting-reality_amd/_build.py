@@ -29,7 +29,7 @@ INCLUDE = os.path.join(os.path.dirname(_PKG_DIR), "include")
 SOURCES = ["train.hip", "gemm_f32_b.hip", "gemm_f32_a.hip", "gemm_f16x3.hip", "gemm_bf16x3.hip", "gemm_bf16_ws_ring.hip", "gemm_f16_ws_ring.hip",
            "gemm_bf16_b.hip", "gemm_f16_b.hip", "gemm_bf16_a.hip", "gemm_bf16_c.hip", "gemm_f16_c.hip", "gemm_bf16_ws_dx.hip", "gemm_f16_ws_dx.hip",
            "gemm_f16_a.hip", "gemm_f16x3_ws.hip", "attention.hip", "gemm_fp8.hip", "conv_halo.hip", "gemm_nloop.hip", "gemm_pers.hip", "gemm_conv.hip", "norm.hip", "elementwise.hip",
-           "frontend.hip", "fp8.hip"]
+           "frontend.hip", "fp8.hip", "program.hip"]
 # -pragma-unroll-threshold: the epilogue loops of the GEMM family index their accumulator arrays by the loop counter, so a loop the
 # optimizer declines to unroll ("unrolled size is too large", default 16 K instructions) sends 64-160 accumulators per lane to scratch
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",

@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1, MF_F16 = 0, 1, 2, 3, 4, 5, 6
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class MfhipError(RuntimeError):
@@ -143,9 +143,14 @@ EXPORTS = [
     "mf_sizeof_wgrad_desc", "mf_conv_wgrad_ws_floats", "mf_conv_wgrad", "mf_split_pack", "mf_transpose", "mf_transpose_bf16", "mf_colsum_ws_floats", "mf_colsum",
     "mf_sizeof_groupnorm_bwd_desc", "mf_groupnorm_bwd", "mf_groupnorm_bwd_ws_floats", "mf_groupnorm_bwd_streams", "mf_layernorm_bwd", "mf_layernorm_bwd_parts", "mf_softmax_bwd", "mf_silu_bwd", "mf_geglu_bwd",
     "mf_zero_insert2x", "mf_sumpool2x2", "mf_mse_grad", "mf_sumsq_ws_doubles", "mf_sumsq", "mf_clip_coef", "mf_adamw",
+    # step programs (csrc/program.cpp; program.py records them)
+    "mf_memcpy2d", "mf_memset", "mf_program_load", "mf_program_destroy", "mf_program_num_buffers", "mf_program_buffer_info",
+    "mf_program_find_buffer", "mf_program_bind", "mf_program_num_calls", "mf_program_meta", "mf_program_run",
+    "mf_denoise_step_fused", "mf_unet_forward", "mf_brushnet_forward",
 ]
 
 _lib: Optional[C.CDLL] = None
+_RECORDER = None        # program.Recorder's proxy while a step program is being recorded: every launch goes through it
 
 
 def lib_path() -> str:
@@ -156,6 +161,8 @@ def lib_path() -> str:
 def load() -> C.CDLL:
     """Load libmfhip.so (after torch, so that its libamdhip64.so.7 is the one HIP runtime in-process)."""
     global _lib
+    if _RECORDER is not None:
+        return _RECORDER
     if _lib is not None:
         return _lib
     path = lib_path()
@@ -446,8 +453,8 @@ def _tuned_config(d: "GemmDesc", key: tuple):
     hit = cache.get(ks)
     if hit is not None and not (RETUNE and ks not in _tune_new):
         return hit
-    if torch.cuda.is_current_stream_capturing():
-        return (0, 0)
+    if torch.cuda.is_current_stream_capturing() or _RECORDER is not None:
+        return (0, 0)           # (a recorded pass, like a capture, must not contain the tuner's trial launches: warm up first)
     lib = load()
     global _tune_misses
     _tune_misses += 1

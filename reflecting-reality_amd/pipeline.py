@@ -727,7 +727,8 @@ class StableDiffusionBrushNetPipeline:
 
         # A graph captured by an earlier call with this key serves every step, the first included: what depends on the
         # prompt alone (its device copy, the cross-attention K / V^T) is recomputed into the buffers the graph reads.
-        replay_all = (st["graph"] is not None and os.environ.get("MFHIP_EAGER_FIRST") != "1"      # A/B switch
+        export = getattr(self, "_export_step_to", None)           # export_denoise_step(): step 1 is recorded instead of replayed
+        replay_all = (export is None and st["graph"] is not None and os.environ.get("MFHIP_EAGER_FIRST") != "1"      # A/B switch
                       and self.unet.bind_prompt(pe))
         for i in range(len(ts)):
             t_cur.copy_(tvals[i:i + 1])
@@ -738,6 +739,8 @@ class StableDiffusionBrushNetPipeline:
                 temb_b.copy_(st["temb_tab"][1][i])
             if i == 0 and not replay_all:
                 one_step()                                   # eager: tunes GEMMs, binds the prompt K/V, sizes scratch
+            elif export is not None and i == 1:
+                self._export_step(export, one_step, st, lat, coef_cur, temb_u, temb_b, cond, coefs, fused_ddim, len(ts), guidance_scale, cond_scale)
             else:
                 if st["graph"] is None:
                     torch.cuda.synchronize()
@@ -763,6 +766,50 @@ class StableDiffusionBrushNetPipeline:
                     lat.copy_(new)
             bar.update()
         return lat.clone()
+
+    def _export_step(self, path, one_step, st, lat, coef_cur, temb_u, temb_b, cond, coefs, fused_ddim, nsteps, guidance_scale, cond_scale):
+        """Record the eager pass of ONE denoise step (the loop body of pipeline_brushnet.py:1250-1332) as a step program
+        (program.py; replayed by mf_denoise_step_fused without Python).  The step runs as it would have; the file holds the
+        buffers as they were BEFORE it, so replaying the file reproduces this very step."""
+        import json
+        from . import program
+        if not fused_ddim:
+            raise NotImplementedError("export_denoise_step: the fused step carries DDIM's update (scheduling_ddim.py:404-450); multistep "
+                                      "schedulers keep host-side state between steps")
+        if temb_u is None:
+            raise NotImplementedError("export_denoise_step needs precompute_time_embedding (the step reads one row block of the schedule's table)")
+        named = dict(latents=lat, coef4=coef_cur, temb_unet=temb_u, temb_brushnet=temb_b, cond=cond)
+        tables = {"table.coef4": coefs.contiguous(), "table.temb_unet": st["temb_tab"][0].contiguous(), "table.temb_brushnet": st["temb_tab"][1].contiguous()}
+        lat0 = lat.clone()
+        with program.Recorder(named, tables) as rec:
+            one_step()
+        lat1 = lat.clone()
+        lat.copy_(lat0)
+        meta = dict(entry="mf_denoise_step_fused", reference="pipelines/brushnet/pipeline_brushnet.py:1250-1332", precision=self.unet.prec.name,
+                    latents=list(lat.shape), steps=nsteps, recorded_step=1, guidance_scale=float(guidance_scale),
+                    conditioning_scale=cond_scale if isinstance(cond_scale, (int, float)) else list(cond_scale),
+                    temb_unet=list(temb_u.shape), temb_brushnet=list(temb_b.shape), brushnet_once=bool(self._brushnet_once))
+        self._export_info = rec.save(path, meta=json.dumps(meta))
+        self._export_info["meta"] = meta
+        lat.copy_(lat1)
+
+    def export_denoise_step(self, path: str, **call_kwargs) -> dict:
+        """Run the pipeline once and write the denoise step's program to `path` (see program.py / include/mfhip.h "step programs").
+        `call_kwargs`: what __call__ takes; the program is specialised on their shapes, the prompt (its cross-attention K / V^T are
+        constants of the file), the guidance and conditioning scales, and the schedule (its tables travel as named constants)."""
+        if self.device.type != "cuda":
+            raise hip.MfhipError("export_denoise_step needs the device: a program is a recording of real launches")
+        self._export_step_to, self._export_info = path, None
+        try:
+            call_kwargs.setdefault("output_type", "latent")
+            out = self(**call_kwargs)
+        finally:
+            self._export_step_to = None
+        if self._export_info is None:
+            raise hip.MfhipError("export_denoise_step: the call did not reach a second denoise step on the graph path (num_inference_steps >= 2, "
+                                 "use_graph left on)")
+        self._export_info["result"] = out
+        return self._export_info
 
     def _sched_step(self, noise_pred, t, latents, eta, generator):
         import inspect

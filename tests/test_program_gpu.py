@@ -1,0 +1,229 @@
+"""Step programs (reflecting_reality_amd/program.py, csrc/program.hip, include/mfhip.h "step programs"): the C-ABI call sequence of
+a whole pass, recorded once and replayed by the library without the models — mf_denoise_step_fused, mf_unet_forward,
+mf_brushnet_forward of SURVEY.md section 8(b).  The bar is bit-exactness against the Python-sequenced pass on the same inputs
+(the replay launches the same kernels with the same descriptors), for the loop body of pipeline_brushnet.py:1250-1332 and for
+the two networks on their own."""
+import ctypes as C
+import json
+import struct
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from reflecting_reality_amd import hip, program, synth  # noqa: E402
+from test_pipeline_gpu import _tiny_pipe  # noqa: E402
+
+DEV = "cuda"
+
+
+def _call_args(inp, steps, noise, **kw):
+    args = dict(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], image=inp["image"],
+                mask=inp["mask"], depth=inp["depth"], num_inference_steps=steps, guidance_scale=7.5, latents=inp["latents"].clone(),
+                output_type="latent", height=16, width=32, conditioning_noise=noise)
+    args.update(kw)
+    return args
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16", "f16x3"])
+def test_denoise_step_program_replays_the_loop_bit_exactly(prec, tmp_path):
+    """Export step 1 of a 5-step run, then drive ALL five steps from the file alone (tables -> io buffers -> mf_program_run):
+    the latents after every step equal the pipeline's own (hipGraph replay), bit for bit."""
+    pipe = _tiny_pipe(prec)
+    inp = synth.pipeline_inputs(2, 16, 32, seed=7, cross_dim=32, vae_scale=2)
+    noise = torch.randn(4, 4, 8, 16, generator=torch.Generator().manual_seed(3))
+    per_step = []
+
+    def grab(p, i, t, kw):
+        per_step.append(kw["latents"].detach().float().cpu().clone())
+        return {}
+    ref = pipe(**_call_args(inp, 5, noise, callback_on_step_end=grab, callback_on_step_end_tensor_inputs=["latents"])).images.float().cpu()
+    assert len(per_step) == 5 and torch.equal(per_step[-1], ref)
+    pipe._graph_state = None
+    path = str(tmp_path / "step.mfprog")
+    info = pipe.export_denoise_step(path, **_call_args(inp, 5, noise))
+    assert torch.equal(info["result"].images.float().cpu(), ref), "the exporting run itself must not change the result"
+    assert info["calls"] > 20 and "mf_gemm_conv" in info["entries"] and "mf_cfg_ddim_step_dev" in info["entries"]
+    print(f"[{prec}] program: {info['calls']} calls, {info['buffers']} buffers, {info['bytes'] / 1e6:.1f} MB file "
+          f"({info['const_bytes'] / 1e6:.1f} MB constants, {info['workspace_bytes'] / 1e6:.1f} MB workspace), entries {info['entries']}")
+    del pipe
+    prog = program.Program(path, DEV)
+    meta = json.loads(prog.meta)
+    assert meta["entry"] == "mf_denoise_step_fused" and meta["steps"] == 5 and prog.num_calls == info["calls"]
+    # (1) the file as it is reproduces the recorded step: latents after step 0 -> latents after step 1
+    assert torch.equal(prog.buffer("latents", torch.float32).view(per_step[0].shape).cpu(), per_step[0])
+    prog.run()
+    torch.cuda.synchronize()
+    assert torch.equal(prog.buffer("latents", torch.float32).view(per_step[1].shape).cpu(), per_step[1])
+    # (2) the whole loop through mf_denoise_step_fused with the HOST's own io buffers
+    lib = hip.load()
+    lat = inp["latents"].to(DEV).float().contiguous()
+    coef = prog.buffer("table.coef4", torch.float32).view(5, 4)
+    tu = prog.buffer("table.temb_unet", torch.float32).view(5, -1)
+    tb = prog.buffer("table.temb_brushnet", torch.float32).view(5, -1)
+    c_cur, tu_cur, tb_cur = torch.empty_like(coef[0]), torch.empty_like(tu[0]), torch.empty_like(tb[0])
+    for i in range(5):
+        c_cur.copy_(coef[i]); tu_cur.copy_(tu[i]); tb_cur.copy_(tb[i])
+        hip._check(lib.mf_denoise_step_fused(prog._h, C.c_void_p(lat.data_ptr()), C.c_void_p(c_cur.data_ptr()), C.c_void_p(tu_cur.data_ptr()),
+                                             C.c_void_p(tb_cur.data_ptr()), hip._stream()), "mf_denoise_step_fused")
+        torch.cuda.synchronize()
+        assert torch.equal(lat.cpu(), per_step[i]), f"step {i}: the replayed program differs from the pipeline by {(lat.cpu() - per_step[i]).abs().max()}"
+    # (3) the replay is capturable: one hipGraph of the program, replayed
+    lat.copy_(inp["latents"].to(DEV).float())
+    c_cur.copy_(coef[0]); tu_cur.copy_(tu[0]); tb_cur.copy_(tb[0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        prog.run()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lat.cpu(), per_step[0])
+    prog.close()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_unet_and_brushnet_programs_match_the_models(prec, tmp_path):
+    """mf_brushnet_forward writes the 28 residuals the model returns; mf_unet_forward, fed with them, the model's noise prediction."""
+    pipe = _tiny_pipe(prec)
+    unet, bn = pipe.unet, pipe.brushnet
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 8, 16, generator=g).to(DEV)
+    cond = torch.randn(2, 5, 8, 16, generator=g).to(DEV)
+    ehs = torch.randn(2, 7, 32, generator=g).to(DEV)
+    tvals = torch.tensor([801.0, 401.0], device=DEV)
+    tab_b, tab_u = bn.time_embedding_table(tvals, 2), unet.time_embedding_table(tvals, 2)
+    temb_b, temb_u = tab_b[0].clone(), tab_u[0].clone()
+    t = torch.zeros(1, device=DEV)
+    down, mid, up = bn(x, t, encoder_hidden_states=None, brushnet_cond=cond, conditioning_scale=1.0, return_dict=False, _temb=temb_b)
+    res = list(down) + [mid] + list(up)
+    eps = unet(x, t, encoder_hidden_states=ehs, down_block_add_samples=list(down), mid_block_add_sample=mid, up_block_add_samples=list(up),
+               return_dict=False, _temb=temb_u)[0]
+    ref_res = [r.clone() for r in res]
+    pb, pu = str(tmp_path / "brushnet.mfprog"), str(tmp_path / "unet.mfprog")
+    ib = program.export_brushnet(bn, pb, x, temb_b, cond)
+    iu = program.export_unet(unet, pu, x, temb_u, ehs, down, mid, up)
+    assert ib["meta"]["residuals"] == len(res) == iu["meta"]["residuals"]
+    lib = hip.load()
+    # new inputs: another timestep's rows, other latents — the programs are functions of their io buffers
+    x2 = torch.randn(2, 4, 8, 16, generator=g).to(DEV)
+    cond2 = torch.randn(2, 5, 8, 16, generator=g).to(DEV)
+    temb_b2, temb_u2 = tab_b[1].clone(), tab_u[1].clone()
+    down2, mid2, up2 = bn(x2, t, encoder_hidden_states=None, brushnet_cond=cond2, conditioning_scale=1.0, return_dict=False, _temb=temb_b2)
+    res2 = [r.clone() for r in list(down2) + [mid2] + list(up2)]
+    eps2 = unet(x2, t, encoder_hidden_states=ehs, down_block_add_samples=list(down2), mid_block_add_sample=mid2, up_block_add_samples=list(up2),
+                return_dict=False, _temb=temb_u2)[0].clone()
+    progb, progu = program.Program(pb, DEV), program.Program(pu, DEV)
+    outs = [torch.empty_strided(r.shape, r.stride(), dtype=r.dtype, device=DEV) for r in ref_res]
+    ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+    for xx, tt, cc, want in ((x, temb_b, cond, ref_res), (x2, temb_b2, cond2, res2)):
+        hip._check(lib.mf_brushnet_forward(progb._h, C.c_void_p(xx.data_ptr()), C.c_void_p(tt.data_ptr()), C.c_void_p(cc.data_ptr()), ptrs, len(outs),
+                                           hip._stream()), "mf_brushnet_forward")
+        torch.cuda.synchronize()
+        for i, (o, w) in enumerate(zip(outs, want)):
+            assert torch.equal(o, w), f"residual {i} differs by {(o.float() - w.float()).abs().max()}"
+    eps_out = torch.empty_like(eps)
+    for xx, tt, want_res, want in ((x, temb_u, ref_res, eps), (x2, temb_u2, res2, eps2)):
+        rp = (C.c_void_p * len(want_res))(*[r.data_ptr() for r in want_res])
+        hip._check(lib.mf_unet_forward(progu._h, C.c_void_p(xx.data_ptr()), C.c_void_p(tt.data_ptr()), rp, len(want_res), C.c_void_p(eps_out.data_ptr()),
+                                       hip._stream()), "mf_unet_forward")
+        torch.cuda.synchronize()
+        assert torch.equal(eps_out, want), f"eps differs by {(eps_out - want).abs().max()}"
+    # an entry called on a program that was not exported for it is refused, with the buffer it misses
+    rc = lib.mf_denoise_step_fused(progu._h, C.c_void_p(x.data_ptr()), None, None, None, hip._stream())
+    assert rc != 0 and b"latents" in lib.mf_last_error()
+    progb.close(); progu.close()
+
+
+def test_recorder_refuses_what_it_cannot_replay():
+    """No partial exports: a torch kernel that is not a copy / fill, an entry without a thunk, a launch on another stream."""
+    a = torch.ones(64, device=DEV)
+    b = torch.ones(64, device=DEV)
+    hip.load()
+    with pytest.raises(program.ProgramError, match="aten::add"):
+        with program.Recorder(dict(a=a)):
+            _ = a + b
+    assert hip._RECORDER is None
+    with pytest.raises(program.ProgramError, match="no replay thunk"):
+        with program.Recorder(dict(a=a)):
+            hip.silu_bwd(a, b)
+    assert hip._RECORDER is None
+    side = torch.cuda.Stream()
+    with pytest.raises(program.ProgramError, match="another stream"):
+        with program.Recorder(dict(a=a)):
+            with torch.cuda.stream(side):
+                hip.silu_f32(a)
+    # copies, fills and concatenations ARE recorded (as mf_memcpy2d / mf_memset) and replay
+    with program.Recorder(dict(a=a)) as rec:
+        c = torch.cat([a, b])
+        d = c.view(2, 64)[:, :16].contiguous()            # a strided copy: 2 rows of 64 bytes, 256 apart
+        e = torch.zeros(8, device=DEV)
+        hip.silu_f32(d.view(-1))
+        del c, e
+    names = [n for n, _ in rec.resolved]
+    assert names.count("mf_memcpy2d") == 3 and names.count("mf_memset") == 1 and names[-1] == "mf_silu_f32"
+
+
+def test_program_file_is_validated(tmp_path):
+    a = torch.arange(64, device=DEV, dtype=torch.float32)
+    with program.Recorder(dict(x=a)) as rec:
+        y = hip.silu_f32(a)
+        rec.output("y", y)
+        want = y.clone()
+    path = str(tmp_path / "p.mfprog")
+    rec.save(path, meta="{}")
+    lib = hip.load()
+    blob = bytearray(open(path, "rb").read())
+    h = C.c_void_p()
+    assert lib.mf_program_load(bytes(blob), C.c_int64(len(blob)), C.byref(h)) == 0
+    assert lib.mf_program_run(h, hip._stream()) != 0 and b"not bound" in lib.mf_last_error()
+    lib.mf_program_destroy(h)
+    bad = bytearray(blob)
+    bad[8:12] = struct.pack("<I", hip.ABI_VERSION - 1)
+    assert lib.mf_program_load(bytes(bad), C.c_int64(len(bad)), C.byref(h)) != 0 and b"ABI" in lib.mf_last_error()
+    bad = bytearray(blob)
+    bad[0] = ord("X")
+    assert lib.mf_program_load(bytes(bad), C.c_int64(len(bad)), C.byref(h)) != 0 and b"magic" in lib.mf_last_error()
+    head_len = struct.unpack("<q", blob[24:32])[0]
+    assert lib.mf_program_load(bytes(blob[:head_len - 8]), C.c_int64(head_len - 8), C.byref(h)) != 0
+    prog = program.Program(path, DEV)
+    prog.run()
+    torch.cuda.synchronize()
+    assert torch.equal(prog.buffer("y", torch.float32), want)
+    prog.buffer("x", torch.float32).mul_(2.0)
+    prog.run()
+    torch.cuda.synchronize()
+    assert torch.equal(prog.buffer("y", torch.float32), hip.silu_f32(a * 2.0))
+    prog.close()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_c_host_runs_the_loop_without_python(graph, tmp_path):
+    """examples/c_host/denoise_host.c: a C program (gcc, the HIP runtime, libmfhip — no Python, no torch in the process) loads the
+    exported step, runs all five steps from the initial noise and writes the latents the pipeline produces, bit for bit."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("no gcc / ROCm headers on this machine")
+    exe = str(tmp_path / "denoise_host")
+    libdir = os.path.join(root, "reflecting-reality_amd", "lib")
+    subprocess.run([gcc, "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{os.path.join(root, 'include')}",
+                    os.path.join(root, "examples", "c_host", "denoise_host.c"), f"-L{libdir}", "-lmfhip", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe],
+                   check=True, capture_output=True, text=True)
+    pipe = _tiny_pipe("bf16")
+    inp = synth.pipeline_inputs(2, 16, 32, seed=7, cross_dim=32, vae_scale=2)
+    noise = torch.randn(4, 4, 8, 16, generator=torch.Generator().manual_seed(3))
+    path = str(tmp_path / "step.mfprog")
+    info = pipe.export_denoise_step(path, **_call_args(inp, 5, noise))
+    ref = info["result"].images.float().cpu()
+    lat_in, lat_out = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    inp["latents"].float().contiguous().numpy().tofile(lat_in)
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{libdir}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe, path, lat_in, lat_out] + (["--graph"] if graph else []), capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    print(out.stdout)
+    import numpy as np
+    got = torch.from_numpy(np.fromfile(lat_out, dtype=np.float32)).view(ref.shape)
+    assert torch.equal(got, ref), f"the C host's latents differ from the pipeline's by {(got - ref).abs().max()}"

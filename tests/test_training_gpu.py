@@ -967,10 +967,13 @@ def test_forward_overflow_skips_the_optimizer_step(graphed):
     assert opt.step_count == 3 and not torch.equal(model.brushnet.flat_w, w)
 
 
-def test_bf16x1_guard_arms_itself_when_the_shapes_start_using_fp16_halves():
+def test_bf16x1_guard_arms_itself_when_the_shapes_start_using_fp16_halves(monkeypatch):
     """the bf16x1 guard was armed from the PREVIOUS step's count of fp16-split attention launches; a step that launches
     them after a step that launched none (the resolution changed) must still read the flags and skip a saturated step."""
     import warnings
+    # the tiny model's 64-token, d = 8 attention on the route the full-size model's short sequences take with MFHIP_NO_FLASH_BWD's twin off
+    monkeypatch.setattr(ops, "FLASH_BWD_MIN_TOKENS", 16)
+    monkeypatch.setattr(ops, "FLASH_BWD_BF16_HEAD_DIMS", ())
     ns = DDPMScheduler(**SD_SCHED)
     model = _model("bf16x1").prepare_training()
     opt = AdamW(model.get_trainable_modules())
