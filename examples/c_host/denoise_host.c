@@ -10,7 +10,9 @@
  *   LD_LIBRARY_PATH=reflecting-reality_amd/lib:/opt/rocm/lib ./denoise_host step.mfprog [latents_in.bin] [latents_out.bin] [--graph]
  *
  * latents_in.bin: the initial noise (NCHW fp32, the io buffer's size); without it the loop starts from the latents the file holds
- * (those before the recorded step).  --graph: capture the program's launches into a hipGraph once and replay it per step. */
+ * (those before the recorded step).  --graph: capture the program's launches into a hipGraph once and replay it per step (measured
+ * SLOWER than the plain calls at BASELINE configs[1], 16.4 vs 15.1 ms per step: in the graph this process captures the two branches of
+ * the step do not overlap, although the same capture made from torch's streams does — DESIGN.md section 5c). */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -111,7 +113,7 @@ int main(int argc, char** argv) {
         free(host);
     }
     hipStream_t stream;
-    HIP_OK(hipStreamCreate(&stream));
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     hipGraphExec_t exec = NULL;
     if (use_graph) {
         /* a first eager run (nothing lazy is left to initialise, but it keeps the capture free of first-use work), on a copy of the latents */
@@ -125,7 +127,7 @@ int main(int argc, char** argv) {
         HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         MF_OKAY(mf_program_run(prog, stream));
         HIP_OK(hipStreamEndCapture(stream, &graph));
-        HIP_OK(hipGraphInstantiate(&exec, graph, NULL, NULL, 0));
+        HIP_OK(hipGraphInstantiateWithFlags(&exec, graph, hipGraphInstantiateFlagAutoFreeOnLaunch));
         HIP_OK(hipFree(keep));
     }
     hipEvent_t e0, e1;

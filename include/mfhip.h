@@ -567,7 +567,14 @@ int mf_adamw(float* w, const float* g, float* m, float* v, int64_t n, float lr, 
  *   MF_PROGRAM_IO         named inputs / outputs ("latents", "coef4", ...): the host's own buffers; the file holds the recorded
  *                         pass's values, so that replaying the file as it is reproduces the recorded pass bit for bit
  * Every buffer must be bound (16-byte aligned device memory of at least `bytes`) before mf_program_run; the library keeps the
- * pointers, never the memory. */
+ * pointers, never the memory.
+ *
+ * Streams: a program recorded inside a hipGraph capture (the denoise step: BrushNet on a side stream under the UNet's encoder,
+ * pipeline.py::_denoise_graph) carries that capture's forks and joins.  Stream 0 is the `stream` argument of mf_program_run; the
+ * others, and the events between them, are created by the first run on the device current then and destroyed by
+ * mf_program_destroy — the only device objects this library ever owns.  Every side stream forks from stream 0 and has joined it
+ * again when the run's last call is enqueued, so runs on one stream are ordered like single launches and the whole run can be
+ * captured (hipStreamBeginCapture on `stream`). */
 #define MF_PROGRAM_CONST 0
 #define MF_PROGRAM_WORKSPACE 1
 #define MF_PROGRAM_IO 2

@@ -21,7 +21,8 @@ struct Arg {
 };
 struct Fixup { uint32_t field_off; int32_t buf; int64_t off; };
 struct Desc { std::vector<uint8_t> bytes; std::vector<Fixup> fix; };
-struct Call { int fn; std::string name; std::vector<Arg> args; std::vector<Desc> descs; };
+struct Call { int fn; uint32_t stream; std::string name; std::vector<Arg> args; std::vector<Desc> descs; };
+enum { F_SYNC_RECORD = -2, F_SYNC_WAIT = -3 };      // "@record" / "@wait": an event of the program recorded on / awaited by one of its streams
 struct Buffer { int32_t kind; int64_t bytes; int64_t data_off; std::string name; void* ptr; };
 
 enum Fn {
@@ -65,6 +66,10 @@ struct mf_program {
     std::vector<Buffer> buffers;
     std::vector<Call> calls;
     std::string meta;
+    uint32_t nstreams = 1, nevents = 0;
+    std::vector<hipStream_t> side;       // streams 1 .. nstreams-1 of a program recorded on several (stream 0 is the caller's)
+    std::vector<hipEvent_t> events;
+    int device = -1;
 };
 
 extern "C" int mf_memcpy2d(void* dst, int64_t dpitch, const void* src, int64_t spitch, int64_t width_bytes, int64_t height, void* stream) {
@@ -97,10 +102,14 @@ extern "C" int mf_program_load(const void* blob, int64_t bytes, mf_program** out
     const uint32_t abi = r.get<uint32_t>(), nbuf = r.get<uint32_t>(), ncall = r.get<uint32_t>(), meta_len = r.get<uint32_t>();
     const int64_t head_len = r.get<int64_t>();
     (void)r.get<int64_t>();
+    const uint32_t nstreams = r.get<uint32_t>(), nevents = r.get<uint32_t>();
     MF_CHECK_ARG(abi == MF_ABI_VERSION, "mf_program_load: the program was recorded against ABI %u, this library is ABI %d (descriptor layouts may differ): export it again",
                  abi, MF_ABI_VERSION);
     MF_CHECK_ARG(head_len <= bytes, "mf_program_load: the blob holds %lld bytes of a %lld-byte header", (long long)bytes, (long long)head_len);
+    MF_CHECK_ARG(nstreams >= 1 && nstreams <= 16 && nevents <= 65536, "mf_program_load: %u streams / %u events", nstreams, nevents);
     mf_program* p = new mf_program();
+    p->nstreams = nstreams;
+    p->nevents = nevents;
     const uint8_t* m = r.take(meta_len);
     if (m) p->meta.assign((const char*)m, meta_len);
     for (uint32_t i = 0; i < nbuf && r.ok; ++i) {
@@ -117,12 +126,34 @@ extern "C" int mf_program_load(const void* blob, int64_t bytes, mf_program** out
     for (uint32_t c = 0; c < ncall && r.ok; ++c) {
         Call call{};
         const uint32_t nl = r.get<uint32_t>(), nargs = r.get<uint32_t>();
+        call.stream = r.get<uint32_t>();
+        (void)r.get<uint32_t>();
         const uint8_t* n = r.take(nl);
         if (!n) break;
         call.name.assign((const char*)n, nl);
         call.fn = -1;
         for (int f = 0; f < F_COUNT; ++f)
             if (call.name == kFns[f].name) call.fn = f;
+        if (call.stream >= nstreams) {
+            mf_set_error("mf_program_load: call %u (%s) on stream %u of %u", c, call.name.c_str(), call.stream, nstreams);
+            delete p;
+            return MF_EINVAL;
+        }
+        if (call.name == "@record" || call.name == "@wait") {
+            Arg arg{};
+            arg.kind = r.get<uint32_t>();
+            arg.buf = r.get<int32_t>();
+            arg.i = r.get<int64_t>();
+            if (nargs != 1 || arg.kind != A_I32 || arg.i < 0 || arg.i >= (int64_t)nevents) {
+                mf_set_error("mf_program_load: call %u: malformed %s", c, call.name.c_str());
+                delete p;
+                return MF_EINVAL;
+            }
+            call.fn = call.name == "@record" ? F_SYNC_RECORD : F_SYNC_WAIT;
+            call.args.push_back(arg);
+            p->calls.push_back(std::move(call));
+            continue;
+        }
         if (call.fn < 0 || strlen(kFns[call.fn].sig) != nargs) {
             mf_set_error("mf_program_load: call %u: entry %s with %u arguments has no replay thunk in this library", c, call.name.c_str(), nargs);
             delete p;
@@ -177,7 +208,12 @@ extern "C" int mf_program_load(const void* blob, int64_t bytes, mf_program** out
     return MF_OK;
 }
 
-extern "C" void mf_program_destroy(mf_program* p) { delete p; }
+extern "C" void mf_program_destroy(mf_program* p) {
+    if (!p) return;
+    for (hipStream_t st : p->side) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : p->events) (void)hipEventDestroy(ev);
+    delete p;
+}
 extern "C" int32_t mf_program_num_buffers(const mf_program* p) { return p ? (int32_t)p->buffers.size() : 0; }
 extern "C" int32_t mf_program_num_calls(const mf_program* p) { return p ? (int32_t)p->calls.size() : 0; }
 extern "C" const char* mf_program_meta(const mf_program* p) { return p ? p->meta.c_str() : ""; }
@@ -207,6 +243,15 @@ extern "C" int mf_program_bind(mf_program* p, int32_t index, void* device_ptr) {
     return MF_OK;
 }
 
+#define HIP_TRY(call, what)                                                    \
+    do {                                                                       \
+        const hipError_t e_ = (call);                                          \
+        if (e_ != hipSuccess) {                                                \
+            mf_set_error("%s: %s", what, hipGetErrorString(e_));               \
+            return MF_ELAUNCH;                                                 \
+        }                                                                      \
+    } while (0)
+
 namespace {
 
 inline void* resolve(const mf_program* p, int32_t buf, int64_t off) { return buf < 0 ? nullptr : (char*)p->buffers[buf].ptr + off; }
@@ -227,7 +272,13 @@ int run_call(const mf_program* prog, const Call& c, void* s) {
             void* ptr = resolve(prog, fx.buf, fx.off);
             memcpy(raw + fx.field_off, &ptr, sizeof(void*));
         }
-        return c.fn == F_GEMM_CONV ? mf_gemm_conv((const mf_gemm_desc*)raw, s) : mf_groupnorm((const mf_groupnorm_desc*)raw, s);
+        if (c.fn == F_GROUPNORM) return mf_groupnorm((const mf_groupnorm_desc*)raw, s);
+        // the HOST out-fields (which row block the partial sums got, whether per-group sums were written) were read when the pass was
+        // recorded — the consumer's descriptor carries the answer; the launch still wants somewhere to write them
+        mf_gemm_desc* g = (mf_gemm_desc*)raw;
+        int32_t rows_unused = 0, grouped_unused = 0;
+        if (g->gn_part) { g->gn_part_rows = &rows_unused; g->gn_grouped = &grouped_unused; }
+        return mf_gemm_conv(g, s);
     }
     case F_LAYERNORM: return mf_layernorm(P(0), I(1), P(2), I(3), FP(4), FP(5), L(6), I(7), F(8), s);
     case F_SOFTMAX_ROWS: return mf_softmax_rows(FP(0), P(1), I(2), L(3), I(4), I(5), s);
@@ -281,8 +332,26 @@ extern "C" int mf_program_run(mf_program* p, void* stream) {
     MF_CHECK_ARG(p, "mf_program_run: null program");
     for (size_t i = 0; i < p->buffers.size(); ++i)
         MF_CHECK_ARG(p->buffers[i].ptr, "mf_program_run: buffer %zu (%s, %lld bytes) is not bound", i, p->buffers[i].name.c_str(), (long long)p->buffers[i].bytes);
+    if (p->side.size() + 1 < p->nstreams || p->events.size() < p->nevents) {
+        // the program's own streams and events, on the device that is current at the first run (the only objects the library owns)
+        HIP_TRY(hipGetDevice(&p->device), "mf_program_run");
+        while (p->side.size() + 1 < p->nstreams) {
+            hipStream_t st;
+            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "mf_program_run(stream)");
+            p->side.push_back(st);
+        }
+        while (p->events.size() < p->nevents) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "mf_program_run(event)");
+            p->events.push_back(ev);
+        }
+    }
     for (size_t i = 0; i < p->calls.size(); ++i) {
-        const int rc = run_call(p, p->calls[i], stream);
+        const Call& c = p->calls[i];
+        void* s = c.stream == 0 ? stream : (void*)p->side[c.stream - 1];
+        if (c.fn == F_SYNC_RECORD) { HIP_TRY(hipEventRecord(p->events[c.args[0].i], (hipStream_t)s), "mf_program_run(record)"); continue; }
+        if (c.fn == F_SYNC_WAIT) { HIP_TRY(hipStreamWaitEvent((hipStream_t)s, p->events[c.args[0].i], 0), "mf_program_run(wait)"); continue; }
+        const int rc = run_call(p, c, s);
         if (rc != MF_OK) return rc;          // (the failing entry has set mf_last_error)
     }
     return MF_OK;

@@ -727,7 +727,9 @@ class StableDiffusionBrushNetPipeline:
 
         # A graph captured by an earlier call with this key serves every step, the first included: what depends on the
         # prompt alone (its device copy, the cross-attention K / V^T) is recomputed into the buffers the graph reads.
-        export = getattr(self, "_export_step_to", None)           # export_denoise_step(): step 1 is recorded instead of replayed
+        export = getattr(self, "_export_step_to", None)           # export_denoise_step(): the capture of step 1 is recorded as a program
+        if export is not None:
+            st["graph"] = None                                    # (a graph kept from an earlier call is captured again)
         replay_all = (export is None and st["graph"] is not None and os.environ.get("MFHIP_EAGER_FIRST") != "1"      # A/B switch
                       and self.unet.bind_prompt(pe))
         for i in range(len(ts)):
@@ -739,20 +741,30 @@ class StableDiffusionBrushNetPipeline:
                 temb_b.copy_(st["temb_tab"][1][i])
             if i == 0 and not replay_all:
                 one_step()                                   # eager: tunes GEMMs, binds the prompt K/V, sizes scratch
-            elif export is not None and i == 1:
-                self._export_step(export, one_step, st, lat, coef_cur, temb_u, temb_b, cond, coefs, fused_ddim, len(ts), guidance_scale, cond_scale)
             else:
                 if st["graph"] is None:
                     torch.cuda.synchronize()
                     graph = torch.cuda.CUDAGraph()
+                    # export_denoise_step(): the captured pass is ALSO written down as a step program (program.py)
+                    rec = self._export_recorder(st, lat, coef_cur, temb_u, temb_b, cond, coefs, fused_ddim) if export is not None else None
                     self._overlap(True)                      # the side stream forks from / joins the capture stream
                     try:
                         # (thread_local: with an initialised process group its watchdog thread may poll events while this thread captures)
                         with torch.cuda.graph(graph, capture_error_mode="thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"):
-                            one_step()
+                            if rec is not None:
+                                with rec:
+                                    one_step()
+                            else:
+                                one_step()
+                    except Exception:
+                        if rec is not None and rec.error is not None:
+                            raise rec.error                  # (not the "unjoined work" the aborted capture reports on top of it)
+                        raise
                     finally:
                         self._overlap(False)
                     st["graph"] = graph                      # capture does not execute: replay below runs this step
+                    if rec is not None:                      # (so the buffers still hold what they held BEFORE the recorded step)
+                        self._export_save(rec, graph, export, lat, temb_u, temb_b, len(ts), i, guidance_scale, cond_scale)
                 st["graph"].replay()
             if not fused_ddim:
                 # multistep schedulers keep references to their inputs (ets, last_sample): hand them copies, not the
@@ -767,11 +779,9 @@ class StableDiffusionBrushNetPipeline:
             bar.update()
         return lat.clone()
 
-    def _export_step(self, path, one_step, st, lat, coef_cur, temb_u, temb_b, cond, coefs, fused_ddim, nsteps, guidance_scale, cond_scale):
-        """Record the eager pass of ONE denoise step (the loop body of pipeline_brushnet.py:1250-1332) as a step program
-        (program.py; replayed by mf_denoise_step_fused without Python).  The step runs as it would have; the file holds the
-        buffers as they were BEFORE it, so replaying the file reproduces this very step."""
-        import json
+    def _export_recorder(self, st, lat, coef_cur, temb_u, temb_b, cond, coefs, fused_ddim):
+        """The recorder of ONE denoise step (the loop body of pipeline_brushnet.py:1250-1332), entered inside the hipGraph capture
+        of that step: the program carries the capture's forks and joins (BrushNet || UNet), replayed by mf_denoise_step_fused."""
         from . import program
         if not fused_ddim:
             raise NotImplementedError("export_denoise_step: the fused step carries DDIM's update (scheduling_ddim.py:404-450); multistep "
@@ -780,18 +790,17 @@ class StableDiffusionBrushNetPipeline:
             raise NotImplementedError("export_denoise_step needs precompute_time_embedding (the step reads one row block of the schedule's table)")
         named = dict(latents=lat, coef4=coef_cur, temb_unet=temb_u, temb_brushnet=temb_b, cond=cond)
         tables = {"table.coef4": coefs.contiguous(), "table.temb_unet": st["temb_tab"][0].contiguous(), "table.temb_brushnet": st["temb_tab"][1].contiguous()}
-        lat0 = lat.clone()
-        with program.Recorder(named, tables) as rec:
-            one_step()
-        lat1 = lat.clone()
-        lat.copy_(lat0)
+        return program.Recorder(named, tables, capture=True)
+
+    def _export_save(self, rec, graph, path, lat, temb_u, temb_b, nsteps, step, guidance_scale, cond_scale):
+        import json
+        rec.finish(graph.pool())
         meta = dict(entry="mf_denoise_step_fused", reference="pipelines/brushnet/pipeline_brushnet.py:1250-1332", precision=self.unet.prec.name,
-                    latents=list(lat.shape), steps=nsteps, recorded_step=1, guidance_scale=float(guidance_scale),
+                    latents=list(lat.shape), steps=nsteps, recorded_step=step, guidance_scale=float(guidance_scale),
                     conditioning_scale=cond_scale if isinstance(cond_scale, (int, float)) else list(cond_scale),
                     temb_unet=list(temb_u.shape), temb_brushnet=list(temb_b.shape), brushnet_once=bool(self._brushnet_once))
         self._export_info = rec.save(path, meta=json.dumps(meta))
         self._export_info["meta"] = meta
-        lat.copy_(lat1)
 
     def export_denoise_step(self, path: str, **call_kwargs) -> dict:
         """Run the pipeline once and write the denoise step's program to `path` (see program.py / include/mfhip.h "step programs").

@@ -58,7 +58,8 @@ _VIEW_OPS = {
     "empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "view", "_unsafe_view", "reshape", "slice", "select", "narrow",
     "as_strided", "detach", "alias", "t", "transpose", "permute", "unsqueeze", "squeeze", "expand", "split", "split_with_sizes",
     "chunk", "unbind", "view_as", "flatten", "unflatten", "_reshape_alias", "lift_fresh", "is_contiguous", "size", "stride",
-    "storage_offset", "numel", "dim", "sym_size", "sym_stride", "sym_numel", "sym_storage_offset", "is_pinned", "_local_scalar_dense_placeholder",
+    "storage_offset", "numel", "dim", "sym_size", "sym_stride", "sym_numel", "sym_storage_offset", "is_pinned",
+    "record_stream",            # an allocator note (which stream consumes the block), not a launch
 }
 
 
@@ -167,9 +168,14 @@ class _TorchOps(TorchDispatchMode):
 class Recorder:
     """with Recorder(named) as rec: <one eager pass>   then   <restore the inputs>; rec.save(path)"""
 
-    def __init__(self, named: Dict[str, torch.Tensor], tables: Optional[Dict[str, torch.Tensor]] = None, device=None):
+    def __init__(self, named: Dict[str, torch.Tensor], tables: Optional[Dict[str, torch.Tensor]] = None, device=None, capture: bool = False):
         """`named`: the io buffers.  `tables`: device tensors stored in the file as named constants although no launch reads them
-        (per-step rows the host copies into an io buffer between runs: DDIM coefficients, time-embedding tables)."""
+        (per-step rows the host copies into an io buffer between runs: DDIM coefficients, time-embedding tables).
+        `capture`: the pass is recorded INSIDE a torch.cuda.graph capture (create the Recorder before the capture begins, enter it
+        inside, call finish(graph.pool()) after the capture ended).  Only this mode takes a pass on several streams: forks and
+        joins (Stream.wait_stream / wait_event, Event.record) become part of the program, and the workspace is the graph's private
+        pool — whose reuse of freed blocks is ordered by the streams' dependencies, not by what had finished on the clock, as an
+        eager pass's would be."""
         self.device = torch.device(device if device is not None else next(iter(named.values())).device)
         self.named = {k: v for k, v in named.items()}
         self.tables = dict(tables or {})
@@ -182,31 +188,89 @@ class Recorder:
         self._before = None
         self._pool = None
         self._ctx = []
+        self.capture = bool(capture)
+        self.error = None
+        self._streams: Dict[int, int] = {}
+        self._events: Dict[int, int] = {}
+        self._patched = []
+        if self.capture:
+            torch.cuda.synchronize(self.device)
+            self._before = torch.cuda.memory_snapshot()
 
     # ---- recording -------------------------------------------------------------------------------------------------------
     def __enter__(self):
         if hip._RECORDER is not None:
             raise ProgramError("a Recorder is already active")
-        if torch.cuda.is_current_stream_capturing():
-            raise ProgramError("record an eager pass, not a hipGraph capture")
         lib = hip.load()
-        torch.cuda.synchronize(self.device)
-        self._before = torch.cuda.memory_snapshot()
-        self._pool = torch.cuda.MemPool()
-        self._stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._enter_contexts()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing != self.capture:
+            raise ProgramError("Recorder(capture=True) is entered inside a torch.cuda.graph capture, a plain Recorder outside one")
+        self._streams = {torch.cuda.current_stream(self.device).cuda_stream: 0}
+        if self.capture:
+            ops_ctx = _TorchOps(self)
+            ops_ctx.__enter__()
+            self._ctx = [ops_ctx]
+            self._patch_syncs()
+        else:
+            torch.cuda.synchronize(self.device)
+            self._before = torch.cuda.memory_snapshot()
+            self._pool = torch.cuda.MemPool()
+            self._enter_contexts()
         hip._RECORDER = _Proxy(self, lib)
         return self
 
     def __exit__(self, *exc):
         hip._RECORDER = None
+        self.error = exc[1] if isinstance(exc[1], ProgramError) else None      # (a capture that ends on an exception reports its own error on top)
+        for obj, name, orig in self._patched:
+            setattr(obj, name, orig)
+        self._patched = []
         for c in self._ctx:
             c.__exit__(*exc)
         self._ctx = []
-        torch.cuda.synchronize(self.device)
-        if exc[0] is None:
-            self._resolve()
+        if not self.capture:
+            torch.cuda.synchronize(self.device)
+            if exc[0] is None:
+                self._resolve(tuple(self._pool.id))
         return False
+
+    def finish(self, pool_id) -> None:
+        """capture mode: after the capture ended — `pool_id` = graph.pool(), the private pool the captured pass allocated from"""
+        if not self.capture:
+            raise ProgramError("finish() belongs to Recorder(capture=True)")
+        self._resolve(tuple(pool_id))
+
+    # ---- streams (capture mode) ----------------------------------------------------------------------------------------------
+    def _sid(self, handle: int) -> int:
+        handle = int(handle or 0)
+        if handle not in self._streams:
+            if not self.capture:
+                raise ProgramError("a launch on another stream than the recording one: an eager pass is recorded on ONE stream "
+                                   "(Recorder(capture=True) takes forks and joins)")
+            self._streams[handle] = len(self._streams)
+        return self._streams[handle]
+
+    def _eid(self, ev) -> int:
+        return self._events.setdefault(id(ev), len(self._events))
+
+    def _patch_syncs(self) -> None:
+        rec = self
+        E = torch.cuda.Event
+        # (torch's Stream.wait_stream / wait_event / record_event all end in Event.record and Event.wait: two patches see every sync)
+        o_record, o_ewait = E.record, E.wait
+
+        def record(self_e, stream=None):
+            st = stream if stream is not None else torch.cuda.current_stream()
+            rec.calls.append(("@record", [(A_I32, rec._eid(self_e))], rec._sid(st.cuda_stream)))
+            return o_record(self_e, st)
+
+        def ewait(self_e, stream=None):
+            st = stream if stream is not None else torch.cuda.current_stream()
+            rec.calls.append(("@wait", [(A_I32, rec._eid(self_e))], rec._sid(st.cuda_stream)))
+            return o_ewait(self_e, st)
+        for obj, name, new, orig in ((E, "record", record, o_record), (E, "wait", ewait, o_ewait)):
+            setattr(obj, name, new)
+            self._patched.append((obj, name, orig))
 
     def output(self, name: str, t: torch.Tensor) -> None:
         """Name a tensor the pass PRODUCED (call inside the `with` block): the program ends with a copy of it into an io buffer of
@@ -215,6 +279,8 @@ class Recorder:
         destination is allocated OUTSIDE the pass's private pool, where no recorded launch can have been.)  The layout — a dense
         permutation, e.g. the channels-last views the models return — goes to `layouts`."""
         nbytes = _dense_bytes(name, t)
+        if self.capture:
+            raise ProgramError("output() is for eager recordings; a captured pass writes its results into named buffers")
         for c in self._ctx:
             c.__exit__(None, None, None)
         o = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device)
@@ -239,8 +305,7 @@ class Recorder:
             raise ProgramError(f"{name}: {len(args)} arguments for signature {sig!r} + stream")
         st = args[-1]
         st = st.value if isinstance(st, C.c_void_p) else st
-        if (st or 0) != self._stream:
-            raise ProgramError(f"{name} was launched on another stream than the recording one: record with the stream overlap off")
+        sid = self._sid(st)
         rec = []
         for kind, a in zip(sig, args[:-1]):
             if kind == "p":
@@ -269,12 +334,13 @@ class Recorder:
                     if val and fname not in _HOST_FIELDS:
                         fix.append((off, int(val)))
                 rec.append((A_DESC, bytes(raw), fix))
-        self.calls.append((name, rec))
+        self.calls.append((name, rec, sid))
 
     def _mem(self, name: str, *vals) -> None:
         sig = SIGNATURES[name]
         kinds = {"p": A_PTR, "i": A_I32, "l": A_I64}
-        self.calls.append((name, [(kinds[k], int(v)) for k, v in zip(sig, vals)]))
+        sid = self._sid(torch.cuda.current_stream(self.device).cuda_stream)
+        self.calls.append((name, [(kinds[k], int(v)) for k, v in zip(sig, vals)], sid))
 
     def _copy(self, dst: torch.Tensor, src: torch.Tensor) -> None:
         if not (dst.is_cuda and src.is_cuda):
@@ -329,9 +395,8 @@ class Recorder:
             self._mem("mf_memset", t.data_ptr(), value, t.numel() * t.element_size())
 
     # ---- address -> (buffer, offset) ---------------------------------------------------------------------------------------
-    def _resolve(self) -> None:
+    def _resolve(self, pool_id: tuple) -> None:
         dev = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        pool_id = tuple(self._pool.id)
         after = torch.cuda.memory_snapshot()
         self.buffers: List[dict] = []            # kind, name, addr, bytes
         index: Dict[Tuple[int, int], int] = {}
@@ -373,7 +438,7 @@ class Recorder:
                 return add(KIND_CONST, f"const.{blocks[i][0]:x}", blocks[i][0], blocks[i][1]), addr - blocks[i][0]
             raise ProgramError(f"device address {addr:#x} of a recorded launch is neither an io buffer, nor alive before the pass, nor allocated by it")
         out = []
-        for name, rec in self.calls:
+        for name, rec, sid in self.calls:
             args = []
             for a in rec:
                 if a[0] == A_PTR:
@@ -382,7 +447,7 @@ class Recorder:
                     args.append((A_DESC, a[1], [(off,) + where(v) for off, v in a[2]]))
                 else:
                     args.append(a)
-            out.append((name, args))
+            out.append((name, args, sid))
         self.resolved = out
         for k, v in self.tables.items():
             self.buffers.append(dict(kind=KIND_CONST, name=k, addr=v.data_ptr(), bytes=v.numel() * v.element_size()))
@@ -392,9 +457,9 @@ class Recorder:
         """Write the program; constants and io buffers carry the bytes they hold NOW (restore the pass's inputs first)."""
         pad8 = lambda b: b + b"\0" * (-len(b) % 8)
         body = bytearray()
-        for name, args in self.resolved:
+        for name, args, sid in self.resolved:
             nb = name.encode()
-            body += struct.pack("<II", len(nb), len(args)) + pad8(nb)
+            body += struct.pack("<IIII", len(nb), len(args), sid, 0) + pad8(nb)
             tail = bytearray()
             for a in args:
                 if a[0] == A_PTR:
@@ -414,7 +479,7 @@ class Recorder:
             nb = b["name"].encode()
             table += struct.pack("<IIqq", b["kind"], len(nb), b["bytes"], 0) + pad8(nb)      # data offset patched below
         metab = pad8(meta.encode())
-        head_len = 8 + 4 * 4 + 8 + 8 + len(metab) + len(table) + len(body)
+        head_len = 8 + 4 * 4 + 8 + 8 + 8 + len(metab) + len(table) + len(body)
         data_off = (head_len + 255) // 256 * 256
         # second pass over the table with the data offsets
         table = bytearray()
@@ -429,7 +494,8 @@ class Recorder:
                 cursor = (cursor + b["bytes"] + 255) // 256 * 256
                 placed.append((off, b))
             table += struct.pack("<IIqq", b["kind"], len(nb), b["bytes"], off) + pad8(nb)
-        head = MAGIC + struct.pack("<IIII", hip.ABI_VERSION, len(self.buffers), len(self.resolved), len(metab)) + struct.pack("<qq", head_len, cursor) + metab
+        nstreams, nevents = max([c[2] for c in self.resolved] + [0]) + 1, len(self._events)
+        head = MAGIC + struct.pack("<IIII", hip.ABI_VERSION, len(self.buffers), len(self.resolved), len(metab)) + struct.pack("<qqII", head_len, cursor, nstreams, nevents) + metab
         torch.cuda.synchronize(self.device)
         with open(path, "wb") as f:
             f.write(head + table + body)
@@ -443,7 +509,7 @@ class Recorder:
         return dict(calls=len(self.resolved), buffers=len(self.buffers), bytes=cursor,
                     const_bytes=sum(b["bytes"] for b in self.buffers if b["kind"] == KIND_CONST),
                     workspace_bytes=sum(b["bytes"] for b in self.buffers if b["kind"] == KIND_WORKSPACE),
-                    entries=sorted({n for n, _ in self.resolved}))
+                    streams=nstreams, events=nevents, entries=sorted({c[0] for c in self.resolved}))
 
 
 def hip_memcpy_d2h(host: torch.Tensor, addr: int, nbytes: int) -> None:

@@ -45,7 +45,8 @@ def test_denoise_step_program_replays_the_loop_bit_exactly(prec, tmp_path):
     info = pipe.export_denoise_step(path, **_call_args(inp, 5, noise))
     assert torch.equal(info["result"].images.float().cpu(), ref), "the exporting run itself must not change the result"
     assert info["calls"] > 20 and "mf_gemm_conv" in info["entries"] and "mf_cfg_ddim_step_dev" in info["entries"]
-    print(f"[{prec}] program: {info['calls']} calls, {info['buffers']} buffers, {info['bytes'] / 1e6:.1f} MB file "
+    assert info["streams"] >= 2 and "@record" in info["entries"] and "@wait" in info["entries"], "the capture's BrushNet || UNet fork is part of the program"
+    print(f"[{prec}] program: {info['calls']} calls on {info['streams']} streams ({info['events']} events), {info['buffers']} buffers, {info['bytes'] / 1e6:.1f} MB file "
           f"({info['const_bytes'] / 1e6:.1f} MB constants, {info['workspace_bytes'] / 1e6:.1f} MB workspace), entries {info['entries']}")
     del pipe
     prog = program.Program(path, DEV)
@@ -159,7 +160,7 @@ def test_recorder_refuses_what_it_cannot_replay():
         e = torch.zeros(8, device=DEV)
         hip.silu_f32(d.view(-1))
         del c, e
-    names = [n for n, _ in rec.resolved]
+    names = [c[0] for c in rec.resolved]
     assert names.count("mf_memcpy2d") == 3 and names.count("mf_memset") == 1 and names[-1] == "mf_silu_f32"
 
 
