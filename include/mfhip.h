@@ -604,6 +604,12 @@ int mf_unet_forward(mf_program* unet, const void* sample, const void* temb, cons
  * pipeline_brushnet.py:1186-1215) and "residual.<i>" (written). */
 int mf_brushnet_forward(mf_program* brushnet, const void* sample, const void* temb, const void* cond, void* const* residuals_out,
                         int32_t n_residuals, void* stream);
+/* AutoencoderKL.decode (models/autoencoders/autoencoder_kl.py:294-318, vae.py:285-351; pipeline_brushnet.py:1342 hands it latents /
+ * scaling_factor): io buffers "z" (NCHW fp32 latents) and "image" (NCHW fp32, written). */
+int mf_vae_decode(mf_program* vae_decoder, const void* z, void* image_out, void* stream);
+/* AutoencoderKL.encode up to the posterior's moments (autoencoder_kl.py:256-291, vae.py:137-167 + quant_conv): io buffers "image"
+ * (NCHW fp32) and "moments" (NHWC fp32 [b][h/8][w/8][2 * latent_channels]: mean | logvar, what mf_vae_sample reads; written). */
+int mf_vae_encode_moments(mf_program* vae_encoder, const void* image, void* moments_out, void* stream);
 /* the device copies / fills a recorded pass contains (torch made them between the launches): hipMemcpy2DAsync / hipMemsetAsync */
 int mf_memcpy2d(void* dst, int64_t dpitch, const void* src, int64_t spitch, int64_t width_bytes, int64_t height, void* stream);
 int mf_memset(void* dst, int32_t value, int64_t bytes, void* stream);

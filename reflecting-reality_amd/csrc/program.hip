@@ -396,3 +396,19 @@ extern "C" int mf_brushnet_forward(mf_program* brushnet, const void* sample, con
     }
     return mf_program_run(brushnet, stream);
 }
+
+extern "C" int mf_vae_decode(mf_program* vae_decoder, const void* z, void* image_out, void* stream) {
+    MF_CHECK_ARG(vae_decoder, "mf_vae_decode: null program");
+    int rc;
+    if ((rc = bind_io(vae_decoder, "mf_vae_decode", "z", z)) != MF_OK) return rc;
+    if ((rc = bind_io(vae_decoder, "mf_vae_decode", "image", image_out)) != MF_OK) return rc;
+    return mf_program_run(vae_decoder, stream);
+}
+
+extern "C" int mf_vae_encode_moments(mf_program* vae_encoder, const void* image, void* moments_out, void* stream) {
+    MF_CHECK_ARG(vae_encoder, "mf_vae_encode_moments: null program");
+    int rc;
+    if ((rc = bind_io(vae_encoder, "mf_vae_encode_moments", "image", image)) != MF_OK) return rc;
+    if ((rc = bind_io(vae_encoder, "mf_vae_encode_moments", "moments", moments_out)) != MF_OK) return rc;
+    return mf_program_run(vae_encoder, stream);
+}

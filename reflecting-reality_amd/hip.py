@@ -146,7 +146,7 @@ EXPORTS = [
     # step programs (csrc/program.cpp; program.py records them)
     "mf_memcpy2d", "mf_memset", "mf_program_load", "mf_program_destroy", "mf_program_num_buffers", "mf_program_buffer_info",
     "mf_program_find_buffer", "mf_program_bind", "mf_program_num_calls", "mf_program_meta", "mf_program_run",
-    "mf_denoise_step_fused", "mf_unet_forward", "mf_brushnet_forward",
+    "mf_denoise_step_fused", "mf_unet_forward", "mf_brushnet_forward", "mf_vae_decode", "mf_vae_encode_moments",
 ]
 
 _lib: Optional[C.CDLL] = None

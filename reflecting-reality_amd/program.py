@@ -641,3 +641,33 @@ def export_unet(model, path: str, sample: torch.Tensor, temb: torch.Tensor, enco
     info = rec.save(path, meta=json.dumps(meta))
     info["meta"] = meta
     return info
+
+
+def export_vae_decode(vae, path: str, z: torch.Tensor) -> dict:
+    """AutoencoderKL.decode (autoencoder_kl.py:294-318) as a program for mf_vae_decode: io buffers "z" (NCHW fp32, latents already divided by
+    the scaling factor as pipeline_brushnet.py:1342 does) and "image" (NCHW fp32)."""
+    import json
+    z = z.to(vae.device).float().contiguous()
+    vae.decode(z, return_dict=False)
+    with Recorder(dict(z=z)) as rec:
+        img = vae.decode(z, return_dict=False)[0]
+        rec.output("image", img)
+    meta = dict(entry="mf_vae_decode", reference="models/autoencoders/autoencoder_kl.py:294-318", precision=vae.prec.name, layouts=rec.layouts)
+    info = rec.save(path, meta=json.dumps(meta))
+    info["meta"] = meta
+    return info
+
+
+def export_vae_encode(vae, path: str, image: torch.Tensor) -> dict:
+    """AutoencoderKL.encode up to the moments (autoencoder_kl.py:256-291) as a program for mf_vae_encode_moments: io buffers "image" (NCHW
+    fp32) and "moments" (NHWC fp32 mean | logvar; mf_vae_sample draws the posterior sample from it, pipeline_brushnet.py:1188)."""
+    import json
+    image = image.to(vae.device).float().contiguous()
+    vae._moments(image)
+    with Recorder(dict(image=image)) as rec:
+        m = vae._moments(image)
+        rec.output("moments", m)
+    meta = dict(entry="mf_vae_encode_moments", reference="models/autoencoders/autoencoder_kl.py:256-291", precision=vae.prec.name, layouts=rec.layouts)
+    info = rec.save(path, meta=json.dumps(meta))
+    info["meta"] = meta
+    return info

@@ -228,3 +228,28 @@ def test_c_host_runs_the_loop_without_python(graph, tmp_path):
     import numpy as np
     got = torch.from_numpy(np.fromfile(lat_out, dtype=np.float32)).view(ref.shape)
     assert torch.equal(got, ref), f"the C host's latents differ from the pipeline's by {(got - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_vae_programs_match_the_model(prec, tmp_path):
+    """mf_vae_decode / mf_vae_encode_moments replay AutoencoderKL.decode / the encoder up to the posterior's moments, bit for bit, on
+    inputs other than the recorded ones."""
+    vae = _tiny_pipe(prec).vae
+    g = torch.Generator().manual_seed(9)
+    z, z2 = (torch.randn(2, 4, 8, 16, generator=g).to(DEV) for _ in range(2))
+    x, x2 = (torch.randn(2, 3, 16, 32, generator=g).to(DEV) for _ in range(2))
+    pd, pe = str(tmp_path / "dec.mfprog"), str(tmp_path / "enc.mfprog")
+    idec, ienc = program.export_vae_decode(vae, pd, z), program.export_vae_encode(vae, pe, x)
+    print(f"[{prec}] decode: {idec['calls']} calls {idec['entries']}; encode: {ienc['calls']} calls")
+    lib = hip.load()
+    dec, enc = program.Program(pd, DEV), program.Program(pe, DEV)
+    for zz, xx in ((z, x), (z2, x2)):
+        want_img = vae.decode(zz, return_dict=False)[0]
+        img = torch.empty_like(want_img)
+        hip._check(lib.mf_vae_decode(dec._h, C.c_void_p(zz.data_ptr()), C.c_void_p(img.data_ptr()), hip._stream()), "mf_vae_decode")
+        want_m = vae._moments(xx)
+        m = torch.empty_like(want_m)
+        hip._check(lib.mf_vae_encode_moments(enc._h, C.c_void_p(xx.data_ptr()), C.c_void_p(m.data_ptr()), hip._stream()), "mf_vae_encode_moments")
+        torch.cuda.synchronize()
+        assert torch.equal(img, want_img) and torch.equal(m, want_m)
+    dec.close(); enc.close()
