@@ -253,3 +253,43 @@ def test_vae_programs_match_the_model(prec, tmp_path):
         torch.cuda.synchronize()
         assert torch.equal(img, want_img) and torch.equal(m, want_m)
     dec.close(); enc.close()
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp8"])
+def test_sdxl_denoise_step_program(prec, tmp_path):
+    """The SDXL pipeline's step (pipeline_brushnet_sd_xl.py:1497-1600: added text_time conditioning, BrushNet-XL, linear
+    projections; fp8 Linears with per-row quantisation in the fp8 mode) exports and replays like SD1.5's."""
+    from oracle import mirrorfusion_ref as R
+    from reflecting_reality_amd import DDIMScheduler, StableDiffusionXLBrushNetPipeline
+    from test_xl_gpu import SD_SCHED, build_xl
+    try:
+        unet, bn, vae = build_xl(prec)
+    except Exception as e:           # (the tiny XL widths may not meet the fp8 kernels' multiples)
+        pytest.skip(f"tiny SDXL does not build in {prec}: {e}")
+    pipe = StableDiffusionXLBrushNetPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, unet=unet,
+                                             brushnet=bn, scheduler=DDIMScheduler(**SD_SCHED, clip_sample=False))
+    pipe.set_progress_bar_config(disable=True)
+    inp = synth.pipeline_inputs(1, 16, 16, seed=99, cross_dim=48, vae_scale=2)
+    gp = torch.Generator().manual_seed(100)
+    pooled, npooled = torch.randn(1, 24, generator=gp), torch.randn(1, 24, generator=gp)
+    noise = torch.randn(2, 4, 8, 8, generator=gp)
+    kw = dict(prompt_embeds=inp["prompt_embeds"], negative_prompt_embeds=inp["negative_prompt_embeds"], pooled_prompt_embeds=pooled,
+              negative_pooled_prompt_embeds=npooled, image=inp["image"], mask=inp["mask"], num_inference_steps=4, guidance_scale=5.0,
+              output_type="latent", brushnet_conditioning_scale=1.0, height=16, width=16, original_size=(24, 20), crops_coords_top_left=(2, 1),
+              target_size=(16, 16), conditioning_noise=noise)
+    ref = pipe(latents=inp["latents"].clone(), **kw).images.float().cpu()
+    pipe._graph_state = None
+    path = str(tmp_path / "xl_step.mfprog")
+    info = pipe.export_denoise_step(path, latents=inp["latents"].clone(), **kw)
+    assert torch.equal(info["result"].images.float().cpu(), ref)
+    print(f"[sdxl {prec}] {info['calls']} calls on {info['streams']} streams, entries {info['entries']}")
+    prog = program.Program(path, DEV)
+    lat = prog.buffer("latents", torch.float32)
+    lat.copy_(inp["latents"].to(DEV).float().reshape(-1))
+    coef, tu, tb = (prog.buffer(n, torch.float32).view(4, -1) for n in ("table.coef4", "table.temb_unet", "table.temb_brushnet"))
+    for i in range(4):
+        prog.buffer("coef4", torch.float32).copy_(coef[i]); prog.buffer("temb_unet", torch.float32).copy_(tu[i]); prog.buffer("temb_brushnet", torch.float32).copy_(tb[i])
+        prog.run()
+    torch.cuda.synchronize()
+    assert torch.equal(lat.view(ref.shape).cpu(), ref)
+    prog.close()
