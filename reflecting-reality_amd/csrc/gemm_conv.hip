@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void gn_colsum_kernel(const char* out, int out
 
 // ... the same for a 16-bit output with 16-byte rows: 32 column groups of 8 channels x 8 row lanes per block, 16-byte loads, the row
 // lanes combined through LDS in lane order (the scalar form above walks R rows with one 2-byte load each: 38 us where this takes ~5)
-template <bool F16>
+// ET: 0 bf16, 1 fp16, 2 fp32 (the split-precision modes keep fp32 activations: two 16-byte loads per 8 channels)
+template <int ET>
 __global__ __launch_bounds__(256) void gn_colsum8_kernel(const char* out, int64_t ldc, int M, int N, int R, float2* part) {
     __shared__ float2 red[8][32][8];
     const int cgl = threadIdx.x & 31, rl = threadIdx.x >> 5, rb = blockIdx.x;
@@ -93,7 +94,13 @@ __global__ __launch_bounds__(256) void gn_colsum8_kernel(const char* out, int64_
         const int m1 = (rb + 1) * R < M ? (rb + 1) * R : M;
         for (int m = rb * R + rl; m < m1; m += 8) {
             float x[8];
-            unpack_h8<F16>(*reinterpret_cast<const uint4*>(out + ((int64_t)m * ldc + n) * 2), x);
+            if constexpr (ET == 2) {
+                const float4* src = reinterpret_cast<const float4*>(out + ((int64_t)m * ldc + n) * 4);
+                const float4 lo = src[0], hi = src[1];
+                x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+            } else {
+                unpack_h8<ET == 1>(*reinterpret_cast<const uint4*>(out + ((int64_t)m * ldc + n) * 2), x);
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += x[e]; q[e] = fmaf(x[e], x[e], q[e]); }
         }
@@ -386,10 +393,11 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     }
     if (d->gn_grouped) *d->gn_grouped = 0;
     auto gn_fallback = [&](hipStream_t st) -> int {     // after the launch(es) that wrote `out`
-        if (mf_is16(d->out_dtype) && d->ldc % 8 == 0 && mf_aligned16(d->out)) {
+        if ((mf_is16(d->out_dtype) || d->out_dtype == MF_F32) && d->ldc % 8 == 0 && mf_aligned16(d->out)) {
             const dim3 g8((unsigned)(a.M / gn_r_fallback), (unsigned)cdiv(a.N, 256));
-            if (d->out_dtype == MF_F16) hipLaunchKernelGGL(gn_colsum8_kernel<true>, g8, dim3(256), 0, st, (const char*)d->out, d->ldc, a.M, a.N, gn_r_fallback, (float2*)d->gn_part);
-            else hipLaunchKernelGGL(gn_colsum8_kernel<false>, g8, dim3(256), 0, st, (const char*)d->out, d->ldc, a.M, a.N, gn_r_fallback, (float2*)d->gn_part);
+            if (d->out_dtype == MF_F16) hipLaunchKernelGGL(gn_colsum8_kernel<1>, g8, dim3(256), 0, st, (const char*)d->out, d->ldc, a.M, a.N, gn_r_fallback, (float2*)d->gn_part);
+            else if (d->out_dtype == MF_F32) hipLaunchKernelGGL(gn_colsum8_kernel<2>, g8, dim3(256), 0, st, (const char*)d->out, d->ldc, a.M, a.N, gn_r_fallback, (float2*)d->gn_part);
+            else hipLaunchKernelGGL(gn_colsum8_kernel<0>, g8, dim3(256), 0, st, (const char*)d->out, d->ldc, a.M, a.N, gn_r_fallback, (float2*)d->gn_part);
         } else
         hipLaunchKernelGGL(gn_colsum_kernel, dim3((unsigned)(a.M / gn_r_fallback), (unsigned)cdiv(a.N, 256)), dim3(256), 0, st,
                            (const char*)d->out, d->out_dtype, d->ldc, a.M, a.N, gn_r_fallback, (float2*)d->gn_part);

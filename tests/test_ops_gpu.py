@@ -948,6 +948,27 @@ def test_groupnorm_partial_sums_fallback_and_variants(case):
     assert (got[..., 0] - ref[..., 0]).abs().max() <= tol_s and (got[..., 1] - ref[..., 1]).abs().max() <= tol_q
 
 
+@pytest.mark.parametrize("prec_name", ["f16x3", "fp32", "fp16"])
+def test_groupnorm_partial_sums_fallback_in_every_storage(prec_name):
+    """The column-sum launch behind a split-K reduce reads the stored output in its own dtype: fp32 storage (the split-precision and
+    fp32 modes) takes the 8-channel form too (two 16-byte loads), not the scalar walk."""
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(12)
+    b, h, w, cin, n = 2, 32, 32, 64, 128
+    x = torch.randn(b, h, w, cin, generator=g)
+    cw = ops.ConvWeight(torch.randn(n, cin, 3, 3, generator=g) * 0.05, torch.randn(n, generator=g), prec, DEV)
+    y = ops.conv2d(x.to(DEV, prec.act), cw, gn_part=True, splitk=2, tile=1)
+    part, rows = y._gn_part[:2]
+    assert rows == 128
+    nb = b * h * w // rows
+    got = part[: nb * n * 2].view(nb, n, 2).double().cpu()
+    ref = _colsum_ref(y.float().cpu(), rows)
+    ymax = float(y.float().abs().max())
+    assert (got[..., 0] - ref[..., 0]).abs().max() <= 2.0 ** -20 * rows * ymax and (got[..., 1] - ref[..., 1]).abs().max() <= 2.0 ** -19 * rows * ymax ** 2
+    y2 = ops.conv2d(x.to(DEV, prec.act), cw, gn_part=True, splitk=2, tile=1)
+    assert torch.equal(y2._gn_part[0][: nb * n * 2], part[: nb * n * 2])
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("c,hw,rows,silu", [(320, 4096, 256, True), (640, 1024, 128, True), (1280, 1024, 128, False), (320, 4096, 64, False)])
 def test_groupnorm_from_producer_group_sums_is_one_launch(dt, c, hw, rows, silu):
