@@ -8,6 +8,10 @@
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_host/denoise_host.c \
  *       -Lreflecting-reality_amd/lib -lmfhip -L/opt/rocm/lib -lamdhip64 -o denoise_host
  *   LD_LIBRARY_PATH=reflecting-reality_amd/lib:/opt/rocm/lib ./denoise_host step.mfprog [latents_in.bin] [latents_out.bin] [--graph]
+ *                                                                           [--prompt bind.mfprog prompt_embeds.bin]
+ *
+ * --prompt: a second program (program.export_bind_prompt) computes the cross-attention K / V^T of NEW prompt embeddings ([2B][77][C] in the
+ * model's storage dtype) into the constants the step reads — the two files name those buffers alike, the host binds them to the same memory.
  *
  * latents_in.bin: the initial noise (NCHW fp32, the io buffer's size); without it the loop starts from the latents the file holds
  * (those before the recorded step).  --graph: capture the program's launches into a hipGraph once and replay it per step (measured
@@ -53,9 +57,12 @@ int main(int argc, char** argv) {
     }
     const char* in_path = NULL;
     const char* out_path = NULL;
+    const char* bind_path = NULL;
+    const char* prompt_path = NULL;
     int use_graph = 0;
     for (int a = 2; a < argc; ++a) {
         if (!strcmp(argv[a], "--graph")) use_graph = 1;
+        else if (!strcmp(argv[a], "--prompt") && a + 2 < argc) { bind_path = argv[a + 1]; prompt_path = argv[a + 2]; a += 2; }
         else if (!in_path) in_path = argv[a];
         else out_path = argv[a];
     }
@@ -115,6 +122,50 @@ int main(int argc, char** argv) {
     }
     hipStream_t stream;
     HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (bind_path) {
+        /* the prompt-binding program: buffers the step program also names (weights, the K / V^T it writes) share the step's memory */
+        FILE* bf = fopen(bind_path, "rb");
+        if (!bf || fread(head, 1, 40, bf) != 40) { fprintf(stderr, "%s: cannot read\n", bind_path); return 1; }
+        memcpy(&head_len, head + 24, 8);
+        blob = malloc((size_t)head_len);
+        fseek(bf, 0, SEEK_SET);
+        if (fread(blob, 1, (size_t)head_len, bf) != (size_t)head_len) { fprintf(stderr, "%s: short header\n", bind_path); return 1; }
+        mf_program* bind = NULL;
+        MF_OKAY(mf_program_load(blob, head_len, &bind));
+        free(blob);
+        int shared = 0;
+        for (int32_t i = 0; i < mf_program_num_buffers(bind); ++i) {
+            int32_t kind; int64_t bytes, off; const char* name;
+            MF_OKAY(mf_program_buffer_info(bind, i, &kind, &bytes, &off, &name));
+            const int32_t j = kind == MF_PROGRAM_WORKSPACE ? -1 : mf_program_find_buffer(prog, name);
+            void* mem = NULL;
+            if (j >= 0) { mem = dev[j]; ++shared; }
+            else {
+                HIP_OK(hipMalloc(&mem, (size_t)(bytes > 0 ? bytes : 16)));
+                if (off >= 0 && bytes > 0) {
+                    void* host = malloc((size_t)bytes);
+                    fseek(bf, (long)off, SEEK_SET);
+                    if (fread(host, 1, (size_t)bytes, bf) != (size_t)bytes) { fprintf(stderr, "short data for buffer %s\n", name); return 1; }
+                    HIP_OK(hipMemcpy(mem, host, (size_t)bytes, hipMemcpyHostToDevice));
+                    free(host);
+                }
+            }
+            if (!strcmp(name, "prompt_embeds")) {
+                FILE* pf = fopen(prompt_path, "rb");
+                void* host = malloc((size_t)bytes);
+                if (!pf || fread(host, 1, (size_t)bytes, pf) != (size_t)bytes) { fprintf(stderr, "%s: need %lld bytes of prompt embeddings\n", prompt_path, (long long)bytes); return 1; }
+                fclose(pf);
+                HIP_OK(hipMemcpy(mem, host, (size_t)bytes, hipMemcpyHostToDevice));
+                free(host);
+            }
+            MF_OKAY(mf_program_bind(bind, i, mem));
+        }
+        fclose(bf);
+        MF_OKAY(mf_program_run(bind, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        printf("prompt bound: %d calls, %d buffers shared with the step program\n", mf_program_num_calls(bind), shared);
+        mf_program_destroy(bind);
+    }
     hipGraphExec_t exec = NULL;
     if (use_graph) {
         /* a first eager run (nothing lazy is left to initialise, but it keeps the capture free of first-use work), on a copy of the latents */

@@ -535,7 +535,10 @@ def _hiprt():
 class Program:
     """A loaded program with torch-owned memory behind every buffer (tests, and Python hosts that want the replay without the models)."""
 
-    def __init__(self, path: str, device="cuda:0"):
+    def __init__(self, path: str, device="cuda:0", share: Optional["Program"] = None):
+        """`share`: another loaded program; buffers of the same name (constants exported by the same process carry the address they
+        had there: the weights, the prompt's K / V^T) are bound to ITS memory instead of a second copy — how a prompt-binding program
+        (export_bind_prompt) writes the constants a denoise-step program reads."""
         self.device = torch.device(device)
         with open(path, "rb") as f:
             head = f.read(8 + 16 + 16)
@@ -555,6 +558,14 @@ class Program:
                 for i in range(lib.mf_program_num_buffers(self._h)):
                     kind, nbytes, off, name = C.c_int32(), C.c_int64(), C.c_int64(), C.c_char_p()
                     hip._check(lib.mf_program_buffer_info(self._h, i, C.byref(kind), C.byref(nbytes), C.byref(off), C.byref(name)), "mf_program_buffer_info")
+                    nm = name.value.decode()
+                    if share is not None and kind.value != KIND_WORKSPACE and nm in share.names:
+                        t = share.tensors[share.names[nm]]
+                        if t.numel() < nbytes.value:
+                            raise ProgramError(f"shared buffer {nm!r}: {t.numel()} bytes there, {nbytes.value} here")
+                        self.tensors[i], self.names[nm] = t, i
+                        hip._check(lib.mf_program_bind(self._h, i, C.c_void_p(t.data_ptr())), "mf_program_bind")
+                        continue
                     t = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=self.device)
                     if off.value >= 0:
                         f.seek(off.value)
@@ -668,6 +679,33 @@ def export_vae_encode(vae, path: str, image: torch.Tensor) -> dict:
         m = vae._moments(image)
         rec.output("moments", m)
     meta = dict(entry="mf_vae_encode_moments", reference="models/autoencoders/autoencoder_kl.py:256-291", precision=vae.prec.name, layouts=rec.layouts)
+    info = rec.save(path, meta=json.dumps(meta))
+    info["meta"] = meta
+    return info
+
+
+def export_bind_prompt(unet, path: str) -> dict:
+    """What depends on the prompt alone — K and V^T of every cross-attention layer (attention_processor.py:1246-1252: to_k / to_v of
+    the prompt embeddings) — as a program: io buffer "prompt_embeds" ([2B, 77, C] in the model's storage dtype, [negative | positive]
+    under classifier-free guidance, pipeline_brushnet.py:1103); the K / V^T it writes are the constants a denoise-step program exported
+    by the same process reads (same buffer names: bind both to the same memory, `Program(..., share=step)`), so a host changes the
+    prompt without exporting the step again.  Call after the UNet has run once with a prompt of the final shape."""
+    import json
+    from . import ops
+    if not unet._cross_kv or getattr(unet, "_ehs_val", None) is None:
+        raise ProgramError("export_bind_prompt: run the UNet (or the pipeline) once first: the K / V^T buffers do not exist yet")
+    ctx = unet._ehs_val
+    skv = ctx.shape[1]
+
+    def run():
+        for b, kv in list(unet._cross_kv.items()):
+            ops.linear(ctx, unet.P[b + "to_k"], out=kv[0])
+            ops.linear_t(ctx, unet.P[b + "to_v"], (skv + 7) // 8 * 8, out=kv[1])
+    run()
+    with Recorder(dict(prompt_embeds=ctx)) as rec:
+        run()
+    meta = dict(entry="mf_program_run", what="cross-attention K / V^T of the prompt", reference="models/attention_processor.py:1246-1252",
+                precision=unet.prec.name, layers=len(unet._cross_kv), layouts=rec.layouts)
     info = rec.save(path, meta=json.dumps(meta))
     info["meta"] = meta
     return info

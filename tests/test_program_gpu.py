@@ -197,7 +197,7 @@ def test_program_file_is_validated(tmp_path):
     prog.close()
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True, "prompt"])
 def test_c_host_runs_the_loop_without_python(graph, tmp_path):
     """examples/c_host/denoise_host.c: a C program (gcc, the HIP runtime, libmfhip — no Python, no torch in the process) loads the
     exported step, runs all five steps from the initial noise and writes the latents the pipeline produces, bit for bit."""
@@ -221,8 +221,19 @@ def test_c_host_runs_the_loop_without_python(graph, tmp_path):
     ref = info["result"].images.float().cpu()
     lat_in, lat_out = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     inp["latents"].float().contiguous().numpy().tofile(lat_in)
+    extra = ["--graph"] if graph is True else []
+    if graph == "prompt":        # another prompt through the prompt-binding program: the step file stays the one exported with the first
+        other = synth.pipeline_inputs(2, 16, 32, seed=8, cross_dim=32, vae_scale=2)
+        bind_path, pe_path = str(tmp_path / "bind.mfprog"), str(tmp_path / "prompt.bin")
+        program.export_bind_prompt(pipe.unet, bind_path)
+        kw = _call_args(inp, 5, noise)
+        kw.update(prompt_embeds=other["prompt_embeds"], negative_prompt_embeds=other["negative_prompt_embeds"])
+        ref = pipe(**kw).images.float().cpu()
+        pe = torch.cat([other["negative_prompt_embeds"], other["prompt_embeds"]]).to(torch.bfloat16).contiguous()
+        pe.view(torch.int16).numpy().tofile(pe_path)
+        extra = ["--prompt", bind_path, pe_path]
     env = dict(os.environ, LD_LIBRARY_PATH=f"{libdir}:/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    out = subprocess.run([exe, path, lat_in, lat_out] + (["--graph"] if graph else []), capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([exe, path, lat_in, lat_out] + extra, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     print(out.stdout)
     import numpy as np
@@ -293,3 +304,39 @@ def test_sdxl_denoise_step_program(prec, tmp_path):
     torch.cuda.synchronize()
     assert torch.equal(lat.view(ref.shape).cpu(), ref)
     prog.close()
+
+
+def test_bind_prompt_program_changes_the_prompt_of_an_exported_step(tmp_path):
+    """export_bind_prompt: the K / V^T a denoise-step program reads as constants are written by a second program from the host's prompt
+    embeddings — the step exported with prompt A, run with prompt B, equals the pipeline's run with prompt B."""
+    pipe = _tiny_pipe("bf16")
+    inp = synth.pipeline_inputs(2, 16, 32, seed=7, cross_dim=32, vae_scale=2)
+    other = synth.pipeline_inputs(2, 16, 32, seed=8, cross_dim=32, vae_scale=2)
+    noise = torch.randn(4, 4, 8, 16, generator=torch.Generator().manual_seed(3))
+    pstep, pbind = str(tmp_path / "step.mfprog"), str(tmp_path / "bind.mfprog")
+    pipe.export_denoise_step(pstep, **_call_args(inp, 5, noise))
+    ib = program.export_bind_prompt(pipe.unet, pbind)
+    assert ib["calls"] == 2 * ib["meta"]["layers"]
+    kw = _call_args(inp, 5, noise)
+    kw.update(prompt_embeds=other["prompt_embeds"], negative_prompt_embeds=other["negative_prompt_embeds"])
+    ref_b = pipe(**kw).images.float().cpu()
+    ref_a = pipe(**_call_args(inp, 5, noise)).images.float().cpu()
+    assert not torch.equal(ref_a, ref_b)
+    del pipe
+    step = program.Program(pstep, DEV)
+    bind = program.Program(pbind, DEV, share=step)
+
+    def loop():
+        step.buffer("latents", torch.float32).copy_(inp["latents"].to(DEV).float().reshape(-1))
+        coef, tu, tb = (step.buffer(n, torch.float32).view(5, -1) for n in ("table.coef4", "table.temb_unet", "table.temb_brushnet"))
+        for i in range(5):
+            step.buffer("coef4", torch.float32).copy_(coef[i]); step.buffer("temb_unet", torch.float32).copy_(tu[i]); step.buffer("temb_brushnet", torch.float32).copy_(tb[i])
+            step.run()
+        torch.cuda.synchronize()
+        return step.buffer("latents", torch.float32).view(ref_a.shape).cpu().clone()
+    assert torch.equal(loop(), ref_a)
+    pe_b = torch.cat([other["negative_prompt_embeds"], other["prompt_embeds"]]).to(DEV, torch.bfloat16).contiguous()
+    bind.buffer("prompt_embeds", torch.bfloat16).copy_(pe_b.reshape(-1))
+    bind.run()
+    assert torch.equal(loop(), ref_b), "the step exported with prompt A, re-bound to prompt B, differs from the pipeline's run with B"
+    bind.close(); step.close()
