@@ -1,0 +1,22 @@
+#!/bin/bash
+# gpurun: bash tools/gpu_session.sh <tag> bash tools/session_t69.sh — same-box A/B: the 64-row persistent tile 69 on the 16x16 level's N = 1280 GEMMs (tune-cache overlay)
+: "${GRAFT_REPO_ROOT:?run through gpurun}"; : "${MF_SESSION_OUT:?run through tools/gpu_session.sh}"
+cd "$GRAFT_REPO_ROOT" || exit 1
+out="$MF_SESSION_OUT"
+cat > "$out/overlay.json" <<'JSON'
+{"_meta": {"tile_table": 1}, "entries": {
+"1,1,2048,1280,1280,1,1,0,0,1,0,0,1,1": [69, 1, 0],
+"1,1,2048,1280,1280,1,1,0,0,1,0,0,16,16": [69, 1, 0],
+"1,1,2048,1280,5120,1,1,0,0,1,0,0,1,1": [69, 1, 0]}}
+JSON
+echo '{"_meta": {"tile_table": 1}, "entries": {}}' > "$out/empty.json"
+for i in 1 2 3; do
+  for v in empty overlay; do
+    MFHIP_TUNE_CACHE="$out/$v.json" timeout 900 python bench.py --no-extra-legs --no-parity-mode --no-cpu-baseline --steps 4 > "$out/b_${v}_$i.json" 2> "$out/b_${v}_$i.err" || tail -n 5 "$out/b_${v}_$i.err"
+    python - "$out/b_${v}_$i.json" "$v" <<'PY'
+import json, sys
+r = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+print(sys.argv[2], r["value"], r["roofline"]["denoise_step"]["ms"])
+PY
+  done
+done
