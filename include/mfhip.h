@@ -59,7 +59,7 @@ extern "C" {
 #define MF_ACT_GEGLU4 2
 
 /* ABI version, bumped on any struct change; checked by the Python host at load time. */
-#define MF_ABI_VERSION 19
+#define MF_ABI_VERSION 20
 int mf_abi_version(void);
 const char* mf_last_error(void);
 /* sizeof() of the descriptor structs, so a foreign-language binding can verify its layout */
@@ -177,6 +177,14 @@ typedef struct mf_gemm_desc {
      *     gn_part[2 * n * (M / R) + 2 * ((m / R) * gn_groups + g)] = (sum, sum of squares) over rows [R (m / R), +R) of group g,
      * and writes 1 to *gn_grouped (a HOST int, else 0): mf_groupnorm then needs no finalize launch at all (grp0 below). */
     int32_t gn_groups; int32_t* gn_grouped;
+    /* Split-K reduce left to the consumer (round 6, ABI 20).  The 8 x 8 / 16 x 16 levels run their 3x3 convs with split-K (M = 512 / 2048
+     * rows cannot fill 256 CUs otherwise); the first conv of a ResnetBlock2D feeds nothing but norm2 (resnet.py:381-393), so the launch that
+     * sums the K slices can be the GroupNorm itself.  defer_reduce != 0: when this call ends with split-K slabs in `ws` and an epilogue of
+     * bias (per column) / temb / alpha only — no residual, activation, scales, folded LayerNorm, vt_out, gn_part; nz == 1; the 8-channel
+     * vector form — the reduce launch is SKIPPED, `out` is NOT written and *deferred_splits (a HOST int) receives the number of slabs
+     * [split][M][n] fp32 in ws; mf_groupnorm takes them as sk_ws (below) and must be the next user of `ws` on this stream.  Otherwise
+     * *deferred_splits = 0 and the call is complete as always. */
+    int32_t defer_reduce; int32_t* deferred_splits;
 } mf_gemm_desc;
 
 int mf_gemm_conv(const mf_gemm_desc* d, void* stream);
@@ -215,6 +223,12 @@ typedef struct mf_groupnorm_desc {
      * [groups].  One segment only (x1 == NULL), at most 64 row blocks per image: every block of the apply pass combines its image's
      * blocks itself (fixed order, double) and the normalisation is ONE launch. */
     const float* grp0; int32_t grp0_rows;
+    /* The input as a deferred split-K reduce (mf_gemm_desc.defer_reduce): x = round(((sum over sk_splits slabs of sk_ws[split][row][c])
+     * + sk_bias[c] + sk_temb[image * sk_ld_temb + c]) * sk_alpha), summed in slab order and rounded to in_dtype — bit for bit what the
+     * reduce launch would have stored — instead of reading x0 (ignored; c1 must be 0).  Only where the one-launch form applies
+     * (hw <= 256, channels % 8 == 0: the levels that split K); refused otherwise.  sk_bias / sk_temb nullable. */
+    const float* sk_ws; int32_t sk_splits;
+    const float* sk_bias; const float* sk_temb; int64_t sk_ld_temb; float sk_alpha;
 } mf_groupnorm_desc;
 int mf_groupnorm(const mf_groupnorm_desc* d, void* stream);
 int64_t mf_groupnorm_ws_floats(int32_t batch, int32_t groups, int32_t channels);

@@ -639,6 +639,13 @@ extern "C" int mf_gemm_conv(const mf_gemm_desc* d, void* stream) {
     }
     MF_CHECK_ARG(launched, "mf_gemm_conv: tile %d is not instantiated for dtype %d (w_split=%d)", tile, d->dtype, d->w_split);
     MF_CHECK_LAUNCH("mf_gemm_conv");
+    if (d->deferred_splits) *d->deferred_splits = 0;
+    if (a.splitk > 1 && a.sk_tickets == nullptr && d->defer_reduce && d->deferred_splits && a.vec_ok && a.nz == 1 && !d->res0 && !d->res1 &&
+        d->act == MF_ACT_NONE && !d->a_scale && !d->w_scale && d->bias_mode == 0 && !d->ln_colsum && !d->vt_out && !d->gn_part && d->ldc == d->n) {
+        // the consumer (mf_groupnorm, sk_ws) sums the slabs: no reduce launch, `out` stays unwritten
+        *d->deferred_splits = a.splitk;
+        return MF_OK;
+    }
     if (a.splitk > 1 && a.sk_tickets == nullptr) {
         const int64_t total = (int64_t)a.M * a.N * a.nz / (a.vec_ok ? 8 : 1);
         int blocks = (int)((total + 255) / 256);

@@ -24,6 +24,8 @@ struct GnArgs {
     // statistics handed over by the producers (mf_gemm_desc.gn_part): per-channel (sum, sum of squares) of every block of rows
     const float2* part0; const float2* part1; int pr0, pr1;
     const float2* grp0; int nch0;      // per-GROUP sums of x0 from its producer: [batch][nch0][G]; fuse_finalize == 2
+    // the input as a deferred split-K reduce (mf_groupnorm_desc.sk_ws): slabs [split][batch * HW][C] fp32, bias / temb / alpha
+    const float* sk_ws; int sk_splits; const float* sk_bias; const float* sk_temb; int64_t sk_ld_temb; float sk_alpha; int64_t sk_mn;
 };
 
 template <bool F16>
@@ -439,10 +441,55 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const GnArgs p, int SC, i
     if (active) {
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            if (lane + i * P < p.HW) load8<F16>(ptr + i * step, p.in_dt, 0, v[i]);
+            if (lane + i * P < p.HW && p.sk_ws == nullptr) load8<F16>(ptr + i * step, p.in_dt, 0, v[i]);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = 0.0f;
+            }
+        }
+        if (p.sk_ws) {
+            // the producer's split-K slabs: summed in slab order, + bias + temb, * alpha, rounded to the storage dtype — what
+            // splitk_reduce_kernel + epilogue_store8 (csrc/gemm_conv.hip) would have stored and this kernel read back
+            float bt[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bt[e] = 0.0f;
+            float tb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.sk_bias) load8<false>(reinterpret_cast<const char*>(p.sk_bias + c), MF_F32, 0, bt);
+            if (p.sk_temb) load8<false>(reinterpret_cast<const char*>(p.sk_temb + (int64_t)b * p.sk_ld_temb + c), MF_F32, 0, tb);
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                if (lane + i * P >= p.HW) continue;
+                const float* src = p.sk_ws + ((int64_t)b * p.HW + lane + i * P) * p.C + c;
+                int z = 0;
+                for (; z + 4 <= p.sk_splits; z += 4) {       // four slabs' loads in flight; the additions keep the slab order
+                    float4 lo[4], hi[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        lo[u] = *reinterpret_cast<const float4*>(src + (z + u) * p.sk_mn);
+                        hi[u] = *reinterpret_cast<const float4*>(src + (z + u) * p.sk_mn + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v[i][0] += lo[u].x; v[i][1] += lo[u].y; v[i][2] += lo[u].z; v[i][3] += lo[u].w;
+                        v[i][4] += hi[u].x; v[i][5] += hi[u].y; v[i][6] += hi[u].z; v[i][7] += hi[u].w;
+                    }
+                }
+                for (; z < p.sk_splits; ++z) {
+                    const float4 lo = *reinterpret_cast<const float4*>(src + z * p.sk_mn);
+                    const float4 hi = *reinterpret_cast<const float4*>(src + z * p.sk_mn + 4);
+                    v[i][0] += lo.x; v[i][1] += lo.y; v[i][2] += lo.z; v[i][3] += lo.w;
+                    v[i][4] += hi.x; v[i][5] += hi.y; v[i][6] += hi.z; v[i][7] += hi.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = v[i][e];
+                    if (p.sk_bias) x += bt[e];
+                    if (p.sk_temb) x += tb[e];
+                    x *= p.sk_alpha;
+                    if (p.in_dt == MF_BF16) x = bf16_to_f32(f32_to_bf16(x));
+                    else if (p.in_dt == MF_F16) x = (float)(_Float16)x;
+                    v[i][e] = x;
+                }
             }
         }
         float s[8], ss[8];
@@ -699,9 +746,18 @@ extern "C" int mf_groupnorm(const mf_groupnorm_desc* d, void* stream) {
         const int P = d->hw < 64 ? d->hw : 64, rows = 4;     // 32x32 (P 128, 8 rows, 128 blocks) measured no faster: 17.3 vs 17.6 us
         const int nthr = (nv * P + 63) / 64 * 64;
         const size_t smem = (size_t)P * sc * sizeof(float2);
-        if (!two_pass && vw == 8 && d->hw <= P * rows && C % sc == 0 && sc / a.cpg <= 8 && nthr <= 1024 && smem <= 64 * 1024 &&
-            mf_aligned16(d->gamma) && mf_aligned16(d->beta) && mf_aligned16(d->x0) && mf_aligned16(d->out) &&
-            (!d->x1 || mf_aligned16(d->x1))) {
+        a.sk_ws = d->sk_ws; a.sk_splits = d->sk_splits; a.sk_bias = d->sk_bias; a.sk_temb = d->sk_temb; a.sk_ld_temb = d->sk_ld_temb;
+        a.sk_alpha = d->sk_alpha; a.sk_mn = (int64_t)d->batch * d->hw * C;
+        const bool slab_ok = vw == 8 && d->hw <= P * rows && C % sc == 0 && sc / a.cpg <= 8 && nthr <= 1024 && smem <= 64 * 1024 &&
+                             mf_aligned16(d->gamma) && mf_aligned16(d->beta) && mf_aligned16(d->x0) && mf_aligned16(d->out) &&
+                             (!d->x1 || mf_aligned16(d->x1));
+        if (d->sk_ws) {
+            MF_CHECK_ARG(slab_ok && d->c1 == 0 && d->sk_splits >= 2 && d->stats_out == nullptr && mf_aligned16(d->sk_ws) &&
+                             (!d->sk_bias || mf_aligned16(d->sk_bias)) && (!d->sk_temb || (mf_aligned16(d->sk_temb) && d->sk_ld_temb % 4 == 0)),
+                         "mf_groupnorm: a deferred split-K input (sk_ws) needs the one-launch form (hw <= 256, channels %% 8 == 0, one segment), "
+                         ">= 2 slabs, 16-byte aligned slabs / bias / temb and no stats_out");
+        }
+        if ((!two_pass || d->sk_ws) && slab_ok) {
             if (f16) hipLaunchKernelGGL((gn_slab_kernel<4, true>), dim3(C / sc, d->batch), dim3(nthr), smem, s, a, sc, nv, P);
             else hipLaunchKernelGGL((gn_slab_kernel<4, false>), dim3(C / sc, d->batch), dim3(nthr), smem, s, a, sc, nv, P);
             MF_CHECK_LAUNCH("mf_groupnorm(slab)");

@@ -278,6 +278,7 @@ int run_call(const mf_program* prog, const Call& c, void* s) {
         mf_gemm_desc* g = (mf_gemm_desc*)raw;
         int32_t rows_unused = 0, grouped_unused = 0;
         if (g->gn_part) { g->gn_part_rows = &rows_unused; g->gn_grouped = &grouped_unused; }
+        if (g->defer_reduce) g->deferred_splits = &grouped_unused;      // (the recorded consumer already expects the slabs)
         return mf_gemm_conv(g, s);
     }
     case F_LAYERNORM: return mf_layernorm(P(0), I(1), P(2), I(3), FP(4), FP(5), L(6), I(7), F(8), s);

@@ -17,7 +17,7 @@ from . import _build
 MF_F32, MF_BF16, MF_F16X3, MF_BF16X3, MF_FP8, MF_BF16X1, MF_F16 = 0, 1, 2, 3, 4, 5, 6
 FP8 = torch.float8_e4m3fn          # OCP e4m3 (gfx950's fp8), 1 byte per element
 ACT_NONE, ACT_SILU, ACT_GEGLU4 = 0, 1, 2
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class MfhipError(RuntimeError):
@@ -54,6 +54,7 @@ class GemmDesc(C.Structure):
         ("sk_tickets", C.c_void_p), ("sk_ticket_cap", C.c_int32),
         ("gn_part", C.c_void_p), ("gn_part_floats", C.c_int64), ("gn_part_rows", C.c_void_p),
         ("gn_groups", C.c_int32), ("gn_grouped", C.c_void_p),
+        ("defer_reduce", C.c_int32), ("deferred_splits", C.c_void_p),
     ]
 
 
@@ -120,6 +121,8 @@ class GroupNormDesc(C.Structure):
         ("ws", C.c_void_p), ("stats_out", C.c_void_p),
         ("part0", C.c_void_p), ("part0_rows", C.c_int32), ("part1", C.c_void_p), ("part1_rows", C.c_int32),
         ("grp0", C.c_void_p), ("grp0_rows", C.c_int32),
+        ("sk_ws", C.c_void_p), ("sk_splits", C.c_int32),
+        ("sk_bias", C.c_void_p), ("sk_temb", C.c_void_p), ("sk_ld_temb", C.c_int64), ("sk_alpha", C.c_float),
     ]
 
 
@@ -220,6 +223,9 @@ def _req_cuda(*ts: Optional[torch.Tensor]) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:
             raise MfhipError("libmfhip ops need device tensors (there is no CPU path)")
+        if t is not None and getattr(t, "_sk_pending", None) is not None:
+            raise MfhipError("a tensor whose split-K reduce was deferred (gemm_conv(defer_reduce=True)) reached an op other than the "
+                             "groupnorm() it was promised to: its memory has not been written")
 
 
 # ---- scratch buffers (split-K slabs, GroupNorm statistics) -------------------------------------
@@ -364,6 +370,7 @@ def pers_linear(m: int, n: int, k: int, dtype: torch.dtype) -> bool:
 
 
 # GroupNorm statistics from the producing GEMM's epilogue (mf_gemm_desc.gn_part -> mf_groupnorm_desc.part0 / part1).  A/B switch.
+DEFER_REDUCE = os.environ.get("MFHIP_DEFER_REDUCE", "1") != "0"     # A/B switch: a resnet's conv1 leaves its split-K reduce to norm2
 GN_FROM_PARTS = os.environ.get("MFHIP_GN_FROM_PARTS", "1") != "0"
 GN_FROM_GROUPS = os.environ.get("MFHIP_GN_FROM_GROUPS", "1") != "0"     # ... per-group sums: no finalize launch either.  A/B switch.
 RETUNE = os.environ.get("MFHIP_RETUNE", "0") == "1"      # developer switch: re-measure every shape once (new tiles were added)
@@ -540,10 +547,11 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
               a_scale: Optional[torch.Tensor] = None, w_scale: Optional[torch.Tensor] = None, a_scale_zs: int = 0,
               w_scale_zs: int = 0, splitk: int = 0, tile: int = 0, ln_colsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
               vt_out: Optional[torch.Tensor] = None, vt_n0: int = 0, vt_tokens: int = 0, sk_fused: bool = False,
-              gn_part: Union[bool, int] = False) -> torch.Tensor:
+              gn_part: Union[bool, int] = False, defer_reduce: bool = False) -> torch.Tensor:
     """Raw descriptor-level call of mf_gemm_conv (see include/mfhip.h). All strides in elements.  `dtype`: a torch
     dtype (bf16 / fp32 compute) or an MF_* compute code (the split codes take fp32 a0 and, with w_split=1, a weight
-    from ops.split_pack)."""
+    from ops.split_pack).  `defer_reduce`: the caller hands `out` to groupnorm() next and to nothing else — a split-K launch may
+    then leave its reduce to that GroupNorm (mf_gemm_desc.defer_reduce): `out` comes back UNWRITTEN with out._sk_pending set."""
     _req_cuda(a0, a1, w, out, bias, temb, res0, res1)
     d = GemmDesc()
     code = dtype if isinstance(dtype, int) else dt_code(dtype)
@@ -641,11 +649,19 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         d.gn_part, d.gn_part_floats, d.gn_part_rows = part.data_ptr(), part.numel(), C.addressof(part_rows)
         # gn_part = the consumer GroupNorm's group count (an int > 1): per-group sums too where the tile allows (no finalize launch then)
         d.gn_groups, d.gn_grouped = (int(gn_part) if (gn_part is not True and int(gn_part) > 1) else 0), C.addressof(grouped)
+    deferred = C.c_int32(0)
+    if defer_reduce and DEFER_REDUCE and not gn_part:
+        d.defer_reduce, d.deferred_splits = 1, C.addressof(deferred)
+
+    def pending():
+        if deferred.value > 0:      # (the slabs stay in this stream's split-K scratch until the GroupNorm that follows has read them)
+            out._sk_pending = (ws, int(deferred.value), bias, temb, ld_temb, float(alpha))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _check(load().mf_gemm_conv(C.byref(d), _stream()), "mf_gemm_conv")
         e1.record()
+        pending()
         PROFILE.append((e0, e1, 2.0 * batch * h_out * w_out * n * kh * kw * (c0 + c1) * nz,
                         (batch * h_out * w_out, n, kh * kw * (c0 + c1), kh, stride, int(upsample), nz, d.tile, d.splitk, int(code))))
         if part is not None:
@@ -658,6 +674,7 @@ def gemm_conv(a0: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, dtype, w_
         d.tile, d.splitk, d.sk_tickets, d.sk_ticket_cap = 0, splitk, None, 0
         rc = load().mf_gemm_conv(C.byref(d), _stream())
     _check(rc, "mf_gemm_conv")
+    pending()
     if part is not None:
         # (buffer, rows per block, G): G > 0 = per-group sums of G groups follow the per-channel ones at float 2 * n * (M / rows)
         out._gn_part = (part, int(part_rows.value), int(d.gn_groups) if grouped.value else 0)
@@ -669,6 +686,9 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, grou
               stats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x0/x1: NHWC [B, H, W, C] (or [B, HW, C]); returns the normalised tensor over cat([x0, x1], -1).  stats_out (fp32
     [B, groups, 2], written): every group's (mean, rstd), which groupnorm_bwd takes as `stats`."""
+    pend = getattr(x0, "_sk_pending", None)
+    if pend is not None:
+        x0._sk_pending = None              # consumed here (x0 itself stays unwritten: nothing else may read it)
     _req_cuda(x0, x1, gamma, beta)
     b = x0.shape[0]
     c0 = x0.shape[-1]
@@ -692,6 +712,11 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, grou
         if stats_out.numel() != b * groups * 2 or not stats_out.is_contiguous():
             raise MfhipError("groupnorm: stats_out is a contiguous [batch, groups, 2] tensor")
         d.stats_out = stats_out.data_ptr()
+    if pend is not None:
+        if x1 is not None or stats_out is not None:
+            raise MfhipError("groupnorm: a deferred split-K input is a single segment without stats_out")
+        ws_t, splits, sk_bias, sk_temb, sk_ld, sk_alpha = pend
+        d.sk_ws, d.sk_splits, d.sk_bias, d.sk_temb, d.sk_ld_temb, d.sk_alpha = ws_t.data_ptr(), splits, _ptr(sk_bias), _ptr(sk_temb), sk_ld, sk_alpha
     if GN_FROM_PARTS and hw > 256:
         # statistics handed over by the producing GEMMs (gemm_conv(..., gn_part=True) attached them to its output tensor)
         p0, p1 = getattr(x0, "_gn_part", None), (getattr(x1, "_gn_part", None) if x1 is not None else None)

@@ -51,7 +51,7 @@ SIGNATURES = {
 _PASS_THROUGH = ("mf_last_error", "mf_abi_version", "mf_gemm_num_tiles", "mf_gemm_tile_shape", "mf_gemm_tile_table_version",
                  "mf_groupnorm_ws_floats", "mf_sizeof_gemm_desc", "mf_sizeof_groupnorm_desc")
 # descriptor fields that are HOST out-pointers (the library reports a choice through them): null in a program
-_HOST_FIELDS = {"gn_part_rows", "gn_grouped"}
+_HOST_FIELDS = {"gn_part_rows", "gn_grouped", "deferred_splits"}
 
 # aten ops that launch nothing (views, allocations, metadata)
 _VIEW_OPS = {

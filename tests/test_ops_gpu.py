@@ -948,6 +948,43 @@ def test_groupnorm_partial_sums_fallback_and_variants(case):
     assert (got[..., 0] - ref[..., 0]).abs().max() <= tol_s and (got[..., 1] - ref[..., 1]).abs().max() <= tol_q
 
 
+@pytest.mark.parametrize("prec_name", ["bf16", "fp16", "f16x3", "fp32"])
+@pytest.mark.parametrize("hw,splitk,tile", [(8, 4, 1), (8, 3, 3), (16, 2, 1), (16, 8, 6)])
+def test_split_k_reduce_deferred_to_the_groupnorm_is_bit_identical(prec_name, hw, splitk, tile, monkeypatch):
+    """mf_gemm_desc.defer_reduce + mf_groupnorm_desc.sk_ws: a split-K conv with bias + temb leaves the summing of its K slices to the
+    GroupNorm that consumes it (a resnet's conv1 -> norm2, resnet.py:381-393) — same bits as reduce launch + GroupNorm, one launch less;
+    a launch that does not split leaves nothing pending; the unwritten tensor is refused by every other op."""
+    prec = ops.Precision.get(prec_name)
+    g = torch.Generator().manual_seed(21)
+    b, cin, n = 4, 320, 320
+    x = (torch.randn(b, hw, hw, cin, generator=g)).to(DEV, prec.act)
+    cw = ops.ConvWeight(torch.randn(n, cin, 3, 3, generator=g) * 0.03, torch.randn(n, generator=g), prec, DEV)
+    temb = torch.randn(b, n, generator=g).to(DEV)
+    norm = (torch.randn(n, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV))
+    try:
+        monkeypatch.setattr(hip, "DEFER_REDUCE", False)
+        y_ref = ops.conv2d(x, cw, temb=temb, splitk=splitk, tile=tile, defer_reduce=True)
+        assert getattr(y_ref, "_sk_pending", None) is None
+        z_ref = ops.groupnorm(y_ref, norm, groups=32, eps=1e-5, silu=True, out_dtype=prec.act)
+    except hip.MfhipError as e:
+        assert "not instantiated" in str(e) or "does not apply" in str(e), e
+        return
+    monkeypatch.setattr(hip, "DEFER_REDUCE", True)
+    y = ops.conv2d(x, cw, temb=temb, splitk=splitk, tile=tile, defer_reduce=True)
+    assert y._sk_pending is not None and y._sk_pending[1] >= 2, "the forced split-K launch should have left its reduce"
+    with pytest.raises(hip.MfhipError, match="deferred"):
+        hip.add(y, y, prec.act)
+    z = ops.groupnorm(y, norm, groups=32, eps=1e-5, silu=True, out_dtype=prec.act)
+    assert y._sk_pending is None
+    assert torch.equal(z, z_ref), f"deferred reduce differs from reduce + GroupNorm by {(z.float() - z_ref.float()).abs().max()}"
+    y1 = ops.conv2d(x, cw, temb=temb, splitk=1, tile=tile, defer_reduce=True)       # no split: complete as always
+    assert getattr(y1, "_sk_pending", None) is None
+    tol = 2e-2 if prec_name in ("bf16", "fp16") else 1e-4
+    check(f"defer_reduce split-K 1 [{prec_name}]", y1, y_ref.float().cpu(), tol, tol)
+    y2 = ops.conv2d(x, cw, temb=temb, res0=y_ref, splitk=splitk, tile=tile, defer_reduce=True)   # a residual: not deferrable
+    assert getattr(y2, "_sk_pending", None) is None
+
+
 @pytest.mark.parametrize("prec_name", ["f16x3", "fp32", "fp16"])
 def test_groupnorm_partial_sums_fallback_in_every_storage(prec_name):
     """The column-sum launch behind a split-K reduce reads the stored output in its own dtype: fp32 storage (the split-precision and
