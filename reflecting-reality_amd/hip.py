@@ -340,6 +340,19 @@ PERS_TILE = 70
 PERS_MIN_NLOOP = int(os.environ.get("MFHIP_PERS_MIN_NLOOP", "2"))
 
 
+def gn_slab_applies(hw: int, c: int, groups: int) -> bool:
+    """Whether mf_groupnorm runs its one-launch form on [*, hw, c] in `groups` groups, one segment (csrc/norm.hip, the dispatch of
+    gn_slab_kernel) — the form a deferred split-K reduce needs (mf_groupnorm_desc.sk_ws)."""
+    if groups <= 0 or c % groups or c % 8:
+        return False
+    cpg = c // groups
+    sc = cpg
+    while sc % 8:
+        sc += cpg
+    p = hw if hw < 64 else 64
+    return hw <= 4 * p and c % sc == 0 and sc // cpg <= 8 and (sc // 8) * p <= 1024 and p * sc * 8 <= 64 * 1024
+
+
 def _pers_applies(m, n, k, kh, kw, stride, pad_t, pad_l, upsample, h_in, h_out, w_in, w_out, c1, nz, temb, res0, res1, out, a0, bias_mode,
                   a_scale, w_scale) -> bool:
     """The call is one tile 70 serves (mf_gemm_conv's own check, gemm_conv.cpp kPersTile) AND its grid gives every block at least

@@ -685,7 +685,7 @@ class _UNetCore(HipModel):
         h = ops.groupnorm(x, P[p + "norm1"], groups=g, eps=eps, silu=True, out_dtype=self._operand_dtype(), x1=x1)
         # conv1's output feeds norm2 and nothing else: above 16 x 16 the launch leaves norm2's statistics (gn_part), up to 16 x 16 —
         # where it runs split-K — it leaves the summing of its K slices to norm2 (defer_reduce: the reduce launch disappears)
-        h = ops.conv2d(h, P[p + "conv1"], temb=self._temb(temb_all, p), gn_part=self.config["norm_num_groups"], defer_reduce=True)
+        h = ops.conv2d(h, P[p + "conv1"], temb=self._temb(temb_all, p), gn_part=self.config["norm_num_groups"], defer_reduce=g)
         h = ops.groupnorm(h, P[p + "norm2"], groups=g, eps=eps, silu=True, out_dtype=self._operand_dtype())
         if join is not None:
             join()

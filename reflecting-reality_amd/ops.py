@@ -242,11 +242,12 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
            res0: Optional[torch.Tensor] = None, res1: Optional[torch.Tensor] = None,
            alpha: float = 1.0, act: int = hip.ACT_NONE, out_dtype: Optional[torch.dtype] = None,
            splitk: int = 0, tile: int = 0, sk_fused: bool = False, gn_part: Union[bool, int] = False,
-           defer_reduce: bool = False) -> torch.Tensor:
+           defer_reduce: Union[bool, int] = False) -> torch.Tensor:
     """Convolution over NHWC x (optionally cat([x, x1], C) and/or nearest-2x upsampled), fused epilogue
     alpha*(conv + bias + temb[b]) + res0 + res1.  padding = int or (top, left, bottom, right).
-    defer_reduce: the caller passes the result to groupnorm() and to nothing else (a resnet's conv1 -> norm2, resnet.py:381-393): on the
-    levels that run split-K (images up to 16 x 16) the launch that sums the K slices is then that GroupNorm (mf_gemm_desc.defer_reduce).
+    defer_reduce (the consumer's group count): the caller passes the result to groupnorm() with that many groups and to nothing else (a
+    resnet's conv1 -> norm2, resnet.py:381-393): on the levels that run split-K (images up to 16 x 16) the launch that sums the K slices is
+    then that GroupNorm (mf_gemm_desc.defer_reduce).
     gn_part: the output feeds a GroupNorm — the launch also leaves per-channel partial sums of its output (mf_gemm_desc.gn_part),
     attached to the returned tensor, and groupnorm() then skips its statistics pass (inference, images above 16 x 16)."""
     b, h, w, c0 = x.shape
@@ -274,8 +275,8 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, *, stride: int = 1,
                   temb=temb, ld_temb=(temb.stride(0) if temb is not None else 0),
                   res0=res0, res1=res1, res1_rows=_shared_rows(res1, b * ho * wo, cw.n), alpha=alpha, act=act, splitk=splitk,
                   tile=tile, sk_fused=sk_fused, gn_part=(gn_part if _want_gn_part(gn_part, ho * wo, cw.n) else False),
-                  defer_reduce=bool(defer_reduce and TAPE is None and ho * wo <= 256 and cw.n % 8 == 0 and res0 is None and res1 is None
-                                    and act == hip.ACT_NONE and not sk_fused))
+                  defer_reduce=bool(defer_reduce and TAPE is None and res0 is None and res1 is None and act == hip.ACT_NONE and not sk_fused
+                                    and hip.gn_slab_applies(ho * wo, cw.n, 32 if defer_reduce is True else int(defer_reduce))))
     if TAPE is not None:
         autograd.record_conv(TAPE, x, x1, cw, out, batch=b, h_in=h, w_in=w, h_out=ho, w_out=wo, stride=stride, pad_t=pt, pad_l=pl,
                              upsample=upsample, temb=temb, res0=res0, res1=res1, alpha=alpha, act=act, x16=(xa, x1a) if fast else None)

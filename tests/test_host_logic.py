@@ -542,3 +542,14 @@ def test_checkpoints_carry_the_lr_schedule(tmp_path):
     p2 = T.save_state(str(tmp_path), 6, StubModel(), o1)
     with pytest.warns(UserWarning, match="no scheduler.bin"):
         T.load_state(p2, StubModel(), None, lr_scheduler=make()[1])
+
+
+def test_gn_slab_predicate_mirrors_the_library():
+    """hip.gn_slab_applies decides on the host whether a conv may leave its split-K reduce to the GroupNorm: it must agree with the
+    dispatch of gn_slab_kernel in csrc/norm.hip for the channel counts of the path, and refuse what that form cannot take."""
+    from reflecting_reality_amd import hip
+    for c in (320, 640, 960, 1280, 1920, 2560):
+        assert hip.gn_slab_applies(64, c, 32) and hip.gn_slab_applies(256, c, 32), c
+        assert not hip.gn_slab_applies(1024, c, 32)
+    assert not hip.gn_slab_applies(64, 3200, 32)       # 100 channels per group: the slab needs 25 x 64 threads
+    assert not hip.gn_slab_applies(64, 324, 32) and not hip.gn_slab_applies(64, 320, 0)
