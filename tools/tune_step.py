@@ -62,6 +62,7 @@ def step_ms(reps=2, steps=16):
 
 rank_path = os.path.join(ROOT, "gpurun_out", "tune_rankings.json")
 t0 = time.time()
+print(f"[tune_step] step with the shipped cache: {step_ms():.3f} ms", flush=True)      # what the result below has to beat on THIS box
 if not a.no_isolated:
     hip.RETUNE, hip.TUNE_GRAPH, hip.TUNE_LOG = True, True, {}
     run(2)                                   # the eager first step re-times every candidate of every key it meets
