@@ -455,61 +455,66 @@ class Recorder:
     # ---- the file -------------------------------------------------------------------------------------------------------
     def save(self, path: str, meta: str = "") -> dict:
         """Write the program; constants and io buffers carry the bytes they hold NOW (restore the pass's inputs first)."""
-        pad8 = lambda b: b + b"\0" * (-len(b) % 8)
-        body = bytearray()
-        for name, args, sid in self.resolved:
-            nb = name.encode()
-            body += struct.pack("<IIII", len(nb), len(args), sid, 0) + pad8(nb)
-            tail = bytearray()
-            for a in args:
-                if a[0] == A_PTR:
-                    body += struct.pack("<Iiq", A_PTR, a[1], a[2])
-                elif a[0] == A_DESC:
-                    body += struct.pack("<Iiq", A_DESC, len(a[2]), len(a[1]))
-                    tail += pad8(a[1])
-                    for off, buf, boff in a[2]:
-                        tail += struct.pack("<Iiq", off, buf, boff)
-                elif a[0] == A_F32:
-                    body += struct.pack("<Iifi", A_F32, 0, a[1], 0)
-                else:
-                    body += struct.pack("<Iiq", a[0], 0, a[1])
-            body += tail
-        table = bytearray()
-        for b in self.buffers:
-            nb = b["name"].encode()
-            table += struct.pack("<IIqq", b["kind"], len(nb), b["bytes"], 0) + pad8(nb)      # data offset patched below
-        metab = pad8(meta.encode())
-        head_len = 8 + 4 * 4 + 8 + 8 + 8 + len(metab) + len(table) + len(body)
-        data_off = (head_len + 255) // 256 * 256
-        # second pass over the table with the data offsets
-        table = bytearray()
-        cursor = data_off
-        placed = []
-        for b in self.buffers:
-            nb = b["name"].encode()
-            if b["kind"] == KIND_WORKSPACE:
-                off = -1
-            else:
-                off = cursor
-                cursor = (cursor + b["bytes"] + 255) // 256 * 256
-                placed.append((off, b))
-            table += struct.pack("<IIqq", b["kind"], len(nb), b["bytes"], off) + pad8(nb)
-        nstreams, nevents = max([c[2] for c in self.resolved] + [0]) + 1, len(self._events)
-        head = MAGIC + struct.pack("<IIII", hip.ABI_VERSION, len(self.buffers), len(self.resolved), len(metab)) + struct.pack("<qqII", head_len, cursor, nstreams, nevents) + metab
+        header, placed, total, nstreams, nevents = serialize_header(self.resolved, self.buffers, len(self._events), meta)
         torch.cuda.synchronize(self.device)
         with open(path, "wb") as f:
-            f.write(head + table + body)
-            assert f.tell() == head_len
+            f.write(header)
             for off, b in placed:
                 f.seek(off)
                 host = torch.empty(b["bytes"], dtype=torch.uint8)
                 hip_memcpy_d2h(host, b["addr"], b["bytes"])
                 f.write(host.numpy().tobytes())
-            f.truncate(cursor)
-        return dict(calls=len(self.resolved), buffers=len(self.buffers), bytes=cursor,
+            f.truncate(total)
+        return dict(calls=len(self.resolved), buffers=len(self.buffers), bytes=total,
                     const_bytes=sum(b["bytes"] for b in self.buffers if b["kind"] == KIND_CONST),
                     workspace_bytes=sum(b["bytes"] for b in self.buffers if b["kind"] == KIND_WORKSPACE),
                     streams=nstreams, events=nevents, entries=sorted({c[0] for c in self.resolved}))
+
+
+def serialize_header(resolved, buffers, nevents: int, meta: str = ""):
+    """The part of a program file mf_program_load parses (csrc/program.hip): magic, ABI version, counts, header length, meta, the buffer
+    table with the file offsets of the buffers that carry data, then every call.  `resolved`: (entry, args, stream) with args
+    (A_I32 | A_I64, value), (A_F32, value), (A_PTR, buffer, offset), (A_DESC, bytes, [(field offset, buffer, offset)]); `buffers`: dicts
+    with kind / name / bytes.  Returns (header bytes, [(file offset, buffer)] to fill in, file length, streams, events)."""
+    pad8 = lambda b: b + b"\0" * (-len(b) % 8)
+    body = bytearray()
+    for name, args, sid in resolved:
+        nb = name.encode()
+        body += struct.pack("<IIII", len(nb), len(args), sid, 0) + pad8(nb)
+        tail = bytearray()
+        for a in args:
+            if a[0] == A_PTR:
+                body += struct.pack("<Iiq", A_PTR, a[1], a[2])
+            elif a[0] == A_DESC:
+                body += struct.pack("<Iiq", A_DESC, len(a[2]), len(a[1]))
+                tail += pad8(a[1])
+                for off, buf, boff in a[2]:
+                    tail += struct.pack("<Iiq", off, buf, boff)
+            elif a[0] == A_F32:
+                body += struct.pack("<Iifi", A_F32, 0, a[1], 0)
+            else:
+                body += struct.pack("<Iiq", a[0], 0, a[1])
+        body += tail
+    metab = pad8(meta.encode())
+    table_len = sum(24 + len(pad8(b["name"].encode())) for b in buffers)
+    head_len = 8 + 4 * 4 + 8 + 8 + 8 + len(metab) + table_len + len(body)
+    cursor = (head_len + 255) // 256 * 256
+    table = bytearray()
+    placed = []
+    for b in buffers:
+        nb = b["name"].encode()
+        if b["kind"] == KIND_WORKSPACE:
+            off = -1
+        else:
+            off = cursor
+            cursor = (cursor + b["bytes"] + 255) // 256 * 256
+            placed.append((off, b))
+        table += struct.pack("<IIqq", b["kind"], len(nb), b["bytes"], off) + pad8(nb)
+    nstreams = max([c[2] for c in resolved] + [0]) + 1
+    head = MAGIC + struct.pack("<IIII", hip.ABI_VERSION, len(buffers), len(resolved), len(metab)) + struct.pack("<qqII", head_len, cursor, nstreams, nevents) + metab
+    out = bytes(head + table + body)
+    assert len(out) == head_len
+    return out, placed, cursor, nstreams, nevents
 
 
 def hip_memcpy_d2h(host: torch.Tensor, addr: int, nbytes: int) -> None:
