@@ -607,7 +607,9 @@ int mf_program_run(mf_program* p, void* stream);
 /* The loop body of pipeline_brushnet.py:1250-1332 — latent doubling, BrushNet, UNet with the 28 injected residuals, classifier-free
  * guidance, DDIM update — as one call: binds the io buffers "latents" (NCHW fp32, updated IN PLACE), "coef4" (the step's
  * {sqrt_at, sqrt_1m_at, sqrt_ap, dir_coef}, mf_cfg_ddim_step_dev), "temb_unet" / "temb_brushnet" (the step's rows of the two
- * time-embedding tables) and runs the program.  A NULL argument keeps the buffer's current binding. */
+ * time-embedding tables) and runs the program.  A NULL argument keeps the buffer's current binding.  A step exported under a
+ * multistep scheduler (PNDM, UniPC: host-side state between steps, scheduling_pndm.py:321-390) has no "coef4": it ends with the guided
+ * noise prediction e = eu + g (ec - eu) in the io buffer "eps" (pipeline_brushnet.py:1310-1312) and the host's scheduler steps from it. */
 int mf_denoise_step_fused(mf_program* step, void* latents, const void* coef4, const void* temb_unet, const void* temb_brushnet, void* stream);
 /* UNet2DConditionModel.forward (unet_2d_condition.py:1037-1311) with BrushNet's residuals injected (:1172-1177, 1218, 1262-1284):
  * io buffers "sample", "temb", "residual.<i>" (i < n_residuals, the order of brushnet.py:896-936: down, mid, up), "eps" (the noise

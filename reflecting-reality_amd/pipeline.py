@@ -783,19 +783,24 @@ class StableDiffusionBrushNetPipeline:
         """The recorder of ONE denoise step (the loop body of pipeline_brushnet.py:1250-1332), entered inside the hipGraph capture
         of that step: the program carries the capture's forks and joins (BrushNet || UNet), replayed by mf_denoise_step_fused."""
         from . import program
-        if not fused_ddim:
-            raise NotImplementedError("export_denoise_step: the fused step carries DDIM's update (scheduling_ddim.py:404-450); multistep "
-                                      "schedulers keep host-side state between steps")
         if temb_u is None:
             raise NotImplementedError("export_denoise_step needs precompute_time_embedding (the step reads one row block of the schedule's table)")
-        named = dict(latents=lat, coef4=coef_cur, temb_unet=temb_u, temb_brushnet=temb_b, cond=cond)
-        tables = {"table.coef4": coefs.contiguous(), "table.temb_unet": st["temb_tab"][0].contiguous(), "table.temb_brushnet": st["temb_tab"][1].contiguous()}
+        named = dict(latents=lat, temb_unet=temb_u, temb_brushnet=temb_b, cond=cond)
+        tables = {"table.temb_unet": st["temb_tab"][0].contiguous(), "table.temb_brushnet": st["temb_tab"][1].contiguous()}
+        if fused_ddim:
+            named["coef4"] = coef_cur
+            tables["table.coef4"] = coefs.contiguous()
+        else:
+            # multistep schedulers (PNDM, UniPC: host-side state between steps, scheduling_pndm.py:321-390): the program ends with the
+            # guided noise prediction in the io buffer "eps"; the update of the latents is the host's (mf_axpby_n)
+            named["eps"] = st["eps"]
         return program.Recorder(named, tables, capture=True)
 
     def _export_save(self, rec, graph, path, lat, temb_u, temb_b, nsteps, step, guidance_scale, cond_scale):
         import json
         rec.finish(graph.pool())
         meta = dict(entry="mf_denoise_step_fused", reference="pipelines/brushnet/pipeline_brushnet.py:1250-1332", precision=self.unet.prec.name,
+                    result="latents (DDIM update inside)" if "coef4" in rec.named else "eps (guided noise prediction; the scheduler update is the host's)",
                     latents=list(lat.shape), steps=nsteps, recorded_step=step, guidance_scale=float(guidance_scale),
                     conditioning_scale=cond_scale if isinstance(cond_scale, (int, float)) else list(cond_scale),
                     temb_unet=list(temb_u.shape), temb_brushnet=list(temb_b.shape), brushnet_once=bool(self._brushnet_once))

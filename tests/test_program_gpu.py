@@ -340,3 +340,37 @@ def test_bind_prompt_program_changes_the_prompt_of_an_exported_step(tmp_path):
     bind.run()
     assert torch.equal(loop(), ref_b), "the step exported with prompt A, re-bound to prompt B, differs from the pipeline's run with B"
     bind.close(); step.close()
+
+
+@pytest.mark.parametrize("sched", ["pndm", "unipc"])
+def test_step_program_with_a_multistep_scheduler_returns_the_noise_prediction(sched, tmp_path):
+    """PNDM / UniPC (the schedulers the reference's scripts select: pipeline default, test_brushnet.py:158) keep host-side state, so their
+    exported step ends with the guided noise prediction ("eps"); the host's scheduler steps from it.  Driving the program with the
+    Python scheduler reproduces the pipeline's latents bit for bit."""
+    from reflecting_reality_amd import PNDMScheduler, UniPCMultistepScheduler
+    from test_pipeline_gpu import SD_SCHED
+    pipe = _tiny_pipe("bf16")
+    mk = (lambda: PNDMScheduler(**SD_SCHED, skip_prk_steps=True)) if sched == "pndm" else (lambda: UniPCMultistepScheduler(**{k: v for k, v in SD_SCHED.items() if k != "set_alpha_to_one"}))
+    pipe.scheduler = mk()
+    inp = synth.pipeline_inputs(2, 16, 32, seed=7, cross_dim=32, vae_scale=2)
+    noise = torch.randn(4, 4, 8, 16, generator=torch.Generator().manual_seed(3))
+    path = str(tmp_path / "step.mfprog")
+    info = pipe.export_denoise_step(path, **_call_args(inp, 6, noise))
+    ref = info["result"].images.float().cpu()
+    assert "eps" in info["meta"]["result"] and "mf_cfg_combine" in info["entries"] and "mf_cfg_ddim_step_dev" not in info["entries"]
+    prog = program.Program(path, DEV)
+    s = mk()
+    s.set_timesteps(6, device=DEV)
+    lat = inp["latents"].to(DEV).float() * s.init_noise_sigma
+    tu, tb = (prog.buffer(n, torch.float32) for n in ("table.temb_unet", "table.temb_brushnet"))
+    ts = s.timesteps
+    tu, tb = tu.view(len(ts), -1), tb.view(len(ts), -1)
+    for i, t in enumerate(ts):
+        prog.buffer("latents", torch.float32).copy_(lat.reshape(-1))
+        prog.buffer("temb_unet", torch.float32).copy_(tu[i]); prog.buffer("temb_brushnet", torch.float32).copy_(tb[i])
+        prog.run()
+        eps = prog.buffer("eps", torch.float32).view(lat.shape).clone()
+        lat = s.step(eps, t, lat, return_dict=False)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(lat.float().cpu(), ref), f"{sched}: program + host scheduler differ from the pipeline by {(lat.float().cpu() - ref).abs().max()}"
+    prog.close()
